@@ -1,0 +1,138 @@
+"""ctypes binding of libdgcnn_hip.so (the C ABI declared in include/dgcnn_hip.h).
+
+The shared library is built IN-TREE next to this file (``dgcnn_amd/libdgcnn_hip.so``) by
+``dgcnn_amd/csrc/Makefile`` (``hipcc --offload-arch=gfx950``); ``build()`` runs that.
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+K = 30
+CAT = 97
+HID1 = 128
+FLAT = 352
+NUM_SEG = 16
+
+# name -> (restype, argtypes); must list every symbol include/dgcnn_hip.h declares
+SIGNATURES = {
+    "dgcnn_version": (c_int, []),
+    "dgcnn_param_layout": (c_int64, [c_int, c_int, ctypes.POINTER(c_int64)]),
+    "dgcnn_workspace_bytes": (c_int64, [c_int] * 5),
+    "dgcnn_workspace_offset": (c_int64, [c_char_p] + [c_int] * 5),
+    "dgcnn_graph_prep": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
+    "dgcnn_gcn_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p]),
+    "dgcnn_sortpool_fwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
+    "dgcnn_sortpool_bwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
+    "dgcnn_model_forward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_int, c_uint64, c_void_p]),
+    "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p]),
+    "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
+                                c_void_p]),
+    "dgcnn_accumulate_metrics": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_ERR = {-1: "DGCNN_EINVAL (bad size / null pointer)", -2: "DGCNN_ELAUNCH (HIP launch error)",
+        -3: "DGCNN_EUNSUPPORTED (shape outside this build)"}
+
+
+class DgcnnError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libdgcnn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise DgcnnError(f"building {LIB_PATH} failed (exit {res.returncode}):\n{res.stdout[-4000:]}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library; raises loudly when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DgcnnError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            f"Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise DgcnnError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = L.dgcnn_version()
+    if v != ABI_VERSION:
+        raise DgcnnError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise DgcnnError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def param_layout(F: int, C: int):
+    """(offsets[16], padded_total) of the flat parameter buffer, straight from the C ABI."""
+    arr = (c_int64 * NUM_SEG)()
+    total = lib().dgcnn_param_layout(F, C, arr)
+    if total < 0:
+        raise DgcnnError(f"dgcnn_param_layout(F={F}, C={C}) failed: {_ERR.get(total, total)}")
+    return list(arr), int(total)
+
+
+def workspace_bytes(N: int, E: int, B: int, F: int, C: int) -> int:
+    n = lib().dgcnn_workspace_bytes(N, E, B, F, C)
+    if n < 0:
+        raise DgcnnError(f"dgcnn_workspace_bytes failed: {_ERR.get(n, n)}")
+    return int(n)
+
+
+def workspace_offset(name: str, N: int, E: int, B: int, F: int, C: int) -> int:
+    o = lib().dgcnn_workspace_offset(name.encode(), N, E, B, F, C)
+    if o < 0:
+        raise DgcnnError(f"unknown workspace region {name!r}")
+    return int(o)
+
+
+# (region, dtype-name, shape-lambda) for tests/tools that look inside the workspace
+def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
+    """Typed torch view of a named workspace region (tests and tools)."""
+    import torch
+    shapes = {
+        "err": (torch.int32, (4,)), "rowptr": (torch.int32, (N + 1,)), "rowptr_t": (torch.int32, (N + 1,)),
+        "colidx": (torch.int32, (E,)), "colidx_t": (torch.int32, (E,)), "dinv": (torch.float32, (N,)),
+        "graph_ptr": (torch.int32, (B + 1,)),
+        "x1": (torch.float32, (N, 32)), "x2": (torch.float32, (N, 32)), "x3": (torch.float32, (N, 32)),
+        "x4": (torch.float32, (N,)), "perm": (torch.int32, (B, K)), "pooled": (torch.float32, (B, K * CAT)),
+        "a5": (torch.float32, (B, 16, K)), "a6": (torch.float32, (B, FLAT)), "a1d": (torch.float32, (B, HID1)),
+        "drop_mask": (torch.uint8, (B, HID1)), "dlogit": (torch.float32, (B, C)),
+        "gp1": (torch.float32, (N, 32)), "gp2": (torch.float32, (N, 32)), "gp3": (torch.float32, (N, 32)),
+        "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)),
+    }
+    dt, shape = shapes[name]
+    off = workspace_offset(name, N, E, B, F, C)
+    numel = 1
+    for s in shape:
+        numel *= s
+    nbytes = numel * torch.empty(0, dtype=dt).element_size()
+    return ws[off:off + nbytes].view(dt).view(shape)

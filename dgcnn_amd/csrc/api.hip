@@ -1,0 +1,174 @@
+// api.hip -- extern "C" entry points of libdgcnn_hip.so (see include/dgcnn_hip.h) and the
+// orchestration of the whole-model forward / backward as a chain of launches on one stream.
+#include "dg_common.h"
+
+extern "C" {
+
+int dgcnn_version(void) { return DGCNN_ABI_VERSION; }
+
+int64_t dgcnn_param_layout(int F, int C, int64_t offsets[DGCNN_NUM_PARAM_SEGMENTS]) {
+  DgParams p;
+  const int rc = dg_param_layout(F, C, &p);
+  if (rc != DGCNN_OK) return rc;
+  if (offsets)
+    for (int i = 0; i < DGCNN_NUM_PARAM_SEGMENTS; ++i) offsets[i] = p.off[i];
+  return p.total;
+}
+
+int64_t dgcnn_workspace_bytes(int N, int E, int B, int F, int C) {
+  DgWs w;
+  const int rc = dg_ws_layout(N, E, B, F, C, &w);
+  return rc != DGCNN_OK ? rc : w.total;
+}
+
+int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int C) {
+  DgWs w;
+  if (!name || dg_ws_layout(N, E, B, F, C, &w) != DGCNN_OK) return -1;
+#define X(n) if (strcmp(name, #n) == 0) return w.n;
+  DG_WS_REGIONS(X)
+#undef X
+  if (strcmp(name, "P32") == 0) return w.P32;
+  if (strcmp(name, "P1") == 0) return w.P1;
+  return -1;
+}
+
+int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
+                     int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
+                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag,
+                     dgcnn_stream_t stream) {
+  if (!batch || !rowptr || !rowptr_t || !dinv || !graph_ptr || !scratch || !err_flag) return DGCNN_EINVAL;
+  if (E > 0 && (!edge_index || !colidx || !colidx_t)) return DGCNN_EINVAL;
+  return dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, rowptr_t, colidx_t, dinv, graph_ptr,
+                        scratch, scratch + (N + 1), err_flag, (hipStream_t)stream);
+}
+
+int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                  const float* x, int Fin, const float* W, const float* bias, int Fout,
+                  float* out, float* hs_scratch, dgcnn_stream_t stream) {
+  if (!rowptr || !dinv || !x || !W || !bias || !out || !hs_scratch) return DGCNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = dg_launch_lin_first(N, Fin, x, W, dinv, hs_scratch, Fout, s);
+  if (rc != DGCNN_OK) return rc;
+  if (Fout == 32) return dg_launch_gcn_fwd32(2, N, rowptr, colidx, dinv, hs_scratch, bias, out, nullptr, nullptr, s);
+  if (Fout == 1) return dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, hs_scratch, bias, out, s);
+  return DGCNN_EUNSUPPORTED;
+}
+
+int dgcnn_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
+                       const float* x3, const float* x4, float* pooled, int32_t* perm,
+                       dgcnn_stream_t stream) {
+  if (!graph_ptr || !x1 || !x2 || !x3 || !x4 || !pooled || !perm) return DGCNN_EINVAL;
+  return dg_launch_sortpool_fwd(N, B, graph_ptr, x1, x2, x3, x4, pooled, perm, (hipStream_t)stream);
+}
+
+int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
+                       float* g1, float* g2, float* g3, float* g4, dgcnn_stream_t stream) {
+  if (!graph_ptr || !perm || !gpooled || !g1 || !g2 || !g3 || !g4) return DGCNN_EINVAL;
+  return dg_launch_sortpool_bwd(N, B, graph_ptr, perm, gpooled, g1, g2, g3, g4, (hipStream_t)stream);
+}
+
+#define DG_TRY(expr) do { const int rc__ = (expr); if (rc__ != DGCNN_OK) return rc__; } while (0)
+
+int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
+                        const float* x, const int64_t* edge_index, const int64_t* batch,
+                        void* ws, float* logp, int training, uint64_t seed, dgcnn_stream_t stream) {
+  if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0) return DGCNN_EINVAL;
+  if (E > 0 && !edge_index) return DGCNN_EINVAL;
+  DgParams pl; DgWs wl;
+  DG_TRY(dg_param_layout(F, C, &pl));
+  DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* rowptr = dg_ptr<int32_t>(ws, wl.rowptr);
+  int32_t* colidx = dg_ptr<int32_t>(ws, wl.colidx);
+  float* dinv = dg_ptr<float>(ws, wl.dinv);
+  float* hsA = dg_ptr<float>(ws, wl.hsA);
+  float* hsB = dg_ptr<float>(ws, wl.hsB);
+  float* h4s = dg_ptr<float>(ws, wl.h4s);
+  float *x1 = dg_ptr<float>(ws, wl.x1), *x2 = dg_ptr<float>(ws, wl.x2), *x3 = dg_ptr<float>(ws, wl.x3),
+        *x4 = dg_ptr<float>(ws, wl.x4);
+
+  // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
+  DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
+                        dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
+                        dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
+                        dg_ptr<int32_t>(ws, wl.err), s));
+  // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
+  // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
+  DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
+  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s));
+  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s));
+  DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s));
+  DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
+  // SortPooling + tail
+  DG_TRY(dg_launch_sortpool_fwd(N, B, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
+                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), s));
+  DG_TRY(dg_launch_tail_fwd(B, C, params, &pl, dg_ptr<float>(ws, wl.pooled), dg_ptr<float>(ws, wl.a5),
+                            dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask),
+                            logp, training, seed, s));
+  return DGCNN_OK;
+}
+
+static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
+                                  void* ws, const float* logp, const float* glogp, const int64_t* y,
+                                  float loss_scale, int training, float* grads, hipStream_t s) {
+  DgParams pl; DgWs wl;
+  DG_TRY(dg_param_layout(F, C, &pl));
+  DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
+  const int32_t* rowptr_t = dg_cptr<int32_t>(ws, wl.rowptr_t);
+  const int32_t* colidx_t = dg_cptr<int32_t>(ws, wl.colidx_t);
+  const float* dinv = dg_cptr<float>(ws, wl.dinv);
+  float *gasA = dg_ptr<float>(ws, wl.gasA), *gasB = dg_ptr<float>(ws, wl.gasB), *gas4 = dg_ptr<float>(ws, wl.gas4);
+  float *gp1 = dg_ptr<float>(ws, wl.gp1), *gp2 = dg_ptr<float>(ws, wl.gp2), *gp3 = dg_ptr<float>(ws, wl.gp3);
+  const float *x1 = dg_cptr<float>(ws, wl.x1), *x2 = dg_cptr<float>(ws, wl.x2), *x3 = dg_cptr<float>(ws, wl.x3),
+              *x4 = dg_cptr<float>(ws, wl.x4);
+
+  if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)pl.total, s) != hipSuccess) return DGCNN_ELAUNCH;
+  DG_TRY(dg_launch_tail_bwd(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm),
+                            dinv, x4, dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6),
+                            dg_cptr<float>(ws, wl.a1d), logp, glogp, y, loss_scale, training,
+                            dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
+                            dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
+                            dg_ptr<float>(ws, wl.lossv), s));
+  // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
+  DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s));
+  // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
+  DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
+                             dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+  // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
+  DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
+                             dg_ptr<float>(ws, wl.pb2), wl.P32, s));
+  // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
+  DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
+                             dg_ptr<float>(ws, wl.pb1), wl.P32, s));
+  // every weight gradient, fixed-order reductions
+  DG_TRY(dg_launch_wgrad(N, B, F, C, &pl, &wl, ws, grads, s));
+  return DGCNN_OK;
+}
+
+int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
+                         const float* x, void* ws, const float* logp,
+                         const float* glogp, const int64_t* y, float loss_scale, int training,
+                         float* grads, dgcnn_stream_t stream) {
+  if (!params || !x || !ws || !logp || !grads || N <= 0 || B <= 0) return DGCNN_EINVAL;
+  if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
+  return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, glogp, y, loss_scale, training ? 1 : 0,
+                                grads, (hipStream_t)stream);
+}
+
+int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                    float lr, float beta1, float beta2, float eps, int zero_grads, dgcnn_stream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return DGCNN_EINVAL;
+  return dg_launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, zero_grads,
+                        (hipStream_t)stream);
+}
+
+int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C, float* metrics,
+                             dgcnn_stream_t stream) {
+  DgWs wl;
+  if (!ws || !metrics) return DGCNN_EINVAL;
+  DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
+  return dg_launch_metrics(B, dg_cptr<float>(ws, wl.lossv), metrics, (hipStream_t)stream);
+}
+
+}  // extern "C"

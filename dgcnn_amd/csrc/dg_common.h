@@ -1,0 +1,231 @@
+// dg_common.h -- shared host/device helpers for libdgcnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/dgcnn_hip.h"
+
+#define DG_WAVE 64
+#define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
+#define DG_TILE_THREADS 1024  // 16 waves: one wave per destination node
+#define DG_MAX_PART 1024      // cap on per-workgroup partial-gradient slots
+#define DG_LDS_PAD 36         // row stride (floats) of 16x32 LDS tiles: 16-B aligned rows
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DG_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return DGCNN_ELAUNCH; \
+  } while (0)
+
+static inline int64_t dg_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int dg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Flat parameter layout (see include/dgcnn_hip.h)
+// ---------------------------------------------------------------------------------------
+struct DgParams {
+  int64_t off[DGCNN_NUM_PARAM_SEGMENTS];
+  int64_t total;
+};
+static inline int dg_param_layout(int F, int C, DgParams* p) {
+  if (F < 1 || F > DGCNN_MAX_F || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  const int64_t sizes[DGCNN_NUM_PARAM_SEGMENTS] = {
+      (int64_t)DGCNN_HID * F, DGCNN_HID, DGCNN_HID * DGCNN_HID, DGCNN_HID,
+      DGCNN_HID * DGCNN_HID, DGCNN_HID, DGCNN_HID, 1,
+      DGCNN_C5 * DGCNN_CAT, DGCNN_C5, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, DGCNN_C6,
+      (int64_t)DGCNN_HID1 * DGCNN_FLAT, DGCNN_HID1, (int64_t)C * DGCNN_HID1, C};
+  int64_t o = 0;
+  for (int i = 0; i < DGCNN_NUM_PARAM_SEGMENTS; ++i) {
+    o = dg_align(o, 4);
+    p->off[i] = o;
+    o += sizes[i];
+  }
+  p->total = dg_align(o, 4);
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Workspace layout.  Every region is 256-B aligned.
+// ---------------------------------------------------------------------------------------
+#define DG_WS_REGIONS(X) \
+  X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) \
+  X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
+  X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
+  X(pa4) X(pb3) X(pb2) X(pb1)
+
+struct DgWs {
+#define X(n) int64_t n;
+  DG_WS_REGIONS(X)
+#undef X
+  int64_t total;
+  int P32;   // partial slots (= grid) of the F=32 backward kernels
+  int P1;    // partial slots (= grid) of the F=1 backward kernel
+};
+
+static inline int dg_grid32(int N) {
+  int tiles = dg_cdiv(N, DG_TILE);
+  return tiles < 1 ? 1 : (tiles > DG_MAX_PART ? DG_MAX_PART : tiles);
+}
+static inline int dg_grid1(int N) {   // F=1 kernels: 4 waves (256 threads) per workgroup, wave per node
+  int b = dg_cdiv(N, 4);
+  return b < 1 ? 1 : (b > DG_MAX_PART ? DG_MAX_PART : b);
+}
+
+static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
+  if (N < 0 || E < 0 || B < 0 || F < 1 || F > DGCNN_MAX_F || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  int64_t o = 0;
+  const int64_t n = N, e = E, b = B;
+  w->P32 = dg_grid32(N);
+  w->P1 = dg_grid1(N);
+#define R(name, bytes) do { w->name = o; o = dg_align(o + (int64_t)(bytes), 256); } while (0)
+  R(err, 16);
+  R(cnt_in, 4 * (n + 1));
+  R(cnt_out, 4 * (n + 1));
+  R(rowptr, 4 * (n + 1));
+  R(rowptr_t, 4 * (n + 1));
+  R(colidx, 4 * e);
+  R(colidx_t, 4 * e);
+  R(dinv, 4 * n);
+  R(graph_ptr, 4 * (b + 1));
+  R(hsA, 4 * n * 32);
+  R(hsB, 4 * n * 32);
+  R(h4s, 4 * n);
+  R(x1, 4 * n * 32);
+  R(x2, 4 * n * 32);
+  R(x3, 4 * n * 32);
+  R(x4, 4 * n);
+  R(perm, 4 * b * DGCNN_K);
+  R(pooled, 4 * b * DGCNN_K * DGCNN_CAT);
+  R(a5, 4 * b * DGCNN_C5 * DGCNN_K);
+  R(a6, 4 * b * DGCNN_FLAT);
+  R(a1d, 4 * b * DGCNN_HID1);
+  R(drop_mask, b * DGCNN_HID1);
+  R(dlogit, 4 * b * C);
+  R(gz1, 4 * b * DGCNN_HID1);
+  R(gz6, 4 * b * DGCNN_FLAT);
+  R(gz5, 4 * b * DGCNN_C5 * DGCNN_K);
+  R(gp1, 4 * n * 32);
+  R(gp2, 4 * n * 32);
+  R(gp3, 4 * n * 32);
+  R(gas4, 4 * n);
+  R(gasA, 4 * n * 32);
+  R(gasB, 4 * n * 32);
+  R(lossv, 4 * 2 * b);
+  R(gb4p, 4 * b);
+  R(pa4, 4 * (int64_t)w->P1 * 64);
+  R(pb3, 4 * (int64_t)w->P32 * 1056);
+  R(pb2, 4 * (int64_t)w->P32 * 1056);
+  R(pb1, 4 * (int64_t)w->P32 * 32 * F);
+#undef R
+  w->total = o;
+  return DGCNN_OK;
+}
+
+template <typename T>
+static inline T* dg_ptr(void* ws, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+template <typename T>
+static inline const T* dg_cptr(const void* ws, int64_t off) {
+  return reinterpret_cast<const T*>(static_cast<const char*>(ws) + off);
+}
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float dg_wave_sum(float v) {
+  // fixed butterfly order -> deterministic
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+__device__ __forceinline__ float4 dg_add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 dg_shfl_xor4(float4 a, int m) {
+  return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
+}
+// counter-based dropout bit: splitmix64 of (seed, index); keep with probability 1/2
+__device__ __forceinline__ bool dg_keep(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (z >> 63) != 0;
+}
+// all-ascending bitonic sorting network over data[0..n) executed by one whole workgroup;
+// the tail up to the next power of two is virtual +inf padding (compare-exchanges that
+// would touch it are no-ops because every comparison sorts ascending).
+template <typename T, typename PTR>
+__device__ void dg_block_bitonic(PTR data, int n) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  const int half = P >> 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    const int hk = k >> 1;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {   // flip stage
+      const int blk = i / hk, within = i - blk * hk;
+      const int a = blk * k + within, b = blk * k + k - 1 - within;
+      if (b < n) {
+        const T va = data[a], vb = data[b];
+        if (va > vb) { data[a] = vb; data[b] = va; }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {                  // disperse stages
+      for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const int blk = i / j, within = i - blk * j;
+        const int a = blk * 2 * j + within, b = a + j;
+        if (b < n) {
+          const T va = data[a], vb = data[b];
+          if (va > vb) { data[a] = vb; data[b] = va; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+#endif
+
+// kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
+int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
+                   int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
+                   float* dinv, int32_t* graph_ptr, int32_t* cnt_in, int32_t* cnt_out, int32_t* err,
+                   hipStream_t s);
+int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
+                        int Fout, hipStream_t s);
+// mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
+int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                        const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
+                        hipStream_t s);
+int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                       const float* h4s, const float* bias, float* x4, hipStream_t s);
+int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
+                       const float* gas4, const float* W4, const float* x3, const float* gp3,
+                       float* gas3, float* pa4, int P1, hipStream_t s);
+// which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
+int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
+                        const float* dinv, const float* gas, const float* Wl, const float* xprev,
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s);
+int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
+                           const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s);
+int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
+                           float* g1, float* g2, float* g3, float* g4, hipStream_t s);
+int dg_launch_tail_fwd(int B, int C, const float* params, const DgParams* pl, const float* pooled,
+                       float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training,
+                       uint64_t seed, hipStream_t s);
+int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                       const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
+                       const float* a1d, const float* logp, const float* glogp, const int64_t* y,
+                       float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
+                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
+                       hipStream_t s);
+int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
+                    float* grads, hipStream_t s);
+int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
+                   float b2, float eps, int zero_grads, hipStream_t s);
+int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s);

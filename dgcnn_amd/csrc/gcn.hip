@@ -1,0 +1,439 @@
+// gcn.hip -- graph-convolution layer kernels, forward and backward (gfx950 / CDNA4).
+//
+// Replaces PyG GCNConv as the reference calls it (/root/reference/model.py:13-16,30-33) plus the
+// torch.tanh around it and the torch.cat of model.py:34 (each layer writes its own [N,32] slab):
+//     h      = x W^T                                   (Linear, no bias)      "dense step" -> MFMA
+//     out[i] = dinv[i] * ( sum_{j in N_in(i)} dinv[j] h[j] + dinv[i] h[i] ) + b   (gather, no atomics)
+//     x'     = tanh(out)
+// Data layout in HBM: every per-node activation slab is [N,32] fp32 row-major (128-B rows);
+// the linear output is stored PRE-SCALED by the source factor, hs[j] = dinv[j]*h[j], so the
+// gather loop needs exactly one index load and one 128-B row load per edge.
+//
+// Forward kernel shape (F=32): one wavefront per destination node, 16 nodes (16 waves) per
+// workgroup.  Lane l = (g = l>>3, q = l&7): neighbour group g (8 neighbours in flight per
+// wave-instruction), float4 column chunk q (channels 4q..4q+3) -> every row read is 8 lanes x 16 B
+// = one coalesced 128-B line.  The 8 partial sums are combined by a fixed xor-butterfly
+// (wavefront segmented reduction, deterministic).  Epilogue: dst scale, bias, tanh, store the
+// row, and keep the 16x32 tile in LDS; the NEXT layer's X.W^T is then done on the tile with
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) and stored pre-scaled.
+//
+// Backward is the same gather on the transposed graph (CSR by source) applied to
+// gas[i] = dinv[i] * dL/d(out)[i], followed on the LDS tile by
+//     dL/dx_prev = gh . W       (MFMA)            dL/dW += gh^T . x_prev   (MFMA, K = nodes)
+// with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
+#include "dg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
+// FOUT = 32: 8 rows x 32 channels per 256-thread pass.  FOUT = 1: one wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
+              const float* __restrict__ dinv, float* __restrict__ hs) {
+  extern __shared__ __attribute__((aligned(16))) float Wt[];   // [F][32] (transposed: conflict-free)
+  for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
+    const int c = t / F, k = t - c * F;
+    Wt[k * 32 + c] = W[t];
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  for (int i = blockIdx.x * 8 + r; i < N; i += gridDim.x * 8) {
+    const float* xr = x + (size_t)i * F;
+    float acc = 0.f;
+    for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
+    hs[(size_t)i * 32 + c] = dinv[i] * acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_lin_first1(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
+             const float* __restrict__ dinv, float* __restrict__ hs) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
+    const float* xr = x + (size_t)i * F;
+    float acc = 0.f;
+    for (int k = lane; k < F; k += 64) acc = fmaf(xr[k], W[k], acc);
+    acc = dg_wave_sum(acc);
+    if (lane == 0) hs[i] = dinv[i] * acc;
+  }
+}
+
+int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
+                        int Fout, hipStream_t s) {
+  if (N <= 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
+  if (Fout == 32) {
+    int grid = dg_cdiv(N, 8);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_lin_first32, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, hs);
+  } else if (Fout == 1) {
+    int grid = dg_cdiv(N, 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_lin_first1, dim3(grid), dim3(256), 0, s, N, F, x, W, dinv, hs);
+  } else {
+    return DGCNN_EUNSUPPORTED;
+  }
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather of one destination row: returns (in every lane with g==0, and in fact all lanes) the
+// float4 chunk q of   sum_{e in [start,end)} src[col[e]]  +  src[self]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src, const int* __restrict__ col,
+                                                  int start, int end, int self, int lane) {
+  const int g = lane >> 3, q = lane & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = start; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int cj = lane < cnt ? col[base + lane] : 0;
+    const int iters = (cnt + 7) >> 3;
+    for (int it = 0; it < iters; ++it) {
+      const int idx = it * 8 + g;
+      const int j = __shfl(cj, idx);
+      if (idx < cnt) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)j * 32 + 4 * q);
+        acc = dg_add4(acc, v);
+      }
+    }
+  }
+  if (g == 0) {   // self loop term, added last in group 0 (PyG appends self loops at the end)
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)self * 32 + 4 * q);
+    acc = dg_add4(acc, v);
+  }
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 32));
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, F = 32.  MODE 0: fused next 32x32 linear on MFMA -> hs_next [N,32]
+//                   MODE 1: fused next 32->1 linear (dot)   -> hs_next [N]
+//                   MODE 2: no post-step (stand-alone layer)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(DG_TILE_THREADS)
+k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+            const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
+            float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next) {
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+
+  float wreg[8];
+  if (MODE == 0 && wave < 2) {   // B operand of the post-step: B[k][n] = Wn[n][k]
+    const int c = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[c * 32 + 4 * kk + (lane >> 4)];
+  }
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1) w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+
+  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int i = tile * DG_TILE + wave;
+    if (i < N) {
+      const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
+      const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
+      const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane);
+      const float di = dinv[i];
+      float4 val;
+      val.x = tanhf(fmaf(di, acc.x, b4.x));
+      val.y = tanhf(fmaf(di, acc.y, b4.y));
+      val.z = tanhf(fmaf(di, acc.z, b4.z));
+      val.w = tanhf(fmaf(di, acc.w, b4.w));
+      if (g == 0) {
+        *reinterpret_cast<float4*>(xout + (size_t)i * 32 + 4 * q) = val;
+        if (MODE == 0) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = val;
+      }
+      if (MODE == 1) {
+        float p = val.x * w4.x;
+        p = fmaf(val.y, w4.y, p);
+        p = fmaf(val.z, w4.z, p);
+        p = fmaf(val.w, w4.w, p);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        if (lane == 0) hs_next[i] = di * p;
+      }
+    } else if (MODE == 0 && g == 0) {
+      *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (MODE == 0) {
+      __syncthreads();
+      if (wave < 2) {   // [16 nodes x 32] . W^T -> 16x16 block `wave` of the [16 x 32] result
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float a = xt[lane & 15][4 * kk + (lane >> 4)];
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+          if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dinv[node] * d[r];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                        const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
+                        hipStream_t s) {
+  if (N <= 0) return DGCNN_EINVAL;
+  const int tiles = dg_cdiv(N, DG_TILE);
+  const int grid = tiles > 8192 ? 8192 : tiles;
+  if (mode == 0)
+    hipLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
+                       bias, xout, Wnext, hs_next);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
+                       bias, xout, Wnext, hs_next);
+  else
+    hipLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
+                       bias, xout, Wnext, hs_next);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, F = 1 (conv4): wave per node, lanes across neighbours.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dg_gather_row1(const float* __restrict__ src, const int* __restrict__ col,
+                                                int start, int end, int lane) {
+  float s = 0.f;
+  for (int e = start + lane; e < end; e += 64) s += src[col[e]];
+  return dg_wave_sum(s);
+}
+
+__global__ void __launch_bounds__(256)
+k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+           const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
+           float* __restrict__ x4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float b = bias[0];
+  for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
+    const int start = rowptr[i], end = rowptr[i + 1];
+    const float s = dg_gather_row1(h4s, colidx, start, end, lane) + h4s[i];
+    if (lane == 0) x4[i] = tanhf(fmaf(dinv[i], s, b));
+  }
+}
+
+int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                       const float* h4s, const float* bias, float* x4, hipStream_t s) {
+  if (N <= 0) return DGCNN_EINVAL;
+  int grid = dg_cdiv(N, 4);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of conv4 (F_out = 1) fused with the start of conv3's backward:
+//   gh4[j]  = dinv[j] * ( sum_{i in N_out(j)} gas4[i] + gas4[j] )            (scalar per node)
+//   gx3[j]  = gh4[j] * W4 + gp3[j]          (gp3 = SortPooling gradient slab of layer 3)
+//   ga3[j]  = gx3[j] * (1 - x3[j]^2)        gas3[j] = dinv[j] * ga3[j]
+//   partials: dW4 += gh4[j] * x3[j]   (32)  ,  db3 += ga3[j]   (32)
+// wave per node; lanes 0..31 = channel.  pa4[P1][64] = per-workgroup partial {dW4, db3}.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
+           const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
+           const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
+           float* __restrict__ pa4) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane & 31;
+  const float w4c = W4[c];
+  float pW = 0.f, pb = 0.f;
+  for (int j = blockIdx.x * 4 + w; j < N; j += gridDim.x * 4) {
+    const int start = rowptr_t[j], end = rowptr_t[j + 1];
+    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
+    const float dj = dinv[j];
+    const float gh = dj * s;
+    if (lane < 32) {
+      const float xv = x3[(size_t)j * 32 + c];
+      const float gx = fmaf(gh, w4c, gp3[(size_t)j * 32 + c]);
+      const float ga = gx * (1.f - xv * xv);
+      gas3[(size_t)j * 32 + c] = dj * ga;
+      pW = fmaf(gh, xv, pW);
+      pb += ga;
+    }
+  }
+  if (lane < 32) { red[w][c] = pW; red[w][32 + c] = pb; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = v;
+  }
+}
+
+int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
+                       const float* gas4, const float* W4, const float* x3, const float* gp3,
+                       float* gas3, float* pa4, int P1, hipStream_t s) {
+  if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
+                     pa4);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of a 32-wide layer l (l = 3, 2): input gas_l [N,32] (= dinv * dL/d pre-activation)
+//   gh[j]      = dinv[j] * ( sum_{i in N_out(j)} gas_l[i] + gas_l[j] )        -> LDS tile [16][32]
+//   dW_l      += gh^T . x_{l-1}          (MFMA 16x16x4, K = 16 nodes of the tile; waves 2..5)
+//   gx_{l-1}   = gh . W_l + gp_{l-1}     (MFMA; waves 0..1)
+//   ga_{l-1}   = gx_{l-1} * (1 - x_{l-1}^2) ; gas_{l-1} = dinv * ga_{l-1} ; db_{l-1} += ga_{l-1}
+// part[P][1056] = per-workgroup {dW_l [32x32], db_{l-1} [32]}.
+//
+// FIRST = true (layer 1): x_{l-1} is the raw input x [N,F]; only dW_1 [32,F] is produced
+// (data.x needs no gradient, /root/reference/train.py:36-40).  part[P][32*F].
+// ---------------------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ void __launch_bounds__(DG_TILE_THREADS)
+k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
+            const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
+            const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
+            float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+
+  // persistent accumulators
+  float wreg[8];
+  f32x4 accW = {0.f, 0.f, 0.f, 0.f};
+  float pb = 0.f;
+  float acc1[(32 * DGCNN_MAX_F) / DG_TILE_THREADS];   // FIRST: 16 outputs per thread max
+  if (FIRST) {
+#pragma unroll
+    for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) acc1[u] = 0.f;
+  } else if (wave < 2) {   // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + wave * 16 + (lane & 15)];
+  }
+
+  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int j = tile * DG_TILE + wave;
+    if (j < N) {
+      const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
+      const int end = __builtin_amdgcn_readfirstlane(rowptr_t[j + 1]);
+      float4 acc = dg_gather_row32(gas, colidx_t, start, end, j, lane);
+      const float dj = dinv[j];
+      acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
+      if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = acc;
+      if (!FIRST && g == 1)
+        *reinterpret_cast<float4*>(&xt[wave][4 * q]) =
+            *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
+      if (FIRST)
+        for (int k = lane; k < F; k += 64) xs[wave * F + k] = xprev[(size_t)j * F + k];
+    } else {
+      if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!FIRST && g == 1) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FIRST)
+        for (int k = lane; k < F; k += 64) xs[wave * F + k] = 0.f;
+    }
+    __syncthreads();
+    if (FIRST) {
+      // dW1[c][k] += sum_node ght[node][c] * xs[node][k] ; output o = k*32 + c (c fastest -> conflict-free)
+      const int total = 32 * F;
+#pragma unroll
+      for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
+        const int o = u * DG_TILE_THREADS + threadIdx.x;
+        if (o < total) {
+          const int k = o >> 5, c = o & 31;
+          float a = acc1[u];
+#pragma unroll
+          for (int nd = 0; nd < DG_TILE; ++nd) a = fmaf(ght[nd][c], xs[nd * F + k], a);
+          acc1[u] = a;
+        }
+      }
+    } else {
+      if (wave < 2) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float a = ght[lane & 15][4 * kk + (lane >> 4)];
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+        }
+        const int c = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (lane >> 4) * 4 + r;
+          const int node = tile * DG_TILE + row;
+          if (node < N) {
+            const float xv = xt[row][c];
+            const float gx = d[r] + gpprev[(size_t)node * 32 + c];
+            const float ga = gx * (1.f - xv * xv);
+            gas_prev[(size_t)node * 32 + c] = dinv[node] * ga;
+            pb += ga;
+          }
+        }
+      } else if (wave < 6) {   // dW block (mb, nb): A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n]
+        const int mb = (wave - 2) >> 1, nb = (wave - 2) & 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + (lane >> 4);
+          const float a = ght[k][mb * 16 + (lane & 15)];
+          const float b = xt[k][nb * 16 + (lane & 15)];
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accW, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // write this workgroup's partials
+  if (FIRST) {
+    const int total = 32 * F;
+    float* dst = part + (size_t)blockIdx.x * total;
+#pragma unroll
+    for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
+      const int o = u * DG_TILE_THREADS + threadIdx.x;
+      if (o < total) {
+        const int k = o >> 5, c = o & 31;
+        dst[c * F + k] = acc1[u];     // stored in W1's own [32,F] layout
+      }
+    }
+  } else {
+    float* dst = part + (size_t)blockIdx.x * 1056;
+    if (wave < 2) {
+      // lanes l, l+16, l+32, l+48 hold the same column: fixed-order combine
+      pb += __shfl_xor(pb, 16);
+      pb += __shfl_xor(pb, 32);
+      if (lane < 16) dst[1024 + wave * 16 + lane] = pb;
+    } else if (wave < 6) {
+      const int mb = (wave - 2) >> 1, nb = (wave - 2) & 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mb * 16 + (lane >> 4) * 4 + r;     // output channel of W_l
+        const int col = nb * 16 + (lane & 15);             // input channel
+        dst[row * 32 + col] = accW[r];
+      }
+    }
+  }
+}
+
+int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
+                        const float* dinv, const float* gas, const float* Wl, const float* xprev,
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s) {
+  if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
+  const int tiles = dg_cdiv(N, DG_TILE);
+  if (first) {
+    if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
+    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
+                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part);
+  } else {
+    hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,
+                       dinv, gas, Wl, xprev, gpprev, gas_prev, part);
+  }
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}

@@ -1,0 +1,562 @@
+// tail.hip -- SortPooling readout and the dense tail, forward and backward (gfx950).
+//
+// One workgroup per graph (graphs are independent in every op below):
+//   SortAggregation(k=30)                     /root/reference/model.py:17,35  [PyG]
+//   Conv1d(1,16,97,97)+ReLU, MaxPool1d(2,2)   model.py:18,20,37-38
+//   Conv1d(16,32,5,1)+ReLU, flatten 352       model.py:19,39-40
+//   Linear(352,128)+ReLU, Dropout(.5)         model.py:21-22,41-42
+//   Linear(128,C), log_softmax                model.py:23,43
+// and their autograd (what `loss.backward()`, /root/reference/train.py:40, runs for these ops),
+// plus nn.NLLLoss() (train.py:39,98) when labels are handed in directly.
+//
+// The per-graph sort runs entirely in LDS: keys are packed as (descending-ordered float bits of
+// channel 96, node index) 64-bit words, so one ascending integer sort gives "key descending,
+// ties by lower node index" -- this build's documented tie-break (the reference's is undefined).
+//   n <= 256  : rank sort (each thread counts smaller keys; no barriers)
+//   n <= 4096 : bitonic network in LDS
+//   n  > 4096 : k rounds of workgroup-wide arg-min selection (keys stay in HBM/L2)
+#include "dg_common.h"
+
+#define SP_THREADS 256
+#define SP_LDS_KEYS 4096
+#define KCAT (DGCNN_K * DGCNN_CAT)   // 2910
+
+__device__ __forceinline__ unsigned long long dg_pack_key(float key, int idx) {
+  key = key + 0.0f;                       // -0.0 -> +0.0 so signed zeros tie like in torch.sort
+  unsigned int u = __float_as_uint(key);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order-preserving map
+  u = ~u;                                            // descending key
+  return ((unsigned long long)u << 32) | (unsigned int)idx;
+}
+
+// selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none)
+__device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
+                               unsigned long long* red, int* sel) {
+  const int tid = threadIdx.x;
+  const int m = n < DGCNN_K ? n : DGCNN_K;
+  if (tid < DGCNN_K) sel[tid] = -1;
+  __syncthreads();
+  if (n <= SP_THREADS) {
+    if (tid < n) keys[tid] = dg_pack_key(x4[n0 + tid], tid);
+    __syncthreads();
+    if (tid < n) {
+      const unsigned long long my = keys[tid];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += keys[j] < my ? 1 : 0;
+      if (rank < DGCNN_K) sel[rank] = tid;
+    }
+  } else if (n <= SP_LDS_KEYS) {
+    for (int t = tid; t < n; t += SP_THREADS) keys[t] = dg_pack_key(x4[n0 + t], t);
+    __syncthreads();
+    dg_block_bitonic<unsigned long long>(keys, n);
+    if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
+  } else {
+    unsigned long long prev = 0ull;
+    for (int r = 0; r < m; ++r) {
+      unsigned long long best = ~0ull;
+      for (int t = tid; t < n; t += SP_THREADS) {
+        const unsigned long long p = dg_pack_key(x4[n0 + t], t);
+        if ((r == 0 || p > prev) && p < best) best = p;
+      }
+      // workgroup min: wave shuffle then LDS
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+      }
+      if ((tid & 63) == 0) red[tid >> 6] = best;
+      __syncthreads();
+      unsigned long long b0 = red[0];
+      for (int w = 1; w < SP_THREADS / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
+      prev = b0;
+      if (tid == 0) sel[r] = (int)(b0 & 0xffffffffull);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float dg_cat_load(const float* __restrict__ x1, const float* __restrict__ x2,
+                                             const float* __restrict__ x3, const float* __restrict__ x4,
+                                             int node, int c) {
+  if (c < 32) return x1[(size_t)node * 32 + c];
+  if (c < 64) return x2[(size_t)node * 32 + c - 32];
+  if (c < 96) return x3[(size_t)node * 32 + c - 64];
+  return x4[node];
+}
+
+__global__ void __launch_bounds__(SP_THREADS)
+k_sortpool_fwd(const int* __restrict__ graph_ptr, const float* __restrict__ x1, const float* __restrict__ x2,
+               const float* __restrict__ x3, const float* __restrict__ x4, float* __restrict__ pooled,
+               int* __restrict__ perm) {
+  __shared__ unsigned long long keys[SP_LDS_KEYS];
+  __shared__ unsigned long long red[SP_THREADS / 64];
+  __shared__ int sel[DGCNN_K];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  dg_select_topk(x4, n0, n, keys, red, sel);
+  if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
+  float* out = pooled + (size_t)b * KCAT;
+  for (int o = tid; o < KCAT; o += SP_THREADS) {
+    const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
+    const int ln = sel[s];
+    out[o] = ln >= 0 ? dg_cat_load(x1, x2, x3, x4, n0 + ln, c) : 0.f;   // zero padding (fill -> 0)
+  }
+}
+
+int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
+                           const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s) {
+  if (B <= 0 || N <= 0) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_sortpool_fwd, dim3(B), dim3(SP_THREADS), 0, s, graph_ptr, x1, x2, x3, x4, pooled, perm);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// stand-alone SortPooling backward: dense per-node gradient slabs (zero for unselected nodes)
+__global__ void __launch_bounds__(SP_THREADS)
+k_sortpool_bwd(const int* __restrict__ graph_ptr, const int* __restrict__ perm, const float* __restrict__ gpooled,
+               float* __restrict__ g1, float* __restrict__ g2, float* __restrict__ g3, float* __restrict__ g4) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  for (int t = tid; t < n * 32; t += SP_THREADS) {
+    g1[(size_t)n0 * 32 + t] = 0.f; g2[(size_t)n0 * 32 + t] = 0.f; g3[(size_t)n0 * 32 + t] = 0.f;
+  }
+  for (int t = tid; t < n; t += SP_THREADS) g4[n0 + t] = 0.f;
+  __syncthreads();
+  const int m = n < DGCNN_K ? n : DGCNN_K;
+  for (int o = tid; o < m * DGCNN_CAT; o += SP_THREADS) {
+    const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
+    const int node = perm[b * DGCNN_K + s];
+    const float v = gpooled[(size_t)b * KCAT + o];
+    if (c < 32) g1[(size_t)node * 32 + c] = v;
+    else if (c < 64) g2[(size_t)node * 32 + c - 32] = v;
+    else if (c < 96) g3[(size_t)node * 32 + c - 64] = v;
+    else g4[node] = v;
+  }
+}
+
+int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
+                           float* g1, float* g2, float* g3, float* g4, hipStream_t s) {
+  if (B <= 0 || N <= 0) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_sortpool_bwd, dim3(B), dim3(SP_THREADS), 0, s, graph_ptr, perm, gpooled, g1, g2, g3, g4);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail forward, one workgroup (256 threads) per graph
+// ---------------------------------------------------------------------------------------------
+struct TailW {   // device pointers into the flat parameter buffer
+  const float *W5, *b5, *W6, *b6, *Wf1, *bf1, *Wf2, *bf2;
+};
+static inline TailW dg_tail_w(const float* params, const DgParams* pl) {
+  TailW w;
+  w.W5 = params + pl->off[8];  w.b5 = params + pl->off[9];
+  w.W6 = params + pl->off[10]; w.b6 = params + pl->off[11];
+  w.Wf1 = params + pl->off[12]; w.bf1 = params + pl->off[13];
+  w.Wf2 = params + pl->off[14]; w.bf2 = params + pl->off[15];
+  return w;
+}
+
+__global__ void __launch_bounds__(SP_THREADS)
+k_tail_fwd(int C, TailW w, const float* __restrict__ pooled, float* __restrict__ a5g, float* __restrict__ a6g,
+           float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
+           uint64_t seed) {
+  __shared__ float sp[KCAT];
+  __shared__ float a5s[DGCNN_C5 * DGCNN_K];
+  __shared__ float p5[DGCNN_C5 * DGCNN_T5];
+  __shared__ float flat[DGCNN_FLAT];
+  __shared__ float a1s[DGCNN_HID1];
+  __shared__ float lg[DGCNN_MAX_C];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  for (int o = tid; o < KCAT; o += SP_THREADS) sp[o] = pooled[(size_t)b * KCAT + o];
+  __syncthreads();
+  // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
+  for (int t = tid; t < DGCNN_C5 * DGCNN_K; t += SP_THREADS) {
+    const int o = t / DGCNN_K, s = t - o * DGCNN_K;
+    float acc = w.b5[o];
+    const float* wr = w.W5 + o * DGCNN_CAT;
+    const float* xr = sp + s * DGCNN_CAT;
+    for (int m = 0; m < DGCNN_CAT; ++m) acc = fmaf(wr[m], xr[m], acc);
+    acc = fmaxf(acc, 0.f);
+    a5s[t] = acc;
+    a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + t] = acc;
+  }
+  __syncthreads();
+  // MaxPool1d(2,2): [16,30] -> [16,15]
+  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
+    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
+    p5[t] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
+  }
+  __syncthreads();
+  // conv6: [16,15] -> [32,11], kernel 5, ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
+  for (int t = tid; t < DGCNN_FLAT; t += SP_THREADS) {
+    const int oc = t / DGCNN_T6, tt = t - oc * DGCNN_T6;
+    float acc = w.b6[oc];
+    const float* wr = w.W6 + oc * (DGCNN_C5 * DGCNN_KW6);
+    for (int c = 0; c < DGCNN_C5; ++c)
+#pragma unroll
+      for (int d = 0; d < DGCNN_KW6; ++d) acc = fmaf(wr[c * DGCNN_KW6 + d], p5[c * DGCNN_T5 + tt + d], acc);
+    acc = fmaxf(acc, 0.f);
+    flat[t] = acc;
+    a6g[(size_t)b * DGCNN_FLAT + t] = acc;
+  }
+  __syncthreads();
+  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  wave per output row, lanes across the 352 inputs
+  for (int j = wv; j < DGCNN_HID1; j += SP_THREADS / 64) {
+    const float* wr = w.Wf1 + (size_t)j * DGCNN_FLAT;
+    float acc = 0.f;
+    for (int m = lane; m < DGCNN_FLAT; m += 64) acc = fmaf(wr[m], flat[m], acc);
+    acc = dg_wave_sum(acc);
+    if (lane == 0) {
+      float a = fmaxf(acc + w.bf1[j], 0.f);
+      uint8_t keep = 1;
+      if (training) {
+        keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
+        a = keep ? a * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
+      }
+      a1s[j] = a;
+      a1dg[(size_t)b * DGCNN_HID1 + j] = a;
+      maskg[(size_t)b * DGCNN_HID1 + j] = keep;
+    }
+  }
+  __syncthreads();
+  // classifier_2: 128 -> C
+  for (int c = wv; c < C; c += SP_THREADS / 64) {
+    const float* wr = w.Wf2 + c * DGCNN_HID1;
+    float acc = fmaf(wr[lane], a1s[lane], 0.f);
+    acc = fmaf(wr[lane + 64], a1s[lane + 64], acc);
+    acc = dg_wave_sum(acc);
+    if (lane == 0) lg[c] = acc + w.bf2[c];
+  }
+  __syncthreads();
+  // log_softmax over C (C <= 64): wave 0
+  if (wv == 0) {
+    const float v = lane < C ? lg[lane] : -INFINITY;
+    float mx = v;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = lane < C ? expf(v - mx) : 0.f;
+    e = dg_wave_sum(e);
+    if (lane < C) logp[(size_t)b * C + lane] = (v - mx) - logf(e);
+  }
+}
+
+int dg_launch_tail_fwd(int B, int C, const float* params, const DgParams* pl, const float* pooled,
+                       float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training,
+                       uint64_t seed, hipStream_t s) {
+  if (B <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_tail_fwd, dim3(B), dim3(SP_THREADS), 0, s, C, dg_tail_w(params, pl), pooled, a5, a6, a1d,
+                     drop_mask, logp, training, seed);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail backward (data gradients), one workgroup per graph.  Also scatters the SortPooling
+// gradient to dense per-node slabs gp1..gp3 [N,32] and produces gas4 = dinv * dL/d(pre-act of conv4).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SP_THREADS)
+k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+           const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
+           const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
+           const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
+           float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
+           float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
+           float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv) {
+  __shared__ float dl[DGCNN_MAX_C];
+  __shared__ float gz1s[DGCNN_HID1];
+  __shared__ float gz6s[DGCNN_FLAT];
+  __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
+  __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
+  __shared__ float ga4s[DGCNN_K];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  const int msel = n < DGCNN_K ? n : DGCNN_K;
+
+  // 1. d(loss)/d(logits) from the upstream gradient wrt log-probs (or from labels: NLL mean)
+  if (wv == 0) {
+    const float lp = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
+    float g = 0.f;
+    if (glogp) {
+      g = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
+    } else {
+      const float sc = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;
+      const int yb = (int)y[b];
+      g = (lane == yb) ? -sc : 0.f;
+      // loss and accuracy bookkeeping (train.py:44-45): first max index like torch.argmax
+      float mx = lp;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const unsigned long long ball = __ballot(lane < C && lp == mx);
+      const int am = __ffsll((long long)ball) - 1;
+      const float lpy = __shfl(lp, yb);
+      if (lane == 0) { lossv[2 * b] = -lpy * sc; lossv[2 * b + 1] = (am == yb) ? 1.f : 0.f; }
+    }
+    const float sg = dg_wave_sum(g);
+    const float d = lane < C ? g - expf(lp) * sg : 0.f;
+    if (lane < C) { dl[lane] = d; dlogit[(size_t)b * C + lane] = d; }
+  }
+  __syncthreads();
+  // 2. through classifier_2, dropout, ReLU
+  if (tid < DGCNN_HID1) {
+    float ga = 0.f;
+    for (int c = 0; c < C; ++c) ga = fmaf(dl[c], w.Wf2[c * DGCNN_HID1 + tid], ga);
+    const float a = a1dg[(size_t)b * DGCNN_HID1 + tid];
+    const float gz = (a != 0.f) ? (training ? ga * 2.0f : ga) : 0.f;
+    gz1s[tid] = gz;
+    gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
+  }
+  __syncthreads();
+  // 3. through classifier_1 and the ReLU after conv6
+  for (int m = tid; m < DGCNN_FLAT; m += SP_THREADS) {
+    float gf = 0.f;
+    for (int j = 0; j < DGCNN_HID1; ++j) gf = fmaf(gz1s[j], w.Wf1[(size_t)j * DGCNN_FLAT + m], gf);
+    const float g6 = a6g[(size_t)b * DGCNN_FLAT + m] > 0.f ? gf : 0.f;
+    gz6s[m] = g6;
+    gz6g[(size_t)b * DGCNN_FLAT + m] = g6;
+  }
+  __syncthreads();
+  // 4. conv6 data gradient -> [16,15]
+  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
+    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
+    float acc = 0.f;
+    for (int oc = 0; oc < DGCNN_C6; ++oc)
+#pragma unroll
+      for (int d = 0; d < DGCNN_KW6; ++d) {
+        const int tt = u - d;
+        if (tt >= 0 && tt < DGCNN_T6)
+          acc = fmaf(gz6s[oc * DGCNN_T6 + tt], w.W6[(oc * DGCNN_C5 + c) * DGCNN_KW6 + d], acc);
+      }
+    gp5[t] = acc;
+  }
+  __syncthreads();
+  // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
+  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
+    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
+    const float a0 = a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u];
+    const float a1 = a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u + 1];
+    const float gp = gp5[t];
+    const bool first = !(a1 > a0);
+    const float g0 = (first && a0 > 0.f) ? gp : 0.f;
+    const float g1 = (!first && a1 > 0.f) ? gp : 0.f;
+    gz5s[c * DGCNN_K + 2 * u] = g0;
+    gz5s[c * DGCNN_K + 2 * u + 1] = g1;
+    gz5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u] = g0;
+    gz5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u + 1] = g1;
+  }
+  // 6. clear this graph's rows of the dense SortPooling-gradient slabs
+  for (int t = tid; t < n * 32; t += SP_THREADS) {
+    gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
+  }
+  for (int t = tid; t < n; t += SP_THREADS) gas4[n0 + t] = 0.f;
+  if (tid < DGCNN_K) ga4s[tid] = 0.f;
+  __syncthreads();
+  // 7. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
+  for (int o = tid; o < msel * DGCNN_CAT; o += SP_THREADS) {
+    const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
+    const int node = perm[b * DGCNN_K + s];
+    float v = 0.f;
+#pragma unroll
+    for (int oc = 0; oc < DGCNN_C5; ++oc) v = fmaf(gz5s[oc * DGCNN_K + s], w.W5[oc * DGCNN_CAT + c], v);
+    if (c < 32) gp1[(size_t)node * 32 + c] = v;
+    else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
+    else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
+    else {
+      const float xv = x4[node];
+      const float ga = v * (1.f - xv * xv);      // tanh'
+      gas4[node] = dinv[node] * ga;
+      ga4s[s] = ga;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {     // db4 partial of this graph, fixed order
+    float sum = 0.f;
+    for (int s = 0; s < DGCNN_K; ++s) sum += ga4s[s];
+    gb4p[b] = sum;
+  }
+}
+
+int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                       const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
+                       const float* a1d, const float* logp, const float* glogp, const int64_t* y,
+                       float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
+                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
+                       hipStream_t s) {
+  if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(SP_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
+                     x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
+                     gas4, gb4p, lossv);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients: one thread per output element, sequential (fixed-order) reduction over the
+// batch / over per-workgroup partials.  No floating-point atomics -> bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB };
+#define WG_MAX_SEG 20
+struct WgSeg {
+  int type;
+  int count;         // number of outputs
+  int block0;        // first block of this segment
+  int P;             // WG_REDUCE: number of partials ; WG_SUMB: B
+  int stride;        // WG_REDUCE: floats between partial slots
+  const float* src;  // WG_REDUCE / WG_SUMB: partial base (+offset)
+  float* out;
+};
+struct WgArgs {
+  int nseg, B, C;
+  const float *dlogit, *a1d, *gz1, *a6, *gz6, *a5, *gz5, *pooled;
+  WgSeg seg[WG_MAX_SEG];
+};
+
+__global__ void __launch_bounds__(256)
+k_wgrad(WgArgs A) {
+  int si = 0;
+  for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
+  const WgSeg sg = A.seg[si];
+  const int i = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
+  if (i >= sg.count) return;
+  const int B = A.B, C = A.C;
+  float acc = 0.f;
+  switch (sg.type) {
+    case WG_REDUCE:
+      for (int p = 0; p < sg.P; ++p) acc += sg.src[(size_t)p * sg.stride + i];
+      break;
+    case WG_SUMB:
+      for (int b = 0; b < sg.P; ++b) acc += sg.src[b];
+      break;
+    case WG_FC2W: {
+      const int c = i / DGCNN_HID1, j = i - c * DGCNN_HID1;
+      for (int b = 0; b < B; ++b) acc = fmaf(A.dlogit[(size_t)b * C + c], A.a1d[(size_t)b * DGCNN_HID1 + j], acc);
+    } break;
+    case WG_FC2B:
+      for (int b = 0; b < B; ++b) acc += A.dlogit[(size_t)b * C + i];
+      break;
+    case WG_FC1W: {
+      const int j = i / DGCNN_FLAT, m = i - j * DGCNN_FLAT;
+      for (int b = 0; b < B; ++b) acc = fmaf(A.gz1[(size_t)b * DGCNN_HID1 + j], A.a6[(size_t)b * DGCNN_FLAT + m], acc);
+    } break;
+    case WG_FC1B:
+      for (int b = 0; b < B; ++b) acc += A.gz1[(size_t)b * DGCNN_HID1 + i];
+      break;
+    case WG_C6W: {   // i = (oc*16 + c)*5 + d
+      const int d = i % DGCNN_KW6, c = (i / DGCNN_KW6) % DGCNN_C5, oc = i / (DGCNN_KW6 * DGCNN_C5);
+      for (int b = 0; b < B; ++b) {
+        const float* a5b = A.a5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K;
+        const float* g6 = A.gz6 + (size_t)b * DGCNN_FLAT + oc * DGCNN_T6;
+#pragma unroll
+        for (int t = 0; t < DGCNN_T6; ++t) {
+          const float p = fmaxf(a5b[2 * (t + d)], a5b[2 * (t + d) + 1]);
+          acc = fmaf(g6[t], p, acc);
+        }
+      }
+    } break;
+    case WG_C6B:
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int t = 0; t < DGCNN_T6; ++t) acc += A.gz6[(size_t)b * DGCNN_FLAT + i * DGCNN_T6 + t];
+      break;
+    case WG_C5W: {   // i = o*97 + m
+      const int o = i / DGCNN_CAT, m = i - o * DGCNN_CAT;
+      for (int b = 0; b < B; ++b) {
+        const float* g5 = A.gz5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K;
+        const float* pr = A.pooled + (size_t)b * KCAT + m;
+        for (int s = 0; s < DGCNN_K; ++s) acc = fmaf(g5[s], pr[s * DGCNN_CAT], acc);
+      }
+    } break;
+    case WG_C5B:
+      for (int b = 0; b < B; ++b)
+        for (int s = 0; s < DGCNN_K; ++s) acc += A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + i * DGCNN_K + s];
+      break;
+  }
+  sg.out[i] = acc;
+}
+
+int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
+                    float* grads, hipStream_t s) {
+  WgArgs A;
+  memset(&A, 0, sizeof(A));
+  A.B = B; A.C = C;
+  A.dlogit = dg_cptr<float>(ws, wl->dlogit); A.a1d = dg_cptr<float>(ws, wl->a1d);
+  A.gz1 = dg_cptr<float>(ws, wl->gz1); A.a6 = dg_cptr<float>(ws, wl->a6);
+  A.gz6 = dg_cptr<float>(ws, wl->gz6); A.a5 = dg_cptr<float>(ws, wl->a5);
+  A.gz5 = dg_cptr<float>(ws, wl->gz5); A.pooled = dg_cptr<float>(ws, wl->pooled);
+  int nb = 0, ns = 0;
+  auto add = [&](int type, int count, float* out, const float* src, int P, int stride) {
+    WgSeg& g = A.seg[ns++];
+    g.type = type; g.count = count; g.block0 = nb; g.P = P; g.stride = stride; g.src = src; g.out = out;
+    nb += dg_cdiv(count, 256);
+  };
+  const float* pb1 = dg_cptr<float>(ws, wl->pb1);
+  const float* pb2 = dg_cptr<float>(ws, wl->pb2);
+  const float* pb3 = dg_cptr<float>(ws, wl->pb3);
+  const float* pa4 = dg_cptr<float>(ws, wl->pa4);
+  // big one first so its blocks start early
+  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, grads + pl->off[12], nullptr, 0, 0);
+  add(WG_FC1B, DGCNN_HID1, grads + pl->off[13], nullptr, 0, 0);
+  add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, grads + pl->off[10], nullptr, 0, 0);
+  add(WG_C6B, DGCNN_C6, grads + pl->off[11], nullptr, 0, 0);
+  add(WG_C5W, DGCNN_C5 * DGCNN_CAT, grads + pl->off[8], nullptr, 0, 0);
+  add(WG_C5B, DGCNN_C5, grads + pl->off[9], nullptr, 0, 0);
+  add(WG_FC2W, C * DGCNN_HID1, grads + pl->off[14], nullptr, 0, 0);
+  add(WG_FC2B, C, grads + pl->off[15], nullptr, 0, 0);
+  add(WG_REDUCE, 32 * F, grads + pl->off[0], pb1, wl->P32, 32 * F);          // dW1
+  add(WG_REDUCE, 32, grads + pl->off[1], pb2 + 1024, wl->P32, 1056);          // db1 (from layer-2 backward)
+  add(WG_REDUCE, 1024, grads + pl->off[2], pb2, wl->P32, 1056);               // dW2
+  add(WG_REDUCE, 32, grads + pl->off[3], pb3 + 1024, wl->P32, 1056);          // db2 (from layer-3 backward)
+  add(WG_REDUCE, 1024, grads + pl->off[4], pb3, wl->P32, 1056);               // dW3
+  add(WG_REDUCE, 32, grads + pl->off[5], pa4 + 32, wl->P1, 64);               // db3 (from conv4 backward)
+  add(WG_REDUCE, 32, grads + pl->off[6], pa4, wl->P1, 64);                    // dW4
+  add(WG_SUMB, 1, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), B, 0);    // db4
+  A.nseg = ns;
+  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
+  DG_CHECK_LAUNCH();
+  (void)N;
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults semantics) + fused zero_grad; metrics accumulation
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+       float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;          // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - (lr / bc1) * (mi / denom);
+  if (zero_grads) g[i] = 0.f;
+}
+
+int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
+                   float b2, float eps, int zero_grads, hipStream_t s) {
+  if (n <= 0 || step < 1) return DGCNN_EINVAL;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                     (float)bc1, (float)sqrt(bc2), zero_grads);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+__global__ void k_metrics(int B, const float* __restrict__ lossv, float* __restrict__ metrics) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float l = 0.f, c = 0.f;
+    for (int b = 0; b < B; ++b) { l += lossv[2 * b]; c += lossv[2 * b + 1]; }
+    metrics[0] += l;
+    metrics[1] += c;
+  }
+}
+
+int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s) {
+  if (B <= 0) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_metrics, dim3(1), dim3(64), 0, s, B, lossv, metrics);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}

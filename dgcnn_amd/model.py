@@ -1,0 +1,242 @@
+"""``Model`` -- drop-in replacement of the reference's network class, running on the
+hand-written HIP path behind the C ABI (``include/dgcnn_hip.h``).
+
+Boundary kept from the reference:
+
+* ``Model(num_features, num_classes)``                     /root/reference/model.py:10
+* ``forward(data) -> [B, num_classes]`` log-probabilities, reading exactly ``data.x``,
+  ``data.edge_index``, ``data.batch``                       /root/reference/model.py:26-45
+* an ``nn.Module``: ``.to(device)``, ``.parameters()``, ``.train()/.eval()`` (Dropout),
+  ``.state_dict()`` with the reference's key names (PyG GCNConv: ``convN.lin.weight``,
+  ``convN.bias``; ``conv5/conv6/classifier_1/classifier_2`` ``.weight/.bias``)
+  /root/reference/train.py:97-99,129
+* differentiable wrt every parameter (``loss.backward()``, train.py:40).
+
+Inside, nothing of the reference's op sequence is replayed with torch ops: forward is one
+``dgcnn_model_forward`` call, backward one ``dgcnn_model_backward`` call, each a chain of HIP
+kernel launches on the current torch stream.  All parameters live in ONE flat fp32 buffer
+(``flat_params``); the ``nn.Parameter`` objects are views into it, so the same buffer is the
+gradient all-reduce bucket and the fused-Adam operand.
+
+There is NO CPU/eager fallback: on a CPU tensor, or without ``libdgcnn_hip.so``, this raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+K_SORT = 30
+
+
+class _Lin(nn.Module):
+    """Holds ``weight`` so the key is ``convN.lin.weight`` like PyG's GCNConv."""
+
+    def __init__(self, fin: int, fout: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+
+
+class GCNConvParams(nn.Module):
+    """Parameter container of one graph-convolution layer (``GCNConv(fin, fout)`` at
+    /root/reference/model.py:13-16).  PyG init: glorot-uniform weight, zero bias."""
+
+    def __init__(self, fin: int, fout: int):
+        super().__init__()
+        self.in_channels, self.out_channels = fin, fout
+        self.lin = _Lin(fin, fout)
+        self.bias = nn.Parameter(torch.zeros(fout))
+        a = math.sqrt(6.0 / (fin + fout))
+        with torch.no_grad():
+            self.lin.weight.uniform_(-a, a)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}"
+
+
+class SortPoolSpec(nn.Module):
+    """Stands where ``SortAggregation(k=30)`` stands in the reference (model.py:17)."""
+
+    def __init__(self, k: int = K_SORT):
+        super().__init__()
+        self.k = k
+
+    def extra_repr(self) -> str:
+        return f"k={self.k}"
+
+
+def _batch_size_of(data) -> int:
+    B = getattr(data, "num_graphs", None)
+    if B is None:
+        B = int(data.batch[-1].item()) + 1      # host sync, as in the reference's SortAggregation
+    return int(B)
+
+
+class _DGCNNFunction(torch.autograd.Function):
+    """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
+
+    @staticmethod
+    def forward(ctx, model, x, edge_index, batch, B, training, seed, *params):
+        L = _lib.lib()
+        N, F = x.shape
+        E = edge_index.shape[1]
+        C = model.num_classes
+        flat = model.flat_params
+        ws = torch.empty(_lib.workspace_bytes(N, E, B, F, C), dtype=torch.uint8, device=x.device)
+        logp = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
+                                         edge_index.data_ptr() if E else None, batch.data_ptr(),
+                                         ws.data_ptr(), logp.data_ptr(), int(training), seed, stream),
+                   "dgcnn_model_forward")
+        ctx.model = model
+        ctx.dims = (N, E, B, F, C, int(training))
+        ctx.save_for_backward(x, ws, logp)
+        model._last_ws = ws
+        model._last_dims = (N, E, B, F, C)
+        return logp
+
+    @staticmethod
+    def backward(ctx, glogp):
+        L = _lib.lib()
+        model = ctx.model
+        N, E, B, F, C, training = ctx.dims
+        x, ws, logp = ctx.saved_tensors
+        glogp = glogp.contiguous()
+        flat = model.flat_params
+        grads = torch.empty_like(flat)       # fresh buffer: p.grad views stay valid until dropped
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
+                                          logp.data_ptr(), glogp.data_ptr(), None, 0.0, training,
+                                          grads.data_ptr(), stream), "dgcnn_model_backward")
+        model._last_flat_grad = grads
+        views = model._views_of(grads)
+        return (None, None, None, None, None, None, None, *views)
+
+
+class Model(nn.Module):
+    def __init__(self, num_features: int, num_classes: int):
+        super().__init__()
+        self.num_features, self.num_classes = int(num_features), int(num_classes)
+        # same attribute names as /root/reference/model.py:13-24 (parameter containers only;
+        # none of these torch modules is ever called)
+        self.conv1 = GCNConvParams(num_features, 32)
+        self.conv2 = GCNConvParams(32, 32)
+        self.conv3 = GCNConvParams(32, 32)
+        self.conv4 = GCNConvParams(32, 1)
+        self.sort_pool = SortPoolSpec(K_SORT)
+        self.conv5 = nn.Conv1d(1, 16, 97, 97)
+        self.conv6 = nn.Conv1d(16, 32, 5, 1)
+        self.pool = nn.MaxPool1d(2, 2)
+        self.classifier_1 = nn.Linear(352, 128)
+        self.drop_out = nn.Dropout(0.5)
+        self.classifier_2 = nn.Linear(128, num_classes)
+        self.relu = nn.ReLU(inplace=True)
+        self._flat: Optional[torch.Tensor] = None
+        self._offsets: Optional[List[int]] = None
+        self._total = 0
+        self._fwd_count = 0
+        self._seed_base: Optional[int] = None
+        self._last_ws = None
+        self._last_dims = None
+        self._last_flat_grad = None
+
+    # ---- flat parameter buffer ---------------------------------------------------------
+    def _param_list(self) -> List[nn.Parameter]:
+        """Parameters in the order of the C-ABI flat layout (include/dgcnn_hip.h)."""
+        return [self.conv1.lin.weight, self.conv1.bias, self.conv2.lin.weight, self.conv2.bias,
+                self.conv3.lin.weight, self.conv3.bias, self.conv4.lin.weight, self.conv4.bias,
+                self.conv5.weight, self.conv5.bias, self.conv6.weight, self.conv6.bias,
+                self.classifier_1.weight, self.classifier_1.bias,
+                self.classifier_2.weight, self.classifier_2.bias]
+
+    def _views_of(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        out = []
+        for p, off in zip(self._param_list(), self._offsets):
+            out.append(flat[off:off + p.numel()].view(p.shape))
+        return out
+
+    def _is_flat(self) -> bool:
+        if self._flat is None:
+            return False
+        base = self._flat.data_ptr()
+        for p, off in zip(self._param_list(), self._offsets):
+            if p.data_ptr() != base + 4 * off or p.device != self._flat.device:
+                return False
+        return True
+
+    def flatten_parameters(self) -> torch.Tensor:
+        """(Re)pack all parameters into one flat fp32 device buffer and re-point each
+        ``nn.Parameter`` at its slice.  Called lazily; needed again after ``.to()`` or
+        ``load_state_dict`` moved/replaced parameter storage."""
+        plist = self._param_list()
+        dev = plist[0].device
+        if self._offsets is None:
+            self._offsets, self._total = _lib.param_layout(self.num_features, self.num_classes)
+        flat = torch.zeros(self._total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(plist, self._offsets):
+                if p.dtype != torch.float32:
+                    raise _lib.DgcnnError("dgcnn_amd.Model computes in fp32; parameters must be float32")
+                flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+            for p, off in zip(plist, self._offsets):
+                p.data = flat[off:off + p.numel()].view(p.shape)
+        self._flat = flat
+        return flat
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        if not self._is_flat():
+            self.flatten_parameters()
+        return self._flat
+
+    @property
+    def flat_numel(self) -> int:
+        if self._offsets is None:
+            self._offsets, self._total = _lib.param_layout(self.num_features, self.num_classes)
+        return self._total
+
+    # ---- forward -----------------------------------------------------------------------
+    def _next_seed(self) -> int:
+        if self._seed_base is None:
+            self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._fwd_count += 1
+        return (self._seed_base * 0x9E3779B97F4A7C15 + self._fwd_count * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    @staticmethod
+    def _check_inputs(x, edge_index, batch):
+        if not x.is_cuda:
+            raise _lib.DgcnnError(
+                "dgcnn_amd.Model runs only on an AMD GPU through libdgcnn_hip.so; got a CPU tensor "
+                "(there is deliberately no CPU fallback)")
+        if x.dtype != torch.float32 or x.dim() != 2:
+            raise _lib.DgcnnError(f"data.x must be [N,F] float32, got {x.dtype} {tuple(x.shape)}")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise _lib.DgcnnError("data.edge_index must be [2,E] int64")
+        if batch.dtype != torch.int64 or batch.shape[0] != x.shape[0]:
+            raise _lib.DgcnnError("data.batch must be [N] int64")
+
+    def forward(self, data):
+        x, edge_index, batch = data.x, data.edge_index, data.batch          # model.py:27
+        self._check_inputs(x, edge_index, batch)
+        if x.shape[1] != self.num_features:
+            raise _lib.DgcnnError(f"data.x has {x.shape[1]} features, model expects {self.num_features}")
+        x, edge_index, batch = x.contiguous(), edge_index.contiguous(), batch.contiguous()
+        B = _batch_size_of(data)
+        flat = self.flat_params
+        if flat.device != x.device:
+            raise _lib.DgcnnError(f"model on {flat.device}, data on {x.device}")
+        training = self.training
+        seed = self._next_seed() if training else 0
+        return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, *self._param_list())
+
+    # ---- introspection used by tests / tools ---------------------------------------------
+    def last_workspace_view(self, name: str) -> torch.Tensor:
+        """Typed view of a region of the workspace of the most recent forward."""
+        if self._last_ws is None:
+            raise _lib.DgcnnError("no forward has run yet")
+        return _lib.ws_view(self._last_ws, name, *self._last_dims)

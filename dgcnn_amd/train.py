@@ -1,0 +1,166 @@
+"""Training / evaluation step harness on the fused HIP path.
+
+Restates the per-batch body of the reference loops -- ``train()`` /root/reference/train.py:27-47
+and ``test()`` train.py:49-66 -- with the same semantics:
+
+    pred = model(data); loss = NLLLoss()(pred, y); loss.backward()
+    optimizer.step(); optimizer.zero_grad()                       (Adam defaults, train.py:99)
+    running_loss += loss.item(); correct += (pred.argmax(1) == y).sum().item()
+
+but as four C-ABI calls per batch and NO host synchronisation: forward, backward (NLL gradient
+generated in-kernel from the labels), [one flat gradient all-reduce when data-parallel], fused
+Adam + zero_grad; loss / #correct accumulate in a 2-float device buffer that is read once per
+epoch (the reference syncs twice per batch, train.py:44-45).
+
+PyG / visdom cannot travel to the GPU box, so the reference's ``train.py`` itself cannot run there;
+this is the build's own harness for the same step.  The drop-in route (reference loop + this
+build's ``Model`` + torch's Adam) also works and is what tests/test_gpu_dropin.py exercises.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .model import Model, _batch_size_of
+
+
+class Trainer:
+    """Fused train/eval step for a :class:`dgcnn_amd.Model`.
+
+    lr/betas/eps default to ``torch.optim.Adam`` defaults, which is what the reference uses
+    (``Adam(model.parameters())``, /root/reference/train.py:99).
+    ``process_group``: when given (data parallel, one process per GPU), gradients are summed over
+    ranks with ONE all-reduce of the flat buffer per step and the loss is scaled by the GLOBAL
+    batch size, so N ranks x B/N graphs reproduce one rank x B graphs.
+    """
+
+    def __init__(self, model: Model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None):
+        self.model = model
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.pg = process_group
+        self.step_count = 0
+        flat = model.flat_params
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.grads = torch.zeros_like(flat)
+        self.metrics = torch.zeros(2, dtype=torch.float32, device=flat.device)
+        self._ws = None
+        self._ws_bytes = 0
+        self._logp = None
+
+    # ---- buffers reused across steps (sizes only grow) -------------------------------------
+    def _buffers(self, N, E, B, F, C, device):
+        need = _lib.workspace_bytes(N, E, B, F, C)
+        if self._ws is None or need > self._ws_bytes or self._ws.device != device:
+            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._ws_bytes = self._ws.numel()
+        if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != device:
+            self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=device)
+        return self._ws, self._logp
+
+    def _dims(self, data):
+        x, ei = data.x, data.edge_index
+        Model._check_inputs(x, ei, data.batch)
+        return x.shape[0], ei.shape[1], _batch_size_of(data), x.shape[1], self.model.num_classes
+
+    def forward_backward(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
+        """forward + NLL(mean) + backward into ``self.grads``; returns the log-probs view [B,C].
+        No optimizer step, no sync."""
+        L = _lib.lib()
+        m = self.model
+        N, E, B, F, C = self._dims(data)
+        dev = data.x.device
+        ws, logp = self._buffers(N, E, B, F, C, dev)
+        flat = m.flat_params
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        training = 1 if m.training else 0
+        seed = m._next_seed() if training else 0
+        x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+        _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
+                                         ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
+                                         logp.data_ptr(), training, seed, stream), "dgcnn_model_forward")
+        scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
+        _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
+                                          logp.data_ptr(), None, y.data_ptr(), scale, training,
+                                          self.grads.data_ptr(), stream), "dgcnn_model_backward")
+        _lib.check(L.dgcnn_accumulate_metrics(B, ws.data_ptr(), N, E, F, C, self.metrics.data_ptr(), stream),
+                   "dgcnn_accumulate_metrics")
+        m._last_ws, m._last_dims = ws, (N, E, B, F, C)
+        return logp[:B]
+
+    def optimizer_step(self) -> None:
+        """Adam + zero_grad over the flat buffer (train.py:41-42)."""
+        L = _lib.lib()
+        flat = self.model.flat_params
+        self.step_count += 1
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        _lib.check(L.dgcnn_adam_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), flat.numel(), self.step_count, self.lr,
+                                     self.betas[0], self.betas[1], self.eps, 1, stream), "dgcnn_adam_step")
+
+    def train_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
+        """One iteration of the body of the reference ``train()`` loop (train.py:36-45)."""
+        logp = self.forward_backward(data, y, global_batch)
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+        self.optimizer_step()
+        return logp
+
+    @torch.no_grad()
+    def eval_step(self, data, y) -> torch.Tensor:
+        """Body of the reference ``test()`` loop (train.py:59-64): forward only + metrics."""
+        L = _lib.lib()
+        m = self.model
+        was = m.training
+        m.eval()
+        try:
+            N, E, B, F, C = self._dims(data)
+            dev = data.x.device
+            ws, logp = self._buffers(N, E, B, F, C, dev)
+            flat = m.flat_params
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+            _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
+                                             ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
+                                             logp.data_ptr(), 0, 0, stream), "dgcnn_model_forward")
+            lp = logp[:B]
+            # metrics with plain torch ops (evaluation is not the timed hot path)
+            self.metrics[0] += -lp.gather(1, y.view(-1, 1)).mean()
+            self.metrics[1] += (lp.argmax(dim=1) == y).sum()
+        finally:
+            m.train(was)
+        return lp
+
+    def reset_metrics(self) -> None:
+        self.metrics.zero_()
+
+    def read_metrics(self) -> Tuple[float, float]:
+        """(sum of per-batch mean losses, number correct) -- ONE host sync."""
+        v = self.metrics.tolist()
+        return float(v[0]), float(v[1])
+
+    # ---- epoch loops with the reference's return values ------------------------------------
+    def train_epoch(self, batches: Iterable, num_samples: int) -> Tuple[float, float]:
+        """``train()`` of train.py:27-47: returns (running_loss/num_batches, correct/num_samples*100)."""
+        self.model.train()
+        self.reset_metrics()
+        nb = 0
+        for b in batches:
+            self.train_step(b, b.y)
+            nb += 1
+        loss, correct = self.read_metrics()
+        return loss / max(nb, 1), correct / max(num_samples, 1) * 100.0
+
+    def test_epoch(self, batches: Iterable, num_samples: int) -> Tuple[float, float]:
+        """``test()`` of train.py:49-66."""
+        self.reset_metrics()
+        nb = 0
+        for b in batches:
+            self.eval_step(b, b.y)
+            nb += 1
+        loss, correct = self.read_metrics()
+        return loss / max(nb, 1), correct / max(num_samples, 1) * 100.0

@@ -1,0 +1,185 @@
+/*
+ * dgcnn_hip.h -- C ABI of libdgcnn_hip.so: the MI355X (gfx950) implementation of the
+ * DGCNN forward+backward hot path of leftthomas/DGCNN.
+ *
+ * The reference has NO native interface of its own: its plugin boundary is the Python
+ * nn.Module protocol, `Model(num_features, num_classes).forward(data)`
+ * (/root/reference/model.py:9-45, used at /root/reference/train.py:13,37,60,97), and all
+ * graph arithmetic is delegated to PyTorch Geometric (model.py:5-6).  This header defines
+ * what sits UNDER that boundary in this build: plain pointers and
+ * sizes, no torch types, every entry point `extern "C"`.  Each function cites the
+ * reference line(s) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - returns 0 on success, a negative DGCNN_E* code on a bad argument or a HIP launch error;
+ *   - never allocates, never synchronises, never throws; all buffers are caller-owned
+ *     DEVICE memory (the caller is PyTorch-ROCm's allocator); work is enqueued on `stream`
+ *     (pass torch.cuda.current_stream().cuda_stream);
+ *   - stateless and re-entrant across streams (no globals besides read-only tables);
+ *   - fp32 arithmetic, int64 graph indices in (as the reference), int32 indices inside;
+ *   - results are run-to-run bit-reproducible: no floating-point atomics anywhere.
+ */
+#ifndef DGCNN_HIP_H
+#define DGCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGCNN_ABI_VERSION 1
+
+/* error codes */
+#define DGCNN_OK            0
+#define DGCNN_EINVAL       -1   /* bad size / null pointer / unsupported shape */
+#define DGCNN_ELAUNCH      -2   /* hipGetLastError() != hipSuccess after a launch */
+#define DGCNN_EUNSUPPORTED -3   /* shape outside what this build handles */
+
+/* fixed architecture constants of the reference model (/root/reference/model.py:13-23) */
+#define DGCNN_HID     32   /* GCN widths 32/32/32/1            model.py:13-16 */
+#define DGCNN_CAT     97   /* 32+32+32+1 concatenated channels model.py:34    */
+#define DGCNN_K       30   /* SortAggregation(k=30)            model.py:17    */
+#define DGCNN_C5      16   /* Conv1d(1,16,97,97)               model.py:18    */
+#define DGCNN_C6      32   /* Conv1d(16,32,5,1)                model.py:19    */
+#define DGCNN_KW6      5
+#define DGCNN_T5      15   /* after MaxPool1d(2,2)             model.py:20    */
+#define DGCNN_T6      11   /* 15-5+1                                           */
+#define DGCNN_FLAT   352   /* 32*11 = Linear(352,128) in-feats model.py:21    */
+#define DGCNN_HID1   128   /* Linear(352,128)                  model.py:21    */
+#define DGCNN_MAX_F  512   /* largest num_features this build accepts */
+#define DGCNN_MAX_C   64   /* largest num_classes this build accepts  */
+
+typedef void* dgcnn_stream_t;   /* a hipStream_t */
+
+int dgcnn_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Parameter layout.  All learnable parameters live in ONE flat fp32 buffer (also the
+ * gradient all-reduce bucket and the Adam state shape).  Segment order, each start
+ * rounded up to a multiple of 4 floats:
+ *   0 conv1.lin.weight [32,F]   1 conv1.bias [32]     (GCNConv(F,32)   model.py:13)
+ *   2 conv2.lin.weight [32,32]  3 conv2.bias [32]     (GCNConv(32,32)  model.py:14)
+ *   4 conv3.lin.weight [32,32]  5 conv3.bias [32]     (GCNConv(32,32)  model.py:15)
+ *   6 conv4.lin.weight [1,32]   7 conv4.bias [1]      (GCNConv(32,1)   model.py:16)
+ *   8 conv5.weight [16,1,97]    9 conv5.bias [16]     (model.py:18)
+ *  10 conv6.weight [32,16,5]   11 conv6.bias [32]     (model.py:19)
+ *  12 classifier_1.weight [128,352]  13 classifier_1.bias [128]  (model.py:21)
+ *  14 classifier_2.weight [C,128]    15 classifier_2.bias [C]    (model.py:23)
+ * dgcnn_param_layout fills offsets[16] (in floats) and returns the padded total length,
+ * or a negative error code.
+ * ---------------------------------------------------------------------------------- */
+#define DGCNN_NUM_PARAM_SEGMENTS 16
+int64_t dgcnn_param_layout(int F, int C, int64_t offsets[DGCNN_NUM_PARAM_SEGMENTS]);
+
+/* ------------------------------------------------------------------------------------
+ * Workspace.  One caller-owned device arena holds the per-batch graph structure, the
+ * activations saved for backward and all temporaries.  dgcnn_workspace_bytes gives its
+ * size for a batch of N nodes, E directed edges (self loops included in E are fine),
+ * B graphs.  dgcnn_workspace_offset returns the byte offset of a named region (for tests
+ * and tools; names listed in DESIGN.md), or -1.
+ * ---------------------------------------------------------------------------------- */
+int64_t dgcnn_workspace_bytes(int N, int E, int B, int F, int C);
+int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int C);
+
+/* ------------------------------------------------------------------------------------
+ * Graph preparation: replaces `remove_self_loops` (model.py:28) and the structural half
+ * of PyG `gcn_norm` that the reference re-runs inside each of its four GCNConv calls
+ * (model.py:30-33): drop self loops, count in-degree, dinv = (indeg+1)^-1/2, and build
+ * CSR by target (for forward) and CSR by source (for backward), neighbours ascending.
+ * Also derives graph_ptr[B+1] (node range of each graph) from the sorted `batch` vector
+ * (what PyG `to_dense_batch` derives inside SortAggregation, model.py:35).
+ *   edge_index [2,E] int64 row-major (row 0 = source, row 1 = target)   model.py:27
+ *   batch      [N]   int64, sorted, values in [0,B)                     model.py:27
+ * Outputs: rowptr[N+1], colidx[E], rowptr_t[N+1], colidx_t[E] (int32; only the first
+ * rowptr[N] entries of colidx are meaningful), dinv[N] f32, graph_ptr[B+1] int32.
+ * scratch: 2*N+2 int32.  err_flag: 1 int32, set non-zero if an edge endpoint is out of range.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
+                     int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
+                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag,
+                     dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * One graph-convolution layer, forward: out = tanh( D~^-1/2 (A+I) D~^-1/2 (x W^T) + b ).
+ * Replaces `torch.tanh(self.convN(x, edge_index))` (model.py:30-33; PyG GCNConv:
+ * linear without bias first, then gather/scale/scatter-add over edges, then + bias).
+ *   x [N,Fin] f32, W [Fout,Fin], bias [Fout], Fout in {32, 1}, out [N,Fout] (row stride Fout)
+ *   hs_scratch [N,Fout] f32 (the pre-scaled linear output dinv[j] * (x W^T)[j])
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                  const float* x, int Fin, const float* W, const float* bias, int Fout,
+                  float* out, float* hs_scratch, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * SortPooling forward: replaces `self.sort_pool(x, batch)` = PyG SortAggregation(k=30)
+ * (model.py:17,35).  Per graph: order nodes by the LAST channel descending (ties: lower
+ * node index first -- the reference's tie order is undefined), take the first min(n,k)
+ * rows, zero-pad to k, flatten node-major.
+ *   x1,x2,x3 [N,32], x4 [N]  (the four tanh(GCN) outputs; channel 96 = x4 is the key)
+ *   pooled [B, k*97] f32,  perm [B,k] int32 (global node index, -1 = padding)
+ * sortpool_bwd scatters a gradient wrt `pooled` back to dense per-node gradients
+ * (zero for unselected nodes): g1,g2,g3 [N,32], g4 [N].
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_sortpool_fwd(int N, int B, const int32_t* graph_ptr,
+                       const float* x1, const float* x2, const float* x3, const float* x4,
+                       float* pooled, int32_t* perm, dgcnn_stream_t stream);
+int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm,
+                       const float* gpooled, float* g1, float* g2, float* g3, float* g4,
+                       dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-model forward: replaces `Model.forward(data)` (model.py:26-45).
+ *   params : flat parameter buffer (dgcnn_param_layout)
+ *   x [N,F] f32, edge_index [2,E] i64, batch [N] i64          (data.x/.edge_index/.batch)
+ *   ws     : workspace arena (dgcnn_workspace_bytes); afterwards holds everything
+ *            dgcnn_model_backward needs
+ *   logp   : [B,C] f32 log-probabilities (F.log_softmax output, model.py:43)
+ *   training != 0 applies Dropout(0.5) (model.py:22,42) with a counter-based mask drawn
+ *            from `seed` (mask is exported in the workspace region "drop_mask" [B,128] u8)
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
+                        const float* x, const int64_t* edge_index, const int64_t* batch,
+                        void* ws, float* logp, int training, uint64_t seed,
+                        dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-model backward: what `loss.backward()` (/root/reference/train.py:40) executes for
+ * the ops of Model.forward.  Exactly one of (glogp, y) must be non-null:
+ *   glogp [B,C] f32 : upstream gradient wrt the log-probabilities (drop-in autograd path)
+ *   y     [B]   i64 : labels; the kernel then uses glogp = d/dlogp of nn.NLLLoss() mean
+ *                     (train.py:39,98) scaled by `loss_scale` (1/B_global for data parallel;
+ *                     pass 0 for 1/B) and writes per-graph loss/correct into ws ("lossv").
+ *   training: the same flag the matching dgcnn_model_forward was called with (dropout scale)
+ *   grads : flat gradient buffer (same layout as params), OVERWRITTEN (not accumulated)
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
+                         const float* x, void* ws, const float* logp,
+                         const float* glogp, const int64_t* y, float loss_scale, int training,
+                         float* grads, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Adam step over the flat buffer: replaces `optimizer.step(); optimizer.zero_grad()`
+ * (train.py:41-42) for torch.optim.Adam defaults (train.py:99: lr 1e-3, betas .9/.999,
+ * eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based step count.
+ * zero_grads != 0 also clears `grads`.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                    int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                    int zero_grads, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Metrics: folds the per-graph loss / correct flags left in the workspace by
+ * dgcnn_model_backward (label mode) into a device-side accumulator
+ * metrics[0] += sum_b loss_b (already scaled by loss_scale), metrics[1] += #correct,
+ * replacing the two `.item()` host syncs per batch of train.py:44-45.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C,
+                             float* metrics, dgcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGCNN_HIP_H */

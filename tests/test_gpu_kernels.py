@@ -1,0 +1,279 @@
+"""GPU parity tests of the individual C-ABI entry points against the oracle (bit-exact for
+integer/index work and pure data movement; stated tolerances for floating point)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dgcnn_amd import _lib, synth
+from oracle import kats, ref_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run_prep(ei, batch, N, B):
+    L = _lib.lib()
+    E = ei.shape[1]
+    ei_d, b_d = ei.to(DEV).contiguous(), batch.to(DEV).contiguous()
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    rowptr_t = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    colidx = torch.full((max(E, 1),), -7, dtype=torch.int32, device=DEV)
+    colidx_t = torch.full((max(E, 1),), -7, dtype=torch.int32, device=DEV)
+    dinv = torch.empty(N, dtype=torch.float32, device=DEV)
+    gptr = torch.empty(B + 1, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
+    err = torch.ones(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, b_d.data_ptr(), N, B, rowptr.data_ptr(),
+                                  colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), _stream()), "prep")
+    torch.cuda.synchronize()
+    return rowptr.cpu(), colidx.cpu(), rowptr_t.cpu(), colidx_t.cpu(), dinv.cpu(), gptr.cpu(), int(err.item())
+
+
+def csr_reference(ei, N):
+    """numpy CSR by target / by source, self loops dropped, neighbours ascending (duplicates kept)."""
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    def build(rows, cols):
+        order = np.lexsort((cols, rows))
+        r, c = rows[order], cols[order]
+        ptr = np.zeros(N + 1, dtype=np.int64)
+        np.add.at(ptr, r + 1, 1)
+        return np.cumsum(ptr).astype(np.int32), c.astype(np.int32)
+    rp, ci = build(dst, src)
+    rpt, cit = build(src, dst)
+    indeg = np.diff(rp)
+    return rp, ci, rpt, cit, indeg
+
+
+def random_multigraph(seed, sizes, deg, self_loops=True, dups=True, directed=True):
+    g = torch.Generator().manual_seed(seed)
+    eis, bs, off = [], [], 0
+    for gi, n in enumerate(sizes):
+        m = int(n * deg)
+        s = torch.randint(0, n, (m,), generator=g)
+        d = torch.randint(0, n, (m,), generator=g)
+        if not self_loops:
+            keep = s != d
+            s, d = s[keep], d[keep]
+        e = torch.stack([s, d])
+        if not directed:
+            e = torch.cat([e, e.flip(0)], 1)
+        if dups and m > 2:
+            e = torch.cat([e, e[:, :3]], 1)
+        eis.append(e + off)
+        bs.append(torch.full((n,), gi, dtype=torch.int64))
+        off += n
+    return torch.cat(eis, 1).contiguous(), torch.cat(bs), off
+
+
+@pytest.mark.parametrize("case", ["mixed", "undirected", "no_edges", "hub_lds", "hub_global", "single_node_graphs"])
+def test_graph_prep_bit_exact(case):
+    if case == "mixed":
+        ei, batch, N = random_multigraph(1, [5, 1, 40, 17, 300], 3.0)
+    elif case == "undirected":
+        ei, batch, N = random_multigraph(2, [64, 65, 2], 6.0, self_loops=False, dups=False, directed=False)
+    elif case == "no_edges":
+        ei, batch, N = torch.zeros(2, 0, dtype=torch.int64), torch.tensor([0, 0, 1]), 3
+    elif case == "hub_lds":       # one row of degree 3000 -> workgroup bitonic in LDS
+        n = 3001
+        leaves = torch.randperm(n - 1) + 1
+        ei = torch.stack([leaves, torch.zeros(n - 1, dtype=torch.int64)])
+        ei = torch.cat([ei, ei.flip(0)], 1)
+        batch, N = torch.zeros(n, dtype=torch.int64), n
+    elif case == "hub_global":    # degree 9000 > 8192 -> in-place global bitonic path
+        n = 9001
+        leaves = torch.randperm(n - 1) + 1
+        ei = torch.stack([leaves, torch.zeros(n - 1, dtype=torch.int64)])
+        batch, N = torch.zeros(n, dtype=torch.int64), n
+    else:
+        ei = torch.tensor([[0, 1], [1, 0]])
+        batch, N = torch.tensor([0, 0, 1, 2, 4]), 5     # graph 3 is EMPTY, graphs 1,2,4 single nodes
+    B = int(batch.max()) + 1
+    rp, ci, rpt, cit, dinv, gptr, err = run_prep(ei, batch, N, B)
+    assert err == 0
+    erp, eci, erpt, ecit, indeg = csr_reference(ei, N)
+    np.testing.assert_array_equal(rp.numpy(), erp)
+    np.testing.assert_array_equal(rpt.numpy(), erpt)
+    np.testing.assert_array_equal(ci.numpy()[:erp[-1]], eci)
+    np.testing.assert_array_equal(cit.numpy()[:erpt[-1]], ecit)
+    want = torch.from_numpy(indeg.astype(np.float32) + 1).pow(-0.5)
+    np.testing.assert_allclose(dinv.numpy(), want.numpy(), rtol=1.2e-7, atol=0)
+    egp = np.searchsorted(batch.numpy(), np.arange(B + 1), side="left").astype(np.int32)
+    np.testing.assert_array_equal(gptr.numpy(), egp)
+
+
+def test_graph_prep_flags_out_of_range_edges():
+    ei = torch.tensor([[0, 1, 7], [1, 0, 0]])
+    *_, err = run_prep(ei, torch.zeros(3, dtype=torch.int64), 3, 1)
+    assert err != 0
+
+
+def run_gcn(x, ei, W, b, Fout):
+    L = _lib.lib()
+    N, Fin = x.shape
+    batch = torch.zeros(N, dtype=torch.int64)
+    E = ei.shape[1]
+    ei_d = ei.to(DEV).contiguous()
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    rowptr_t = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    colidx = torch.zeros(max(E, 1), dtype=torch.int32, device=DEV)
+    colidx_t = torch.zeros(max(E, 1), dtype=torch.int32, device=DEV)
+    dinv = torch.empty(N, dtype=torch.float32, device=DEV)
+    gptr = torch.empty(2, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    bd = batch.to(DEV)
+    _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, bd.data_ptr(), N, 1, rowptr.data_ptr(),
+                                  colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), _stream()), "prep")
+    xd, Wd, bd2 = x.to(DEV).contiguous(), W.to(DEV).contiguous(), b.to(DEV).contiguous()
+    out = torch.full((N, Fout), float("nan"), device=DEV)
+    hs = torch.empty(N, Fout, device=DEV)
+    _lib.check(L.dgcnn_gcn_fwd(N, rowptr.data_ptr(), colidx.data_ptr(), dinv.data_ptr(), xd.data_ptr(), Fin,
+                               Wd.data_ptr(), bd2.data_ptr(), Fout, out.data_ptr(), hs.data_ptr(), _stream()), "gcn_fwd")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("kat", kats.gcn_kats(), ids=lambda k: k.name)
+@pytest.mark.parametrize("Fout", [32, 1])
+def test_gcn_layer_hand_kats(kat, Fout):
+    """closed-form KATs through graph_prep + gcn_fwd; the KAT's weight rows are embedded in a
+    [Fout,F] matrix (remaining rows zero -> tanh(bias=0) = 0)."""
+    fo = kat.weight.shape[0]
+    if Fout == 1 and fo != 1:
+        pytest.skip("KAT has 2 outputs")
+    x = torch.tensor(kat.x, dtype=torch.float32)
+    F = x.shape[1]
+    W = torch.zeros(Fout, F); W[:fo] = torch.tensor(kat.weight, dtype=torch.float32)
+    b = torch.zeros(Fout); b[:fo] = torch.tensor(kat.bias, dtype=torch.float32)
+    out = run_gcn(x, torch.tensor(kat.edge_index), W, b, Fout)
+    np.testing.assert_allclose(out[:, :fo].numpy(), np.tanh(kat.expected), rtol=0, atol=2e-6)
+    if Fout > fo:
+        assert float(out[:, fo:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Fin,Fout,n,deg", [(1, 32, 300, 20.0), (5, 32, 77, 3.0), (38, 32, 500, 4.0), (90, 32, 260, 5.0),
+                                            (32, 32, 1000, 37.0), (32, 1, 1000, 37.0), (200, 32, 50, 2.0),
+                                            (32, 32, 130, 100.0)])
+def test_gcn_layer_vs_oracle(Fin, Fout, n, deg):
+    g = torch.Generator().manual_seed(Fin * 1000 + n)
+    ei, _, N = random_multigraph(Fin + n, [n], deg)
+    x = torch.randn(N, Fin, generator=g)
+    W = torch.randn(Fout, Fin, generator=g) * (1.0 / np.sqrt(Fin))
+    b = torch.randn(Fout, generator=g) * 0.1
+    out = run_gcn(x, ei, W, b, Fout)
+    ei_ns = ref_ops.remove_self_loops(ei)
+    ref64 = torch.tanh(ref_ops.gcn_conv(x.double(), ei_ns, W.double(), b.double()))
+    ref32 = torch.tanh(ref_ops.gcn_conv(x, ei_ns, W, b))
+    e64 = float((out.double() - ref64).abs().max())
+    e32 = float((ref32.double() - ref64).abs().max())
+    assert e64 <= 3e-6, (e64, e32)          # fp32 kernel vs fp64 truth; the fp32 CPU oracle itself is at e32
+
+
+def run_sortpool(x, batch, B):
+    L = _lib.lib()
+    N = x.shape[0]
+    gptr = torch.from_numpy(np.searchsorted(batch.numpy(), np.arange(B + 1)).astype(np.int32)).to(DEV)
+    xs = [x[:, :32].contiguous().to(DEV), x[:, 32:64].contiguous().to(DEV), x[:, 64:96].contiguous().to(DEV),
+          x[:, 96].contiguous().to(DEV)]
+    pooled = torch.full((B, 30 * 97), float("nan"), device=DEV)
+    perm = torch.full((B, 30), -9, dtype=torch.int32, device=DEV)
+    _lib.check(L.dgcnn_sortpool_fwd(N, B, gptr.data_ptr(), *[t.data_ptr() for t in xs], pooled.data_ptr(),
+                                    perm.data_ptr(), _stream()), "sortpool_fwd")
+    torch.cuda.synchronize()
+    return pooled.cpu(), perm.cpu(), gptr
+
+
+@pytest.mark.parametrize("sizes", [[5, 30, 31, 64, 1], [200, 256, 257], [300, 1000, 4096], [4097, 6000, 29]],
+                         ids=["small", "rank256", "bitonic", "select"])
+def test_sortpool_bit_exact_vs_oracle(sizes):
+    g = torch.Generator().manual_seed(sum(sizes))
+    N = sum(sizes)
+    x = torch.randn(N, 97, generator=g)
+    x[:, 96] = torch.tanh(x[:, 96])
+    batch = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
+    pooled, perm, _ = run_sortpool(x, batch, len(sizes))
+    ref = ref_ops.sort_pool(x, batch, 30, len(sizes), stable=True)
+    assert torch.equal(pooled, ref)            # pure data movement: bit exact
+
+
+def test_sortpool_ties_lower_index_first_and_signed_zero():
+    x = torch.zeros(70, 97)
+    x[:, 0] = torch.arange(70)
+    x[:, 96] = 0.25                 # all keys tie -> nodes 0..29 in index order
+    x[3, 96] = -0.0; x[4, 96] = 0.0; x[5, 96] = 0.5
+    x[6:, 96] = -1.0
+    batch = torch.zeros(70, dtype=torch.int64)
+    pooled, perm, _ = run_sortpool(x, batch, 1)
+    assert perm[0, :6].tolist() == [5, 0, 1, 2, 3, 4]      # -0.0 and +0.0 tie, index order kept
+    assert perm[0, 6:].tolist() == list(range(6, 30))
+    ref = ref_ops.sort_pool(x, batch, 30, 1, stable=True)
+    assert torch.equal(pooled, ref)
+
+
+@pytest.mark.parametrize("kat", kats.sortpool_kats(), ids=lambda k: k.name)
+def test_sortpool_hand_kats_via_k30(kat):
+    """The ABI fixes k=30; embed the D=2 KAT in channels (0, 96) and compare the first rows."""
+    N = kat.x.shape[0]
+    x = torch.zeros(N, 97)
+    x[:, 0] = torch.tensor(kat.x[:, 0], dtype=torch.float32)
+    x[:, 96] = torch.tensor(kat.x[:, 1], dtype=torch.float32)
+    batch = torch.tensor(kat.batch)
+    B = int(batch.max()) + 1
+    pooled, perm, _ = run_sortpool(x, batch, B)
+    ref = ref_ops.sort_pool(x, batch, 30, B, stable=True)
+    assert torch.equal(pooled, ref)
+    for g in range(B):
+        n = int((batch == g).sum())
+        want = [p for p in kat.perm[g].tolist() if p >= 0]
+        if n <= kat.k:          # then the KAT's order is the full order
+            assert perm[g, :len(want)].tolist() == want
+
+
+def test_sortpool_bwd_exact():
+    L = _lib.lib()
+    sizes = [10, 45, 30]
+    N, B = sum(sizes), 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 97, generator=g, requires_grad=True)
+    batch = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
+    pooled, perm, gptr = run_sortpool(x.detach(), batch, B)
+    gp = torch.randn(B, 2910, generator=g)
+    ref_ops.sort_pool(x, batch, 30, B, stable=True).backward(gp)
+    outs = [torch.full((N, 32), float("nan"), device=DEV) for _ in range(3)] + [torch.full((N,), float("nan"), device=DEV)]
+    permd, gpd = perm.to(DEV), gp.to(DEV)
+    _lib.check(L.dgcnn_sortpool_bwd(N, B, gptr.data_ptr(), permd.data_ptr(), gpd.data_ptr(),
+                                    *[t.data_ptr() for t in outs], _stream()), "sortpool_bwd")
+    torch.cuda.synchronize()
+    got = torch.cat([outs[0], outs[1], outs[2], outs[3].view(-1, 1)], 1).cpu()
+    # padded slots carry gradient only into real rows; oracle zeroes the masked ones the same way
+    assert torch.equal(got, x.grad)
+
+
+def test_adam_matches_torch_adam():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    n = 5000
+    p0 = torch.randn(n, generator=g)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt])            # defaults, as /root/reference/train.py:99
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))
+        pt.grad = gr.clone()
+        opt.step()
+        gd = gr.to(DEV)
+        _lib.check(L.dgcnn_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, step, 1e-3, 0.9,
+                                     0.999, 1e-8, 1, _stream()), "adam")
+        torch.cuda.synchronize()
+        assert float(gd.abs().max()) == 0.0          # fused zero_grad
+        np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=2e-6, atol=2e-7)
