@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py -- graphs/sec of the DGCNN training step (forward + NLL + backward + Adam) on
+COLLAB-shaped batches of 50 graphs, the metric BASELINE.json names.
+
+    python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic graphs, i.e. the body of the
+reference loop /root/reference/train.py:36-42: forward, mean NLL, backward, Adam step, zero_grad.
+Inputs (x, edge_index, batch, y of every batch) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line with the contract fields plus:
+  "roofline"     -- the 32-wide aggregation kernel (k_gcn_fwd32): algorithmic bytes per launch
+                    (SURVEY.md §8(d) D4 compulsory-traffic model) / its average launch duration,
+                    measured with HIP events recorded around that launch on its own stream during a
+                    second, instrumented pass over the same steps (event-pair overhead calibrated
+                    and subtracted; both raw and corrected values are reported)
+  "cpu_baseline" -- the oracle's fp32 op-sequence restatement of the reference path (oracle/ref_ops.py,
+                    "port": PyG itself cannot run here) timed on the host cores, rank 0, N=1 only.
+
+Multi-GPU: one process per GPU, each rank trains on its own batches of 50 graphs per step (weak
+scaling, per-GPU work fixed), gradients summed with ONE flat RCCL all-reduce per step and the loss
+scaled by the global batch 50*N.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="COLLAB", help="synthetic shape (dgcnn_amd.synth.SHAPES)")
+    ap.add_argument("--batch", type=int, default=50, help="graphs per step per GPU")
+    ap.add_argument("--pool", type=int, default=40, help="distinct batches resident in HBM per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int:
+    """one aggregation call of width F, element size s, int32 CSR:
+    4*E~ (colidx) + 4*(N+1) (rowptr) + 4*N (dinv) + s*N*F (read H) + s*N*F (write out),
+    E~ = non-self-loop edges + N self loops.  Each array counted once (compulsory traffic)."""
+    Et = E_noself + N
+    return 4 * Et + 4 * (N + 1) + 4 * N + 2 * s * N * F
+
+
+def cpu_baseline(batches_cpu, F, C, seconds):
+    """Oracle port of the reference step (fwd + NLL + bwd + Adam) on the host cores."""
+    from oracle import ref_ops                      # checker/baseline leg only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(324)
+    model = ref_ops.RefModel(F, C)
+    model.train()
+    opt = torch.optim.Adam(model.parameters())
+    n = len(batches_cpu)
+    for i in range(2):
+        ref_ops.train_step(model, opt, batches_cpu[i % n], batches_cpu[i % n].y)
+    t0 = time.perf_counter()
+    steps = graphs = 0
+    while True:
+        b = batches_cpu[steps % n]
+        ref_ops.train_step(model, opt, b, b.y)
+        steps += 1
+        graphs += b.num_graphs
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 400:
+            break
+    return {"value": graphs / el, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps (fwd+NLL+bwd+Adam) of oracle/ref_ops.py (torch-CPU restatement of the "
+                      f"reference op sequence; PyG itself is unavailable) on the same synthetic batches, "
+                      f"{el:.1f} s, torch {torch.__version__}, {cores} threads",
+            "ms_per_step": 1e3 * el / steps}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an AMD GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import torch.distributed as dist
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from dgcnn_amd import _lib, synth
+    from dgcnn_amd.model import Model
+    from dgcnn_amd.train import Trainer
+    L = _lib.lib()
+
+    shape = synth.SHAPES[args.workload]
+    F, C, B = shape.num_features, shape.num_classes, args.batch
+    # every rank draws its own graphs: rank r owns graph ids [r*pool*B, (r+1)*pool*B)
+    graphs = synth.make_graphs(args.workload, args.pool * B, start=rank * args.pool * B)
+    batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
+    batches = [b.to(dev) for b in batches_cpu]
+    nb = len(batches)
+    avgN = sum(b.num_nodes for b in batches_cpu) / nb
+    avgE = sum(b.num_edges for b in batches_cpu) / nb
+
+    torch.manual_seed(324)                    # identical replicas on every rank
+    model = Model(F, C).to(dev)
+    model.train()
+    tr = Trainer(model, process_group=pg)
+    gb = B * world
+
+    def step(i):
+        b = batches[i % nb]
+        tr.train_step(b, b.y, global_batch=gb)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss_sum, correct = tr.read_metrics()
+    value = args.steps * B * world / el
+
+    extra = {}
+    roofline = None
+    if rank == 0:
+        # ---- forward+backward only (no optimizer), reported beside the headline --------------
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            b = batches[i % nb]
+            tr.forward_backward(b, b.y, global_batch=gb)
+        torch.cuda.synchronize(dev)
+        extra["fwd_bwd_only_graphs_per_s_rank0"] = args.steps * B / (time.perf_counter() - t1)
+
+    if rank == 0 and not args.no_roofline:
+        # ---- roofline of the dominant kernel: instrumented pass over the same steps ----------
+        def ev():
+            p = ctypes.c_void_p()
+            _lib.check(L.dgcnn_event_create(ctypes.byref(p)), "event_create")
+            return p
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        pairs = []
+        # calibrate the cost of an empty event pair on this stream
+        cal = []
+        for _ in range(64):
+            a, bb = ev(), ev()
+            L.dgcnn_event_record(a, stream)
+            L.dgcnn_event_record(bb, stream)
+            cal.append((a, bb))
+        torch.cuda.synchronize(dev)
+        ms = ctypes.c_float()
+        cal_us = []
+        for a, bb in cal:
+            L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms))
+            cal_us.append(ms.value * 1e3)
+            L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
+        cal_us.sort()
+        overhead_us = cal_us[len(cal_us) // 2]
+        nprof = min(args.steps, 300)
+        for i in range(nprof):
+            a, bb = ev(), ev()
+            which = i % 3                       # conv1 / conv2 / conv3 aggregation, round robin
+            _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")
+            b = batches[i % nb]
+            tr.train_step(b, b.y, global_batch=gb) if world == 1 else tr.forward_backward(b, b.y, global_batch=gb)
+            pairs.append((a, bb, b.num_nodes, b.num_edges))
+        torch.cuda.synchronize(dev)
+        tot_us = tot_bytes = 0.0
+        raw = []
+        for a, bb, n_, e_ in pairs:
+            L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms))
+            raw.append(ms.value * 1e3)
+            tot_us += ms.value * 1e3
+            tot_bytes += algorithmic_bytes_agg(n_, e_)          # synthetic graphs have no self loops
+            L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
+        avg_raw = tot_us / len(pairs)
+        avg_corr = max(avg_raw - overhead_us, 1e-3)
+        bytes_per_launch = tot_bytes / len(pairs)
+        achieved = bytes_per_launch / (avg_corr * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_gcn_fwd32 (32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": avg_corr, "avg_launch_us_raw_events": avg_raw, "event_pair_overhead_us": overhead_us,
+                    "launches_measured": len(pairs),
+                    "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at B=50 the launch "
+                            "moves ~1.5 MB and is latency-bound, see DESIGN.md for the batch-size sweep"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batches_cpu, F, C, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "graphs/sec fwd+bwd (+Adam step), COLLAB-shape batch=50 per GPU" if args.workload == "COLLAB" and B == 50
+                      else f"graphs/sec fwd+bwd (+Adam step), {args.workload}-shape batch={B} per GPU",
+            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shape synthetic graphs (SURVEY §8(d) D2 cfg: n~N(75,30) clip[32,492], "
+                                   f"mean degree ~37, F={F}, C={C}), batch_size={B} per GPU, {nb} distinct resident batches per GPU"
+                       if args.workload == "COLLAB" else f"{args.workload}-shape synthetic graphs, batch_size={B} per GPU",
+                       "global_batch": gb, "avg_nodes_per_batch": avgN, "avg_directed_edges_per_batch": avgE,
+                       "parallelism": f"dp{world}", "step": "forward + NLL(mean) + backward + fused Adam + zero_grad "
+                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) inside every step"},
+            "train_loss_mean": loss_sum / max(args.steps + args.warmup, 1), "correct_frac_rank0": correct / ((args.steps + args.warmup) * B),
+        }
+        out.update(extra)
+        if roofline is not None:
+            out["roofline"] = roofline
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_port"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,11 @@ SIGNATURES = {
     "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
                                 c_void_p]),
     "dgcnn_accumulate_metrics": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dgcnn_profile_next_forward": (c_int, [c_int, c_void_p, c_void_p]),
+    "dgcnn_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "dgcnn_event_record": (c_int, [c_void_p, c_void_p]),
+    "dgcnn_event_elapsed_ms": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float)]),
+    "dgcnn_event_destroy": (c_int, [c_void_p]),
 }
 
 _ERR = {-1: "DGCNN_EINVAL (bad size / null pointer)", -2: "DGCNN_ELAUNCH (HIP launch error)",
@@ -71,6 +76,7 @@ def lib() -> ctypes.CDLL:
         raise DgcnnError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             f"Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`.")
+    import torch  # noqa: F401  -- load PyTorch-ROCm's libamdhip64.so.7 FIRST so both share one HIP runtime
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -2,7 +2,39 @@
 // orchestration of the whole-model forward / backward as a chain of launches on one stream.
 #include "dg_common.h"
 
+// one-shot, thread-local profiling request (see dgcnn_profile_next_forward)
+static thread_local int g_prof_which = -1;
+static thread_local hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
+#define DG_PROF_BEGIN(idx) do { if (g_prof_which == (idx)) hipEventRecord(g_prof_a, s); } while (0)
+#define DG_PROF_END(idx) do { if (g_prof_which == (idx)) hipEventRecord(g_prof_b, s); } while (0)
+
 extern "C" {
+
+int dgcnn_profile_next_forward(int which, void* ev_start, void* ev_stop) {
+  if (which < 0 || which > 2 || !ev_start || !ev_stop) return DGCNN_EINVAL;
+  g_prof_which = which; g_prof_a = (hipEvent_t)ev_start; g_prof_b = (hipEvent_t)ev_stop;
+  return DGCNN_OK;
+}
+int dgcnn_event_create(void** ev) {
+  if (!ev) return DGCNN_EINVAL;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return DGCNN_ELAUNCH;
+  *ev = (void*)e;
+  return DGCNN_OK;
+}
+int dgcnn_event_record(void* ev, dgcnn_stream_t stream) {
+  if (!ev) return DGCNN_EINVAL;
+  return hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
+}
+int dgcnn_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+  if (!ev_start || !ev_stop || !ms) return DGCNN_EINVAL;
+  if (hipEventSynchronize((hipEvent_t)ev_stop) != hipSuccess) return DGCNN_ELAUNCH;
+  return hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
+}
+int dgcnn_event_destroy(void* ev) {
+  if (!ev) return DGCNN_EINVAL;
+  return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
+}
 
 int dgcnn_version(void) { return DGCNN_ABI_VERSION; }
 
@@ -95,9 +127,14 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
+  DG_PROF_BEGIN(0);
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s));
+  DG_PROF_END(0); DG_PROF_BEGIN(1);
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s));
+  DG_PROF_END(1); DG_PROF_BEGIN(2);
   DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s));
+  DG_PROF_END(2);
+  g_prof_which = -1;
   DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
   // SortPooling + tail
   DG_TRY(dg_launch_sortpool_fwd(N, B, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,

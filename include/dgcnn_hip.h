@@ -179,6 +179,21 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
 int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C,
                              float* metrics, dgcnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Measurement helpers (used by bench.py for the roofline line; not part of the data path).
+ * dgcnn_profile_next_forward arms a ONE-SHOT, thread-local request: the next
+ * dgcnn_model_forward issued by this thread records ev_start / ev_stop (hipEvent_t created
+ * with dgcnn_event_create) on its stream immediately around the `which`-th 32-wide
+ * aggregation launch (0 = conv1, 1 = conv2, 2 = conv3).  The other calls are thin wrappers
+ * of hipEventCreate / hipEventRecord / hipEventSynchronize+hipEventElapsedTime /
+ * hipEventDestroy so the bench does not need a second HIP binding.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_profile_next_forward(int which, void* ev_start, void* ev_stop);
+int dgcnn_event_create(void** ev);
+int dgcnn_event_record(void* ev, dgcnn_stream_t stream);
+int dgcnn_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int dgcnn_event_destroy(void* ev);
+
 #ifdef __cplusplus
 }
 #endif
