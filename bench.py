@@ -64,15 +64,27 @@ def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int
 def cpu_baseline(batches_cpu, F, C, seconds):
     """Oracle port of the reference step (fwd + NLL + bwd + Adam) on the host cores."""
     from oracle import ref_ops                      # checker/baseline leg only
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(324)
     model = ref_ops.RefModel(F, C)
     model.train()
     opt = torch.optim.Adam(model.parameters())
     n = len(batches_cpu)
-    for i in range(2):
-        ref_ops.train_step(model, opt, batches_cpu[i % n], batches_cpu[i % n].y)
+    # The reference runs torch's default intra-op threading; on a many-core host the small ops of
+    # this path get SLOWER with every core (oversubscription), so probe a few thread counts and time
+    # the best one -- the baseline is the port at its fastest, not at its default.
+    probe = {}
+    for th in sorted({1, 4, 8, 16, 32, min(64, ncpu)}):
+        if th > ncpu:
+            continue
+        torch.set_num_threads(th)
+        ref_ops.train_step(model, opt, batches_cpu[0], batches_cpu[0].y)
+        t0 = time.perf_counter()
+        for i in range(2):
+            ref_ops.train_step(model, opt, batches_cpu[(1 + i) % n], batches_cpu[(1 + i) % n].y)
+        probe[th] = (time.perf_counter() - t0) / 2
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     steps = graphs = 0
     while True:
@@ -86,7 +98,8 @@ def cpu_baseline(batches_cpu, F, C, seconds):
     return {"value": graphs / el, "unit": "graphs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} training steps (fwd+NLL+bwd+Adam) of oracle/ref_ops.py (torch-CPU restatement of the "
                       f"reference op sequence; PyG itself is unavailable) on the same synthetic batches, "
-                      f"{el:.1f} s, torch {torch.__version__}, {cores} threads",
+                      f"{el:.1f} s, torch {torch.__version__}, {cores} threads (best of probe "
+                      f"{ {k: round(v * 1e3, 1) for k, v in probe.items()} } ms/step; host has {ncpu} logical CPUs)",
             "ms_per_step": 1e3 * el / steps}
 
 
@@ -177,51 +190,34 @@ def main():
             p = ctypes.c_void_p()
             _lib.check(L.dgcnn_event_create(ctypes.byref(p)), "event_create")
             return p
-        stream = torch.cuda.current_stream(dev).cuda_stream
         pairs = []
-        # calibrate the cost of an empty event pair on this stream
-        cal = []
-        for _ in range(64):
-            a, bb = ev(), ev()
-            L.dgcnn_event_record(a, stream)
-            L.dgcnn_event_record(bb, stream)
-            cal.append((a, bb))
-        torch.cuda.synchronize(dev)
         ms = ctypes.c_float()
-        cal_us = []
-        for a, bb in cal:
-            L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms))
-            cal_us.append(ms.value * 1e3)
-            L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
-        cal_us.sort()
-        overhead_us = cal_us[len(cal_us) // 2]
         nprof = min(args.steps, 300)
         for i in range(nprof):
             a, bb = ev(), ev()
             which = i % 3                       # conv1 / conv2 / conv3 aggregation, round robin
+            # the events are attached to that ONE dispatch (hipExtLaunchKernelGGL): their elapsed time
+            # is the kernel's own start->end, the same timestamps rocprofv3 reports
             _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")
             b = batches[i % nb]
             tr.train_step(b, b.y, global_batch=gb) if world == 1 else tr.forward_backward(b, b.y, global_batch=gb)
             pairs.append((a, bb, b.num_nodes, b.num_edges))
         torch.cuda.synchronize(dev)
         tot_us = tot_bytes = 0.0
-        raw = []
         for a, bb, n_, e_ in pairs:
-            L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms))
-            raw.append(ms.value * 1e3)
+            _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
             tot_bytes += algorithmic_bytes_agg(n_, e_)          # synthetic graphs have no self loops
             L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
-        avg_raw = tot_us / len(pairs)
-        avg_corr = max(avg_raw - overhead_us, 1e-3)
+        avg_us = max(tot_us / len(pairs), 1e-3)
         bytes_per_launch = tot_bytes / len(pairs)
-        achieved = bytes_per_launch / (avg_corr * 1e-6) / 1e9
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_gcn_fwd32 (32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "avg_launch_us": avg_corr, "avg_launch_us_raw_events": avg_raw, "event_pair_overhead_us": overhead_us,
-                    "launches_measured": len(pairs),
+                    "avg_launch_us": avg_us, "launches_measured": len(pairs),
+                    "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
                     "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at B=50 the launch "
                             "moves ~1.5 MB and is latency-bound, see DESIGN.md for the batch-size sweep"}
 

@@ -32,6 +32,7 @@ class Graph:
     x: torch.Tensor            # [n, F] float32
     edge_index: torch.Tensor   # [2, e] int64, row0 = source, row1 = target
     y: int = 0
+    coalesced_undirected: bool = False   # sorted by (src,dst), no dups/self loops, both directions
 
     @property
     def num_nodes(self) -> int:
@@ -50,9 +51,10 @@ class Batch:
     /root/reference/train.py:36 (``sample.to(device)``) and returns a new Batch.
     """
 
-    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "_prep_cache")
+    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected")
 
-    def __init__(self, x, edge_index, batch, y=None, num_graphs: Optional[int] = None):
+    def __init__(self, x, edge_index, batch, y=None, num_graphs: Optional[int] = None,
+                 coalesced_undirected: bool = False):
         if x.dim() != 2:
             raise ValueError(f"x must be [N,F], got {tuple(x.shape)}")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -69,7 +71,9 @@ class Batch:
             else:
                 num_graphs = int(batch[-1].item()) + 1 if batch.numel() else 0
         self.num_graphs = int(num_graphs)
-        self._prep_cache = None
+        # host-side promise about the edge list layout (see DGCNN_FLAG_COALESCED_UNDIRECTED in
+        # include/dgcnn_hip.h); verified on the device, never trusted blindly
+        self.coalesced_undirected = bool(coalesced_undirected)
 
     @property
     def num_nodes(self) -> int:
@@ -81,11 +85,13 @@ class Batch:
 
     def to(self, device, non_blocking: bool = False) -> "Batch":
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)
-        return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs)
+        return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
+                     self.coalesced_undirected)
 
     def pin_memory(self) -> "Batch":
         mv = lambda t: None if t is None else t.pin_memory()
-        return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs)
+        return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
+                     self.coalesced_undirected)
 
     def __repr__(self) -> str:
         return (f"Batch(graphs={self.num_graphs}, nodes={self.num_nodes}, "
@@ -105,11 +111,13 @@ def collate(graphs: Sequence[Graph]) -> Batch:
         bs.append(torch.full((n,), g, dtype=torch.int64))
         ys.append(int(gr.y))
         off += n
+    # concatenating coalesced undirected graphs with growing node offsets keeps the union coalesced
+    cu = all(getattr(gr, "coalesced_undirected", False) for gr in graphs)
     return Batch(torch.cat(xs, 0).contiguous(),
                  torch.cat(eis, 1).contiguous(),
                  torch.cat(bs, 0),
                  torch.tensor(ys, dtype=torch.int64),
-                 num_graphs=len(graphs))
+                 num_graphs=len(graphs), coalesced_undirected=cu)
 
 
 def indegree_feature(edge_index: torch.Tensor, num_nodes: int,
@@ -169,5 +177,6 @@ def split_batch(b: Batch, parts: int) -> List[Batch]:
         sub_ei = ei[:, emask] - n0
         dev = b.x.device
         out.append(Batch(b.x[n0:n1], sub_ei.to(dev), (b.batch[n0:n1] - g0),
-                         None if b.y is None else b.y[g0:g1], num_graphs=g1 - g0))
+                         None if b.y is None else b.y[g0:g1], num_graphs=g1 - g0,
+                         coalesced_undirected=b.coalesced_undirected))
     return out

@@ -5,8 +5,8 @@
 // one-shot, thread-local profiling request (see dgcnn_profile_next_forward)
 static thread_local int g_prof_which = -1;
 static thread_local hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
-#define DG_PROF_BEGIN(idx) do { if (g_prof_which == (idx)) hipEventRecord(g_prof_a, s); } while (0)
-#define DG_PROF_END(idx) do { if (g_prof_which == (idx)) hipEventRecord(g_prof_b, s); } while (0)
+#define DG_PROF_A(idx) (g_prof_which == (idx) ? g_prof_a : nullptr)
+#define DG_PROF_B(idx) (g_prof_which == (idx) ? g_prof_b : nullptr)
 
 extern "C" {
 
@@ -66,12 +66,14 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
 
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                      int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
-                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag,
+                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag, int flags,
                      dgcnn_stream_t stream) {
   if (!batch || !rowptr || !rowptr_t || !dinv || !graph_ptr || !scratch || !err_flag) return DGCNN_EINVAL;
   if (E > 0 && (!edge_index || !colidx || !colidx_t)) return DGCNN_EINVAL;
+  // stand-alone entry: plain semantics "err_flag[0..1] != 0 on error" -> clear, then tag with epoch 1
+  if (hipMemsetAsync(err_flag, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return DGCNN_ELAUNCH;
   return dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, rowptr_t, colidx_t, dinv, graph_ptr,
-                        scratch, scratch + (N + 1), err_flag, (hipStream_t)stream);
+                        scratch, scratch + (N + 1), err_flag, flags, 1u, (hipStream_t)stream);
 }
 
 int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
@@ -103,8 +105,9 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, float* logp, int training, uint64_t seed, dgcnn_stream_t stream) {
-  if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0) return DGCNN_EINVAL;
+                        void* ws, float* logp, int training, uint64_t seed, int flags, uint32_t epoch,
+                        dgcnn_stream_t stream) {
+  if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
@@ -123,31 +126,29 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
-                        dg_ptr<int32_t>(ws, wl.err), s));
+                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
-  DG_PROF_BEGIN(0);
-  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s));
-  DG_PROF_END(0); DG_PROF_BEGIN(1);
-  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s));
-  DG_PROF_END(1); DG_PROF_BEGIN(2);
-  DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s));
-  DG_PROF_END(2);
+  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
+                             DG_PROF_A(0), DG_PROF_B(0)));
+  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,
+                             DG_PROF_A(1), DG_PROF_B(1)));
+  DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
+                             DG_PROF_A(2), DG_PROF_B(2)));
   g_prof_which = -1;
   DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
-  // SortPooling + tail
-  DG_TRY(dg_launch_sortpool_fwd(N, B, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
-                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), s));
-  DG_TRY(dg_launch_tail_fwd(B, C, params, &pl, dg_ptr<float>(ws, wl.pooled), dg_ptr<float>(ws, wl.a5),
-                            dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask),
-                            logp, training, seed, s));
+  // SortPooling + the whole dense tail: one launch, one workgroup per graph
+  DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
+                               dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
+                               dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
+                               dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s));
   return DGCNN_OK;
 }
 
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
-                                  float loss_scale, int training, float* grads, hipStream_t s) {
+                                  float loss_scale, int training, float* grads, float* metrics, hipStream_t s) {
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -159,7 +160,6 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   const float *x1 = dg_cptr<float>(ws, wl.x1), *x2 = dg_cptr<float>(ws, wl.x2), *x3 = dg_cptr<float>(ws, wl.x3),
               *x4 = dg_cptr<float>(ws, wl.x4);
 
-  if (hipMemsetAsync(grads, 0, sizeof(float) * (size_t)pl.total, s) != hipSuccess) return DGCNN_ELAUNCH;
   DG_TRY(dg_launch_tail_bwd(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm),
                             dinv, x4, dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6),
                             dg_cptr<float>(ws, wl.a1d), logp, glogp, y, loss_scale, training,
@@ -179,18 +179,18 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                              dg_ptr<float>(ws, wl.pb1), wl.P32, s));
   // every weight gradient, fixed-order reductions
-  DG_TRY(dg_launch_wgrad(N, B, F, C, &pl, &wl, ws, grads, s));
+  DG_TRY(dg_launch_wgrad(N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, s));
   return DGCNN_OK;
 }
 
 int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
                          const float* glogp, const int64_t* y, float loss_scale, int training,
-                         float* grads, dgcnn_stream_t stream) {
+                         float* grads, float* metrics, dgcnn_stream_t stream) {
   if (!params || !x || !ws || !logp || !grads || N <= 0 || B <= 0) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, glogp, y, loss_scale, training ? 1 : 0,
-                                grads, (hipStream_t)stream);
+                                grads, metrics, (hipStream_t)stream);
 }
 
 int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,

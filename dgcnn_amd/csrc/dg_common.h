@@ -195,13 +195,13 @@ __device__ void dg_block_bitonic(PTR data, int n) {
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* cnt_in, int32_t* cnt_out, int32_t* err,
-                   hipStream_t s);
+                   int flags, uint32_t epoch, hipStream_t s);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
                         int Fout, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s);
+                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                        const float* h4s, const float* bias, float* x4, hipStream_t s);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
@@ -215,9 +215,10 @@ int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* 
                            const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s);
 int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
                            float* g1, float* g2, float* g3, float* g4, hipStream_t s);
-int dg_launch_tail_fwd(int B, int C, const float* params, const DgParams* pl, const float* pooled,
-                       float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training,
-                       uint64_t seed, hipStream_t s);
+int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                          const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
+                          int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
+                          int training, uint64_t seed, hipStream_t s);
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
@@ -225,7 +226,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                        hipStream_t s);
 int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, hipStream_t s);
+                    float* grads, float* metrics, hipStream_t s);
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);
 int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s);

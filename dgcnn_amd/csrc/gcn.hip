@@ -22,6 +22,7 @@
 //     dL/dx_prev = gh . W       (MFMA)            dL/dW += gh^T . x_prev   (MFMA, K = nodes)
 // with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
 #include "dg_common.h"
+#include <hip/hip_ext.h>
 
 // ---------------------------------------------------------------------------------------------
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
@@ -183,19 +184,21 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
 
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s) {
+                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   const int grid = tiles > 8192 ? 8192 : tiles;
+  // hipExtLaunchKernelGGL attaches the events to THIS dispatch (its own start/end timestamps, the
+  // same ones rocprofv3 reports); with null events it is a plain launch.
   if (mode == 0)
-    hipLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
-                       bias, xout, Wnext, hs_next);
+    hipExtLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   else if (mode == 1)
-    hipLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
-                       bias, xout, Wnext, hs_next);
+    hipExtLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   else
-    hipLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, N, tiles, rowptr, colidx, dinv, hs,
-                       bias, xout, Wnext, hs_next);
+    hipExtLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

@@ -29,14 +29,15 @@ __device__ __forceinline__ unsigned long long dg_pack_key(float key, int idx) {
   return ((unsigned long long)u << 32) | (unsigned int)idx;
 }
 
-// selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none)
+// selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none).
+// Works for any workgroup size that is a multiple of 64 (<= 1024).
 __device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
                                unsigned long long* red, int* sel) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
   const int m = n < DGCNN_K ? n : DGCNN_K;
   if (tid < DGCNN_K) sel[tid] = -1;
   __syncthreads();
-  if (n <= SP_THREADS) {
+  if (n <= 256) {
     if (tid < n) keys[tid] = dg_pack_key(x4[n0 + tid], tid);
     __syncthreads();
     if (tid < n) {
@@ -46,7 +47,7 @@ __device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsi
       if (rank < DGCNN_K) sel[rank] = tid;
     }
   } else if (n <= SP_LDS_KEYS) {
-    for (int t = tid; t < n; t += SP_THREADS) keys[t] = dg_pack_key(x4[n0 + t], t);
+    for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
     __syncthreads();
     dg_block_bitonic<unsigned long long>(keys, n);
     if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
@@ -54,19 +55,18 @@ __device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsi
     unsigned long long prev = 0ull;
     for (int r = 0; r < m; ++r) {
       unsigned long long best = ~0ull;
-      for (int t = tid; t < n; t += SP_THREADS) {
+      for (int t = tid; t < n; t += T) {
         const unsigned long long p = dg_pack_key(x4[n0 + t], t);
         if ((r == 0 || p > prev) && p < best) best = p;
       }
-      // workgroup min: wave shuffle then LDS
-      for (int o = 32; o > 0; o >>= 1) {
+      for (int o = 32; o > 0; o >>= 1) {       // workgroup min: wave shuffle then LDS
         const unsigned long long other = __shfl_xor(best, o);
         best = other < best ? other : best;
       }
       if ((tid & 63) == 0) red[tid >> 6] = best;
       __syncthreads();
       unsigned long long b0 = red[0];
-      for (int w = 1; w < SP_THREADS / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
+      for (int w = 1; w < T / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
       prev = b0;
       if (tid == 0) sel[r] = (int)(b0 & 0xffffffffull);
       __syncthreads();
@@ -89,7 +89,7 @@ k_sortpool_fwd(const int* __restrict__ graph_ptr, const float* __restrict__ x1, 
                const float* __restrict__ x3, const float* __restrict__ x4, float* __restrict__ pooled,
                int* __restrict__ perm) {
   __shared__ unsigned long long keys[SP_LDS_KEYS];
-  __shared__ unsigned long long red[SP_THREADS / 64];
+  __shared__ unsigned long long red[16];
   __shared__ int sel[DGCNN_K];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
@@ -143,8 +143,11 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// tail forward, one workgroup (256 threads) per graph
+// readout forward = SortPooling + the whole dense tail, ONE workgroup of 1024 threads per graph.
+// LDS plan (bytes): region A 32 KiB = sort keys, afterwards reused for the pooled rows (11640),
+// conv5 weights (6208) and conv6 weights (10240); small activations after it.
 // ---------------------------------------------------------------------------------------------
+#define RD_THREADS 1024
 struct TailW {   // device pointers into the flat parameter buffer
   const float *W5, *b5, *W6, *b6, *Wf1, *bf1, *Wf2, *bf2;
 };
@@ -156,75 +159,124 @@ static inline TailW dg_tail_w(const float* params, const DgParams* pl) {
   w.Wf2 = params + pl->off[14]; w.bf2 = params + pl->off[15];
   return w;
 }
+#define NW5 (DGCNN_C5 * DGCNN_CAT)                 // 1552
+#define NW6 (DGCNN_C6 * DGCNN_C5 * DGCNN_KW6)      // 2560
 
-__global__ void __launch_bounds__(SP_THREADS)
-k_tail_fwd(int C, TailW w, const float* __restrict__ pooled, float* __restrict__ a5g, float* __restrict__ a6g,
-           float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
-           uint64_t seed) {
-  __shared__ float sp[KCAT];
+// SORT = true: do the SortPooling selection/gather here (graph_ptr, x1..x4 given, pooled/perm written)
+// SORT = false: `pooled` is an input (stand-alone tail on precomputed rows)
+template <bool SORT>
+__global__ void __launch_bounds__(RD_THREADS)
+k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
+              const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
+              float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
+              float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
+              uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) unsigned long long regionA[SP_LDS_KEYS];
+  __shared__ unsigned long long red[16];
+  __shared__ int sel[DGCNN_K];
   __shared__ float a5s[DGCNN_C5 * DGCNN_K];
   __shared__ float p5[DGCNN_C5 * DGCNN_T5];
   __shared__ float flat[DGCNN_FLAT];
   __shared__ float a1s[DGCNN_HID1];
   __shared__ float lg[DGCNN_MAX_C];
+  float* sp = reinterpret_cast<float*>(regionA);          // [2910]
+  float* W5s = sp + 2912;                                 // [1552]
+  float* W6s = W5s + NW5;                                 // [2560]   (2912+1552+2560)*4 = 28096 <= 32768
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-  for (int o = tid; o < KCAT; o += SP_THREADS) sp[o] = pooled[(size_t)b * KCAT + o];
+  if (SORT) {
+    const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+    dg_select_topk(x4, n0, n, regionA, red, sel);        // ends with a barrier
+    if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
+    for (int o = tid; o < KCAT; o += RD_THREADS) {
+      const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
+      const int ln = sel[s];
+      const float v = ln >= 0 ? dg_cat_load(x1, x2, x3, x4, n0 + ln, c) : 0.f;
+      sp[o] = v;
+      pooled[(size_t)b * KCAT + o] = v;
+    }
+  } else {
+    for (int o = tid; o < KCAT; o += RD_THREADS) sp[o] = pooled[(size_t)b * KCAT + o];
+  }
+  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
+  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
   __syncthreads();
   // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
-  for (int t = tid; t < DGCNN_C5 * DGCNN_K; t += SP_THREADS) {
-    const int o = t / DGCNN_K, s = t - o * DGCNN_K;
+  if (tid < DGCNN_C5 * DGCNN_K) {
+    const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
     float acc = w.b5[o];
-    const float* wr = w.W5 + o * DGCNN_CAT;
+    const float* wr = W5s + o * DGCNN_CAT;
     const float* xr = sp + s * DGCNN_CAT;
+#pragma unroll 8
     for (int m = 0; m < DGCNN_CAT; ++m) acc = fmaf(wr[m], xr[m], acc);
     acc = fmaxf(acc, 0.f);
-    a5s[t] = acc;
-    a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + t] = acc;
+    a5s[tid] = acc;
+    a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
   }
   __syncthreads();
   // MaxPool1d(2,2): [16,30] -> [16,15]
-  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
-    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
-    p5[t] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
+  if (tid < DGCNN_C5 * DGCNN_T5) {
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+    p5[tid] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
   }
   __syncthreads();
   // conv6: [16,15] -> [32,11], kernel 5, ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
-  for (int t = tid; t < DGCNN_FLAT; t += SP_THREADS) {
-    const int oc = t / DGCNN_T6, tt = t - oc * DGCNN_T6;
+  if (tid < DGCNN_FLAT) {
+    const int oc = tid / DGCNN_T6, tt = tid - oc * DGCNN_T6;
     float acc = w.b6[oc];
-    const float* wr = w.W6 + oc * (DGCNN_C5 * DGCNN_KW6);
+    const float* wr = W6s + oc * (DGCNN_C5 * DGCNN_KW6);
+#pragma unroll 4
     for (int c = 0; c < DGCNN_C5; ++c)
 #pragma unroll
       for (int d = 0; d < DGCNN_KW6; ++d) acc = fmaf(wr[c * DGCNN_KW6 + d], p5[c * DGCNN_T5 + tt + d], acc);
     acc = fmaxf(acc, 0.f);
-    flat[t] = acc;
-    a6g[(size_t)b * DGCNN_FLAT + t] = acc;
+    flat[tid] = acc;
+    a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
   }
   __syncthreads();
-  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  wave per output row, lanes across the 352 inputs
-  for (int j = wv; j < DGCNN_HID1; j += SP_THREADS / 64) {
-    const float* wr = w.Wf1 + (size_t)j * DGCNN_FLAT;
-    float acc = 0.f;
-    for (int m = lane; m < DGCNN_FLAT; m += 64) acc = fmaf(wr[m], flat[m], acc);
-    acc = dg_wave_sum(acc);
-    if (lane == 0) {
-      float a = fmaxf(acc + w.bf1[j], 0.f);
-      uint8_t keep = 1;
-      if (training) {
-        keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
-        a = keep ? a * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
+  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; 4 rows per pass so that
+  // 22 weight loads are in flight per lane before the first reduction.
+  {
+    const float f0 = flat[lane], f1 = flat[lane + 64], f2 = flat[lane + 128], f3 = flat[lane + 192],
+                f4 = flat[lane + 256], f5 = lane < 32 ? flat[lane + 320] : 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = wv * 8 + pass * 4 + u;
+        const float* wr = w.Wf1 + (size_t)j * DGCNN_FLAT;
+        float a = wr[lane] * f0;
+        a = fmaf(wr[lane + 64], f1, a);
+        a = fmaf(wr[lane + 128], f2, a);
+        a = fmaf(wr[lane + 192], f3, a);
+        a = fmaf(wr[lane + 256], f4, a);
+        if (lane < 32) a = fmaf(wr[lane + 320], f5, a);
+        acc[u] = a;
       }
-      a1s[j] = a;
-      a1dg[(size_t)b * DGCNN_HID1 + j] = a;
-      maskg[(size_t)b * DGCNN_HID1 + j] = keep;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = wv * 8 + pass * 4 + u;
+        const float tot = dg_wave_sum(acc[u]);
+        if (lane == 0) {
+          float a = fmaxf(tot + w.bf1[j], 0.f);
+          uint8_t keep = 1;
+          if (training) {
+            keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
+            a = keep ? a * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
+          }
+          a1s[j] = a;
+          a1dg[(size_t)b * DGCNN_HID1 + j] = a;
+          maskg[(size_t)b * DGCNN_HID1 + j] = keep;
+        }
+      }
     }
   }
   __syncthreads();
-  // classifier_2: 128 -> C
-  for (int c = wv; c < C; c += SP_THREADS / 64) {
+  // classifier_2: 128 -> C, wave per class
+  for (int c = wv; c < C; c += RD_THREADS / 64) {
     const float* wr = w.Wf2 + c * DGCNN_HID1;
-    float acc = fmaf(wr[lane], a1s[lane], 0.f);
+    float acc = wr[lane] * a1s[lane];
     acc = fmaf(wr[lane + 64], a1s[lane + 64], acc);
     acc = dg_wave_sum(acc);
     if (lane == 0) lg[c] = acc + w.bf2[c];
@@ -241,21 +293,23 @@ k_tail_fwd(int C, TailW w, const float* __restrict__ pooled, float* __restrict__
   }
 }
 
-int dg_launch_tail_fwd(int B, int C, const float* params, const DgParams* pl, const float* pooled,
-                       float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training,
-                       uint64_t seed, hipStream_t s) {
-  if (B <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_tail_fwd, dim3(B), dim3(SP_THREADS), 0, s, C, dg_tail_w(params, pl), pooled, a5, a6, a1d,
-                     drop_mask, logp, training, seed);
+int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                          const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
+                          int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
+                          int training, uint64_t seed, hipStream_t s) {
+  if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2,
+                     x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// tail backward (data gradients), one workgroup per graph.  Also scatters the SortPooling
-// gradient to dense per-node slabs gp1..gp3 [N,32] and produces gas4 = dinv * dL/d(pre-act of conv4).
+// readout backward (data gradients), one workgroup of 1024 threads per graph.  Also scatters the
+// SortPooling gradient to dense per-node slabs gp1..gp3 [N,32] and produces
+// gas4 = dinv * dL/d(pre-activation of conv4).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SP_THREADS)
+__global__ void __launch_bounds__(RD_THREADS)
 k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
            const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
            const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
@@ -263,8 +317,11 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv) {
+  __shared__ float W5s[NW5];
+  __shared__ float W6s[NW6];
   __shared__ float dl[DGCNN_MAX_C];
   __shared__ float gz1s[DGCNN_HID1];
+  __shared__ float gfh[2][DGCNN_FLAT];
   __shared__ float gz6s[DGCNN_FLAT];
   __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
   __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
@@ -272,6 +329,15 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
+
+  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
+  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
+  for (int t = tid; t < n * 32; t += RD_THREADS) {
+    gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
+  }
+  for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
+  if (tid < DGCNN_K) ga4s[tid] = 0.f;
 
   // 1. d(loss)/d(logits) from the upstream gradient wrt log-probs (or from labels: NLL mean)
   if (wv == 0) {
@@ -306,57 +372,65 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
   }
   __syncthreads();
-  // 3. through classifier_1 and the ReLU after conv6
-  for (int m = tid; m < DGCNN_FLAT; m += SP_THREADS) {
-    float gf = 0.f;
-    for (int j = 0; j < DGCNN_HID1; ++j) gf = fmaf(gz1s[j], w.Wf1[(size_t)j * DGCNN_FLAT + m], gf);
-    const float g6 = a6g[(size_t)b * DGCNN_FLAT + m] > 0.f ? gf : 0.f;
-    gz6s[m] = g6;
-    gz6g[(size_t)b * DGCNN_FLAT + m] = g6;
+  // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads)
+  if (tid < 2 * DGCNN_FLAT) {
+    const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
+    const float* wc = w.Wf1 + (size_t)(h * 64) * DGCNN_FLAT + m;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < 64; j += 4) {
+      g0 = fmaf(gz1s[h * 64 + j], wc[(size_t)j * DGCNN_FLAT], g0);
+      g1 = fmaf(gz1s[h * 64 + j + 1], wc[(size_t)(j + 1) * DGCNN_FLAT], g1);
+      g2 = fmaf(gz1s[h * 64 + j + 2], wc[(size_t)(j + 2) * DGCNN_FLAT], g2);
+      g3 = fmaf(gz1s[h * 64 + j + 3], wc[(size_t)(j + 3) * DGCNN_FLAT], g3);
+    }
+    gfh[h][m] = (g0 + g1) + (g2 + g3);
+  }
+  __syncthreads();
+  if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6
+    const float gf = gfh[0][tid] + gfh[1][tid];
+    const float g6 = a6g[(size_t)b * DGCNN_FLAT + tid] > 0.f ? gf : 0.f;
+    gz6s[tid] = g6;
+    gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
   __syncthreads();
   // 4. conv6 data gradient -> [16,15]
-  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
-    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
+  if (tid < DGCNN_C5 * DGCNN_T5) {
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     float acc = 0.f;
+#pragma unroll 4
     for (int oc = 0; oc < DGCNN_C6; ++oc)
 #pragma unroll
       for (int d = 0; d < DGCNN_KW6; ++d) {
         const int tt = u - d;
         if (tt >= 0 && tt < DGCNN_T6)
-          acc = fmaf(gz6s[oc * DGCNN_T6 + tt], w.W6[(oc * DGCNN_C5 + c) * DGCNN_KW6 + d], acc);
+          acc = fmaf(gz6s[oc * DGCNN_T6 + tt], W6s[(oc * DGCNN_C5 + c) * DGCNN_KW6 + d], acc);
       }
-    gp5[t] = acc;
+    gp5[tid] = acc;
   }
   __syncthreads();
   // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
-  for (int t = tid; t < DGCNN_C5 * DGCNN_T5; t += SP_THREADS) {
-    const int c = t / DGCNN_T5, u = t - c * DGCNN_T5;
-    const float a0 = a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u];
-    const float a1 = a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u + 1];
-    const float gp = gp5[t];
+  if (tid < DGCNN_C5 * DGCNN_T5) {
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+    const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
+    const float a0 = a5g[base], a1 = a5g[base + 1];
+    const float gp = gp5[tid];
     const bool first = !(a1 > a0);
     const float g0 = (first && a0 > 0.f) ? gp : 0.f;
     const float g1 = (!first && a1 > 0.f) ? gp : 0.f;
     gz5s[c * DGCNN_K + 2 * u] = g0;
     gz5s[c * DGCNN_K + 2 * u + 1] = g1;
-    gz5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u] = g0;
-    gz5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u + 1] = g1;
+    gz5g[base] = g0;
+    gz5g[base + 1] = g1;
   }
-  // 6. clear this graph's rows of the dense SortPooling-gradient slabs
-  for (int t = tid; t < n * 32; t += SP_THREADS) {
-    gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
-  }
-  for (int t = tid; t < n; t += SP_THREADS) gas4[n0 + t] = 0.f;
-  if (tid < DGCNN_K) ga4s[tid] = 0.f;
   __syncthreads();
-  // 7. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
-  for (int o = tid; o < msel * DGCNN_CAT; o += SP_THREADS) {
+  // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
+  for (int o = tid; o < msel * DGCNN_CAT; o += RD_THREADS) {
     const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
     const int node = perm[b * DGCNN_K + s];
     float v = 0.f;
 #pragma unroll
-    for (int oc = 0; oc < DGCNN_C5; ++oc) v = fmaf(gz5s[oc * DGCNN_K + s], w.W5[oc * DGCNN_CAT + c], v);
+    for (int oc = 0; oc < DGCNN_C5; ++oc) v = fmaf(gz5s[oc * DGCNN_K + s], W5s[oc * DGCNN_CAT + c], v);
     if (c < 32) gp1[(size_t)node * 32 + c] = v;
     else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
     else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
@@ -383,7 +457,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        hipStream_t s) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(SP_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
+  hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
                      x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
                      gas4, gb4p, lossv);
   DG_CHECK_LAUNCH();
@@ -391,18 +465,21 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients: one thread per output element, sequential (fixed-order) reduction over the
-// batch / over per-workgroup partials.  No floating-point atomics -> bit-reproducible.
+// weight gradients.  out[i] = sum_{r<R} term(i, r): every output is owned by a group of LPO
+// consecutive lanes (LPO in {1,8,16,64}) that stride over the reduction index r and then combine
+// with a fixed xor-butterfly -> no floating-point atomics, bit-reproducible, and the long
+// reductions (bias sums over B*30 terms, per-workgroup partials) are no longer serial chains.
 // ---------------------------------------------------------------------------------------------
-enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB };
+enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC };
 #define WG_MAX_SEG 20
 struct WgSeg {
   int type;
   int count;         // number of outputs
+  int lpo;           // lanes per output
+  int R;             // reduction length
   int block0;        // first block of this segment
-  int P;             // WG_REDUCE: number of partials ; WG_SUMB: B
-  int stride;        // WG_REDUCE: floats between partial slots
-  const float* src;  // WG_REDUCE / WG_SUMB: partial base (+offset)
+  int stride;        // WG_REDUCE: floats between partial slots ; WG_METRIC: 2
+  const float* src;  // WG_REDUCE / WG_SUMB / WG_METRIC source
   float* out;
 };
 struct WgArgs {
@@ -411,71 +488,67 @@ struct WgArgs {
   WgSeg seg[WG_MAX_SEG];
 };
 
+__device__ __forceinline__ float dg_wg_term(const WgArgs& A, const WgSeg& sg, int i, int r) {
+  const int C = A.C;
+  switch (sg.type) {
+    case WG_REDUCE: return sg.src[(size_t)r * sg.stride + i];
+    case WG_SUMB:   return sg.src[r];
+    case WG_METRIC: return sg.src[(size_t)r * 2 + i];
+    case WG_FC2W: { const int c = i / DGCNN_HID1, j = i - c * DGCNN_HID1;
+                    return A.dlogit[(size_t)r * C + c] * A.a1d[(size_t)r * DGCNN_HID1 + j]; }
+    case WG_FC2B:   return A.dlogit[(size_t)r * C + i];
+    case WG_FC1W: { const int j = i / DGCNN_FLAT, m = i - j * DGCNN_FLAT;
+                    return A.gz1[(size_t)r * DGCNN_HID1 + j] * A.a6[(size_t)r * DGCNN_FLAT + m]; }
+    case WG_FC1B:   return A.gz1[(size_t)r * DGCNN_HID1 + i];
+    case WG_C6W: {  // i = (oc*16 + c)*5 + d ; r = b*11 + t
+      const int d = i % DGCNN_KW6, c = (i / DGCNN_KW6) % DGCNN_C5, oc = i / (DGCNN_KW6 * DGCNN_C5);
+      const int b = r / DGCNN_T6, t = r - b * DGCNN_T6;
+      const float* a5b = A.a5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * (t + d);
+      return A.gz6[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + t] * fmaxf(a5b[0], a5b[1]); }
+    case WG_C6B: {  const int b = r / DGCNN_T6, t = r - b * DGCNN_T6;
+                    return A.gz6[(size_t)b * DGCNN_FLAT + i * DGCNN_T6 + t]; }
+    case WG_C5W: {  // i = o*97 + m ; r = b*30 + s
+      const int o = i / DGCNN_CAT, m = i - o * DGCNN_CAT;
+      const int b = r / DGCNN_K, s = r - b * DGCNN_K;
+      return A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K + s] * A.pooled[(size_t)b * KCAT + s * DGCNN_CAT + m]; }
+    case WG_C5B: {  const int b = r / DGCNN_K, s = r - b * DGCNN_K;
+                    return A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + i * DGCNN_K + s]; }
+  }
+  return 0.f;
+}
+
 __global__ void __launch_bounds__(256)
 k_wgrad(WgArgs A) {
   int si = 0;
   for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
   const WgSeg sg = A.seg[si];
-  const int i = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
-  if (i >= sg.count) return;
-  const int B = A.B, C = A.C;
-  float acc = 0.f;
-  switch (sg.type) {
-    case WG_REDUCE:
-      for (int p = 0; p < sg.P; ++p) acc += sg.src[(size_t)p * sg.stride + i];
-      break;
-    case WG_SUMB:
-      for (int b = 0; b < sg.P; ++b) acc += sg.src[b];
-      break;
-    case WG_FC2W: {
-      const int c = i / DGCNN_HID1, j = i - c * DGCNN_HID1;
-      for (int b = 0; b < B; ++b) acc = fmaf(A.dlogit[(size_t)b * C + c], A.a1d[(size_t)b * DGCNN_HID1 + j], acc);
-    } break;
-    case WG_FC2B:
-      for (int b = 0; b < B; ++b) acc += A.dlogit[(size_t)b * C + i];
-      break;
-    case WG_FC1W: {
-      const int j = i / DGCNN_FLAT, m = i - j * DGCNN_FLAT;
-      for (int b = 0; b < B; ++b) acc = fmaf(A.gz1[(size_t)b * DGCNN_HID1 + j], A.a6[(size_t)b * DGCNN_FLAT + m], acc);
-    } break;
-    case WG_FC1B:
-      for (int b = 0; b < B; ++b) acc += A.gz1[(size_t)b * DGCNN_HID1 + i];
-      break;
-    case WG_C6W: {   // i = (oc*16 + c)*5 + d
-      const int d = i % DGCNN_KW6, c = (i / DGCNN_KW6) % DGCNN_C5, oc = i / (DGCNN_KW6 * DGCNN_C5);
-      for (int b = 0; b < B; ++b) {
-        const float* a5b = A.a5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K;
-        const float* g6 = A.gz6 + (size_t)b * DGCNN_FLAT + oc * DGCNN_T6;
-#pragma unroll
-        for (int t = 0; t < DGCNN_T6; ++t) {
-          const float p = fmaxf(a5b[2 * (t + d)], a5b[2 * (t + d) + 1]);
-          acc = fmaf(g6[t], p, acc);
-        }
-      }
-    } break;
-    case WG_C6B:
-      for (int b = 0; b < B; ++b)
-#pragma unroll
-        for (int t = 0; t < DGCNN_T6; ++t) acc += A.gz6[(size_t)b * DGCNN_FLAT + i * DGCNN_T6 + t];
-      break;
-    case WG_C5W: {   // i = o*97 + m
-      const int o = i / DGCNN_CAT, m = i - o * DGCNN_CAT;
-      for (int b = 0; b < B; ++b) {
-        const float* g5 = A.gz5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K;
-        const float* pr = A.pooled + (size_t)b * KCAT + m;
-        for (int s = 0; s < DGCNN_K; ++s) acc = fmaf(g5[s], pr[s * DGCNN_CAT], acc);
-      }
-    } break;
-    case WG_C5B:
-      for (int b = 0; b < B; ++b)
-        for (int s = 0; s < DGCNN_K; ++s) acc += A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + i * DGCNN_K + s];
-      break;
+  const int gid = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
+  const int lpo = sg.lpo;
+  const int i = gid / lpo, r0 = gid - i * lpo;
+  const bool live = i < sg.count;
+  // 4 independent accumulators -> 4 loads in flight per lane; combined in a fixed order
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (live) {
+    const int R = sg.R;
+    int r = r0;
+    for (; r + 3 * lpo < R; r += 4 * lpo) {
+      a0 += dg_wg_term(A, sg, i, r);
+      a1 += dg_wg_term(A, sg, i, r + lpo);
+      a2 += dg_wg_term(A, sg, i, r + 2 * lpo);
+      a3 += dg_wg_term(A, sg, i, r + 3 * lpo);
+    }
+    for (; r < R; r += lpo) a0 += dg_wg_term(A, sg, i, r);
   }
-  sg.out[i] = acc;
+  float acc = (a0 + a1) + (a2 + a3);
+  for (int o = 1; o < lpo; o <<= 1) acc += __shfl_xor(acc, o);
+  if (live && r0 == 0) {
+    if (sg.type == WG_METRIC) sg.out[i] += acc;     // running loss / #correct accumulators
+    else sg.out[i] = acc;
+  }
 }
 
 int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, hipStream_t s) {
+                    float* grads, float* metrics, hipStream_t s) {
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
@@ -484,32 +557,33 @@ int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* 
   A.gz6 = dg_cptr<float>(ws, wl->gz6); A.a5 = dg_cptr<float>(ws, wl->a5);
   A.gz5 = dg_cptr<float>(ws, wl->gz5); A.pooled = dg_cptr<float>(ws, wl->pooled);
   int nb = 0, ns = 0;
-  auto add = [&](int type, int count, float* out, const float* src, int P, int stride) {
+  auto add = [&](int type, int count, int lpo, int R, float* out, const float* src, int stride) {
     WgSeg& g = A.seg[ns++];
-    g.type = type; g.count = count; g.block0 = nb; g.P = P; g.stride = stride; g.src = src; g.out = out;
-    nb += dg_cdiv(count, 256);
+    g.type = type; g.count = count; g.lpo = lpo; g.R = R; g.block0 = nb; g.stride = stride; g.src = src; g.out = out;
+    nb += dg_cdiv(count * lpo, 256);
   };
   const float* pb1 = dg_cptr<float>(ws, wl->pb1);
   const float* pb2 = dg_cptr<float>(ws, wl->pb2);
   const float* pb3 = dg_cptr<float>(ws, wl->pb3);
   const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-  // big one first so its blocks start early
-  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, grads + pl->off[12], nullptr, 0, 0);
-  add(WG_FC1B, DGCNN_HID1, grads + pl->off[13], nullptr, 0, 0);
-  add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, grads + pl->off[10], nullptr, 0, 0);
-  add(WG_C6B, DGCNN_C6, grads + pl->off[11], nullptr, 0, 0);
-  add(WG_C5W, DGCNN_C5 * DGCNN_CAT, grads + pl->off[8], nullptr, 0, 0);
-  add(WG_C5B, DGCNN_C5, grads + pl->off[9], nullptr, 0, 0);
-  add(WG_FC2W, C * DGCNN_HID1, grads + pl->off[14], nullptr, 0, 0);
-  add(WG_FC2B, C, grads + pl->off[15], nullptr, 0, 0);
-  add(WG_REDUCE, 32 * F, grads + pl->off[0], pb1, wl->P32, 32 * F);          // dW1
-  add(WG_REDUCE, 32, grads + pl->off[1], pb2 + 1024, wl->P32, 1056);          // db1 (from layer-2 backward)
-  add(WG_REDUCE, 1024, grads + pl->off[2], pb2, wl->P32, 1056);               // dW2
-  add(WG_REDUCE, 32, grads + pl->off[3], pb3 + 1024, wl->P32, 1056);          // db2 (from layer-3 backward)
-  add(WG_REDUCE, 1024, grads + pl->off[4], pb3, wl->P32, 1056);               // dW3
-  add(WG_REDUCE, 32, grads + pl->off[5], pa4 + 32, wl->P1, 64);               // db3 (from conv4 backward)
-  add(WG_REDUCE, 32, grads + pl->off[6], pa4, wl->P1, 64);                    // dW4
-  add(WG_SUMB, 1, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), B, 0);    // db4
+  const int lpoB = B >= 512 ? 8 : 1;     // classifier_1 weight: thread per output unless the batch is large
+  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, lpoB, B, grads + pl->off[12], nullptr, 0);
+  add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
+  add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
+  add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
+  add(WG_C6B, DGCNN_C6, 64, B * DGCNN_T6, grads + pl->off[11], nullptr, 0);
+  add(WG_C5B, DGCNN_C5, 64, B * DGCNN_K, grads + pl->off[9], nullptr, 0);
+  add(WG_FC2W, C * DGCNN_HID1, 8, B, grads + pl->off[14], nullptr, 0);
+  add(WG_FC2B, C, 64, B, grads + pl->off[15], nullptr, 0);
+  add(WG_REDUCE, 32 * F, 16, wl->P32, grads + pl->off[0], pb1, 32 * F);          // dW1
+  add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
+  add(WG_REDUCE, 1024, 16, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
+  add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
+  add(WG_REDUCE, 1024, 16, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
+  add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
+  add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
+  add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
+  if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
   A.nseg = ns;
   hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
   DG_CHECK_LAUNCH();

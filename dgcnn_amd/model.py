@@ -80,7 +80,7 @@ class _DGCNNFunction(torch.autograd.Function):
     """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, model, x, edge_index, batch, B, training, seed, *params):
+    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, *params):
         L = _lib.lib()
         N, F = x.shape
         E = edge_index.shape[1]
@@ -91,7 +91,8 @@ class _DGCNNFunction(torch.autograd.Function):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          edge_index.data_ptr() if E else None, batch.data_ptr(),
-                                         ws.data_ptr(), logp.data_ptr(), int(training), seed, stream),
+                                         ws.data_ptr(), logp.data_ptr(), int(training), seed, flags,
+                                         model._next_epoch(), stream),
                    "dgcnn_model_forward")
         ctx.model = model
         ctx.dims = (N, E, B, F, C, int(training))
@@ -108,14 +109,14 @@ class _DGCNNFunction(torch.autograd.Function):
         x, ws, logp = ctx.saved_tensors
         glogp = glogp.contiguous()
         flat = model.flat_params
-        grads = torch.empty_like(flat)       # fresh buffer: p.grad views stay valid until dropped
+        grads = torch.zeros_like(flat)       # fresh buffer: p.grad views stay valid until dropped
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), glogp.data_ptr(), None, 0.0, training,
-                                          grads.data_ptr(), stream), "dgcnn_model_backward")
+                                          grads.data_ptr(), None, stream), "dgcnn_model_backward")
         model._last_flat_grad = grads
         views = model._views_of(grads)
-        return (None, None, None, None, None, None, None, *views)
+        return (None, None, None, None, None, None, None, None, *views)
 
 
 class Model(nn.Module):
@@ -144,6 +145,7 @@ class Model(nn.Module):
         self._last_ws = None
         self._last_dims = None
         self._last_flat_grad = None
+        self._epoch = 0
 
     # ---- flat parameter buffer ---------------------------------------------------------
     def _param_list(self) -> List[nn.Parameter]:
@@ -207,6 +209,31 @@ class Model(nn.Module):
         self._fwd_count += 1
         return (self._seed_base * 0x9E3779B97F4A7C15 + self._fwd_count * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
+    def _next_epoch(self) -> int:
+        """non-zero 32-bit tag of a forward call (error words in the workspace are epoch-tagged)."""
+        self._epoch = (self._epoch % 0x7FFFFFFE) + 1
+        return self._epoch
+
+    @staticmethod
+    def _flags_of(data) -> int:
+        return _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
+
+    def check_errors(self) -> None:
+        """Host-side check (one tiny D2H copy = a sync) of the input-error words the most recent
+        forward left in its workspace.  The kernels never mis-compute silently: an out-of-range
+        edge endpoint or a violated ``coalesced_undirected`` promise is flagged here."""
+        if self._last_ws is None:
+            return
+        err = _lib.ws_view(self._last_ws, "err", *self._last_dims).cpu().tolist()
+        e = self._epoch
+        inv = (~e) & 0xFFFFFFFF
+        u = [v & 0xFFFFFFFF for v in err]
+        if u[0] == e and u[2] == inv:
+            raise _lib.DgcnnError("edge_index holds a node id outside [0, N)")
+        if u[1] == e and u[3] == inv:
+            raise _lib.DgcnnError("data.coalesced_undirected was promised but edge_index is not sorted by "
+                                  "(src,dst) / has duplicates or self loops / lacks a reverse edge")
+
     @staticmethod
     def _check_inputs(x, edge_index, batch):
         if not x.is_cuda:
@@ -232,7 +259,8 @@ class Model(nn.Module):
             raise _lib.DgcnnError(f"model on {flat.device}, data on {x.device}")
         training = self.training
         seed = self._next_seed() if training else 0
-        return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, *self._param_list())
+        return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, self._flags_of(data),
+                                    *self._param_list())
 
     # ---- introspection used by tests / tools ---------------------------------------------
     def last_workspace_view(self, name: str) -> torch.Tensor:

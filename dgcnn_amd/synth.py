@@ -121,7 +121,7 @@ def make_graph(shape: Shape, g: int, seed: int = BASE_SEED, force_n: Optional[in
     x = indegree_feature(ei, n, feat).contiguous()
     assert x.shape[1] == shape.num_features, (x.shape, shape)
     y = int(rng.integers(0, shape.num_classes))
-    return Graph(x=x, edge_index=ei, y=y)
+    return Graph(x=x, edge_index=ei, y=y, coalesced_undirected=True)
 
 
 def make_graphs(name: str, count: int, start: int = 0, seed: int = BASE_SEED,
@@ -155,4 +155,5 @@ def tile_batch(b: Batch, times: int) -> Batch:
     eis = torch.cat([b.edge_index + t * N for t in range(times)], 1)
     bs = torch.cat([b.batch + t * b.num_graphs for t in range(times)], 0)
     ys = None if b.y is None else b.y.repeat(times)
-    return Batch(xs, eis, bs, ys, num_graphs=b.num_graphs * times)
+    return Batch(xs, eis, bs, ys, num_graphs=b.num_graphs * times,
+                 coalesced_undirected=b.coalesced_undirected)

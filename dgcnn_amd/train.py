@@ -81,13 +81,13 @@ class Trainer:
         x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
-                                         logp.data_ptr(), training, seed, stream), "dgcnn_model_forward")
+                                         logp.data_ptr(), training, seed, m._flags_of(data), m._next_epoch(),
+                                         stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), None, y.data_ptr(), scale, training,
-                                          self.grads.data_ptr(), stream), "dgcnn_model_backward")
-        _lib.check(L.dgcnn_accumulate_metrics(B, ws.data_ptr(), N, E, F, C, self.metrics.data_ptr(), stream),
-                   "dgcnn_accumulate_metrics")
+                                          self.grads.data_ptr(), self.metrics.data_ptr(), stream),
+                   "dgcnn_model_backward")
         m._last_ws, m._last_dims = ws, (N, E, B, F, C)
         return logp[:B]
 
@@ -126,7 +126,9 @@ class Trainer:
             x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
             _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                              ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
-                                             logp.data_ptr(), 0, 0, stream), "dgcnn_model_forward")
+                                             logp.data_ptr(), 0, 0, m._flags_of(data), m._next_epoch(), stream),
+                       "dgcnn_model_forward")
+            m._last_ws, m._last_dims = ws, (N, E, B, F, C)
             lp = logp[:B]
             # metrics with plain torch ops (evaluation is not the timed hot path)
             self.metrics[0] += -lp.gather(1, y.view(-1, 1)).mean()
@@ -139,8 +141,10 @@ class Trainer:
         self.metrics.zero_()
 
     def read_metrics(self) -> Tuple[float, float]:
-        """(sum of per-batch mean losses, number correct) -- ONE host sync."""
+        """(sum of per-batch mean losses, number correct) -- ONE host sync; also surfaces any input
+        error the kernels flagged for the most recent batch."""
         v = self.metrics.tolist()
+        self.model.check_errors()
         return float(v[0]), float(v[1])
 
     # ---- epoch loops with the reference's return values ------------------------------------

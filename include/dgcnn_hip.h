@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 1
+#define DGCNN_ABI_VERSION 2
 
 /* error codes */
 #define DGCNN_OK            0
@@ -53,6 +53,14 @@ extern "C" {
 #define DGCNN_MAX_C   64   /* largest num_classes this build accepts  */
 
 typedef void* dgcnn_stream_t;   /* a hipStream_t */
+
+/* flags of dgcnn_graph_prep / dgcnn_model_forward */
+#define DGCNN_FLAG_COALESCED_UNDIRECTED 1
+/* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
+ * duplicates, no self loops, every edge present in both directions -- what a TU dataset file (and
+ * PyG coalesce/to_undirected) holds, i.e. what the reference's loader feeds model.py:27.  Graph
+ * preparation then needs no atomics and no sort (one launch).  The promise is verified on the
+ * device; a violation is reported through the error words (never silently mis-computed). */
 
 int dgcnn_version(void);
 
@@ -95,11 +103,12 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
  *   batch      [N]   int64, sorted, values in [0,B)                     model.py:27
  * Outputs: rowptr[N+1], colidx[E], rowptr_t[N+1], colidx_t[E] (int32; only the first
  * rowptr[N] entries of colidx are meaningful), dinv[N] f32, graph_ptr[B+1] int32.
- * scratch: 2*N+2 int32.  err_flag: 1 int32, set non-zero if an edge endpoint is out of range.
+ * scratch: 2*N+2 int32.  err_flag: 4 int32; afterwards err_flag[0] != 0 if an edge endpoint is
+ * out of range, err_flag[1] != 0 if DGCNN_FLAG_COALESCED_UNDIRECTED was promised but does not hold.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                      int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
-                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag,
+                     float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag, int flags,
                      dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -139,10 +148,16 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *   logp   : [B,C] f32 log-probabilities (F.log_softmax output, model.py:43)
  *   training != 0 applies Dropout(0.5) (model.py:22,42) with a counter-based mask drawn
  *            from `seed` (mask is exported in the workspace region "drop_mask" [B,128] u8)
+ *   flags  : 0 or DGCNN_FLAG_COALESCED_UNDIRECTED
+ *   epoch  : non-zero tag of this call.  Input errors are reported WITHOUT any host sync or
+ *            memset through the workspace region "err" (4 x u32): the call is in error iff
+ *            err[k] == epoch && err[k+2] == ~epoch  (k = 0: edge endpoint out of range,
+ *            k = 1: COALESCED_UNDIRECTED promised but violated).  The caller checks at its
+ *            next natural sync point.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, float* logp, int training, uint64_t seed,
+                        void* ws, float* logp, int training, uint64_t seed, int flags, uint32_t epoch,
                         dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -153,12 +168,16 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
  *                     (train.py:39,98) scaled by `loss_scale` (1/B_global for data parallel;
  *                     pass 0 for 1/B) and writes per-graph loss/correct into ws ("lossv").
  *   training: the same flag the matching dgcnn_model_forward was called with (dropout scale)
- *   grads : flat gradient buffer (same layout as params), OVERWRITTEN (not accumulated)
+ *   grads : flat gradient buffer (same layout as params); every parameter entry is OVERWRITTEN
+ *           (not accumulated); the <=3-float alignment gaps between segments are never touched,
+ *           so hand in a buffer whose gaps are zero (e.g. allocated zeroed once)
+ *   metrics: optional (label mode only) 2-float device accumulator: metrics[0] += sum_b loss_b,
+ *           metrics[1] += #correct -- replaces the two `.item()` syncs per batch of train.py:44-45
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
                          const float* glogp, const int64_t* y, float loss_scale, int training,
-                         float* grads, dgcnn_stream_t stream);
+                         float* grads, float* metrics, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam step over the flat buffer: replaces `optimizer.step(); optimizer.zero_grad()`
@@ -171,10 +190,9 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     int zero_grads, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Metrics: folds the per-graph loss / correct flags left in the workspace by
- * dgcnn_model_backward (label mode) into a device-side accumulator
- * metrics[0] += sum_b loss_b (already scaled by loss_scale), metrics[1] += #correct,
- * replacing the two `.item()` host syncs per batch of train.py:44-45.
+ * Metrics (stand-alone form of the `metrics` argument above): folds the per-graph loss /
+ * correct flags left in the workspace by dgcnn_model_backward (label mode) into
+ * metrics[0] += sum_b loss_b (already scaled by loss_scale), metrics[1] += #correct.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C,
                              float* metrics, dgcnn_stream_t stream);

@@ -52,7 +52,7 @@ def check_forward_parity(m, b_cpu, sd, logit_tol=LOGIT_TOL):
     m.eval()
     with torch.no_grad():
         logp = m(b_cpu.to("cuda")).cpu()
-    assert int(m.last_workspace_view("err")[0].item()) == 0
+    m.check_errors()
     _, aux = ref_dense.forward_dense(sd, b_cpu.x, b_cpu.edge_index, b_cpu.batch, b_cpu.num_graphs, return_all=True)
     xc = gpu_xcat(m)
     err_x = float((xc.double() - aux["xcat"].detach()).abs().max())

@@ -17,7 +17,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def run_prep(ei, batch, N, B):
+def run_prep(ei, batch, N, B, flags=0):
     L = _lib.lib()
     E = ei.shape[1]
     ei_d, b_d = ei.to(DEV).contiguous(), batch.to(DEV).contiguous()
@@ -28,12 +28,13 @@ def run_prep(ei, batch, N, B):
     dinv = torch.empty(N, dtype=torch.float32, device=DEV)
     gptr = torch.empty(B + 1, dtype=torch.int32, device=DEV)
     scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
-    err = torch.ones(1, dtype=torch.int32, device=DEV)
+    err = torch.ones(4, dtype=torch.int32, device=DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, b_d.data_ptr(), N, B, rowptr.data_ptr(),
                                   colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
-                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), _stream()), "prep")
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), flags, _stream()), "prep")
     torch.cuda.synchronize()
-    return rowptr.cpu(), colidx.cpu(), rowptr_t.cpu(), colidx_t.cpu(), dinv.cpu(), gptr.cpu(), int(err.item())
+    e = err.cpu().tolist()
+    return rowptr.cpu(), colidx.cpu(), rowptr_t.cpu(), colidx_t.cpu(), dinv.cpu(), gptr.cpu(), (e[0], e[1])
 
 
 def csr_reference(ei, N):
@@ -98,7 +99,7 @@ def test_graph_prep_bit_exact(case):
         batch, N = torch.tensor([0, 0, 1, 2, 4]), 5     # graph 3 is EMPTY, graphs 1,2,4 single nodes
     B = int(batch.max()) + 1
     rp, ci, rpt, cit, dinv, gptr, err = run_prep(ei, batch, N, B)
-    assert err == 0
+    assert err == (0, 0)
     erp, eci, erpt, ecit, indeg = csr_reference(ei, N)
     np.testing.assert_array_equal(rp.numpy(), erp)
     np.testing.assert_array_equal(rpt.numpy(), erpt)
@@ -113,7 +114,41 @@ def test_graph_prep_bit_exact(case):
 def test_graph_prep_flags_out_of_range_edges():
     ei = torch.tensor([[0, 1, 7], [1, 0, 0]])
     *_, err = run_prep(ei, torch.zeros(3, dtype=torch.int64), 3, 1)
-    assert err != 0
+    assert err[0] != 0
+
+
+@pytest.mark.parametrize("name", ["MUTAG", "COLLAB", "DD"])
+def test_graph_prep_fast_path_equals_general_path(name):
+    """DGCNN_FLAG_COALESCED_UNDIRECTED (no atomics, no sort, one launch) gives bit-identical structure."""
+    b = synth.make_batch(name, 20, start=400)
+    assert b.coalesced_undirected
+    gen = run_prep(b.edge_index, b.batch, b.num_nodes, b.num_graphs, 0)
+    fast = run_prep(b.edge_index, b.batch, b.num_nodes, b.num_graphs, _lib.FLAG_COALESCED_UNDIRECTED)
+    assert fast[6] == (0, 0) and gen[6] == (0, 0)
+    nnz = int(gen[0][-1])
+    for a, c in zip(gen[:6], fast[:6]):
+        if a.numel() == b.num_edges:
+            assert torch.equal(a[:nnz], c[:nnz])
+        else:
+            assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("violation", ["unsorted", "missing_reverse", "self_loop", "duplicate"])
+def test_graph_prep_fast_path_detects_broken_promise(violation):
+    b = synth.make_batch("PROTEINS", 4, start=10)
+    ei = b.edge_index.clone()
+    if violation == "unsorted":
+        ei[:, [0, 1]] = ei[:, [1, 0]]
+    elif violation == "missing_reverse":
+        s, d = int(ei[0, 5]), int(ei[1, 5])
+        keep = ~((ei[0] == d) & (ei[1] == s))
+        ei = ei[:, keep]
+    elif violation == "self_loop":
+        ei[1, 3] = ei[0, 3]
+    else:
+        ei = torch.cat([ei[:, :4], ei[:, 3:]], 1)
+    *_, err = run_prep(ei, b.batch, b.num_nodes, b.num_graphs, _lib.FLAG_COALESCED_UNDIRECTED)
+    assert err[1] != 0
 
 
 def run_gcn(x, ei, W, b, Fout):
@@ -129,11 +164,11 @@ def run_gcn(x, ei, W, b, Fout):
     dinv = torch.empty(N, dtype=torch.float32, device=DEV)
     gptr = torch.empty(2, dtype=torch.int32, device=DEV)
     scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
-    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    err = torch.zeros(4, dtype=torch.int32, device=DEV)
     bd = batch.to(DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, bd.data_ptr(), N, 1, rowptr.data_ptr(),
                                   colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
-                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), _stream()), "prep")
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), 0, _stream()), "prep")
     xd, Wd, bd2 = x.to(DEV).contiguous(), W.to(DEV).contiguous(), b.to(DEV).contiguous()
     out = torch.full((N, Fout), float("nan"), device=DEV)
     hs = torch.empty(N, Fout, device=DEV)

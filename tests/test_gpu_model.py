@@ -66,6 +66,40 @@ def test_edge_cases_isolated_selfloops_single_graph_empty_edges():
     check_backward_parity(m, b2, sd)
 
 
+def test_broken_layout_promise_is_reported_not_miscomputed():
+    from dgcnn_amd import _lib
+    from dgcnn_amd.batch import Batch
+    sh = synth.SHAPES["MUTAG"]
+    b = synth.make_batch("MUTAG", 4, start=5)
+    ei = b.edge_index.clone()
+    ei[:, [0, 1]] = ei[:, [1, 0]]                      # no longer sorted by (src,dst)
+    m = make_model(sh.num_features, sh.num_classes).eval()
+    sd = cpu_state_dict(m)
+    with torch.no_grad():
+        m(Batch(b.x, ei, b.batch, b.y, coalesced_undirected=True).to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+    # without the promise the general path handles the same edge list correctly
+    check_forward_parity(m, Batch(b.x, ei, b.batch, b.y), sd)
+    # out-of-range node id
+    ei2 = b.edge_index.clone(); ei2[0, 0] = b.num_nodes + 3
+    with torch.no_grad():
+        m(Batch(b.x, ei2, b.batch, b.y).to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+
+
+def test_fast_and_general_prep_paths_give_identical_model_output():
+    from dgcnn_amd.batch import Batch
+    sh = synth.SHAPES["COLLAB"]
+    b = synth.make_batch("COLLAB", 12, start=3000)
+    m = make_model(sh.num_features, sh.num_classes).eval()
+    with torch.no_grad():
+        fast = m(b.to("cuda")).clone()
+        gen = m(Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=False).to("cuda")).clone()
+    assert torch.equal(fast, gen)
+
+
 def test_result_independent_of_batch_composition():
     """a graph's log-probs do not depend on which other graphs share the batch."""
     sh = synth.SHAPES["PROTEINS"]
