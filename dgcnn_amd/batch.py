@@ -51,10 +51,10 @@ class Batch:
     /root/reference/train.py:36 (``sample.to(device)``) and returns a new Batch.
     """
 
-    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected")
+    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected", "max_nodes")
 
     def __init__(self, x, edge_index, batch, y=None, num_graphs: Optional[int] = None,
-                 coalesced_undirected: bool = False):
+                 coalesced_undirected: bool = False, max_nodes: int = 0):
         if x.dim() != 2:
             raise ValueError(f"x must be [N,F], got {tuple(x.shape)}")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -74,6 +74,9 @@ class Batch:
         # host-side promise about the edge list layout (see DGCNN_FLAG_COALESCED_UNDIRECTED in
         # include/dgcnn_hip.h); verified on the device, never trusted blindly
         self.coalesced_undirected = bool(coalesced_undirected)
+        # host-known upper bound of the node count of any single graph (0 = unknown); lets the
+        # forward pick the graph-per-workgroup kernel without a device sync.  Verified on the device.
+        self.max_nodes = int(max_nodes)
 
     @property
     def num_nodes(self) -> int:
@@ -86,12 +89,12 @@ class Batch:
     def to(self, device, non_blocking: bool = False) -> "Batch":
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)
         return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
-                     self.coalesced_undirected)
+                     self.coalesced_undirected, self.max_nodes)
 
     def pin_memory(self) -> "Batch":
         mv = lambda t: None if t is None else t.pin_memory()
         return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
-                     self.coalesced_undirected)
+                     self.coalesced_undirected, self.max_nodes)
 
     def __repr__(self) -> str:
         return (f"Batch(graphs={self.num_graphs}, nodes={self.num_nodes}, "
@@ -117,7 +120,8 @@ def collate(graphs: Sequence[Graph]) -> Batch:
                  torch.cat(eis, 1).contiguous(),
                  torch.cat(bs, 0),
                  torch.tensor(ys, dtype=torch.int64),
-                 num_graphs=len(graphs), coalesced_undirected=cu)
+                 num_graphs=len(graphs), coalesced_undirected=cu,
+                 max_nodes=max(gr.num_nodes for gr in graphs))
 
 
 def indegree_feature(edge_index: torch.Tensor, num_nodes: int,
@@ -178,5 +182,6 @@ def split_batch(b: Batch, parts: int) -> List[Batch]:
         dev = b.x.device
         out.append(Batch(b.x[n0:n1], sub_ei.to(dev), (b.batch[n0:n1] - g0),
                          None if b.y is None else b.y[g0:g1], num_graphs=g1 - g0,
-                         coalesced_undirected=b.coalesced_undirected))
+                         coalesced_undirected=b.coalesced_undirected,
+                         max_nodes=int(n_per[g0:g1].max())))
     return out

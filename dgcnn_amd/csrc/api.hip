@@ -36,6 +36,11 @@ int dgcnn_event_destroy(void* ev) {
   return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
 }
 
+int dgcnn_fused_max_nodes(int F) {
+  if (F < 1 || F > DGCNN_MAX_F) return 0;
+  return dg_fused_max_nodes(F);
+}
+
 int dgcnn_version(void) { return DGCNN_ABI_VERSION; }
 
 int64_t dgcnn_param_layout(int F, int C, int64_t offsets[DGCNN_NUM_PARAM_SEGMENTS]) {
@@ -105,8 +110,8 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, float* logp, int training, uint64_t seed, int flags, uint32_t epoch,
-                        dgcnn_stream_t stream) {
+                        void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
+                        uint32_t epoch, dgcnn_stream_t stream) {
   if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   DgParams pl; DgWs wl;
@@ -127,6 +132,18 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
+  if (max_nodes > 0 && max_nodes <= dg_fused_max_nodes(F)) {
+    // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
+    const int nmax = ((max_nodes + 15) / 16) * 16;
+    DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, params, &pl, x, rowptr, colidx, dinv,
+                               dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
+                               dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
+                               dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,
+                               dg_ptr<int32_t>(ws, wl.err), epoch, s,
+                               g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
+    g_prof_which = -1;
+    return DGCNN_OK;
+  }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));

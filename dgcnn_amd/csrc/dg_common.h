@@ -219,6 +219,13 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                           int training, uint64_t seed, hipStream_t s);
+int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, const float* params, const DgParams* pl,
+                        const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
+                        const int32_t* graph_ptr, float* x1, float* x2, float* x3, float* x4, float* pooled,
+                        int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
+                        int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+int dg_fused_max_nodes(int F);
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,

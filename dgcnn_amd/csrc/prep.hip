@@ -162,49 +162,40 @@ k_prep_zero(int N, int* __restrict__ cnt_in, int* __restrict__ cnt_out) {
 //   rowptr[i] = lower_bound(src, i),  colidx[e] = dst[e],  indeg = outdeg = rowptr[i+1]-rowptr[i].
 // No atomics, no sort, ONE launch.  The promise is VERIFIED on the device (sortedness, range, no self
 // loop, and the reverse edge found by binary search); a violation writes the epoch tag to err[1]/err[3].
-__device__ __forceinline__ int dg_lower_bound64(const int64_t* __restrict__ a, int n, int64_t key) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
+// Kernel A (per edge, O(1) each): range / self-loop / strict (src,dst) order checks, colidx copies,
+// and rowptr by ROW-BOUNDARY detection: the thread at the first edge of source s writes rowptr[k] = t
+// for every k in (previous source, s] (nodes without edges get empty rows); the last edge's thread
+// closes rowptr[(src_last, N]] = E.  graph_ptr by binary search on the sorted batch vector.
 __global__ void __launch_bounds__(256)
-k_prep_fast(const int64_t* __restrict__ ei, int E, int N, const int64_t* __restrict__ batch, int B,
-            int* __restrict__ rowptr, int* __restrict__ colidx, int* __restrict__ rowptr_t,
-            int* __restrict__ colidx_t, float* __restrict__ dinv, int* __restrict__ graph_ptr,
-            unsigned int* __restrict__ err, unsigned int epoch) {
+k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __restrict__ batch, int B,
+              int* __restrict__ rowptr, int* __restrict__ colidx, int* __restrict__ rowptr_t,
+              int* __restrict__ colidx_t, int* __restrict__ graph_ptr, unsigned int* __restrict__ err,
+              unsigned int epoch) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t* src = ei;
   const int64_t* dst = ei + E;
   if (t < E) {
     const int64_t s = src[t], d = dst[t];
-    bool bad = (uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N || s == d;
+    const bool range = (uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N;
+    bool bad = range || s == d;
+    int64_t ps = -1;
     if (t > 0) {
-      const int64_t ps = src[t - 1], pd = dst[t - 1];
+      ps = src[t - 1];
+      const int64_t pd = dst[t - 1];
       bad = bad || !(ps < s || (ps == s && pd < d));
     }
-    if (!bad) {   // reverse edge (d, s) must exist
-      const int lo = dg_lower_bound64(src, E, d), hi = dg_lower_bound64(src, E, d + 1);
-      const int pos = lo + dg_lower_bound64(dst + lo, hi - lo, s);
-      bad = !(pos < hi && dst[pos] == s);
-    }
-    if (bad) {
-      const bool range = (uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N;
-      err[range ? 0 : 1] = epoch; err[range ? 2 : 3] = ~epoch;
-    }
-    colidx[t] = (int)d;
-    colidx_t[t] = (int)d;
-  }
-  if (t <= N) {
-    const int lo = dg_lower_bound64(src, E, (int64_t)t);
-    rowptr[t] = lo; rowptr_t[t] = lo;
-    if (t < N) {
-      const int hi = dg_lower_bound64(src, E, (int64_t)t + 1);
-      dinv[t] = 1.0f / sqrtf((float)(hi - lo + 1));
-    }
+    if (bad) { err[range ? 0 : 1] = epoch; err[range ? 2 : 3] = ~epoch; }
+    // memory safety even when the promise is broken: clamp everything that later indexes memory, so a
+    // flagged batch yields garbage numbers but never an out-of-bounds access
+    const int dc = (uint64_t)d < (uint64_t)N ? (int)d : 0;
+    const int sc = s < 0 ? 0 : (s >= N ? N - 1 : (int)s);
+    const int pc = ps < 0 ? -1 : (ps >= N ? N - 1 : (int)ps);
+    colidx[t] = dc;
+    colidx_t[t] = dc;
+    if (pc < sc || t == 0)
+      for (int k = pc + 1; k <= sc; ++k) { rowptr[k] = t; rowptr_t[k] = t; }
+    if (t == E - 1)
+      for (int k = sc + 1; k <= N; ++k) { rowptr[k] = E; rowptr_t[k] = E; }
   }
   if (t <= B) {
     int lo = 0, hi = N;
@@ -213,6 +204,28 @@ k_prep_fast(const int64_t* __restrict__ ei, int E, int N, const int64_t* __restr
       if (batch[mid] < (int64_t)t) lo = mid + 1; else hi = mid;
     }
     graph_ptr[t] = lo;
+  }
+}
+
+// Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
+// search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.
+__global__ void __launch_bounds__(256)
+k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, const int* __restrict__ rowptr,
+              const int* __restrict__ colidx, float* __restrict__ dinv, unsigned int* __restrict__ err,
+              unsigned int epoch) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N) dinv[t] = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
+  if (t < E) {
+    const int64_t s = ei[t], d = ei[(int64_t)E + t];
+    if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
+      const int end = rowptr[d + 1];
+      int a = rowptr[d], b = end;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (colidx[mid] < (int)s) a = mid + 1; else b = mid;
+      }
+      if (!(a < end && colidx[a] == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
+    }
   }
 }
 
@@ -225,8 +238,11 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
     int work = E > N + 1 ? E : N + 1;
     if (B + 1 > work) work = B + 1;
-    hipLaunchKernelGGL(k_prep_fast, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
-                       colidx, rowptr_t, colidx_t, dinv, graph_ptr, uerr, epoch);
+    hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
+                       colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
+    DG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(E > N ? E : N, 256)), dim3(256), 0, s, edge_index, E, N, rowptr,
+                       colidx, dinv, uerr, epoch);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }

@@ -16,73 +16,7 @@
 //   n <= 4096 : bitonic network in LDS
 //   n  > 4096 : k rounds of workgroup-wide arg-min selection (keys stay in HBM/L2)
 #include "dg_common.h"
-
-#define SP_THREADS 256
-#define SP_LDS_KEYS 4096
-#define KCAT (DGCNN_K * DGCNN_CAT)   // 2910
-
-__device__ __forceinline__ unsigned long long dg_pack_key(float key, int idx) {
-  key = key + 0.0f;                       // -0.0 -> +0.0 so signed zeros tie like in torch.sort
-  unsigned int u = __float_as_uint(key);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order-preserving map
-  u = ~u;                                            // descending key
-  return ((unsigned long long)u << 32) | (unsigned int)idx;
-}
-
-// selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none).
-// Works for any workgroup size that is a multiple of 64 (<= 1024).
-__device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
-                               unsigned long long* red, int* sel) {
-  const int tid = threadIdx.x, T = blockDim.x;
-  const int m = n < DGCNN_K ? n : DGCNN_K;
-  if (tid < DGCNN_K) sel[tid] = -1;
-  __syncthreads();
-  if (n <= 256) {
-    if (tid < n) keys[tid] = dg_pack_key(x4[n0 + tid], tid);
-    __syncthreads();
-    if (tid < n) {
-      const unsigned long long my = keys[tid];
-      int rank = 0;
-      for (int j = 0; j < n; ++j) rank += keys[j] < my ? 1 : 0;
-      if (rank < DGCNN_K) sel[rank] = tid;
-    }
-  } else if (n <= SP_LDS_KEYS) {
-    for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
-    __syncthreads();
-    dg_block_bitonic<unsigned long long>(keys, n);
-    if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
-  } else {
-    unsigned long long prev = 0ull;
-    for (int r = 0; r < m; ++r) {
-      unsigned long long best = ~0ull;
-      for (int t = tid; t < n; t += T) {
-        const unsigned long long p = dg_pack_key(x4[n0 + t], t);
-        if ((r == 0 || p > prev) && p < best) best = p;
-      }
-      for (int o = 32; o > 0; o >>= 1) {       // workgroup min: wave shuffle then LDS
-        const unsigned long long other = __shfl_xor(best, o);
-        best = other < best ? other : best;
-      }
-      if ((tid & 63) == 0) red[tid >> 6] = best;
-      __syncthreads();
-      unsigned long long b0 = red[0];
-      for (int w = 1; w < T / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
-      prev = b0;
-      if (tid == 0) sel[r] = (int)(b0 & 0xffffffffull);
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ float dg_cat_load(const float* __restrict__ x1, const float* __restrict__ x2,
-                                             const float* __restrict__ x3, const float* __restrict__ x4,
-                                             int node, int c) {
-  if (c < 32) return x1[(size_t)node * 32 + c];
-  if (c < 64) return x2[(size_t)node * 32 + c - 32];
-  if (c < 96) return x3[(size_t)node * 32 + c - 64];
-  return x4[node];
-}
+#include "dg_readout.h"
 
 __global__ void __launch_bounds__(SP_THREADS)
 k_sortpool_fwd(const int* __restrict__ graph_ptr, const float* __restrict__ x1, const float* __restrict__ x2,
@@ -147,150 +81,19 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 // LDS plan (bytes): region A 32 KiB = sort keys, afterwards reused for the pooled rows (11640),
 // conv5 weights (6208) and conv6 weights (10240); small activations after it.
 // ---------------------------------------------------------------------------------------------
-#define RD_THREADS 1024
-struct TailW {   // device pointers into the flat parameter buffer
-  const float *W5, *b5, *W6, *b6, *Wf1, *bf1, *Wf2, *bf2;
-};
-static inline TailW dg_tail_w(const float* params, const DgParams* pl) {
-  TailW w;
-  w.W5 = params + pl->off[8];  w.b5 = params + pl->off[9];
-  w.W6 = params + pl->off[10]; w.b6 = params + pl->off[11];
-  w.Wf1 = params + pl->off[12]; w.bf1 = params + pl->off[13];
-  w.Wf2 = params + pl->off[14]; w.bf2 = params + pl->off[15];
-  return w;
-}
-#define NW5 (DGCNN_C5 * DGCNN_CAT)                 // 1552
-#define NW6 (DGCNN_C6 * DGCNN_C5 * DGCNN_KW6)      // 2560
-
-// SORT = true: do the SortPooling selection/gather here (graph_ptr, x1..x4 given, pooled/perm written)
-// SORT = false: `pooled` is an input (stand-alone tail on precomputed rows)
-template <bool SORT>
 __global__ void __launch_bounds__(RD_THREADS)
 k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
               float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
               uint64_t seed) {
-  __shared__ __attribute__((aligned(16))) unsigned long long regionA[SP_LDS_KEYS];
-  __shared__ unsigned long long red[16];
-  __shared__ int sel[DGCNN_K];
-  __shared__ float a5s[DGCNN_C5 * DGCNN_K];
-  __shared__ float p5[DGCNN_C5 * DGCNN_T5];
-  __shared__ float flat[DGCNN_FLAT];
-  __shared__ float a1s[DGCNN_HID1];
-  __shared__ float lg[DGCNN_MAX_C];
-  float* sp = reinterpret_cast<float*>(regionA);          // [2910]
-  float* W5s = sp + 2912;                                 // [1552]
-  float* W6s = W5s + NW5;                                 // [2560]   (2912+1552+2560)*4 = 28096 <= 32768
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-  if (SORT) {
-    const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
-    dg_select_topk(x4, n0, n, regionA, red, sel);        // ends with a barrier
-    if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
-    for (int o = tid; o < KCAT; o += RD_THREADS) {
-      const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
-      const int ln = sel[s];
-      const float v = ln >= 0 ? dg_cat_load(x1, x2, x3, x4, n0 + ln, c) : 0.f;
-      sp[o] = v;
-      pooled[(size_t)b * KCAT + o] = v;
-    }
-  } else {
-    for (int o = tid; o < KCAT; o += RD_THREADS) sp[o] = pooled[(size_t)b * KCAT + o];
-  }
-  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
-  __syncthreads();
-  // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
-  if (tid < DGCNN_C5 * DGCNN_K) {
-    const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
-    float acc = w.b5[o];
-    const float* wr = W5s + o * DGCNN_CAT;
-    const float* xr = sp + s * DGCNN_CAT;
-#pragma unroll 8
-    for (int m = 0; m < DGCNN_CAT; ++m) acc = fmaf(wr[m], xr[m], acc);
-    acc = fmaxf(acc, 0.f);
-    a5s[tid] = acc;
-    a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
-  }
-  __syncthreads();
-  // MaxPool1d(2,2): [16,30] -> [16,15]
-  if (tid < DGCNN_C5 * DGCNN_T5) {
-    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
-    p5[tid] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
-  }
-  __syncthreads();
-  // conv6: [16,15] -> [32,11], kernel 5, ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
-  if (tid < DGCNN_FLAT) {
-    const int oc = tid / DGCNN_T6, tt = tid - oc * DGCNN_T6;
-    float acc = w.b6[oc];
-    const float* wr = W6s + oc * (DGCNN_C5 * DGCNN_KW6);
-#pragma unroll 4
-    for (int c = 0; c < DGCNN_C5; ++c)
-#pragma unroll
-      for (int d = 0; d < DGCNN_KW6; ++d) acc = fmaf(wr[c * DGCNN_KW6 + d], p5[c * DGCNN_T5 + tt + d], acc);
-    acc = fmaxf(acc, 0.f);
-    flat[tid] = acc;
-    a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
-  }
-  __syncthreads();
-  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; 4 rows per pass so that
-  // 22 weight loads are in flight per lane before the first reduction.
-  {
-    const float f0 = flat[lane], f1 = flat[lane + 64], f2 = flat[lane + 128], f3 = flat[lane + 192],
-                f4 = flat[lane + 256], f5 = lane < 32 ? flat[lane + 320] : 0.f;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      float acc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = wv * 8 + pass * 4 + u;
-        const float* wr = w.Wf1 + (size_t)j * DGCNN_FLAT;
-        float a = wr[lane] * f0;
-        a = fmaf(wr[lane + 64], f1, a);
-        a = fmaf(wr[lane + 128], f2, a);
-        a = fmaf(wr[lane + 192], f3, a);
-        a = fmaf(wr[lane + 256], f4, a);
-        if (lane < 32) a = fmaf(wr[lane + 320], f5, a);
-        acc[u] = a;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = wv * 8 + pass * 4 + u;
-        const float tot = dg_wave_sum(acc[u]);
-        if (lane == 0) {
-          float a = fmaxf(tot + w.bf1[j], 0.f);
-          uint8_t keep = 1;
-          if (training) {
-            keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
-            a = keep ? a * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
-          }
-          a1s[j] = a;
-          a1dg[(size_t)b * DGCNN_HID1 + j] = a;
-          maskg[(size_t)b * DGCNN_HID1 + j] = keep;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // classifier_2: 128 -> C, wave per class
-  for (int c = wv; c < C; c += RD_THREADS / 64) {
-    const float* wr = w.Wf2 + c * DGCNN_HID1;
-    float acc = wr[lane] * a1s[lane];
-    acc = fmaf(wr[lane + 64], a1s[lane + 64], acc);
-    acc = dg_wave_sum(acc);
-    if (lane == 0) lg[c] = acc + w.bf2[c];
-  }
-  __syncthreads();
-  // log_softmax over C (C <= 64): wave 0
-  if (wv == 0) {
-    const float v = lane < C ? lg[lane] : -INFINITY;
-    float mx = v;
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float e = lane < C ? expf(v - mx) : 0.f;
-    e = dg_wave_sum(e);
-    if (lane < C) logp[(size_t)b * C + lane] = (v - mx) - logf(e);
-  }
+  __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
+  __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
+  const RdSmem M = dg_rd_carve(region0, small);
+  const int b = blockIdx.x;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  dg_readout_fwd_body(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
+                      training, seed);
 }
 
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
@@ -298,7 +101,7 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                           int training, uint64_t seed, hipStream_t s) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2,
+  hipLaunchKernelGGL(k_readout_fwd, dim3(B), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2,
                      x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
@@ -566,8 +369,7 @@ int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* 
   const float* pb2 = dg_cptr<float>(ws, wl->pb2);
   const float* pb3 = dg_cptr<float>(ws, wl->pb3);
   const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-  const int lpoB = B >= 512 ? 8 : 1;     // classifier_1 weight: thread per output unless the batch is large
-  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, lpoB, B, grads + pl->off[12], nullptr, 0);
+  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, 8, B, grads + pl->off[12], nullptr, 0);
   add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
   add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
   add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);

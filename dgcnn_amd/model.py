@@ -80,7 +80,7 @@ class _DGCNNFunction(torch.autograd.Function):
     """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, *params):
+    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, max_nodes, *params):
         L = _lib.lib()
         N, F = x.shape
         E = edge_index.shape[1]
@@ -92,7 +92,7 @@ class _DGCNNFunction(torch.autograd.Function):
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          edge_index.data_ptr() if E else None, batch.data_ptr(),
                                          ws.data_ptr(), logp.data_ptr(), int(training), seed, flags,
-                                         model._next_epoch(), stream),
+                                         max_nodes, model._next_epoch(), stream),
                    "dgcnn_model_forward")
         ctx.model = model
         ctx.dims = (N, E, B, F, C, int(training))
@@ -116,7 +116,7 @@ class _DGCNNFunction(torch.autograd.Function):
                                           grads.data_ptr(), None, stream), "dgcnn_model_backward")
         model._last_flat_grad = grads
         views = model._views_of(grads)
-        return (None, None, None, None, None, None, None, None, *views)
+        return (None, None, None, None, None, None, None, None, None, *views)
 
 
 class Model(nn.Module):
@@ -218,6 +218,12 @@ class Model(nn.Module):
     def _flags_of(data) -> int:
         return _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
 
+    def _max_nodes_of(self, data) -> int:
+        """per-graph node bound for the fused path; honours ``self.use_fused`` (tests flip it)."""
+        if not getattr(self, "use_fused", True):
+            return 0
+        return int(getattr(data, "max_nodes", 0) or 0)
+
     def check_errors(self) -> None:
         """Host-side check (one tiny D2H copy = a sync) of the input-error words the most recent
         forward left in its workspace.  The kernels never mis-compute silently: an out-of-range
@@ -231,8 +237,10 @@ class Model(nn.Module):
         if u[0] == e and u[2] == inv:
             raise _lib.DgcnnError("edge_index holds a node id outside [0, N)")
         if u[1] == e and u[3] == inv:
-            raise _lib.DgcnnError("data.coalesced_undirected was promised but edge_index is not sorted by "
-                                  "(src,dst) / has duplicates or self loops / lacks a reverse edge")
+            raise _lib.DgcnnError("a host-side promise about the batch does not hold: coalesced_undirected "
+                                  "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
+                                  "present), max_nodes (too small), or block-diagonality (an edge leaves its "
+                                  "graph) -- the forward result of this batch is invalid")
 
     @staticmethod
     def _check_inputs(x, edge_index, batch):
@@ -260,7 +268,7 @@ class Model(nn.Module):
         training = self.training
         seed = self._next_seed() if training else 0
         return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, self._flags_of(data),
-                                    *self._param_list())
+                                    self._max_nodes_of(data), *self._param_list())
 
     # ---- introspection used by tests / tools ---------------------------------------------
     def last_workspace_view(self, name: str) -> torch.Tensor:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 2
+#define DGCNN_ABI_VERSION 3
 
 /* error codes */
 #define DGCNN_OK            0
@@ -51,6 +51,7 @@ extern "C" {
 #define DGCNN_HID1   128   /* Linear(352,128)                  model.py:21    */
 #define DGCNN_MAX_F  512   /* largest num_features this build accepts */
 #define DGCNN_MAX_C   64   /* largest num_classes this build accepts  */
+#define DGCNN_FUSED_MAX_NODES 576  /* upper bound of the graph-per-workgroup path (LDS capacity) */
 
 typedef void* dgcnn_stream_t;   /* a hipStream_t */
 
@@ -149,6 +150,11 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *   training != 0 applies Dropout(0.5) (model.py:22,42) with a counter-based mask drawn
  *            from `seed` (mask is exported in the workspace region "drop_mask" [B,128] u8)
  *   flags  : 0 or DGCNN_FLAG_COALESCED_UNDIRECTED
+ *   max_nodes: host-known upper bound of the node count of any single graph of the batch
+ *            (PyG's collate knows it; 0 = unknown).  When 0 < max_nodes <= dgcnn_fused_max_nodes(F)
+ *            the graph-per-workgroup fused kernel runs (whole forward in one launch, activations in
+ *            LDS); otherwise the general tiled kernels.  Both give bit-identical results.  A hint
+ *            that is too small is detected on the device and reported through the error words.
  *   epoch  : non-zero tag of this call.  Input errors are reported WITHOUT any host sync or
  *            memset through the workspace region "err" (4 x u32): the call is in error iff
  *            err[k] == epoch && err[k+2] == ~epoch  (k = 0: edge endpoint out of range,
@@ -157,8 +163,9 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, float* logp, int training, uint64_t seed, int flags, uint32_t epoch,
-                        dgcnn_stream_t stream);
+                        void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
+                        uint32_t epoch, dgcnn_stream_t stream);
+int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
 
 /* ------------------------------------------------------------------------------------
  * Whole-model backward: what `loss.backward()` (/root/reference/train.py:40) executes for
@@ -202,7 +209,8 @@ int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C,
  * dgcnn_profile_next_forward arms a ONE-SHOT, thread-local request: the next
  * dgcnn_model_forward issued by this thread records ev_start / ev_stop (hipEvent_t created
  * with dgcnn_event_create) on its stream immediately around the `which`-th 32-wide
- * aggregation launch (0 = conv1, 1 = conv2, 2 = conv3).  The other calls are thin wrappers
+ * aggregation launch (0 = conv1, 1 = conv2, 2 = conv3), or around the single fused forward kernel
+ * when that path runs.  The other calls are thin wrappers
  * of hipEventCreate / hipEventRecord / hipEventSynchronize+hipEventElapsedTime /
  * hipEventDestroy so the bench does not need a second HIP binding.
  * ---------------------------------------------------------------------------------- */

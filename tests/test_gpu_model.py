@@ -100,6 +100,58 @@ def test_fast_and_general_prep_paths_give_identical_model_output():
     assert torch.equal(fast, gen)
 
 
+@pytest.mark.parametrize("name,bs", [("MUTAG", 50), ("PROTEINS", 50), ("COLLAB", 50), ("COLLAB_REAL", 20), ("DD", 6)])
+def test_fused_graph_per_workgroup_path_is_bit_identical_to_tiled_path(name, bs):
+    from dgcnn_amd import _lib
+    sh = synth.SHAPES[name]
+    b = synth.make_batch(name, bs, start=700)
+    lim = _lib.lib().dgcnn_fused_max_nodes(sh.num_features)
+    if b.max_nodes > lim:
+        pytest.skip(f"largest graph {b.max_nodes} > fused limit {lim}")
+    m = make_model(sh.num_features, sh.num_classes)
+    bg = b.to("cuda")
+    outs = {}
+    for fused in (True, False):
+        m.use_fused = fused
+        m.train(); m._seed_base, m._fwd_count = 5, 0
+        lp = m(bg)
+        torch.nn.functional.nll_loss(lp, bg.y).backward()
+        outs[fused] = (lp.detach().clone(), m._last_flat_grad.clone(),
+                       m.last_workspace_view("x3").clone(), m.last_workspace_view("perm").clone())
+        m.check_errors()
+    for a, c in zip(outs[True], outs[False]):
+        assert torch.equal(a, c)
+
+
+def test_fused_path_flags_bad_hints():
+    from dgcnn_amd import _lib
+    from dgcnn_amd.batch import Batch
+    sh = synth.SHAPES["PROTEINS"]
+    b = synth.make_batch("PROTEINS", 6, start=20)
+    m = make_model(sh.num_features, sh.num_classes).eval()
+    # max_nodes hint smaller than the largest graph
+    small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=max(b.max_nodes - 1, 1))
+    with torch.no_grad():
+        m(small.to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+    # an edge that leaves its graph (not block diagonal) under the fused path
+    ei = b.edge_index.clone()
+    n_first = int((b.batch == 0).sum())
+    extra = torch.tensor([[0, n_first], [n_first, 0]])
+    bad = Batch(b.x, torch.cat([ei, extra], 1), b.batch, b.y, coalesced_undirected=False, max_nodes=b.max_nodes)
+    with torch.no_grad():
+        m(bad.to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+    # the tiled path accepts cross-graph edges (it is a plain sparse aggregation)
+    m.use_fused = False
+    sd = cpu_state_dict(m)
+    with torch.no_grad():
+        m(bad.to("cuda"))
+    m.check_errors()
+
+
 def test_result_independent_of_batch_composition():
     """a graph's log-probs do not depend on which other graphs share the batch."""
     sh = synth.SHAPES["PROTEINS"]
