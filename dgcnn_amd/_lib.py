@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_COALESCED_UNDIRECTED = 1
 
 K = 30
@@ -34,8 +34,9 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p]),
     "dgcnn_sortpool_fwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
     "dgcnn_sortpool_bwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
-    "dgcnn_model_forward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_int, c_uint64, c_int, c_int, ctypes.c_uint32,
-                                    c_void_p]),
+    "dgcnn_model_forward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_int, c_uint64, c_int, c_int, c_int,
+                                    ctypes.c_uint32, c_void_p]),
+    "dgcnn_debug_phase_clocks": (c_int, [c_void_p]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,

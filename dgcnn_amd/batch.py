@@ -51,10 +51,10 @@ class Batch:
     /root/reference/train.py:36 (``sample.to(device)``) and returns a new Batch.
     """
 
-    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected", "max_nodes")
+    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected", "max_nodes", "max_edges")
 
     def __init__(self, x, edge_index, batch, y=None, num_graphs: Optional[int] = None,
-                 coalesced_undirected: bool = False, max_nodes: int = 0):
+                 coalesced_undirected: bool = False, max_nodes: int = 0, max_edges: int = 0):
         if x.dim() != 2:
             raise ValueError(f"x must be [N,F], got {tuple(x.shape)}")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -77,6 +77,7 @@ class Batch:
         # host-known upper bound of the node count of any single graph (0 = unknown); lets the
         # forward pick the graph-per-workgroup kernel without a device sync.  Verified on the device.
         self.max_nodes = int(max_nodes)
+        self.max_edges = int(max_edges)     # same, for the directed-edge count of any single graph
 
     @property
     def num_nodes(self) -> int:
@@ -89,12 +90,12 @@ class Batch:
     def to(self, device, non_blocking: bool = False) -> "Batch":
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)
         return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
-                     self.coalesced_undirected, self.max_nodes)
+                     self.coalesced_undirected, self.max_nodes, self.max_edges)
 
     def pin_memory(self) -> "Batch":
         mv = lambda t: None if t is None else t.pin_memory()
         return Batch(mv(self.x), mv(self.edge_index), mv(self.batch), mv(self.y), self.num_graphs,
-                     self.coalesced_undirected, self.max_nodes)
+                     self.coalesced_undirected, self.max_nodes, self.max_edges)
 
     def __repr__(self) -> str:
         return (f"Batch(graphs={self.num_graphs}, nodes={self.num_nodes}, "
@@ -121,7 +122,7 @@ def collate(graphs: Sequence[Graph]) -> Batch:
                  torch.cat(bs, 0),
                  torch.tensor(ys, dtype=torch.int64),
                  num_graphs=len(graphs), coalesced_undirected=cu,
-                 max_nodes=max(gr.num_nodes for gr in graphs))
+                 max_nodes=max(gr.num_nodes for gr in graphs), max_edges=max(gr.num_edges for gr in graphs))
 
 
 def indegree_feature(edge_index: torch.Tensor, num_nodes: int,
@@ -183,5 +184,5 @@ def split_batch(b: Batch, parts: int) -> List[Batch]:
         out.append(Batch(b.x[n0:n1], sub_ei.to(dev), (b.batch[n0:n1] - g0),
                          None if b.y is None else b.y[g0:g1], num_graphs=g1 - g0,
                          coalesced_undirected=b.coalesced_undirected,
-                         max_nodes=int(n_per[g0:g1].max())))
+                         max_nodes=int(n_per[g0:g1].max()), max_edges=int(e_per[g0:g1].max())))
     return out

@@ -36,6 +36,11 @@ int dgcnn_event_destroy(void* ev) {
   return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
 }
 
+int dgcnn_debug_phase_clocks(void* dev_u64x16) {
+  dg_fused_set_debug(reinterpret_cast<unsigned long long*>(dev_u64x16));
+  return DGCNN_OK;
+}
+
 int dgcnn_fused_max_nodes(int F) {
   if (F < 1 || F > DGCNN_MAX_F) return 0;
   return dg_fused_max_nodes(F);
@@ -111,7 +116,7 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
-                        uint32_t epoch, dgcnn_stream_t stream) {
+                        int max_edges, uint32_t epoch, dgcnn_stream_t stream) {
   if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   DgParams pl; DgWs wl;
@@ -135,7 +140,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   if (max_nodes > 0 && max_nodes <= dg_fused_max_nodes(F)) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
-    DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, params, &pl, x, rowptr, colidx, dinv,
+    DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,
                                dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
                                dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
                                dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,

@@ -6,8 +6,8 @@
 #include "../../include/dgcnn_hip.h"
 
 #define DG_WAVE 64
-#define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
-#define DG_TILE_THREADS 1024  // 16 waves: one wave per destination node
+#define DG_TILE 32            // destination nodes per workgroup tile in the F=32 GCN kernels
+#define DG_TILE_THREADS 1024  // 16 waves x 2 half-waves: one half-wave per destination node, lane = channel
 #define DG_MAX_PART 1024      // cap on per-workgroup partial-gradient slots
 #define DG_LDS_PAD 36         // row stride (floats) of 16x32 LDS tiles: 16-B aligned rows
 
@@ -67,8 +67,8 @@ static inline int dg_grid32(int N) {
   int tiles = dg_cdiv(N, DG_TILE);
   return tiles < 1 ? 1 : (tiles > DG_MAX_PART ? DG_MAX_PART : tiles);
 }
-static inline int dg_grid1(int N) {   // F=1 kernels: 4 waves (256 threads) per workgroup, wave per node
-  int b = dg_cdiv(N, 4);
+static inline int dg_grid1(int N) {   // conv4 backward: 4 waves (256 threads) per workgroup, half-wave per node
+  int b = dg_cdiv(N, 8);
   return b < 1 ? 1 : (b > DG_MAX_PART ? DG_MAX_PART : b);
 }
 
@@ -219,13 +219,15 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                           int training, uint64_t seed, hipStream_t s);
-int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, const float* params, const DgParams* pl,
+int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const int32_t* graph_ptr, float* x1, float* x2, float* x3, float* x4, float* pooled,
                         int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_fused_max_nodes(int F);
+void dg_fused_set_debug(unsigned long long* p);
+#define DG_GATHER_UNROLL 8
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,

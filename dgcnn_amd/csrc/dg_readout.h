@@ -121,7 +121,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ x3,
     const float* __restrict__ x4, float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g,
     float* __restrict__ a6g, float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp,
-    int training, uint64_t seed) {
+    int training, uint64_t seed, unsigned long long* dbg = nullptr) {
+#define RD_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   float* sp = reinterpret_cast<float*>(M.region0);        // [2910]
   float* W5s = sp + 2912;                                 // [1552]
   float* W6s = W5s + NW5;                                 // [2560]   (2912+1552+2560)*4 = 28096 <= 32768
@@ -130,6 +131,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
+  RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
   for (int o = tid; o < KCAT; o += RD_THREADS) {
     const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
@@ -141,6 +143,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
   for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
   __syncthreads();
+  RD_MARK(9);
   // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
   if (tid < DGCNN_C5 * DGCNN_K) {
     const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
@@ -154,6 +157,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
   }
   __syncthreads();
+  RD_MARK(10);
   // MaxPool1d(2,2): [16,30] -> [16,15]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
@@ -174,6 +178,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
   }
   __syncthreads();
+  RD_MARK(11);
   // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; 4 rows per pass so that
   // 22 weight loads are in flight per lane before the first reduction.
   {
@@ -213,6 +218,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     }
   }
   __syncthreads();
+  RD_MARK(12);
   // classifier_2: 128 -> C, wave per class
   for (int c = wv; c < C; c += RD_THREADS / 64) {
     const float* wr = w.Wf2 + c * DGCNN_HID1;
@@ -231,5 +237,6 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     e = dg_wave_sum(e);
     if (lane < C) logp[(size_t)b * C + lane] = (v - mx) - logf(e);
   }
+  RD_MARK(13);
+#undef RD_MARK
 }
-

@@ -1,76 +1,100 @@
-// fused.hip -- graph-per-workgroup fused kernels (gfx950 / CDNA4).
+// fused.hip -- graph-per-workgroup fused forward kernel (gfx950 / CDNA4).
 //
 // At the reference's batch size (50 graphs, ~75 nodes each; /root/reference/train.py:21) one graph's
-// whole activation state (n x 32 fp32 per layer = n * 128 B) fits in a CU's 160 KiB LDS, and the
-// per-op chain of tail.hip/gcn.hip is bound by kernel boundaries and dependent HBM/L2 round trips,
-// not by bandwidth.  k_fused_fwd therefore runs, for ONE graph per workgroup (16 waves), the entire
-// forward of /root/reference/model.py:26-45 in a single launch:
+// whole activation state (n x 32 fp32 per layer = n * 128 B) AND its adjacency fit in a CU's 160 KiB
+// LDS, and the per-op chain of gcn.hip/tail.hip is bound by kernel boundaries and dependent HBM/L2
+// round trips, not by bandwidth.  k_fused_fwd therefore runs, for ONE graph per workgroup (16 waves),
+// the entire forward of /root/reference/model.py:26-45 in a single launch:
 //
-//     conv1 linear (x W1^T, pre-scaled)                    -> H   (LDS, [n][32])
-//     3 x { gather over CSR rows from H (LDS) + self, dst scale, bias, tanh -> X (LDS) and x_l (HBM, saved)
-//           next layer's X W^T on v_mfma_f32_16x16x4_f32    -> H   (LDS, overwritten in place) }
-//     conv4 (32 -> 1) as a dot product + scalar gather      -> x4  (LDS keys + HBM)
-//     SortPooling (LDS sort of the keys) + conv5/pool/conv6/MLP/log_softmax (dg_readout.h)
+//     stage this graph's CSR (row pointers + local neighbour ids) and dinv in LDS   (one coalesced pass)
+//     conv1 linear (x W1^T, pre-scaled)                          -> H (LDS, [n][32])
+//     3 x { half-wave per node, lane = channel: sequential sum over the row's neighbours read from H
+//           (ds_read_b32, conflict-free) + self, dst scale, bias, tanh -> X (LDS) and x_l (HBM, saved)
+//           next layer's X W^T on v_mfma_f32_16x16x4_f32           -> H (LDS, overwritten in place) }
+//     conv4 (32 -> 1): per-node dot + scalar gather              -> x4 (LDS sort keys + HBM)
+//     SortPooling (LDS sort) + conv5/pool/conv6/MLP/log_softmax  (dg_readout.h)
 //
-// Neighbour rows are read from LDS (ds_read_b128, 8 rows per wave-instruction), never from HBM/L2;
-// HBM sees each array once: x, rowptr/colidx (4 passes, L2-resident), and the x1..x4 slabs written
-// once because backward needs them.  Requirements (checked by the host before choosing this path):
-// every graph has at most `nmax` nodes with nmax <= FG_MAX_NODES, and the batch is block-diagonal
-// (an edge leaving its graph is flagged through the error words and skipped).
+// Inside the layer loop there is NO global load at all: indices, neighbour rows, scales all come
+// from LDS.  HBM sees x, the CSR slice and dinv once, and the x1..x4 slabs written once because
+// backward needs them.  Summation order is the canonical one of gcn.hip (sequential over ascending
+// neighbours, self last), so this path is bit-identical to the tiled kernels.
+//
+// Requirements (host hints, verified on the device and reported through the error words): every
+// graph has at most nmax nodes, the batch is block-diagonal (an edge leaving its graph is flagged
+// and skipped).  A graph with more than emax_lds edges simply reads its neighbour ids from global.
 #include "dg_common.h"
 #include "dg_readout.h"
 #include <hip/hip_ext.h>
 
 #define FG_THREADS 1024
-#define FG_WAVES 16
+#define FG_SLOTS 32          // node slots per pass: 16 waves x 2 half-waves
 
 // LDS layout (bytes), dynamic:
-//   region0 : max(2 * nmax * 128, 32*F*4 + nmax*128, RD_REGION0_BYTES)     H | X   (aliased later by the readout)
-//   dv      : nmax * 4      dinv of this graph's nodes
-//   h4s     : nmax * 4      pre-scaled conv4 linear output
-//   x4s     : nmax * 4      conv4 output = sort keys
-//   small   : RD_SMALL_BYTES
+//   region0 : max(2*nmax*128, 32*F*4 + nmax*128, RD_REGION0_BYTES)    H | X   (aliased later by the readout)
+//   dv, h4s, x4s : nmax*4 each ;  rp : (nmax+1)*4 ;  cl : emax_lds*4 ;  small : RD_SMALL_BYTES
+static inline size_t fg_a16(size_t x) { return (x + 15) & ~(size_t)15; }
 static inline size_t fg_region0_bytes(int nmax, int F) {
   size_t a = (size_t)2 * nmax * 128;
   size_t b = (size_t)32 * F * 4 + (size_t)nmax * 128;
   size_t r = a > b ? a : b;
   if (r < RD_REGION0_BYTES) r = RD_REGION0_BYTES;
-  return (r + 15) & ~(size_t)15;
+  return fg_a16(r);
 }
-static inline size_t fg_lds_bytes(int nmax, int F) {
-  return fg_region0_bytes(nmax, F) + (size_t)3 * (((size_t)nmax * 4 + 15) & ~(size_t)15) + RD_SMALL_BYTES + 16;
+static inline size_t fg_lds_bytes(int nmax, int F, int emax_lds) {
+  return fg_region0_bytes(nmax, F) + 3 * fg_a16((size_t)nmax * 4) + fg_a16((size_t)(nmax + 1) * 4) +
+         fg_a16((size_t)emax_lds * 4) + RD_SMALL_BYTES + 16;
+}
+#define FG_LDS_CAP (160 * 1024)
+
+template <bool LDSCOL>
+__device__ __forceinline__ float fg_gather_seq32(const float* __restrict__ H, const int* __restrict__ col,
+                                                 int start, int end, int self, int c, int n0, int n, bool* bad) {
+  float acc = 0.f;
+  int e = start;
+  for (; e + DG_GATHER_UNROLL <= end; e += DG_GATHER_UNROLL) {
+    int j[DG_GATHER_UNROLL];
+    float v[DG_GATHER_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DG_GATHER_UNROLL; ++u) j[u] = LDSCOL ? col[e + u] : col[e + u] - n0;
+#pragma unroll
+    for (int u = 0; u < DG_GATHER_UNROLL; ++u) {
+      const bool ok = (unsigned)j[u] < (unsigned)n;
+      if (!ok) *bad = true;
+      v[u] = ok ? H[j[u] * 32 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
+  }
+  for (; e < end; ++e) {
+    const int j = LDSCOL ? col[e] : col[e] - n0;
+    if ((unsigned)j < (unsigned)n) acc += H[j * 32 + c]; else *bad = true;
+  }
+  acc += H[self * 32 + c];
+  return acc;
 }
 
-__device__ __forceinline__ float4 fg_gather_lds(const float* __restrict__ H, const int* __restrict__ col,
-                                                int start, int end, int self_local, int n0, int n, int lane,
-                                                bool* bad) {
-  const int g = lane >> 3, q = lane & 7;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int base = start; base < end; base += 64) {
-    const int cnt = min(64, end - base);
-    const int cj = lane < cnt ? col[base + lane] - n0 : 0;
-    const int iters = (cnt + 7) >> 3;
-    for (int it = 0; it < iters; ++it) {
-      const int idx = it * 8 + g;
-      const int j = __shfl(cj, idx);
-      if (idx < cnt) {
-        if ((unsigned)j < (unsigned)n) {
-          const float4 v = *reinterpret_cast<const float4*>(H + j * 32 + 4 * q);
-          acc = dg_add4(acc, v);
-        } else {
-          *bad = true;
-        }
-      }
+template <bool LDSCOL>
+__device__ __forceinline__ float fg_gather_seq1(const float* __restrict__ h, const int* __restrict__ col,
+                                                int start, int end, int self, int n0, int n, bool* bad) {
+  float s = 0.f;
+  int e = start;
+  for (; e + 8 <= end; e += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = LDSCOL ? col[e + u] : col[e + u] - n0;
+      const bool ok = (unsigned)j < (unsigned)n;
+      if (!ok) *bad = true;
+      v[u] = ok ? h[j] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
-  if (g == 0) {
-    const float4 v = *reinterpret_cast<const float4*>(H + self_local * 32 + 4 * q);
-    acc = dg_add4(acc, v);
+  for (; e < end; ++e) {
+    const int j = LDSCOL ? col[e] : col[e] - n0;
+    if ((unsigned)j < (unsigned)n) s += h[j]; else *bad = true;
   }
-  acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
-  acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
-  acc = dg_add4(acc, dg_shfl_xor4(acc, 32));
-  return acc;
+  return s + h[self];
 }
 
 struct FgW {   // GCN parameters (device pointers into the flat buffer)
@@ -78,51 +102,61 @@ struct FgW {   // GCN parameters (device pointers into the flat buffer)
 };
 
 __global__ void __launch_bounds__(FG_THREADS)
-k_fused_fwd(int F, int C, int nmax, size_t region0_bytes, FgW gw, TailW tw, const float* __restrict__ xin,
-            const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ dinv,
-            const int* __restrict__ graph_ptr, float* __restrict__ x1, float* __restrict__ x2,
-            float* __restrict__ x3, float* __restrict__ x4, float* __restrict__ pooled, int* __restrict__ perm,
-            float* __restrict__ a5g, float* __restrict__ a6g, float* __restrict__ a1dg,
+k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, TailW tw,
+            const float* __restrict__ xin, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+            const float* __restrict__ dinv, const int* __restrict__ graph_ptr, float* __restrict__ x1,
+            float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, float* __restrict__ pooled,
+            int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g, float* __restrict__ a1dg,
             uint8_t* __restrict__ maskg, float* __restrict__ logp, int training, uint64_t seed,
-            unsigned int* __restrict__ err, unsigned int epoch) {
+            unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg) {
+#define FG_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 3, q = lane & 7;
+  const int c = lane & 31;
+  const int slot = wave * 2 + (lane >> 5);
   const size_t nb4 = ((size_t)nmax * 4 + 15) & ~(size_t)15;
   float* H = reinterpret_cast<float*>(smem);
   float* X = H + (size_t)nmax * 32;
-  float* dv = reinterpret_cast<float*>(smem + region0_bytes);
-  float* h4s = reinterpret_cast<float*>(smem + region0_bytes + nb4);
-  float* x4s = reinterpret_cast<float*>(smem + region0_bytes + 2 * nb4);
-  char* small = smem + region0_bytes + 3 * nb4;
+  char* p = smem + region0_bytes;
+  float* dv = reinterpret_cast<float*>(p);  p += nb4;
+  float* h4s = reinterpret_cast<float*>(p); p += nb4;
+  float* x4s = reinterpret_cast<float*>(p); p += nb4;
+  int* rp = reinterpret_cast<int*>(p);      p += (((size_t)(nmax + 1) * 4 + 15) & ~(size_t)15);
+  int* cl = reinterpret_cast<int*>(p);      p += (((size_t)emax_lds * 4 + 15) & ~(size_t)15);
+  char* small = p;
   bool bad = false;
+  FG_MARK(0);
 
   if (n > nmax) {      // host hint violated: flag and produce nothing for this graph (never overrun LDS)
     if (tid == 0) { err[1] = epoch; err[3] = ~epoch; }
     return;
   }
-
-  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]; W1 staged transposed after H ----
+  // ---- stage CSR slice, dinv, W1^T ----
+  const int e0 = rowptr[n0], e1 = rowptr[n0 + n];
+  const int ne = e1 - e0;
+  const bool ldscol = ne <= emax_lds;            // workgroup-uniform
+  for (int t = tid; t <= n; t += FG_THREADS) rp[t] = rowptr[n0 + t] - (ldscol ? e0 : 0);
+  for (int t = tid; t < n; t += FG_THREADS) dv[t] = dinv[n0 + t];
+  if (ldscol)
+    for (int t = tid; t < ne; t += FG_THREADS) cl[t] = colidx[e0 + t] - n0;
   float* Wt = X;                       // [F][32], X is free until the first gather
   for (int t = tid; t < 32 * F; t += FG_THREADS) {
-    const int c = t / F, k = t - c * F;
-    Wt[k * 32 + c] = gw.W1[t];
-  }
-  for (int t = tid; t < n; t += FG_THREADS) dv[t] = dinv[n0 + t];
-  __syncthreads();
-  {
-    const int c = tid & 31;
-    for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
-      const float* xr = xin + (size_t)(n0 + i) * F;
-      float acc = 0.f;
-      for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-      H[i * 32 + c] = dv[i] * acc;
-    }
+    const int cc = t / F, k = t - cc * F;
+    Wt[k * 32 + cc] = gw.W1[t];
   }
   __syncthreads();
+  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k] ----
+  for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
+    const float* xr = xin + (size_t)(n0 + i) * F;
+    float acc = 0.f;
+    for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
+    H[i * 32 + c] = dv[i] * acc;
+  }
+  __syncthreads();
+  FG_MARK(1);
 
   // ---- three 32-wide layers ----
 #pragma unroll 1
@@ -130,48 +164,28 @@ k_fused_fwd(int F, int C, int nmax, size_t region0_bytes, FgW gw, TailW tw, cons
     const float* bias = layer == 0 ? gw.b1 : (layer == 1 ? gw.b2 : gw.b3);
     const float* Wn = layer == 0 ? gw.W2 : (layer == 1 ? gw.W3 : gw.W4);
     float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
-    const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+    const float bc = bias[c];
     float wreg[8];
-    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (layer < 2) {        // B operand of the MFMA post-step: B[k][nn] = Wn[nb*16+nn][k], nb = wave & 1
-      const int c = (wave & 1) * 16 + (lane & 15);
+      const int cc = (wave & 1) * 16 + (lane & 15);
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[c * 32 + 4 * kk + (lane >> 4)];
-    } else {
-      w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
+      for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[cc * 32 + 4 * kk + (lane >> 4)];
     }
-    // gather phase: wave per destination node
-    for (int i = wave; i < n; i += FG_WAVES) {
-      const int start = __builtin_amdgcn_readfirstlane(rowptr[n0 + i]);
-      const int end = __builtin_amdgcn_readfirstlane(rowptr[n0 + i + 1]);
-      const float4 acc = fg_gather_lds(H, colidx, start, end, i, n0, n, lane, &bad);
-      const float di = dv[i];
-      float4 val;
-      val.x = tanhf(fmaf(di, acc.x, b4.x));
-      val.y = tanhf(fmaf(di, acc.y, b4.y));
-      val.z = tanhf(fmaf(di, acc.z, b4.z));
-      val.w = tanhf(fmaf(di, acc.w, b4.w));
-      if (g == 0) {
-        *reinterpret_cast<float4*>(X + i * 32 + 4 * q) = val;
-        *reinterpret_cast<float4*>(xout + (size_t)(n0 + i) * 32 + 4 * q) = val;
-      }
-      if (layer == 2) {     // conv4's linear: 32 -> 1 dot product, pre-scaled
-        float p = val.x * w4.x;
-        p = fmaf(val.y, w4.y, p);
-        p = fmaf(val.z, w4.z, p);
-        p = fmaf(val.w, w4.w, p);
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        p += __shfl_xor(p, 4);
-        if (lane == 0) h4s[i] = di * p;
-      }
+    // gather phase: half-wave per destination node, lane = channel, everything from LDS
+    for (int i = slot; i < n; i += FG_SLOTS) {
+      const int start = rp[i], end = rp[i + 1];
+      const float acc = ldscol ? fg_gather_seq32<true>(H, cl, start, end, i, c, n0, n, &bad)
+                               : fg_gather_seq32<false>(H, colidx, start, end, i, c, n0, n, &bad);
+      const float val = tanhf(fmaf(dv[i], acc, bc));
+      X[i * 32 + c] = val;
+      xout[(size_t)(n0 + i) * 32 + c] = val;
     }
     __syncthreads();
     if (layer < 2) {
       // next layer's linear on MFMA: 16x16 blocks (tile, nb) of [n x 32] = X . Wn^T, written to H in place
       const int nb = wave & 1;
       const int tiles = (n + 15) >> 4;
-      for (int tile = wave >> 1; tile < tiles; tile += FG_WAVES / 2) {
+      for (int tile = wave >> 1; tile < tiles; tile += 8) {
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
         const int arow = tile * 16 + (lane & 15);
 #pragma unroll
@@ -185,51 +199,65 @@ k_fused_fwd(int F, int C, int nmax, size_t region0_bytes, FgW gw, TailW tw, cons
           if (row < n) H[row * 32 + nb * 16 + (lane & 15)] = dv[row] * d[r];
         }
       }
-      __syncthreads();
+    } else {
+      // conv4's linear (32 -> 1): sequential 32-term dot per node, pre-scaled
+      for (int i = tid; i < n; i += FG_THREADS) {
+        float pacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) pacc = fmaf(X[i * 32 + k], Wn[k], pacc);
+        h4s[i] = dv[i] * pacc;
+      }
     }
+    __syncthreads();
+    FG_MARK(2 + layer);
   }
 
-  // ---- conv4 aggregation (F = 1): wave per node, lanes across neighbours ----
+  // ---- conv4 aggregation (F = 1): thread per node, sequential ----
   {
     const float b4s = gw.b4[0];
-    for (int i = wave; i < n; i += FG_WAVES) {
-      const int start = rowptr[n0 + i], end = rowptr[n0 + i + 1];
-      float s = 0.f;
-      for (int e = start + lane; e < end; e += 64) {
-        const int j = colidx[e] - n0;
-        if ((unsigned)j < (unsigned)n) s += h4s[j]; else bad = true;
-      }
-      s = dg_wave_sum(s) + h4s[i];
-      if (lane == 0) {
-        const float v = tanhf(fmaf(dv[i], s, b4s));
-        x4s[i] = v;
-        x4[n0 + i] = v;
-      }
+    for (int i = tid; i < n; i += FG_THREADS) {
+      const float s = ldscol ? fg_gather_seq1<true>(h4s, cl, rp[i], rp[i + 1], i, n0, n, &bad)
+                             : fg_gather_seq1<false>(h4s, colidx, rp[i], rp[i + 1], i, n0, n, &bad);
+      const float v = tanhf(fmaf(dv[i], s, b4s));
+      x4s[i] = v;
+      x4[n0 + i] = v;
     }
   }
   if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
   __syncthreads();      // x1..x4 of this graph are complete (and visible to this workgroup)
+  FG_MARK(5);
 
   // ---- SortPooling + dense tail (keys from LDS, rows from the slabs just written) ----
   const RdSmem M = dg_rd_carve(smem, small);
   dg_readout_fwd_body(M, b, n0, n, C, tw, x4s, 0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
-                      training, seed);
+                      training, seed, dbg);
+#undef FG_MARK
 }
 
-int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, const float* params, const DgParams* pl,
+static thread_local unsigned long long* g_fg_dbg = nullptr;
+void dg_fused_set_debug(unsigned long long* p) { g_fg_dbg = p; }
+
+// choose how many neighbour ids to keep in LDS for (nmax, F, emax): all of them if they fit, else none
+static int fg_choose_emax_lds(int nmax, int F, int emax) {
+  if (emax > 0 && fg_lds_bytes(nmax, F, emax) <= FG_LDS_CAP) return emax;
+  return 0;
+}
+
+int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const int32_t* graph_ptr, float* x1, float* x2, float* x3, float* x4, float* pooled,
                         int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0 || B <= 0 || nmax <= 0 || nmax > DGCNN_FUSED_MAX_NODES) return DGCNN_EINVAL;
+  const int emax_lds = fg_choose_emax_lds(nmax, F, emax);
   const size_t r0 = fg_region0_bytes(nmax, F);
-  const size_t lds = fg_lds_bytes(nmax, F);
-  if (lds > 160 * 1024) return DGCNN_EUNSUPPORTED;
+  const size_t lds = fg_lds_bytes(nmax, F, emax_lds);
+  if (lds > FG_LDS_CAP) return DGCNN_EUNSUPPORTED;
   static bool attr_set = false;      // raise the dynamic-LDS cap once per process (idempotent)
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+                            FG_LDS_CAP) != hipSuccess)
       return DGCNN_ELAUNCH;
     attr_set = true;
   }
@@ -238,10 +266,10 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, const float* param
   gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5];
   gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
-  hipExtLaunchKernelGGL(k_fused_fwd, dim3(B), dim3(FG_THREADS), lds, s, ev_start, ev_stop, 0, F, C, nmax, r0, gw,
-                        dg_tail_w(params, pl), x,
-                     rowptr, colidx, dinv, graph_ptr, x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp,
-                     training, seed, reinterpret_cast<unsigned int*>(err), epoch);
+  hipExtLaunchKernelGGL(k_fused_fwd, dim3(B), dim3(FG_THREADS), lds, s, ev_start, ev_stop, 0, F, C, nmax, emax_lds, r0,
+                        gw, dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, x1, x2, x3, x4, pooled, perm,
+                        a5, a6, a1d, drop_mask, logp, training, seed, reinterpret_cast<unsigned int*>(err), epoch,
+                        g_fg_dbg);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -250,6 +278,6 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, const float* param
 int dg_fused_max_nodes(int F) {
   int best = 0;
   for (int nm = 16; nm <= DGCNN_FUSED_MAX_NODES; nm += 16)
-    if (fg_lds_bytes(nm, F) <= 160 * 1024) best = nm;
+    if (fg_lds_bytes(nm, F, 0) <= FG_LDS_CAP) best = nm;
   return best;
 }

@@ -80,7 +80,7 @@ class _DGCNNFunction(torch.autograd.Function):
     """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, max_nodes, *params):
+    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, max_nodes, max_edges, *params):
         L = _lib.lib()
         N, F = x.shape
         E = edge_index.shape[1]
@@ -92,7 +92,7 @@ class _DGCNNFunction(torch.autograd.Function):
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          edge_index.data_ptr() if E else None, batch.data_ptr(),
                                          ws.data_ptr(), logp.data_ptr(), int(training), seed, flags,
-                                         max_nodes, model._next_epoch(), stream),
+                                         max_nodes, max_edges, model._next_epoch(), stream),
                    "dgcnn_model_forward")
         ctx.model = model
         ctx.dims = (N, E, B, F, C, int(training))
@@ -116,7 +116,7 @@ class _DGCNNFunction(torch.autograd.Function):
                                           grads.data_ptr(), None, stream), "dgcnn_model_backward")
         model._last_flat_grad = grads
         views = model._views_of(grads)
-        return (None, None, None, None, None, None, None, None, None, *views)
+        return (None, None, None, None, None, None, None, None, None, None, *views)
 
 
 class Model(nn.Module):
@@ -268,7 +268,8 @@ class Model(nn.Module):
         training = self.training
         seed = self._next_seed() if training else 0
         return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, self._flags_of(data),
-                                    self._max_nodes_of(data), *self._param_list())
+                                    self._max_nodes_of(data), int(getattr(data, "max_edges", 0) or 0),
+                                    *self._param_list())
 
     # ---- introspection used by tests / tools ---------------------------------------------
     def last_workspace_view(self, name: str) -> torch.Tensor:

@@ -156,4 +156,5 @@ def tile_batch(b: Batch, times: int) -> Batch:
     bs = torch.cat([b.batch + t * b.num_graphs for t in range(times)], 0)
     ys = None if b.y is None else b.y.repeat(times)
     return Batch(xs, eis, bs, ys, num_graphs=b.num_graphs * times,
-                 coalesced_undirected=b.coalesced_undirected, max_nodes=b.max_nodes)
+                 coalesced_undirected=b.coalesced_undirected, max_nodes=b.max_nodes,
+                 max_edges=b.max_edges)

@@ -82,7 +82,7 @@ class Trainer:
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
                                          logp.data_ptr(), training, seed, m._flags_of(data), m._max_nodes_of(data),
-                                         m._next_epoch(), stream), "dgcnn_model_forward")
+                                         int(getattr(data, "max_edges", 0) or 0), m._next_epoch(), stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), None, y.data_ptr(), scale, training,
@@ -127,7 +127,7 @@ class Trainer:
             _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                              ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
                                              logp.data_ptr(), 0, 0, m._flags_of(data), m._max_nodes_of(data),
-                                             m._next_epoch(), stream),
+                                             int(getattr(data, "max_edges", 0) or 0), m._next_epoch(), stream),
                        "dgcnn_model_forward")
             m._last_ws, m._last_dims = ws, (N, E, B, F, C)
             lp = logp[:B]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 3
+#define DGCNN_ABI_VERSION 4
 
 /* error codes */
 #define DGCNN_OK            0
@@ -155,6 +155,8 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *            the graph-per-workgroup fused kernel runs (whole forward in one launch, activations in
  *            LDS); otherwise the general tiled kernels.  Both give bit-identical results.  A hint
  *            that is too small is detected on the device and reported through the error words.
+ *   max_edges: host-known upper bound of the directed-edge count of any single graph (0 = unknown);
+ *            lets the fused kernel also keep each graph's neighbour ids in LDS when they fit.
  *   epoch  : non-zero tag of this call.  Input errors are reported WITHOUT any host sync or
  *            memset through the workspace region "err" (4 x u32): the call is in error iff
  *            err[k] == epoch && err[k+2] == ~epoch  (k = 0: edge endpoint out of range,
@@ -164,7 +166,7 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
-                        uint32_t epoch, dgcnn_stream_t stream);
+                        int max_edges, uint32_t epoch, dgcnn_stream_t stream);
 int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
 
 /* ------------------------------------------------------------------------------------
@@ -219,6 +221,9 @@ int dgcnn_event_create(void** ev);
 int dgcnn_event_record(void* ev, dgcnn_stream_t stream);
 int dgcnn_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int dgcnn_event_destroy(void* ev);
+/* debugging aid: subsequent fused forward launches of this thread store clock64() stamps of workgroup 0's
+ * phases into the given device buffer of 16 x u64 (NULL switches it off) */
+int dgcnn_debug_phase_clocks(void* dev_u64x16);
 
 #ifdef __cplusplus
 }

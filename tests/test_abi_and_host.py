@@ -71,7 +71,7 @@ def test_bad_shapes_rejected(built_lib):
         _lib.param_layout(4, 1000)
     assert built_lib.dgcnn_workspace_bytes(-1, 0, 1, 1, 2) < 0
     # null pointers are refused before any launch
-    assert built_lib.dgcnn_model_forward(10, 0, 1, 1, 2, None, None, None, None, None, None, 0, 0, 0, 0, 1, None) == -1
+    assert built_lib.dgcnn_model_forward(10, 0, 1, 1, 2, None, None, None, None, None, None, 0, 0, 0, 0, 0, 1, None) == -1
     assert built_lib.dgcnn_adam_step(None, None, None, None, 10, 1, 1e-3, .9, .999, 1e-8, 1, None) == -1
 
 

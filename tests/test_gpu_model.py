@@ -130,7 +130,8 @@ def test_fused_path_flags_bad_hints():
     b = synth.make_batch("PROTEINS", 6, start=20)
     m = make_model(sh.num_features, sh.num_classes).eval()
     # max_nodes hint smaller than the largest graph
-    small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=max(b.max_nodes - 1, 1))
+    assert b.max_nodes > 16
+    small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=16)
     with torch.no_grad():
         m(small.to("cuda"))
     with pytest.raises(_lib.DgcnnError):
