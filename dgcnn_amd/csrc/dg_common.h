@@ -133,15 +133,35 @@ static inline const T* dg_cptr(const void* ws, int64_t off) {
 // device helpers
 // ---------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Wave-wide sum on the DPP data path (no LDS crossbar round trips): quad swaps, row rotations,
+// then row broadcasts; fixed order -> deterministic.  The total is returned in EVERY lane (read back
+// from lane 63 through an SGPR).  Same sequence as rocPRIM's wave64 DPP reduce.
+#define DG_DPP(v, ctrl, rmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, true))
 __device__ __forceinline__ float dg_wave_sum(float v) {
-  // fixed butterfly order -> deterministic
-  v += __shfl_xor(v, 32);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
+  v += DG_DPP(v, 0xB1, 0xf);    // quad_perm:[1,0,3,2]
+  v += DG_DPP(v, 0x4E, 0xf);    // quad_perm:[2,3,0,1]
+  v += DG_DPP(v, 0x124, 0xf);   // row_ror:4
+  v += DG_DPP(v, 0x128, 0xf);   // row_ror:8     -> every lane holds its 16-lane row total
+  v += DG_DPP(v, 0x142, 0xa);   // row_bcast:15  -> rows 1,3 += previous row
+  v += DG_DPP(v, 0x143, 0xc);   // row_bcast:31  -> rows 2,3 += lanes 0..31 total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over each 32-lane half separately (lanes 0..31 / 32..63); result in every lane of the half
+__device__ __forceinline__ float dg_half_sum(float v) {
+  v += DG_DPP(v, 0xB1, 0xf);
+  v += DG_DPP(v, 0x4E, 0xf);
+  v += DG_DPP(v, 0x124, 0xf);
+  v += DG_DPP(v, 0x128, 0xf);
+  v += DG_DPP(v, 0x142, 0xa);   // lanes 16..31 (and 48..63) now hold the half total
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return (threadIdx.x & 32) ? hi : lo;
+}
+// workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
+// (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
+__device__ __forceinline__ void dg_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ float4 dg_add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

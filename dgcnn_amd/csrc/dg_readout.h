@@ -130,6 +130,13 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
+  // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
+  // the first n*8 <= 4096*8 bytes of region0 only when n > 1456; W5s starts at byte 11648)
+  const bool early_w = n * 8 <= 11648;
+  if (early_w) {
+    for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
+    for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  }
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
@@ -140,8 +147,10 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     sp[o] = v;
     pooled[(size_t)b * KCAT + o] = v;
   }
-  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  if (!early_w) {
+    for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
+    for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  }
   __syncthreads();
   RD_MARK(9);
   // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
@@ -179,41 +188,38 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(11);
-  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; 4 rows per pass so that
-  // 22 weight loads are in flight per lane before the first reduction.
+  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows: all 44 weight loads of a lane are
+  // issued before the first reduction (one L2 round trip), reductions on the DPP path.
   {
     const float f0 = flat[lane], f1 = flat[lane + 64], f2 = flat[lane + 128], f3 = flat[lane + 192],
                 f4 = flat[lane + 256], f5 = lane < 32 ? flat[lane + 320] : 0.f;
+    float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      float acc[4];
+    for (int u = 0; u < 8; ++u) {
+      const float* wr = w.Wf1 + (size_t)(wv * 8 + u) * DGCNN_FLAT;
+      wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
+      wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = wv * 8 + pass * 4 + u;
-        const float* wr = w.Wf1 + (size_t)j * DGCNN_FLAT;
-        float a = wr[lane] * f0;
-        a = fmaf(wr[lane + 64], f1, a);
-        a = fmaf(wr[lane + 128], f2, a);
-        a = fmaf(wr[lane + 192], f3, a);
-        a = fmaf(wr[lane + 256], f4, a);
-        if (lane < 32) a = fmaf(wr[lane + 320], f5, a);
-        acc[u] = a;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = wv * 8 + pass * 4 + u;
-        const float tot = dg_wave_sum(acc[u]);
-        if (lane == 0) {
-          float a = fmaxf(tot + w.bf1[j], 0.f);
-          uint8_t keep = 1;
-          if (training) {
-            keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
-            a = keep ? a * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
-          }
-          a1s[j] = a;
-          a1dg[(size_t)b * DGCNN_HID1 + j] = a;
-          maskg[(size_t)b * DGCNN_HID1 + j] = keep;
+    for (int u = 0; u < 8; ++u) {
+      const int j = wv * 8 + u;
+      float a = wv0[u] * f0;
+      a = fmaf(wv1[u], f1, a);
+      a = fmaf(wv2[u], f2, a);
+      a = fmaf(wv3[u], f3, a);
+      a = fmaf(wv4[u], f4, a);
+      a = fmaf(wv5[u], f5, a);
+      const float tot = dg_wave_sum(a);
+      if (lane == 0) {
+        float av = fmaxf(tot + w.bf1[j], 0.f);
+        uint8_t keep = 1;
+        if (training) {
+          keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
+          av = keep ? av * 2.0f : 0.f;     // p = 0.5 -> scale 1/(1-p) = 2
         }
+        a1s[j] = av;
+        a1dg[(size_t)b * DGCNN_HID1 + j] = av;
+        maskg[(size_t)b * DGCNN_HID1 + j] = keep;
       }
     }
   }

@@ -26,76 +26,30 @@
 #include "dg_readout.h"
 #include <hip/hip_ext.h>
 
+__device__ __forceinline__ size_t fg_a16_dev(size_t x) { return (x + 15) & ~(size_t)15; }
+
 #define FG_THREADS 1024
 #define FG_SLOTS 32          // node slots per pass: 16 waves x 2 half-waves
+#define FG_RS 33             // row stride (floats) of H and X: conflict-free for lane=channel rows AND MFMA A reads
 
 // LDS layout (bytes), dynamic:
-//   region0 : max(2*nmax*128, 32*F*4 + nmax*128, RD_REGION0_BYTES)    H | X   (aliased later by the readout)
-//   dv, h4s, x4s : nmax*4 each ;  rp : (nmax+1)*4 ;  cl : emax_lds*4 ;  small : RD_SMALL_BYTES
+//   region0 : max(2*(nmax+1)*RS*4, (nmax+1)*RS*4 + 32*F*4, RD_REGION0_BYTES)   H | X  (aliased later by the readout)
+//             row nmax of H is an all-zero row: padded / invalid neighbour slots point at it
+//   dv, h4s, x4s : (nmax+1)*4 each ;  rp : (nmax+1)*4 ;  cl : emax_lds*4 (+32 slack) ;  prm : 160*4 ;  small
 static inline size_t fg_a16(size_t x) { return (x + 15) & ~(size_t)15; }
 static inline size_t fg_region0_bytes(int nmax, int F) {
-  size_t a = (size_t)2 * nmax * 128;
-  size_t b = (size_t)32 * F * 4 + (size_t)nmax * 128;
+  const size_t row = (size_t)(nmax + 1) * FG_RS * 4;
+  size_t a = 2 * row;
+  size_t b = row + (size_t)32 * F * 4;
   size_t r = a > b ? a : b;
   if (r < RD_REGION0_BYTES) r = RD_REGION0_BYTES;
   return fg_a16(r);
 }
 static inline size_t fg_lds_bytes(int nmax, int F, int emax_lds) {
-  return fg_region0_bytes(nmax, F) + 3 * fg_a16((size_t)nmax * 4) + fg_a16((size_t)(nmax + 1) * 4) +
-         fg_a16((size_t)emax_lds * 4) + RD_SMALL_BYTES + 16;
+  return fg_region0_bytes(nmax, F) + 4 * fg_a16((size_t)(nmax + 1) * 4) + fg_a16((size_t)emax_lds * 4 + 32) +
+         160 * 4 + RD_SMALL_BYTES + 16;
 }
 #define FG_LDS_CAP (160 * 1024)
-
-template <bool LDSCOL>
-__device__ __forceinline__ float fg_gather_seq32(const float* __restrict__ H, const int* __restrict__ col,
-                                                 int start, int end, int self, int c, int n0, int n, bool* bad) {
-  float acc = 0.f;
-  int e = start;
-  for (; e + DG_GATHER_UNROLL <= end; e += DG_GATHER_UNROLL) {
-    int j[DG_GATHER_UNROLL];
-    float v[DG_GATHER_UNROLL];
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) j[u] = LDSCOL ? col[e + u] : col[e + u] - n0;
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) {
-      const bool ok = (unsigned)j[u] < (unsigned)n;
-      if (!ok) *bad = true;
-      v[u] = ok ? H[j[u] * 32 + c] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
-  }
-  for (; e < end; ++e) {
-    const int j = LDSCOL ? col[e] : col[e] - n0;
-    if ((unsigned)j < (unsigned)n) acc += H[j * 32 + c]; else *bad = true;
-  }
-  acc += H[self * 32 + c];
-  return acc;
-}
-
-template <bool LDSCOL>
-__device__ __forceinline__ float fg_gather_seq1(const float* __restrict__ h, const int* __restrict__ col,
-                                                int start, int end, int self, int n0, int n, bool* bad) {
-  float s = 0.f;
-  int e = start;
-  for (; e + 8 <= end; e += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int j = LDSCOL ? col[e + u] : col[e + u] - n0;
-      const bool ok = (unsigned)j < (unsigned)n;
-      if (!ok) *bad = true;
-      v[u] = ok ? h[j] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; e < end; ++e) {
-    const int j = LDSCOL ? col[e] : col[e] - n0;
-    if ((unsigned)j < (unsigned)n) s += h[j]; else *bad = true;
-  }
-  return s + h[self];
-}
 
 struct FgW {   // GCN parameters (device pointers into the flat buffer)
   const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;
@@ -117,15 +71,17 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31;
   const int slot = wave * 2 + (lane >> 5);
-  const size_t nb4 = ((size_t)nmax * 4 + 15) & ~(size_t)15;
+  const int nz = nmax;                                   // index of the zero row
+  const size_t nb4 = fg_a16_dev((size_t)(nmax + 1) * 4);
   float* H = reinterpret_cast<float*>(smem);
-  float* X = H + (size_t)nmax * 32;
+  float* X = H + (size_t)(nmax + 1) * FG_RS;
   char* p = smem + region0_bytes;
   float* dv = reinterpret_cast<float*>(p);  p += nb4;
   float* h4s = reinterpret_cast<float*>(p); p += nb4;
   float* x4s = reinterpret_cast<float*>(p); p += nb4;
-  int* rp = reinterpret_cast<int*>(p);      p += (((size_t)(nmax + 1) * 4 + 15) & ~(size_t)15);
-  int* cl = reinterpret_cast<int*>(p);      p += (((size_t)emax_lds * 4 + 15) & ~(size_t)15);
+  int* rp = reinterpret_cast<int*>(p);      p += nb4;
+  int* cl = reinterpret_cast<int*>(p);      p += fg_a16_dev((size_t)emax_lds * 4 + 32);
+  float* prm = reinterpret_cast<float*>(p); p += 160 * 4;   // b1|b2|b3 (96) W4 (32) b4 (1)
   char* small = p;
   bool bad = false;
   FG_MARK(0);
@@ -134,14 +90,33 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     if (tid == 0) { err[1] = epoch; err[3] = ~epoch; }
     return;
   }
-  // ---- stage CSR slice, dinv, W1^T ----
+  // ---- preload every GCN parameter used later (no global load inside the layer loop) ----
+  float wreg2[8], wreg3[8];     // B operands of the two MFMA post-steps: B[k][nn] = W[nb*16+nn][k], nb = wave & 1
+  {
+    const int cc = (wave & 1) * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      wreg2[kk] = gw.W2[cc * 32 + 4 * kk + (lane >> 4)];
+      wreg3[kk] = gw.W3[cc * 32 + 4 * kk + (lane >> 4)];
+    }
+  }
+  if (tid < 32) { prm[tid] = gw.b1[tid]; prm[32 + tid] = gw.b2[tid]; prm[64 + tid] = gw.b3[tid]; prm[96 + tid] = gw.W4[tid]; }
+  if (tid == 32) prm[128] = gw.b4[0];
+  // ---- stage CSR slice, dinv, W1^T; zero row ----
   const int e0 = rowptr[n0], e1 = rowptr[n0 + n];
   const int ne = e1 - e0;
   const bool ldscol = ne <= emax_lds;            // workgroup-uniform
   for (int t = tid; t <= n; t += FG_THREADS) rp[t] = rowptr[n0 + t] - (ldscol ? e0 : 0);
   for (int t = tid; t < n; t += FG_THREADS) dv[t] = dinv[n0 + t];
   if (ldscol)
-    for (int t = tid; t < ne; t += FG_THREADS) cl[t] = colidx[e0 + t] - n0;
+    for (int t = tid; t < ne; t += FG_THREADS) {
+      const int j = colidx[e0 + t] - n0;
+      const bool ok = (unsigned)j < (unsigned)n;
+      if (!ok) bad = true;
+      cl[t] = ok ? j : nz;
+    }
+  if (tid < 32) H[nz * FG_RS + tid] = 0.f;
+  if (tid == 0) h4s[nz] = 0.f;
   float* Wt = X;                       // [F][32], X is free until the first gather
   for (int t = tid; t < 32 * F; t += FG_THREADS) {
     const int cc = t / F, k = t - cc * F;
@@ -153,34 +128,60 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     const float* xr = xin + (size_t)(n0 + i) * F;
     float acc = 0.f;
     for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-    H[i * 32 + c] = dv[i] * acc;
+    H[i * FG_RS + c] = dv[i] * acc;
   }
-  __syncthreads();
+  dg_lds_barrier();
   FG_MARK(1);
 
-  // ---- three 32-wide layers ----
-#pragma unroll 1
-  for (int layer = 0; layer < 3; ++layer) {
-    const float* bias = layer == 0 ? gw.b1 : (layer == 1 ? gw.b2 : gw.b3);
-    const float* Wn = layer == 0 ? gw.W2 : (layer == 1 ? gw.W3 : gw.W4);
-    float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
-    const float bc = bias[c];
-    float wreg[8];
-    if (layer < 2) {        // B operand of the MFMA post-step: B[k][nn] = Wn[nb*16+nn][k], nb = wave & 1
-      const int cc = (wave & 1) * 16 + (lane & 15);
+  // ---- three 32-wide layers: LDS only, raw LDS barriers (global stores of x_l stay in flight) ----
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[cc * 32 + 4 * kk + (lane >> 4)];
-    }
-    // gather phase: half-wave per destination node, lane = channel, everything from LDS
+  for (int layer = 0; layer < 3; ++layer) {
+    float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
+    const float bc = prm[layer * 32 + c];
+    const float w4c = prm[96 + c];
+    // gather phase: half-wave per destination node, lane = channel
     for (int i = slot; i < n; i += FG_SLOTS) {
       const int start = rp[i], end = rp[i + 1];
-      const float acc = ldscol ? fg_gather_seq32<true>(H, cl, start, end, i, c, n0, n, &bad)
-                               : fg_gather_seq32<false>(H, colidx, start, end, i, c, n0, n, &bad);
+      float acc = 0.f;
+      if (ldscol) {
+        for (int e = start; e < end; e += DG_GATHER_UNROLL) {
+          int j[DG_GATHER_UNROLL];
+          float v[DG_GATHER_UNROLL];
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) { const int jj = cl[e + u]; j[u] = (e + u < end) ? jj : nz; }
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = H[j[u] * FG_RS + c];
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
+        }
+      } else {
+        for (int e = start; e < end; e += DG_GATHER_UNROLL) {
+          int j[DG_GATHER_UNROLL];
+          float v[DG_GATHER_UNROLL];
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) {
+            const bool real = e + u < end;
+            const int jj = real ? colidx[e + u] - n0 : 0;
+            const bool ok = !real || (unsigned)jj < (unsigned)n;
+            if (!ok) bad = true;
+            j[u] = (real && ok) ? jj : nz;
+          }
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = H[j[u] * FG_RS + c];
+#pragma unroll
+          for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
+        }
+      }
+      acc += H[i * FG_RS + c];
       const float val = tanhf(fmaf(dv[i], acc, bc));
-      X[i * 32 + c] = val;
+      X[i * FG_RS + c] = val;
       xout[(size_t)(n0 + i) * 32 + c] = val;
+      if (layer == 2) {     // conv4's linear (32 -> 1): per-channel products, fixed-order half-wave sum
+        const float pacc = dg_half_sum(val * w4c);
+        if (c == 0) h4s[i] = dv[i] * pacc;
+      }
     }
-    __syncthreads();
+    dg_lds_barrier();
     if (layer < 2) {
       // next layer's linear on MFMA: 16x16 blocks (tile, nb) of [n x 32] = X . Wn^T, written to H in place
       const int nb = wave & 1;
@@ -190,41 +191,52 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
         const int arow = tile * 16 + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          const float a = arow < n ? X[arow * 32 + 4 * kk + (lane >> 4)] : 0.f;
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+          const float a = arow < n ? X[arow * FG_RS + 4 * kk + (lane >> 4)] : 0.f;
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, layer == 0 ? wreg2[kk] : wreg3[kk], d, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = tile * 16 + (lane >> 4) * 4 + r;
-          if (row < n) H[row * 32 + nb * 16 + (lane & 15)] = dv[row] * d[r];
+          if (row < n) H[row * FG_RS + nb * 16 + (lane & 15)] = dv[row] * d[r];
         }
       }
-    } else {
-      // conv4's linear (32 -> 1): sequential 32-term dot per node, pre-scaled
-      for (int i = tid; i < n; i += FG_THREADS) {
-        float pacc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) pacc = fmaf(X[i * 32 + k], Wn[k], pacc);
-        h4s[i] = dv[i] * pacc;
-      }
+      dg_lds_barrier();
     }
-    __syncthreads();
     FG_MARK(2 + layer);
   }
 
-  // ---- conv4 aggregation (F = 1): thread per node, sequential ----
+  // ---- conv4 aggregation (F = 1): thread per node, sequential, padded with the zero slot ----
   {
-    const float b4s = gw.b4[0];
+    const float b4s = prm[128];
     for (int i = tid; i < n; i += FG_THREADS) {
-      const float s = ldscol ? fg_gather_seq1<true>(h4s, cl, rp[i], rp[i + 1], i, n0, n, &bad)
-                             : fg_gather_seq1<false>(h4s, colidx, rp[i], rp[i + 1], i, n0, n, &bad);
-      const float v = tanhf(fmaf(dv[i], s, b4s));
-      x4s[i] = v;
-      x4[n0 + i] = v;
+      const int start = rp[i], end = rp[i + 1];
+      float s = 0.f;
+      for (int e = start; e < end; e += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          int jj;
+          if (ldscol) { const int t = cl[e + u]; jj = (e + u < end) ? t : nz; }
+          else {
+            const bool real = e + u < end;
+            jj = real ? colidx[e + u] - n0 : 0;
+            const bool ok = !real || (unsigned)jj < (unsigned)n;
+            if (!ok) bad = true;
+            if (!(real && ok)) jj = nz;
+          }
+          v[u] = h4s[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      s += h4s[i];
+      const float v4 = tanhf(fmaf(dv[i], s, b4s));
+      x4s[i] = v4;
+      x4[n0 + i] = v4;
     }
   }
   if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
-  __syncthreads();      // x1..x4 of this graph are complete (and visible to this workgroup)
+  __syncthreads();      // full barrier: x1..x4 of this graph are complete and visible to this workgroup
   FG_MARK(5);
 
   // ---- SortPooling + dense tail (keys from LDS, rows from the slabs just written) ----

@@ -88,21 +88,20 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 // neighbour, fully coalesced); loads are issued 8 neighbours at a time, adds applied in order.
 // No cross-lane reduction is needed at all.
 // ---------------------------------------------------------------------------------------------
+// Batches of 8: the tail batch is padded with +0.0f terms (x + 0.0f == x), identical in both paths.
 __device__ __forceinline__ float dg_gather_seq32(const float* __restrict__ src, const int* __restrict__ col,
                                                  int start, int end, int self, int c) {
   float acc = 0.f;
-  int e = start;
-  for (; e + DG_GATHER_UNROLL <= end; e += DG_GATHER_UNROLL) {
+  for (int e = start; e < end; e += DG_GATHER_UNROLL) {
     int j[DG_GATHER_UNROLL];
     float v[DG_GATHER_UNROLL];
 #pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) j[u] = col[e + u];
+    for (int u = 0; u < DG_GATHER_UNROLL; ++u) j[u] = (e + u < end) ? col[e + u] : self;
 #pragma unroll
     for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = src[(size_t)j[u] * 32 + c];
 #pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
+    for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += (e + u < end) ? v[u] : 0.f;
   }
-  for (; e < end; ++e) acc += src[(size_t)col[e] * 32 + c];
   acc += src[(size_t)self * 32 + c];
   return acc;
 }
@@ -143,8 +142,12 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
       val = tanhf(fmaf(dinv[i], acc, bc));
       xout[(size_t)i * 32 + c] = val;
     }
-    if (MODE != 2) xt[slot][c] = val;
-    if (MODE != 2) __syncthreads();
+    if (MODE == 1) {     // conv4's linear (32 -> 1): per-channel products, fixed-order half-wave sum
+      const float pacc = dg_half_sum(val * wc);
+      if (c == 0 && i < N) hs_next[i] = dinv[i] * pacc;
+    }
+    if (MODE == 0) xt[slot][c] = val;
+    if (MODE == 0) __syncthreads();
     if (MODE == 0 && wave < 4) {   // [32 nodes x 32] . Wn^T as four 16x16 blocks
       const int rb = wave >> 1, nb = wave & 1;
       f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -159,18 +162,8 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
         if (node < N) hs_next[(size_t)node * 32 + nb * 16 + (lane & 15)] = dinv[node] * d[r];
       }
     }
-    if (MODE == 1 && threadIdx.x < DG_NODES_PER_WG) {   // conv4's linear: sequential 32-term dot per node
-      const int node = tile * DG_NODES_PER_WG + threadIdx.x;
-      if (node < N) {
-        float p = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) p = fmaf(xt[threadIdx.x][k], Wn[k], p);
-        hs_next[node] = dinv[node] * p;
-      }
-    }
-    if (MODE != 2) __syncthreads();
+    if (MODE == 0) __syncthreads();
   }
-  (void)wc;
 }
 
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
@@ -201,15 +194,13 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 __device__ __forceinline__ float dg_gather_seq1(const float* __restrict__ src, const int* __restrict__ col,
                                                 int start, int end, int self) {
   float s = 0.f;
-  int e = start;
-  for (; e + 8 <= end; e += 8) {
+  for (int e = start; e < end; e += 8) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[col[e + u]];
+    for (int u = 0; u < 8; ++u) v[u] = src[(e + u < end) ? col[e + u] : self];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 8; ++u) s += (e + u < end) ? v[u] : 0.f;
   }
-  for (; e < end; ++e) s += src[col[e]];
   return s + src[self];
 }
 
