@@ -82,8 +82,9 @@ int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int
   if (E > 0 && (!edge_index || !colidx || !colidx_t)) return DGCNN_EINVAL;
   // stand-alone entry: plain semantics "err_flag[0..1] != 0 on error" -> clear, then tag with epoch 1
   if (hipMemsetAsync(err_flag, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return DGCNN_ELAUNCH;
+  // graph_eptr (first edge position per graph) is an internal by-product: park it in the scratch tail
   return dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, rowptr_t, colidx_t, dinv, graph_ptr,
-                        scratch, scratch + (N + 1), err_flag, flags, 1u, (hipStream_t)stream);
+                        scratch + 2 * (N + 1), scratch, scratch + (N + 1), err_flag, flags, 1u, (hipStream_t)stream);
 }
 
 int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
@@ -135,13 +136,14 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
-                        dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
+                        dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
   if (max_nodes > 0 && max_nodes <= dg_fused_max_nodes(F)) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
     DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,
-                               dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
+                               dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr), x1, x2, x3, x4,
+                               dg_ptr<float>(ws, wl.pooled),
                                dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
                                dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,
                                dg_ptr<int32_t>(ws, wl.err), epoch, s,

@@ -49,7 +49,7 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
 // Workspace layout.  Every region is 256-B aligned.
 // ---------------------------------------------------------------------------------------
 #define DG_WS_REGIONS(X) \
-  X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) \
+  X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
   X(pa4) X(pb3) X(pb2) X(pb1)
@@ -88,6 +88,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(colidx_t, 4 * e);
   R(dinv, 4 * n);
   R(graph_ptr, 4 * (b + 1));
+  R(graph_eptr, 4 * (b + 1));
   R(hsA, 4 * n * 32);
   R(hsB, 4 * n * 32);
   R(h4s, 4 * n);
@@ -158,6 +159,70 @@ __device__ __forceinline__ float dg_half_sum(float v) {
   const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
   return (threadIdx.x & 32) ? hi : lo;
 }
+// -----------------------------------------------------------------------------------------------
+// Cooperative row gather, CANONICAL ORDER (see gcn.hip): half-wave per destination node, lane c = channel.
+// Per round the 32 lanes of a half load 32 neighbour indices with ONE coalesced read; each index is
+// then broadcast through an SGPR (v_readlane) so the 32 row reads of a round are all independent --
+// no index->row dependent round trip per neighbour.  Rows are summed sequentially in ascending
+// neighbour order, the self term last; slots past the end of a row add +0.0f.
+//   IDX(e)   -> neighbour id stored at edge position e            (global or LDS)
+//   ROW(j)   -> this lane's channel of row j                      (global or LDS)
+//   PAD      -> an id whose ROW() may be read safely for padding slots
+// Both halves of the wave iterate in lockstep; the trip counts are wave-uniform.
+// -----------------------------------------------------------------------------------------------
+#define DG_RL(v, l) __builtin_amdgcn_readlane((v), (l))
+template <bool ZERO_PAD, typename IDX, typename ROW>
+__device__ __forceinline__ float dg_coop_gather32(int start, int end, int pad, int c, bool upper, IDX idx_at,
+                                                  ROW row_of) {
+  float acc = 0.f;
+  int len = end - start;
+  if (len < 0) len = 0;
+  const int len_other = upper ? DG_RL(len, 0) : DG_RL(len, 32);
+  const int maxlen = len > len_other ? len : len_other;        // identical in all 64 lanes
+  const int umax = __builtin_amdgcn_readfirstlane(maxlen);
+  for (int base = 0; base < umax; base += 32) {
+    const int cnt = len - base;                                  // may be <= 0 for the shorter half
+    const int my = (c < cnt) ? idx_at(start + base + c) : pad;
+    int rem = umax - base;
+    if (rem > 32) rem = 32;
+    for (int u = 0; u < rem; u += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int lo = DG_RL(my, (u + k) & 31), hi = DG_RL(my, 32 + ((u + k) & 31));
+        v[k] = row_of(upper ? hi : lo);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += (ZERO_PAD || (u + k < cnt)) ? v[k] : 0.f;
+    }
+  }
+  return acc;
+}
+// scalar version (F = 1): the 32 lanes of a half fetch 32 neighbour VALUES at once, then the values are
+// summed sequentially in ascending order through readlane (same value in every lane of the half)
+template <typename IDX, typename VAL>
+__device__ __forceinline__ float dg_coop_gather1(int start, int end, int c, bool upper, IDX idx_at, VAL val_of) {
+  float s = 0.f;
+  int len = end - start;
+  if (len < 0) len = 0;
+  const int len_other = upper ? DG_RL(len, 0) : DG_RL(len, 32);
+  const int maxlen = len > len_other ? len : len_other;
+  const int umax = __builtin_amdgcn_readfirstlane(maxlen);
+  for (int base = 0; base < umax; base += 32) {
+    const int cnt = len - base;
+    const float mine = (c < cnt) ? val_of(idx_at(start + base + c)) : 0.f;
+    const int mi = __builtin_bit_cast(int, mine);
+    int rem = umax - base;
+    if (rem > 32) rem = 32;
+    for (int u = 0; u < rem; ++u) {
+      const float lo = __builtin_bit_cast(float, DG_RL(mi, u & 31));
+      const float hi = __builtin_bit_cast(float, DG_RL(mi, 32 + (u & 31)));
+      s += upper ? hi : lo;      // padded slots hold +0.0f
+    }
+  }
+  return s;
+}
+
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {
@@ -214,8 +279,8 @@ __device__ void dg_block_bitonic(PTR data, int n) {
 // kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
-                   float* dinv, int32_t* graph_ptr, int32_t* cnt_in, int32_t* cnt_out, int32_t* err,
-                   int flags, uint32_t epoch, hipStream_t s);
+                   float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
                         int Fout, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
@@ -241,8 +306,8 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           int training, uint64_t seed, hipStream_t s);
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                        const int32_t* graph_ptr, float* x1, float* x2, float* x3, float* x4, float* pooled,
-                        int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
+                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* x1, float* x2, float* x3, float* x4,
+                        float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_fused_max_nodes(int F);

@@ -55,22 +55,28 @@ struct FgW {   // GCN parameters (device pointers into the flat buffer)
   const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;
 };
 
+#define FG_XPF 4      // conv1: x rows of the first FG_XPF passes are prefetched into registers at kernel start
+
 __global__ void __launch_bounds__(FG_THREADS)
 k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, TailW tw,
             const float* __restrict__ xin, const int* __restrict__ rowptr, const int* __restrict__ colidx,
-            const float* __restrict__ dinv, const int* __restrict__ graph_ptr, float* __restrict__ x1,
-            float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, float* __restrict__ pooled,
-            int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g, float* __restrict__ a1dg,
-            uint8_t* __restrict__ maskg, float* __restrict__ logp, int training, uint64_t seed,
-            unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg) {
+            const float* __restrict__ dinv, const int* __restrict__ graph_ptr, const int* __restrict__ graph_eptr,
+            float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
+            float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
+            float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
+            uint64_t seed, unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg) {
 #define FG_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
-  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  // one round trip: node range and edge range of this graph
+  const int n0 = graph_ptr[b], n1 = graph_ptr[b + 1];
+  const int e0 = graph_eptr[b], e1 = graph_eptr[b + 1];
+  const int n = n1 - n0, ne = e1 - e0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31;
-  const int slot = wave * 2 + (lane >> 5);
+  const bool upper = lane >= 32;
+  const int slot = wave * 2 + (upper ? 1 : 0);
   const int nz = nmax;                                   // index of the zero row
   const size_t nb4 = fg_a16_dev((size_t)(nmax + 1) * 4);
   float* H = reinterpret_cast<float*>(smem);
@@ -90,7 +96,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     if (tid == 0) { err[1] = epoch; err[3] = ~epoch; }
     return;
   }
-  // ---- preload every GCN parameter used later (no global load inside the layer loop) ----
+  // ---- second round trip, everything in parallel: parameters, CSR slice, dinv, first x rows ----
   float wreg2[8], wreg3[8];     // B operands of the two MFMA post-steps: B[k][nn] = W[nb*16+nn][k], nb = wave & 1
   {
     const int cc = (wave & 1) * 16 + (lane & 15);
@@ -100,11 +106,14 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
       wreg3[kk] = gw.W3[cc * 32 + 4 * kk + (lane >> 4)];
     }
   }
+  float xpre[FG_XPF];           // x[i][c] for i = slot + 32*pf (only the first 32 feature columns)
+#pragma unroll
+  for (int pf = 0; pf < FG_XPF; ++pf) {
+    const int i = slot + FG_SLOTS * pf;
+    xpre[pf] = (i < n && c < F) ? xin[(size_t)(n0 + i) * F + c] : 0.f;
+  }
   if (tid < 32) { prm[tid] = gw.b1[tid]; prm[32 + tid] = gw.b2[tid]; prm[64 + tid] = gw.b3[tid]; prm[96 + tid] = gw.W4[tid]; }
   if (tid == 32) prm[128] = gw.b4[0];
-  // ---- stage CSR slice, dinv, W1^T; zero row ----
-  const int e0 = rowptr[n0], e1 = rowptr[n0 + n];
-  const int ne = e1 - e0;
   const bool ldscol = ne <= emax_lds;            // workgroup-uniform
   for (int t = tid; t <= n; t += FG_THREADS) rp[t] = rowptr[n0 + t] - (ldscol ? e0 : 0);
   for (int t = tid; t < n; t += FG_THREADS) dv[t] = dinv[n0 + t];
@@ -123,12 +132,30 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     Wt[k * 32 + cc] = gw.W1[t];
   }
   __syncthreads();
-  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k] ----
-  for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
-    const float* xr = xin + (size_t)(n0 + i) * F;
-    float acc = 0.f;
-    for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-    H[i * FG_RS + c] = dv[i] * acc;
+  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (sequential fma chain over k) ----
+  {
+    int pf = 0;
+    for (int base = 0; base < n; base += FG_SLOTS, ++pf) {
+      const int i = base + slot;
+      const bool act = i < n;
+      float acc = 0.f;
+      for (int k0 = 0; k0 < F; k0 += 32) {
+        float xv;
+        if (k0 == 0 && pf < FG_XPF) {
+          xv = pf == 0 ? xpre[0] : (pf == 1 ? xpre[1] : (pf == 2 ? xpre[2] : xpre[3]));
+        } else {
+          xv = (act && k0 + c < F) ? xin[(size_t)(n0 + i) * F + k0 + c] : 0.f;
+        }
+        const int xi = __builtin_bit_cast(int, xv);
+        const int kend = F - k0 < 32 ? F - k0 : 32;
+        for (int k = 0; k < kend; ++k) {        // broadcast x[i][k0+k] of this half through an SGPR
+          const float lo = __builtin_bit_cast(float, DG_RL(xi, k & 31));
+          const float hi = __builtin_bit_cast(float, DG_RL(xi, 32 + (k & 31)));
+          acc = fmaf(upper ? hi : lo, Wt[(k0 + k) * 32 + c], acc);
+        }
+      }
+      if (act) H[i * FG_RS + c] = dv[i] * acc;
+    }
   }
   dg_lds_barrier();
   FG_MARK(1);
@@ -139,46 +166,37 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
     const float bc = prm[layer * 32 + c];
     const float w4c = prm[96 + c];
-    // gather phase: half-wave per destination node, lane = channel
-    for (int i = slot; i < n; i += FG_SLOTS) {
-      const int start = rp[i], end = rp[i + 1];
-      float acc = 0.f;
+    // gather phase: half-wave per destination node, lane = channel; cooperative index fetch
+    for (int base = 0; base < n; base += FG_SLOTS) {
+      const int i = base + slot;
+      const bool act = i < n;
+      const int ii = act ? i : 0;
+      const int start = act ? rp[ii] : 0, end = act ? rp[ii + 1] : 0;
+      float acc;
       if (ldscol) {
-        for (int e = start; e < end; e += DG_GATHER_UNROLL) {
-          int j[DG_GATHER_UNROLL];
-          float v[DG_GATHER_UNROLL];
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) { const int jj = cl[e + u]; j[u] = (e + u < end) ? jj : nz; }
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = H[j[u] * FG_RS + c];
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
-        }
+        acc = dg_coop_gather32<true>(start, end, nz, c, upper, [&](int e) { return cl[e]; },
+                                     [&](int j) { return H[j * FG_RS + c]; });
       } else {
-        for (int e = start; e < end; e += DG_GATHER_UNROLL) {
-          int j[DG_GATHER_UNROLL];
-          float v[DG_GATHER_UNROLL];
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) {
-            const bool real = e + u < end;
-            const int jj = real ? colidx[e + u] - n0 : 0;
-            const bool ok = !real || (unsigned)jj < (unsigned)n;
-            if (!ok) bad = true;
-            j[u] = (real && ok) ? jj : nz;
-          }
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = H[j[u] * FG_RS + c];
-#pragma unroll
-          for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += v[u];
-        }
+        acc = dg_coop_gather32<true>(
+            start, end, nz, c, upper,
+            [&](int e) {
+              const int jj = colidx[e] - n0;
+              const bool ok = (unsigned)jj < (unsigned)n;
+              if (!ok) bad = true;
+              return ok ? jj : nz;
+            },
+            [&](int j) { return H[j * FG_RS + c]; });
       }
-      acc += H[i * FG_RS + c];
-      const float val = tanhf(fmaf(dv[i], acc, bc));
-      X[i * FG_RS + c] = val;
-      xout[(size_t)(n0 + i) * 32 + c] = val;
+      acc += H[ii * FG_RS + c];
+      float val = 0.f;
+      if (act) {
+        val = tanhf(fmaf(dv[i], acc, bc));
+        X[i * FG_RS + c] = val;
+        xout[(size_t)(n0 + i) * 32 + c] = val;
+      }
       if (layer == 2) {     // conv4's linear (32 -> 1): per-channel products, fixed-order half-wave sum
         const float pacc = dg_half_sum(val * w4c);
-        if (c == 0) h4s[i] = dv[i] * pacc;
+        if (act && c == 0) h4s[i] = dv[i] * pacc;
       }
     }
     dg_lds_barrier();
@@ -205,34 +223,34 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     FG_MARK(2 + layer);
   }
 
-  // ---- conv4 aggregation (F = 1): thread per node, sequential, padded with the zero slot ----
+  // ---- conv4 aggregation (F = 1): half-wave per node, 32 neighbour values per fetch, sequential sum ----
   {
     const float b4s = prm[128];
-    for (int i = tid; i < n; i += FG_THREADS) {
-      const int start = rp[i], end = rp[i + 1];
-      float s = 0.f;
-      for (int e = start; e < end; e += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          int jj;
-          if (ldscol) { const int t = cl[e + u]; jj = (e + u < end) ? t : nz; }
-          else {
-            const bool real = e + u < end;
-            jj = real ? colidx[e + u] - n0 : 0;
-            const bool ok = !real || (unsigned)jj < (unsigned)n;
-            if (!ok) bad = true;
-            if (!(real && ok)) jj = nz;
-          }
-          v[u] = h4s[jj];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+    for (int base = 0; base < n; base += FG_SLOTS) {
+      const int i = base + slot;
+      const bool act = i < n;
+      const int ii = act ? i : 0;
+      const int start = act ? rp[ii] : 0, end = act ? rp[ii + 1] : 0;
+      float s;
+      if (ldscol) {
+        s = dg_coop_gather1(start, end, c, upper, [&](int e) { return cl[e]; }, [&](int j) { return h4s[j]; });
+      } else {
+        s = dg_coop_gather1(
+            start, end, c, upper,
+            [&](int e) {
+              const int jj = colidx[e] - n0;
+              const bool ok = (unsigned)jj < (unsigned)n;
+              if (!ok) bad = true;
+              return ok ? jj : nz;
+            },
+            [&](int j) { return h4s[j]; });
       }
-      s += h4s[i];
-      const float v4 = tanhf(fmaf(dv[i], s, b4s));
-      x4s[i] = v4;
-      x4[n0 + i] = v4;
+      s += h4s[ii];
+      if (act && c == 0) {
+        const float v4 = tanhf(fmaf(dv[i], s, b4s));
+        x4s[i] = v4;
+        x4[n0 + i] = v4;
+      }
     }
   }
   if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
@@ -257,8 +275,8 @@ static int fg_choose_emax_lds(int nmax, int F, int emax) {
 
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                        const int32_t* graph_ptr, float* x1, float* x2, float* x3, float* x4, float* pooled,
-                        int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
+                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* x1, float* x2, float* x3, float* x4,
+                        float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0 || B <= 0 || nmax <= 0 || nmax > DGCNN_FUSED_MAX_NODES) return DGCNN_EINVAL;
@@ -279,7 +297,7 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5];
   gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   hipExtLaunchKernelGGL(k_fused_fwd, dim3(B), dim3(FG_THREADS), lds, s, ev_start, ev_stop, 0, F, C, nmax, emax_lds, r0,
-                        gw, dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, x1, x2, x3, x4, pooled, perm,
+                        gw, dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, graph_eptr, x1, x2, x3, x4, pooled, perm,
                         a5, a6, a1d, drop_mask, logp, training, seed, reinterpret_cast<unsigned int*>(err), epoch,
                         g_fg_dbg);
   DG_CHECK_LAUNCH();

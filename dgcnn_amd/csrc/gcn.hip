@@ -88,22 +88,12 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 // neighbour, fully coalesced); loads are issued 8 neighbours at a time, adds applied in order.
 // No cross-lane reduction is needed at all.
 // ---------------------------------------------------------------------------------------------
-// Batches of 8: the tail batch is padded with +0.0f terms (x + 0.0f == x), identical in both paths.
 __device__ __forceinline__ float dg_gather_seq32(const float* __restrict__ src, const int* __restrict__ col,
-                                                 int start, int end, int self, int c) {
-  float acc = 0.f;
-  for (int e = start; e < end; e += DG_GATHER_UNROLL) {
-    int j[DG_GATHER_UNROLL];
-    float v[DG_GATHER_UNROLL];
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) j[u] = (e + u < end) ? col[e + u] : self;
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) v[u] = src[(size_t)j[u] * 32 + c];
-#pragma unroll
-    for (int u = 0; u < DG_GATHER_UNROLL; ++u) acc += (e + u < end) ? v[u] : 0.f;
-  }
-  acc += src[(size_t)self * 32 + c];
-  return acc;
+                                                 int start, int end, int self, int c, bool upper) {
+  const float acc = dg_coop_gather32<false>(
+      start, end, self, c, upper, [&](int e) { return col[e]; },
+      [&](int j) { return src[(size_t)j * 32 + c]; });
+  return acc + src[(size_t)self * 32 + c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,10 +125,12 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
 
   for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
     const int i = tile * DG_NODES_PER_WG + slot;
+    const bool act = i < N;                    // the cooperative gather needs every lane: no divergence here
+    const int ii = act ? i : 0;
+    const int start = act ? rowptr[ii] : 0, end = act ? rowptr[ii + 1] : 0;
+    const float acc = dg_gather_seq32(hs, colidx, start, end, ii, c, half != 0);
     float val = 0.f;
-    if (i < N) {
-      const int start = rowptr[i], end = rowptr[i + 1];
-      const float acc = dg_gather_seq32(hs, colidx, start, end, i, c);
+    if (act) {
       val = tanhf(fmaf(dinv[i], acc, bc));
       xout[(size_t)i * 32 + c] = val;
     }
@@ -191,16 +183,11 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 // forward, F = 1 (conv4): wave per node, lanes across neighbours.
 // ---------------------------------------------------------------------------------------------
 // F = 1 (conv4): thread per node, sequential sum over ascending neighbours, self last (canonical order)
+// half-wave per node; every lane of the half returns the node's sum
 __device__ __forceinline__ float dg_gather_seq1(const float* __restrict__ src, const int* __restrict__ col,
-                                                int start, int end, int self) {
-  float s = 0.f;
-  for (int e = start; e < end; e += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(e + u < end) ? col[e + u] : self];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (e + u < end) ? v[u] : 0.f;
-  }
+                                                int start, int end, int self, int c, bool upper) {
+  const float s = dg_coop_gather1(start, end, c, upper, [&](int e) { return col[e]; },
+                                  [&](int j) { return src[j]; });
   return s + src[self];
 }
 
@@ -208,19 +195,24 @@ __global__ void __launch_bounds__(256)
 k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx,
            const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
            float* __restrict__ x4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane & 31, slot = w * 2 + (lane >> 5);
   const float b = bias[0];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    const float s = dg_gather_seq1(h4s, colidx, rowptr[i], rowptr[i + 1], i);
-    x4[i] = tanhf(fmaf(dinv[i], s, b));
+  for (int base = blockIdx.x * 8; base < N; base += gridDim.x * 8) {     // uniform trip count
+    const int i = base + slot;
+    const bool act = i < N;
+    const int ii = act ? i : 0;
+    const float s = dg_gather_seq1(h4s, colidx, act ? rowptr[ii] : 0, act ? rowptr[ii + 1] : 0, ii, c, lane >= 32);
+    if (act && c == 0) x4[i] = tanhf(fmaf(dinv[i], s, b));
   }
 }
 
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                        const float* h4s, const float* bias, float* x4, hipStream_t s) {
   if (N <= 0) return DGCNN_EINVAL;
-  int grid = dg_cdiv(N, 64);
+  int grid = dg_cdiv(N, 8);
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(64), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
+  hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -243,16 +235,22 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
   const int c = lane & 31, slot = w * 2 + (lane >> 5);      // half-wave per node, lane = channel
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
-  for (int j = blockIdx.x * 8 + slot; j < N; j += gridDim.x * 8) {
-    const float s = dg_gather_seq1(gas4, colidx_t, rowptr_t[j], rowptr_t[j + 1], j);   // broadcast loads
-    const float dj = dinv[j];
-    const float gh = dj * s;
-    const float xv = x3[(size_t)j * 32 + c];
-    const float gx = fmaf(gh, w4c, gp3[(size_t)j * 32 + c]);
-    const float ga = gx * (1.f - xv * xv);
-    gas3[(size_t)j * 32 + c] = dj * ga;
-    pW = fmaf(gh, xv, pW);
-    pb += ga;
+  for (int base = blockIdx.x * 8; base < N; base += gridDim.x * 8) {     // uniform trip count
+    const int j = base + slot;
+    const bool act = j < N;
+    const int jj = act ? j : 0;
+    const float s = dg_gather_seq1(gas4, colidx_t, act ? rowptr_t[jj] : 0, act ? rowptr_t[jj + 1] : 0, jj, c,
+                                   lane >= 32);
+    if (act) {
+      const float dj = dinv[j];
+      const float gh = dj * s;
+      const float xv = x3[(size_t)j * 32 + c];
+      const float gx = fmaf(gh, w4c, gp3[(size_t)j * 32 + c]);
+      const float ga = gx * (1.f - xv * xv);
+      gas3[(size_t)j * 32 + c] = dj * ga;
+      pW = fmaf(gh, xv, pW);
+      pb += ga;
+    }
   }
   red[slot][c] = pW; red[slot][32 + c] = pb;
   __syncthreads();
@@ -315,9 +313,15 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
     const int j = tile * DG_NODES_PER_WG + slot;
     float gh = 0.f, xv = 0.f;
-    if (j < N) {
-      gh = dinv[j] * dg_gather_seq32(gas, colidx_t, rowptr_t[j], rowptr_t[j + 1], j, c);
-      if (!FIRST) xv = xprev[(size_t)j * 32 + c];
+    {
+      const bool act = j < N;                  // cooperative gather: every lane takes part
+      const int jj = act ? j : 0;
+      const float gsum = dg_gather_seq32(gas, colidx_t, act ? rowptr_t[jj] : 0, act ? rowptr_t[jj + 1] : 0, jj, c,
+                                         half != 0);
+      if (act) {
+        gh = dinv[j] * gsum;
+        if (!FIRST) xv = xprev[(size_t)j * 32 + c];
+      }
     }
     ght[slot][c] = gh;
     if (!FIRST) xt[slot][c] = xv;

@@ -86,9 +86,11 @@ k_prep_scan(int N, int* __restrict__ cnt_in, int* __restrict__ cnt_out, int* __r
 
 // ---- 3. fill both adjacency arrays through atomic cursors (order fixed up by step 4) ----
 __global__ void __launch_bounds__(256)
-k_prep_fill(const int64_t* __restrict__ ei, int E, int N, int* __restrict__ cur_in, int* __restrict__ cur_out,
-            int* __restrict__ colidx, int* __restrict__ colidx_t) {
+k_prep_fill(const int64_t* __restrict__ ei, int E, int N, int B, int* __restrict__ cur_in,
+            int* __restrict__ cur_out, int* __restrict__ colidx, int* __restrict__ colidx_t,
+            const int* __restrict__ rowptr, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
   if (t >= E) return;
   const int64_t s = ei[t], d = ei[(int64_t)E + t];
   if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N || s == d) return;
@@ -210,11 +212,12 @@ k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __res
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
 // search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.
 __global__ void __launch_bounds__(256)
-k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, const int* __restrict__ rowptr,
-              const int* __restrict__ colidx, float* __restrict__ dinv, unsigned int* __restrict__ err,
-              unsigned int epoch) {
+k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
+              const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
+              float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < N) dinv[t] = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
+  if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
   if (t < E) {
     const int64_t s = ei[t], d = ei[(int64_t)E + t];
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
@@ -231,8 +234,8 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, const int* __restric
 
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
-                   float* dinv, int32_t* graph_ptr, int32_t* cnt_in, int32_t* cnt_out, int32_t* err,
-                   int flags, uint32_t epoch, hipStream_t s) {
+                   float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s) {
   if (N <= 0 || E < 0 || B <= 0) return DGCNN_EINVAL;
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
@@ -241,8 +244,8 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
     DG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(E > N ? E : N, 256)), dim3(256), 0, s, edge_index, E, N, rowptr,
-                       colidx, dinv, uerr, epoch);
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr,
+                       colidx, graph_ptr, graph_eptr, dinv, uerr, epoch);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
@@ -254,10 +257,10 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
   DG_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, s, N, cnt_in, cnt_out, rowptr, rowptr_t, dinv);
   DG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_prep_fill, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, cnt_in, cnt_out,
+                     colidx, colidx_t, rowptr, graph_ptr, graph_eptr);
+  DG_CHECK_LAUNCH();
   if (E > 0) {
-    hipLaunchKernelGGL(k_prep_fill, dim3(dg_cdiv(E, 256)), dim3(256), 0, s, edge_index, E, N, cnt_in, cnt_out,
-                       colidx, colidx_t);
-    DG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_sort_rows, dim3(dg_cdiv(2 * N, 4)), dim3(256), 0, s, N, rowptr, colidx, rowptr_t,
                        colidx_t);
     DG_CHECK_LAUNCH();

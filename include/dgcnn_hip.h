@@ -104,7 +104,7 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
  *   batch      [N]   int64, sorted, values in [0,B)                     model.py:27
  * Outputs: rowptr[N+1], colidx[E], rowptr_t[N+1], colidx_t[E] (int32; only the first
  * rowptr[N] entries of colidx are meaningful), dinv[N] f32, graph_ptr[B+1] int32.
- * scratch: 2*N+2 int32.  err_flag: 4 int32; afterwards err_flag[0] != 0 if an edge endpoint is
+ * scratch: 2*N+B+3 int32.  err_flag: 4 int32; afterwards err_flag[0] != 0 if an edge endpoint is
  * out of range, err_flag[1] != 0 if DGCNN_FLAG_COALESCED_UNDIRECTED was promised but does not hold.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,

@@ -27,7 +27,7 @@ def run_prep(ei, batch, N, B, flags=0):
     colidx_t = torch.full((max(E, 1),), -7, dtype=torch.int32, device=DEV)
     dinv = torch.empty(N, dtype=torch.float32, device=DEV)
     gptr = torch.empty(B + 1, dtype=torch.int32, device=DEV)
-    scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(2 * N + 4 + 64, dtype=torch.int32, device=DEV)
     err = torch.ones(4, dtype=torch.int32, device=DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, b_d.data_ptr(), N, B, rowptr.data_ptr(),
                                   colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
@@ -163,7 +163,7 @@ def run_gcn(x, ei, W, b, Fout):
     colidx_t = torch.zeros(max(E, 1), dtype=torch.int32, device=DEV)
     dinv = torch.empty(N, dtype=torch.float32, device=DEV)
     gptr = torch.empty(2, dtype=torch.int32, device=DEV)
-    scratch = torch.empty(2 * N + 2, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(2 * N + 4 + 64, dtype=torch.int32, device=DEV)
     err = torch.zeros(4, dtype=torch.int32, device=DEV)
     bd = batch.to(DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, bd.data_ptr(), N, 1, rowptr.data_ptr(),
