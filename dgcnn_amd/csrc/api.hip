@@ -138,7 +138,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
-  if (max_nodes > 0 && max_nodes <= dg_fused_max_nodes(F)) {
+  if (max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F)) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
     DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,

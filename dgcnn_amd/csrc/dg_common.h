@@ -6,8 +6,8 @@
 #include "../../include/dgcnn_hip.h"
 
 #define DG_WAVE 64
-#define DG_TILE 32            // destination nodes per workgroup tile in the F=32 GCN kernels
-#define DG_TILE_THREADS 1024  // 16 waves x 2 half-waves: one half-wave per destination node, lane = channel
+#define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
+#define DG_TILE_THREADS 1024  // 16 waves: one wave per destination node
 #define DG_MAX_PART 1024      // cap on per-workgroup partial-gradient slots
 #define DG_LDS_PAD 36         // row stride (floats) of 16x32 LDS tiles: 16-B aligned rows
 
@@ -67,8 +67,8 @@ static inline int dg_grid32(int N) {
   int tiles = dg_cdiv(N, DG_TILE);
   return tiles < 1 ? 1 : (tiles > DG_MAX_PART ? DG_MAX_PART : tiles);
 }
-static inline int dg_grid1(int N) {   // conv4 backward: 4 waves (256 threads) per workgroup, half-wave per node
-  int b = dg_cdiv(N, 8);
+static inline int dg_grid1(int N) {   // F=1 kernels: 4 waves (256 threads) per workgroup, wave per node
+  int b = dg_cdiv(N, 4);
   return b < 1 ? 1 : (b > DG_MAX_PART ? DG_MAX_PART : b);
 }
 
@@ -159,70 +159,6 @@ __device__ __forceinline__ float dg_half_sum(float v) {
   const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
   return (threadIdx.x & 32) ? hi : lo;
 }
-// -----------------------------------------------------------------------------------------------
-// Cooperative row gather, CANONICAL ORDER (see gcn.hip): half-wave per destination node, lane c = channel.
-// Per round the 32 lanes of a half load 32 neighbour indices with ONE coalesced read; each index is
-// then broadcast through an SGPR (v_readlane) so the 32 row reads of a round are all independent --
-// no index->row dependent round trip per neighbour.  Rows are summed sequentially in ascending
-// neighbour order, the self term last; slots past the end of a row add +0.0f.
-//   IDX(e)   -> neighbour id stored at edge position e            (global or LDS)
-//   ROW(j)   -> this lane's channel of row j                      (global or LDS)
-//   PAD      -> an id whose ROW() may be read safely for padding slots
-// Both halves of the wave iterate in lockstep; the trip counts are wave-uniform.
-// -----------------------------------------------------------------------------------------------
-#define DG_RL(v, l) __builtin_amdgcn_readlane((v), (l))
-template <bool ZERO_PAD, typename IDX, typename ROW>
-__device__ __forceinline__ float dg_coop_gather32(int start, int end, int pad, int c, bool upper, IDX idx_at,
-                                                  ROW row_of) {
-  float acc = 0.f;
-  int len = end - start;
-  if (len < 0) len = 0;
-  const int len_other = upper ? DG_RL(len, 0) : DG_RL(len, 32);
-  const int maxlen = len > len_other ? len : len_other;        // identical in all 64 lanes
-  const int umax = __builtin_amdgcn_readfirstlane(maxlen);
-  for (int base = 0; base < umax; base += 32) {
-    const int cnt = len - base;                                  // may be <= 0 for the shorter half
-    const int my = (c < cnt) ? idx_at(start + base + c) : pad;
-    int rem = umax - base;
-    if (rem > 32) rem = 32;
-    for (int u = 0; u < rem; u += 8) {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int lo = DG_RL(my, (u + k) & 31), hi = DG_RL(my, 32 + ((u + k) & 31));
-        v[k] = row_of(upper ? hi : lo);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc += (ZERO_PAD || (u + k < cnt)) ? v[k] : 0.f;
-    }
-  }
-  return acc;
-}
-// scalar version (F = 1): the 32 lanes of a half fetch 32 neighbour VALUES at once, then the values are
-// summed sequentially in ascending order through readlane (same value in every lane of the half)
-template <typename IDX, typename VAL>
-__device__ __forceinline__ float dg_coop_gather1(int start, int end, int c, bool upper, IDX idx_at, VAL val_of) {
-  float s = 0.f;
-  int len = end - start;
-  if (len < 0) len = 0;
-  const int len_other = upper ? DG_RL(len, 0) : DG_RL(len, 32);
-  const int maxlen = len > len_other ? len : len_other;
-  const int umax = __builtin_amdgcn_readfirstlane(maxlen);
-  for (int base = 0; base < umax; base += 32) {
-    const int cnt = len - base;
-    const float mine = (c < cnt) ? val_of(idx_at(start + base + c)) : 0.f;
-    const int mi = __builtin_bit_cast(int, mine);
-    int rem = umax - base;
-    if (rem > 32) rem = 32;
-    for (int u = 0; u < rem; ++u) {
-      const float lo = __builtin_bit_cast(float, DG_RL(mi, u & 31));
-      const float hi = __builtin_bit_cast(float, DG_RL(mi, 32 + (u & 31)));
-      s += upper ? hi : lo;      // padded slots hold +0.0f
-    }
-  }
-  return s;
-}
-
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {
@@ -311,6 +247,7 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_fused_max_nodes(int F);
+int dg_fused_fits(int nmax, int emax, int F);
 void dg_fused_set_debug(unsigned long long* p);
 #define DG_GATHER_UNROLL 8
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,

@@ -8,16 +8,16 @@
 //
 //     stage this graph's CSR (row pointers + local neighbour ids) and dinv in LDS   (one coalesced pass)
 //     conv1 linear (x W1^T, pre-scaled)                          -> H (LDS, [n][32])
-//     3 x { half-wave per node, lane = channel: sequential sum over the row's neighbours read from H
-//           (ds_read_b32, conflict-free) + self, dst scale, bias, tanh -> X (LDS) and x_l (HBM, saved)
+//     3 x { wave per node: 8 neighbour rows per ds_read_b128 wave-instruction from H + self, fixed xor-
+//           butterfly over the 8 groups, dst scale, bias, tanh      -> X (LDS) and x_l (HBM, saved)
 //           next layer's X W^T on v_mfma_f32_16x16x4_f32           -> H (LDS, overwritten in place) }
 //     conv4 (32 -> 1): per-node dot + scalar gather              -> x4 (LDS sort keys + HBM)
 //     SortPooling (LDS sort) + conv5/pool/conv6/MLP/log_softmax  (dg_readout.h)
 //
 // Inside the layer loop there is NO global load at all: indices, neighbour rows, scales all come
 // from LDS.  HBM sees x, the CSR slice and dinv once, and the x1..x4 slabs written once because
-// backward needs them.  Summation order is the canonical one of gcn.hip (sequential over ascending
-// neighbours, self last), so this path is bit-identical to the tiled kernels.
+// backward needs them.  Lane mapping and summation order are exactly those of gcn.hip's tiled kernels
+// (dg_gather_row32 / dg_gather_row1), so this path is bit-identical to them.
 //
 // Requirements (host hints, verified on the device and reported through the error words): every
 // graph has at most nmax nodes, the batch is block-diagonal (an edge leaving its graph is flagged
@@ -29,8 +29,8 @@
 __device__ __forceinline__ size_t fg_a16_dev(size_t x) { return (x + 15) & ~(size_t)15; }
 
 #define FG_THREADS 1024
-#define FG_SLOTS 32          // node slots per pass: 16 waves x 2 half-waves
-#define FG_RS 33             // row stride (floats) of H and X: conflict-free for lane=channel rows AND MFMA A reads
+#define FG_WAVES 16          // node slots per pass: one wave per destination node
+#define FG_RS 36             // row stride (floats) of H and X: 16-B aligned rows for ds_read_b128, spreads MFMA A reads
 
 // LDS layout (bytes), dynamic:
 //   region0 : max(2*(nmax+1)*RS*4, (nmax+1)*RS*4 + 32*F*4, RD_REGION0_BYTES)   H | X  (aliased later by the readout)
@@ -55,7 +55,33 @@ struct FgW {   // GCN parameters (device pointers into the flat buffer)
   const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;
 };
 
-#define FG_XPF 4      // conv1: x rows of the first FG_XPF passes are prefetched into registers at kernel start
+// same lane mapping / order as dg_gather_row32 (gcn.hip), rows and indices from LDS
+__device__ __forceinline__ float4 fg_gather_row32(const float* __restrict__ H, const int* __restrict__ cl,
+                                                  int start, int end, int self, int lane) {
+  const int g = lane >> 3, q = lane & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = start; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int cj = lane < cnt ? cl[base + lane] : 0;
+    const int iters = (cnt + 7) >> 3;
+    for (int it = 0; it < iters; ++it) {
+      const int idx = it * 8 + g;
+      const int j = __shfl(cj, idx);
+      if (idx < cnt) {
+        const float4 v = *reinterpret_cast<const float4*>(H + j * FG_RS + 4 * q);
+        acc = dg_add4(acc, v);
+      }
+    }
+  }
+  if (g == 0) {
+    const float4 v = *reinterpret_cast<const float4*>(H + self * FG_RS + 4 * q);
+    acc = dg_add4(acc, v);
+  }
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 32));
+  return acc;
+}
 
 __global__ void __launch_bounds__(FG_THREADS)
 k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, TailW tw,
@@ -74,10 +100,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
   const int n = n1 - n0, ne = e1 - e0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31;
-  const bool upper = lane >= 32;
-  const int slot = wave * 2 + (upper ? 1 : 0);
-  const int nz = nmax;                                   // index of the zero row
+  const int g = lane >> 3, q = lane & 7;
   const size_t nb4 = fg_a16_dev((size_t)(nmax + 1) * 4);
   float* H = reinterpret_cast<float*>(smem);
   float* X = H + (size_t)(nmax + 1) * FG_RS;
@@ -89,14 +112,13 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
   int* cl = reinterpret_cast<int*>(p);      p += fg_a16_dev((size_t)emax_lds * 4 + 32);
   float* prm = reinterpret_cast<float*>(p); p += 160 * 4;   // b1|b2|b3 (96) W4 (32) b4 (1)
   char* small = p;
-  bool bad = false;
   FG_MARK(0);
 
-  if (n > nmax) {      // host hint violated: flag and produce nothing for this graph (never overrun LDS)
+  if (n > nmax || ne > emax_lds) {   // host hints violated: flag, produce nothing (never overrun LDS)
     if (tid == 0) { err[1] = epoch; err[3] = ~epoch; }
     return;
   }
-  // ---- second round trip, everything in parallel: parameters, CSR slice, dinv, first x rows ----
+  // ---- second round trip, everything in parallel: parameters, CSR slice, dinv ----
   float wreg2[8], wreg3[8];     // B operands of the two MFMA post-steps: B[k][nn] = W[nb*16+nn][k], nb = wave & 1
   {
     const int cc = (wave & 1) * 16 + (lane & 15);
@@ -106,55 +128,32 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
       wreg3[kk] = gw.W3[cc * 32 + 4 * kk + (lane >> 4)];
     }
   }
-  float xpre[FG_XPF];           // x[i][c] for i = slot + 32*pf (only the first 32 feature columns)
-#pragma unroll
-  for (int pf = 0; pf < FG_XPF; ++pf) {
-    const int i = slot + FG_SLOTS * pf;
-    xpre[pf] = (i < n && c < F) ? xin[(size_t)(n0 + i) * F + c] : 0.f;
-  }
   if (tid < 32) { prm[tid] = gw.b1[tid]; prm[32 + tid] = gw.b2[tid]; prm[64 + tid] = gw.b3[tid]; prm[96 + tid] = gw.W4[tid]; }
   if (tid == 32) prm[128] = gw.b4[0];
-  const bool ldscol = ne <= emax_lds;            // workgroup-uniform
-  for (int t = tid; t <= n; t += FG_THREADS) rp[t] = rowptr[n0 + t] - (ldscol ? e0 : 0);
+  bool bad = false;
+  for (int t = tid; t <= n; t += FG_THREADS) rp[t] = rowptr[n0 + t] - e0;
   for (int t = tid; t < n; t += FG_THREADS) dv[t] = dinv[n0 + t];
-  if (ldscol)
-    for (int t = tid; t < ne; t += FG_THREADS) {
-      const int j = colidx[e0 + t] - n0;
-      const bool ok = (unsigned)j < (unsigned)n;
-      if (!ok) bad = true;
-      cl[t] = ok ? j : nz;
-    }
-  if (tid < 32) H[nz * FG_RS + tid] = 0.f;
-  if (tid == 0) h4s[nz] = 0.f;
+  for (int t = tid; t < ne; t += FG_THREADS) {
+    const int j = colidx[e0 + t] - n0;
+    const bool ok = (unsigned)j < (unsigned)n;
+    if (!ok) bad = true;
+    cl[t] = ok ? j : 0;            // flagged below; clamp keeps LDS reads in range
+  }
+  if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
   float* Wt = X;                       // [F][32], X is free until the first gather
   for (int t = tid; t < 32 * F; t += FG_THREADS) {
     const int cc = t / F, k = t - cc * F;
     Wt[k * 32 + cc] = gw.W1[t];
   }
   __syncthreads();
-  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (sequential fma chain over k) ----
+  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (same fma chain as k_lin_first32) ----
   {
-    int pf = 0;
-    for (int base = 0; base < n; base += FG_SLOTS, ++pf) {
-      const int i = base + slot;
-      const bool act = i < n;
+    const int c = tid & 31;
+    for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
+      const float* xr = xin + (size_t)(n0 + i) * F;
       float acc = 0.f;
-      for (int k0 = 0; k0 < F; k0 += 32) {
-        float xv;
-        if (k0 == 0 && pf < FG_XPF) {
-          xv = pf == 0 ? xpre[0] : (pf == 1 ? xpre[1] : (pf == 2 ? xpre[2] : xpre[3]));
-        } else {
-          xv = (act && k0 + c < F) ? xin[(size_t)(n0 + i) * F + k0 + c] : 0.f;
-        }
-        const int xi = __builtin_bit_cast(int, xv);
-        const int kend = F - k0 < 32 ? F - k0 : 32;
-        for (int k = 0; k < kend; ++k) {        // broadcast x[i][k0+k] of this half through an SGPR
-          const float lo = __builtin_bit_cast(float, DG_RL(xi, k & 31));
-          const float hi = __builtin_bit_cast(float, DG_RL(xi, 32 + (k & 31)));
-          acc = fmaf(upper ? hi : lo, Wt[(k0 + k) * 32 + c], acc);
-        }
-      }
-      if (act) H[i * FG_RS + c] = dv[i] * acc;
+      for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
+      H[i * FG_RS + c] = dv[i] * acc;
     }
   }
   dg_lds_barrier();
@@ -164,39 +163,29 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
 #pragma unroll
   for (int layer = 0; layer < 3; ++layer) {
     float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
-    const float bc = prm[layer * 32 + c];
-    const float w4c = prm[96 + c];
-    // gather phase: half-wave per destination node, lane = channel; cooperative index fetch
-    for (int base = 0; base < n; base += FG_SLOTS) {
-      const int i = base + slot;
-      const bool act = i < n;
-      const int ii = act ? i : 0;
-      const int start = act ? rp[ii] : 0, end = act ? rp[ii + 1] : 0;
-      float acc;
-      if (ldscol) {
-        acc = dg_coop_gather32<true>(start, end, nz, c, upper, [&](int e) { return cl[e]; },
-                                     [&](int j) { return H[j * FG_RS + c]; });
-      } else {
-        acc = dg_coop_gather32<true>(
-            start, end, nz, c, upper,
-            [&](int e) {
-              const int jj = colidx[e] - n0;
-              const bool ok = (unsigned)jj < (unsigned)n;
-              if (!ok) bad = true;
-              return ok ? jj : nz;
-            },
-            [&](int j) { return H[j * FG_RS + c]; });
+    const float4 b4 = *reinterpret_cast<const float4*>(prm + layer * 32 + 4 * q);
+    const float4 w4 = *reinterpret_cast<const float4*>(prm + 96 + 4 * q);
+    for (int i = wave; i < n; i += FG_WAVES) {
+      const float4 acc = fg_gather_row32(H, cl, rp[i], rp[i + 1], i, lane);
+      const float di = dv[i];
+      float4 val;
+      val.x = tanhf(fmaf(di, acc.x, b4.x));
+      val.y = tanhf(fmaf(di, acc.y, b4.y));
+      val.z = tanhf(fmaf(di, acc.z, b4.z));
+      val.w = tanhf(fmaf(di, acc.w, b4.w));
+      if (g == 0) {
+        *reinterpret_cast<float4*>(X + i * FG_RS + 4 * q) = val;
+        *reinterpret_cast<float4*>(xout + (size_t)(n0 + i) * 32 + 4 * q) = val;
       }
-      acc += H[ii * FG_RS + c];
-      float val = 0.f;
-      if (act) {
-        val = tanhf(fmaf(dv[i], acc, bc));
-        X[i * FG_RS + c] = val;
-        xout[(size_t)(n0 + i) * 32 + c] = val;
-      }
-      if (layer == 2) {     // conv4's linear (32 -> 1): per-channel products, fixed-order half-wave sum
-        const float pacc = dg_half_sum(val * w4c);
-        if (act && c == 0) h4s[i] = dv[i] * pacc;
+      if (layer == 2) {     // conv4's linear: 32 -> 1 dot product, pre-scaled (same order as k_gcn_fwd32<1>)
+        float pd = val.x * w4.x;
+        pd = fmaf(val.y, w4.y, pd);
+        pd = fmaf(val.z, w4.z, pd);
+        pd = fmaf(val.w, w4.w, pd);
+        pd += __shfl_xor(pd, 1);
+        pd += __shfl_xor(pd, 2);
+        pd += __shfl_xor(pd, 4);
+        if (lane == 0) h4s[i] = di * pd;
       }
     }
     dg_lds_barrier();
@@ -223,37 +212,21 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     FG_MARK(2 + layer);
   }
 
-  // ---- conv4 aggregation (F = 1): half-wave per node, 32 neighbour values per fetch, sequential sum ----
+  // ---- conv4 aggregation (F = 1): wave per node, lanes across neighbours (same order as dg_gather_row1) ----
   {
     const float b4s = prm[128];
-    for (int base = 0; base < n; base += FG_SLOTS) {
-      const int i = base + slot;
-      const bool act = i < n;
-      const int ii = act ? i : 0;
-      const int start = act ? rp[ii] : 0, end = act ? rp[ii + 1] : 0;
-      float s;
-      if (ldscol) {
-        s = dg_coop_gather1(start, end, c, upper, [&](int e) { return cl[e]; }, [&](int j) { return h4s[j]; });
-      } else {
-        s = dg_coop_gather1(
-            start, end, c, upper,
-            [&](int e) {
-              const int jj = colidx[e] - n0;
-              const bool ok = (unsigned)jj < (unsigned)n;
-              if (!ok) bad = true;
-              return ok ? jj : nz;
-            },
-            [&](int j) { return h4s[j]; });
-      }
-      s += h4s[ii];
-      if (act && c == 0) {
+    for (int i = wave; i < n; i += FG_WAVES) {
+      const int start = rp[i], end = rp[i + 1];
+      float s = 0.f;
+      for (int e = start + lane; e < end; e += 64) s += h4s[cl[e]];
+      s = dg_wave_sum(s) + h4s[i];
+      if (lane == 0) {
         const float v4 = tanhf(fmaf(dv[i], s, b4s));
         x4s[i] = v4;
         x4[n0 + i] = v4;
       }
     }
   }
-  if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
   __syncthreads();      // full barrier: x1..x4 of this graph are complete and visible to this workgroup
   FG_MARK(5);
 
@@ -267,10 +240,11 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
 static thread_local unsigned long long* g_fg_dbg = nullptr;
 void dg_fused_set_debug(unsigned long long* p) { g_fg_dbg = p; }
 
-// choose how many neighbour ids to keep in LDS for (nmax, F, emax): all of them if they fit, else none
-static int fg_choose_emax_lds(int nmax, int F, int emax) {
-  if (emax > 0 && fg_lds_bytes(nmax, F, emax) <= FG_LDS_CAP) return emax;
-  return 0;
+// does a batch with per-graph bounds (nmax nodes, emax directed edges) fit the fused kernel's LDS plan?
+int dg_fused_fits(int nmax, int emax, int F) {
+  if (nmax <= 0 || emax < 0 || nmax > DGCNN_FUSED_MAX_NODES) return 0;
+  const int nm = ((nmax + 15) / 16) * 16;
+  return fg_lds_bytes(nm, F, emax) <= FG_LDS_CAP ? 1 : 0;
 }
 
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
@@ -280,7 +254,7 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
                         int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0 || B <= 0 || nmax <= 0 || nmax > DGCNN_FUSED_MAX_NODES) return DGCNN_EINVAL;
-  const int emax_lds = fg_choose_emax_lds(nmax, F, emax);
+  const int emax_lds = emax;
   const size_t r0 = fg_region0_bytes(nmax, F);
   const size_t lds = fg_lds_bytes(nmax, F, emax_lds);
   if (lds > FG_LDS_CAP) return DGCNN_EUNSUPPORTED;

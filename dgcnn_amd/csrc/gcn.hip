@@ -78,83 +78,107 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// CANONICAL SUMMATION ORDER (shared by the tiled kernels here and the fused kernels in fused.hip, so
-// both paths are bit-identical): every (node, channel) sum is accumulated SEQUENTIALLY over the row's
-// neighbours in ascending index order, the self-loop term last -- the order in which the reference's
-// CPU scatter_add visits a coalesced edge list with the self loops appended at the end
-// (/root/reference/model.py:30-33 via PyG gcn_norm/propagate).
-//
-// Mapping: half-wave per destination node, lane = channel (32 lanes x 4 B = one 128-B row per
-// neighbour, fully coalesced); loads are issued 8 neighbours at a time, adds applied in order.
-// No cross-lane reduction is needed at all.
+// gather of one destination row: returns (in every lane with g==0, and in fact all lanes) the
+// float4 chunk q of   sum_{e in [start,end)} src[col[e]]  +  src[self]
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dg_gather_seq32(const float* __restrict__ src, const int* __restrict__ col,
-                                                 int start, int end, int self, int c, bool upper) {
-  const float acc = dg_coop_gather32<false>(
-      start, end, self, c, upper, [&](int e) { return col[e]; },
-      [&](int j) { return src[(size_t)j * 32 + c]; });
-  return acc + src[(size_t)self * 32 + c];
+__device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src, const int* __restrict__ col,
+                                                  int start, int end, int self, int lane) {
+  const int g = lane >> 3, q = lane & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = start; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int cj = lane < cnt ? col[base + lane] : 0;
+    const int iters = (cnt + 7) >> 3;
+    for (int it = 0; it < iters; ++it) {
+      const int idx = it * 8 + g;
+      const int j = __shfl(cj, idx);
+      if (idx < cnt) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)j * 32 + 4 * q);
+        acc = dg_add4(acc, v);
+      }
+    }
+  }
+  if (g == 0) {   // self loop term, added last in group 0 (PyG appends self loops at the end)
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)self * 32 + 4 * q);
+    acc = dg_add4(acc, v);
+  }
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
+  acc = dg_add4(acc, dg_shfl_xor4(acc, 32));
+  return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, F = 32: 32 destination nodes per workgroup (16 waves x 2 half-waves).
-//   MODE 0: fused next 32x32 linear on MFMA -> hs_next [N,32]
-//   MODE 1: fused next 32->1 linear (dot)   -> hs_next [N]
-//   MODE 2: no post-step (stand-alone layer)
+// forward, F = 32.  MODE 0: fused next 32x32 linear on MFMA -> hs_next [N,32]
+//                   MODE 1: fused next 32->1 linear (dot)   -> hs_next [N]
+//                   MODE 2: no post-step (stand-alone layer)
 // ---------------------------------------------------------------------------------------------
-#define DG_NODES_PER_WG 32
 template <int MODE>
 __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
             float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next) {
-  __shared__ __attribute__((aligned(16))) float xt[DG_NODES_PER_WG][DG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int c = lane & 31, half = lane >> 5;
-  const int slot = wave * 2 + half;              // node slot inside the tile, 0..31
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
 
   float wreg[8];
-  if (MODE == 0 && wave < 4) {   // B operand: block (rb = wave>>1, nb = wave&1): B[k][n] = Wn[nb*16+n][k]
-    const int cc = (wave & 1) * 16 + (lane & 15);
+  if (MODE == 0 && wave < 2) {   // B operand of the post-step: B[k][n] = Wn[n][k]
+    const int c = wave * 16 + (lane & 15);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[cc * 32 + 4 * kk + (lane >> 4)];
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[c * 32 + 4 * kk + (lane >> 4)];
   }
-  const float wc = (MODE == 1) ? Wn[c] : 0.f;
-  const float bc = bias[c];
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1) w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
 
   for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
-    const int i = tile * DG_NODES_PER_WG + slot;
-    const bool act = i < N;                    // the cooperative gather needs every lane: no divergence here
-    const int ii = act ? i : 0;
-    const int start = act ? rowptr[ii] : 0, end = act ? rowptr[ii + 1] : 0;
-    const float acc = dg_gather_seq32(hs, colidx, start, end, ii, c, half != 0);
-    float val = 0.f;
-    if (act) {
-      val = tanhf(fmaf(dinv[i], acc, bc));
-      xout[(size_t)i * 32 + c] = val;
-    }
-    if (MODE == 1) {     // conv4's linear (32 -> 1): per-channel products, fixed-order half-wave sum
-      const float pacc = dg_half_sum(val * wc);
-      if (c == 0 && i < N) hs_next[i] = dinv[i] * pacc;
-    }
-    if (MODE == 0) xt[slot][c] = val;
-    if (MODE == 0) __syncthreads();
-    if (MODE == 0 && wave < 4) {   // [32 nodes x 32] . Wn^T as four 16x16 blocks
-      const int rb = wave >> 1, nb = wave & 1;
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const float a = xt[rb * 16 + (lane & 15)][4 * kk + (lane >> 4)];
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+    const int i = tile * DG_TILE + wave;
+    if (i < N) {
+      const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
+      const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
+      const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane);
+      const float di = dinv[i];
+      float4 val;
+      val.x = tanhf(fmaf(di, acc.x, b4.x));
+      val.y = tanhf(fmaf(di, acc.y, b4.y));
+      val.z = tanhf(fmaf(di, acc.z, b4.z));
+      val.w = tanhf(fmaf(di, acc.w, b4.w));
+      if (g == 0) {
+        *reinterpret_cast<float4*>(xout + (size_t)i * 32 + 4 * q) = val;
+        if (MODE == 0) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = val;
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int node = tile * DG_NODES_PER_WG + rb * 16 + (lane >> 4) * 4 + r;
-        if (node < N) hs_next[(size_t)node * 32 + nb * 16 + (lane & 15)] = dinv[node] * d[r];
+      if (MODE == 1) {
+        float p = val.x * w4.x;
+        p = fmaf(val.y, w4.y, p);
+        p = fmaf(val.z, w4.z, p);
+        p = fmaf(val.w, w4.w, p);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        if (lane == 0) hs_next[i] = di * p;
       }
+    } else if (MODE == 0 && g == 0) {
+      *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (MODE == 0) __syncthreads();
+    if (MODE == 0) {
+      __syncthreads();
+      if (wave < 2) {   // [16 nodes x 32] . W^T -> 16x16 block `wave` of the [16 x 32] result
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float a = xt[lane & 15][4 * kk + (lane >> 4)];
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+          if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dinv[node] * d[r];
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -162,7 +186,7 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0) return DGCNN_EINVAL;
-  const int tiles = dg_cdiv(N, DG_NODES_PER_WG);
+  const int tiles = dg_cdiv(N, DG_TILE);
   const int grid = tiles > 8192 ? 8192 : tiles;
   // hipExtLaunchKernelGGL attaches the events to THIS dispatch (its own start/end timestamps, the
   // same ones rocprofv3 reports); with null events it is a plain launch.
@@ -182,13 +206,11 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 // ---------------------------------------------------------------------------------------------
 // forward, F = 1 (conv4): wave per node, lanes across neighbours.
 // ---------------------------------------------------------------------------------------------
-// F = 1 (conv4): thread per node, sequential sum over ascending neighbours, self last (canonical order)
-// half-wave per node; every lane of the half returns the node's sum
-__device__ __forceinline__ float dg_gather_seq1(const float* __restrict__ src, const int* __restrict__ col,
-                                                int start, int end, int self, int c, bool upper) {
-  const float s = dg_coop_gather1(start, end, c, upper, [&](int e) { return col[e]; },
-                                  [&](int j) { return src[j]; });
-  return s + src[self];
+__device__ __forceinline__ float dg_gather_row1(const float* __restrict__ src, const int* __restrict__ col,
+                                                int start, int end, int lane) {
+  float s = 0.f;
+  for (int e = start + lane; e < end; e += 64) s += src[col[e]];
+  return dg_wave_sum(s);
 }
 
 __global__ void __launch_bounds__(256)
@@ -196,21 +218,18 @@ k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx
            const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
            float* __restrict__ x4) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = lane & 31, slot = w * 2 + (lane >> 5);
   const float b = bias[0];
-  for (int base = blockIdx.x * 8; base < N; base += gridDim.x * 8) {     // uniform trip count
-    const int i = base + slot;
-    const bool act = i < N;
-    const int ii = act ? i : 0;
-    const float s = dg_gather_seq1(h4s, colidx, act ? rowptr[ii] : 0, act ? rowptr[ii + 1] : 0, ii, c, lane >= 32);
-    if (act && c == 0) x4[i] = tanhf(fmaf(dinv[i], s, b));
+  for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
+    const int start = rowptr[i], end = rowptr[i + 1];
+    const float s = dg_gather_row1(h4s, colidx, start, end, lane) + h4s[i];
+    if (lane == 0) x4[i] = tanhf(fmaf(dinv[i], s, b));
   }
 }
 
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                        const float* h4s, const float* bias, float* x4, hipStream_t s) {
   if (N <= 0) return DGCNN_EINVAL;
-  int grid = dg_cdiv(N, 8);
+  int grid = dg_cdiv(N, 4);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
   DG_CHECK_LAUNCH();
@@ -230,20 +249,17 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
            float* __restrict__ pa4) {
-  __shared__ float red[8][64];
+  __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = lane & 31, slot = w * 2 + (lane >> 5);      // half-wave per node, lane = channel
+  const int c = lane & 31;
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
-  for (int base = blockIdx.x * 8; base < N; base += gridDim.x * 8) {     // uniform trip count
-    const int j = base + slot;
-    const bool act = j < N;
-    const int jj = act ? j : 0;
-    const float s = dg_gather_seq1(gas4, colidx_t, act ? rowptr_t[jj] : 0, act ? rowptr_t[jj + 1] : 0, jj, c,
-                                   lane >= 32);
-    if (act) {
-      const float dj = dinv[j];
-      const float gh = dj * s;
+  for (int j = blockIdx.x * 4 + w; j < N; j += gridDim.x * 4) {
+    const int start = rowptr_t[j], end = rowptr_t[j + 1];
+    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
+    const float dj = dinv[j];
+    const float gh = dj * s;
+    if (lane < 32) {
       const float xv = x3[(size_t)j * 32 + c];
       const float gx = fmaf(gh, w4c, gp3[(size_t)j * 32 + c]);
       const float ga = gx * (1.f - xv * xv);
@@ -252,12 +268,10 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
       pb += ga;
     }
   }
-  red[slot][c] = pW; red[slot][32 + c] = pb;
+  if (lane < 32) { red[w][c] = pW; red[w][32 + c] = pb; }
   __syncthreads();
   if (threadIdx.x < 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v += red[k][threadIdx.x];     // fixed order
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = v;
   }
 }
@@ -274,9 +288,9 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
 
 // ---------------------------------------------------------------------------------------------
 // backward of a 32-wide layer l (l = 3, 2): input gas_l [N,32] (= dinv * dL/d pre-activation)
-//   gh[j]      = dinv[j] * ( sum_{i in N_out(j)} gas_l[i] + gas_l[j] )        -> LDS tile [32][32]
-//   dW_l      += gh^T . x_{l-1}          (MFMA 16x16x4, K = 32 nodes of the tile; waves 4..7)
-//   gx_{l-1}   = gh . W_l + gp_{l-1}     (MFMA; waves 0..3)
+//   gh[j]      = dinv[j] * ( sum_{i in N_out(j)} gas_l[i] + gas_l[j] )        -> LDS tile [16][32]
+//   dW_l      += gh^T . x_{l-1}          (MFMA 16x16x4, K = 16 nodes of the tile; waves 2..5)
+//   gx_{l-1}   = gh . W_l + gp_{l-1}     (MFMA; waves 0..1)
 //   ga_{l-1}   = gx_{l-1} * (1 - x_{l-1}^2) ; gas_{l-1} = dinv * ga_{l-1} ; db_{l-1} += ga_{l-1}
 // part[P][1056] = per-workgroup {dW_l [32x32], db_{l-1} [32]}.
 //
@@ -289,13 +303,12 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
             float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float ght[DG_NODES_PER_WG][DG_LDS_PAD];
-  __shared__ __attribute__((aligned(16))) float xt[DG_NODES_PER_WG][DG_LDS_PAD];
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [32][F] raw-input tile
+  __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = lane & 31, half = lane >> 5;
-  const int slot = wave * 2 + half;
+  const int g = lane >> 3, q = lane & 7;
 
   // persistent accumulators
   float wreg[8];
@@ -305,74 +318,75 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   if (FIRST) {
 #pragma unroll
     for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) acc1[u] = 0.f;
-  } else if (wave < 4) {   // B operand of gx = gh . W_l : block (rb = wave>>1, nb = wave&1): B[k][n] = W_l[k][nb*16+n]
+  } else if (wave < 2) {   // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + (wave & 1) * 16 + (lane & 15)];
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + wave * 16 + (lane & 15)];
   }
 
   for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
-    const int j = tile * DG_NODES_PER_WG + slot;
-    float gh = 0.f, xv = 0.f;
-    {
-      const bool act = j < N;                  // cooperative gather: every lane takes part
-      const int jj = act ? j : 0;
-      const float gsum = dg_gather_seq32(gas, colidx_t, act ? rowptr_t[jj] : 0, act ? rowptr_t[jj + 1] : 0, jj, c,
-                                         half != 0);
-      if (act) {
-        gh = dinv[j] * gsum;
-        if (!FIRST) xv = xprev[(size_t)j * 32 + c];
-      }
-    }
-    ght[slot][c] = gh;
-    if (!FIRST) xt[slot][c] = xv;
-    if (FIRST) {
-      for (int k = c; k < F; k += 32) xs[slot * F + k] = j < N ? xprev[(size_t)j * F + k] : 0.f;
+    const int j = tile * DG_TILE + wave;
+    if (j < N) {
+      const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
+      const int end = __builtin_amdgcn_readfirstlane(rowptr_t[j + 1]);
+      float4 acc = dg_gather_row32(gas, colidx_t, start, end, j, lane);
+      const float dj = dinv[j];
+      acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
+      if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = acc;
+      if (!FIRST && g == 1)
+        *reinterpret_cast<float4*>(&xt[wave][4 * q]) =
+            *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
+      if (FIRST)
+        for (int k = lane; k < F; k += 64) xs[wave * F + k] = xprev[(size_t)j * F + k];
+    } else {
+      if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!FIRST && g == 1) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FIRST)
+        for (int k = lane; k < F; k += 64) xs[wave * F + k] = 0.f;
     }
     __syncthreads();
     if (FIRST) {
-      // dW1[cc][k] += sum_node ght[node][cc] * xs[node][k] ; output o = k*32 + cc (cc fastest -> conflict-free)
+      // dW1[c][k] += sum_node ght[node][c] * xs[node][k] ; output o = k*32 + c (c fastest -> conflict-free)
       const int total = 32 * F;
 #pragma unroll
       for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
         const int o = u * DG_TILE_THREADS + threadIdx.x;
         if (o < total) {
-          const int k = o >> 5, cc = o & 31;
+          const int k = o >> 5, c = o & 31;
           float a = acc1[u];
-#pragma unroll 8
-          for (int nd = 0; nd < DG_NODES_PER_WG; ++nd) a = fmaf(ght[nd][cc], xs[nd * F + k], a);
+#pragma unroll
+          for (int nd = 0; nd < DG_TILE; ++nd) a = fmaf(ght[nd][c], xs[nd * F + k], a);
           acc1[u] = a;
         }
       }
     } else {
-      if (wave < 4) {
-        const int rb = wave >> 1, nb = wave & 1;
+      if (wave < 2) {
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          const float a = ght[rb * 16 + (lane & 15)][4 * kk + (lane >> 4)];
+          const float a = ght[lane & 15][4 * kk + (lane >> 4)];
           d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
         }
-        const int cc = nb * 16 + (lane & 15);
+        const int c = wave * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = rb * 16 + (lane >> 4) * 4 + r;
-          const int node = tile * DG_NODES_PER_WG + row;
+          const int row = (lane >> 4) * 4 + r;
+          const int node = tile * DG_TILE + row;
           if (node < N) {
-            const float x_ = xt[row][cc];
-            const float gx = d[r] + gpprev[(size_t)node * 32 + cc];
-            const float ga = gx * (1.f - x_ * x_);
-            gas_prev[(size_t)node * 32 + cc] = dinv[node] * ga;
+            const float xv = xt[row][c];
+            const float gx = d[r] + gpprev[(size_t)node * 32 + c];
+            const float ga = gx * (1.f - xv * xv);
+            gas_prev[(size_t)node * 32 + c] = dinv[node] * ga;
             pb += ga;
           }
         }
-      } else if (wave < 8) {   // dW block (mb, nb): A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n], K = 32 nodes
-        const int mb = (wave - 4) >> 1, nb = (wave - 4) & 1;
+      } else if (wave < 6) {   // dW block (mb, nb): A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n]
+        const int mb = (wave - 2) >> 1, nb = (wave - 2) & 1;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
           const int k = 4 * kk + (lane >> 4);
           const float a = ght[k][mb * 16 + (lane & 15)];
-          const float bq = xt[k][nb * 16 + (lane & 15)];
-          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, accW, 0, 0, 0);
+          const float b = xt[k][nb * 16 + (lane & 15)];
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accW, 0, 0, 0);
         }
       }
     }
@@ -387,27 +401,19 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
       const int o = u * DG_TILE_THREADS + threadIdx.x;
       if (o < total) {
-        const int k = o >> 5, cc = o & 31;
-        dst[cc * F + k] = acc1[u];     // stored in W1's own [32,F] layout
+        const int k = o >> 5, c = o & 31;
+        dst[c * F + k] = acc1[u];     // stored in W1's own [32,F] layout
       }
     }
   } else {
-    // db partial: waves 0..3 hold, per lane, the column sum over their rows; (rb=0,nb) and (rb=1,nb) share
-    // columns -> combine through LDS in a fixed order
-    __shared__ float pbs[4][16];
-    if (wave < 4) {
+    float* dst = part + (size_t)blockIdx.x * 1056;
+    if (wave < 2) {
+      // lanes l, l+16, l+32, l+48 hold the same column: fixed-order combine
       pb += __shfl_xor(pb, 16);
       pb += __shfl_xor(pb, 32);
-      if (lane < 16) pbs[wave][lane] = pb;
-    }
-    __syncthreads();
-    float* dst = part + (size_t)blockIdx.x * 1056;
-    if (threadIdx.x < 32) {
-      const int nb = threadIdx.x >> 4, l = threadIdx.x & 15;
-      dst[1024 + threadIdx.x] = pbs[nb][l] + pbs[2 + nb][l];     // rb = 0 block + rb = 1 block
-    }
-    if (wave >= 4 && wave < 8) {
-      const int mb = (wave - 4) >> 1, nb = (wave - 4) & 1;
+      if (lane < 16) dst[1024 + wave * 16 + lane] = pb;
+    } else if (wave < 6) {
+      const int mb = (wave - 2) >> 1, nb = (wave - 2) & 1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mb * 16 + (lane >> 4) * 4 + r;     // output channel of W_l
@@ -422,10 +428,10 @@ int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const 
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
-  const int tiles = dg_cdiv(N, DG_NODES_PER_WG);
+  const int tiles = dg_cdiv(N, DG_TILE);
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
-    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_NODES_PER_WG * F, s, N, F,
+    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
                        tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part);
   } else {
     hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,

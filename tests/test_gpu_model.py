@@ -108,6 +108,7 @@ def test_fused_graph_per_workgroup_path_is_bit_identical_to_tiled_path(name, bs)
     lim = _lib.lib().dgcnn_fused_max_nodes(sh.num_features)
     if b.max_nodes > lim:
         pytest.skip(f"largest graph {b.max_nodes} > fused limit {lim}")
+    assert b.max_edges > 0
     m = make_model(sh.num_features, sh.num_classes)
     bg = b.to("cuda")
     outs = {}
@@ -131,7 +132,7 @@ def test_fused_path_flags_bad_hints():
     m = make_model(sh.num_features, sh.num_classes).eval()
     # max_nodes hint smaller than the largest graph
     assert b.max_nodes > 16
-    small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=16)
+    small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=16, max_edges=b.max_edges)
     with torch.no_grad():
         m(small.to("cuda"))
     with pytest.raises(_lib.DgcnnError):
@@ -140,7 +141,8 @@ def test_fused_path_flags_bad_hints():
     ei = b.edge_index.clone()
     n_first = int((b.batch == 0).sum())
     extra = torch.tensor([[0, n_first], [n_first, 0]])
-    bad = Batch(b.x, torch.cat([ei, extra], 1), b.batch, b.y, coalesced_undirected=False, max_nodes=b.max_nodes)
+    bad = Batch(b.x, torch.cat([ei, extra], 1), b.batch, b.y, coalesced_undirected=False, max_nodes=b.max_nodes,
+                max_edges=b.max_edges + 2)
     with torch.no_grad():
         m(bad.to("cuda"))
     with pytest.raises(_lib.DgcnnError):
