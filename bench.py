@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--path", choices=["auto", "fused", "tiled"], default="auto",
+                    help="forward kernel family: library heuristic, graph-per-workgroup fused, or tiled")
     return ap.parse_args()
 
 
@@ -59,6 +61,15 @@ def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int
     E~ = non-self-loop edges + N self loops.  Each array counted once (compulsory traffic)."""
     Et = E_noself + N
     return 4 * Et + 4 * (N + 1) + 4 * N + 2 * s * N * F
+
+
+def algorithmic_bytes_fused_fwd(N: int, E_noself: int, B: int, F: int) -> int:
+    """Compulsory traffic of the fused graph-per-workgroup forward kernel, every array once:
+    reads x [N,F], rowptr, colidx, dinv, graph pointers; writes x1..x3 [N,32], x4 [N] (saved for
+    backward), pooled [B,2910], perm, the saved tail activations and the log-probs."""
+    rd = 4 * N * F + 4 * (N + 1) + 4 * E_noself + 4 * N + 8 * (B + 1)
+    wr = 3 * 4 * N * 32 + 4 * N + 4 * B * 2910 + 4 * B * 30 + 4 * B * (480 + 352 + 128) + B * 128 + 4 * B * 3
+    return rd + wr
 
 
 def cpu_baseline(batches_cpu, F, C, seconds):
@@ -142,6 +153,8 @@ def main():
     torch.manual_seed(324)                    # identical replicas on every rank
     model = Model(F, C).to(dev)
     model.train()
+    if args.path != "auto":
+        model.use_fused = args.path == "fused"
     tr = Trainer(model, process_group=pg)
     gb = B * world
 
@@ -192,6 +205,9 @@ def main():
             return p
         pairs = []
         ms = ctypes.c_float()
+        b0 = batches_cpu[0]
+        fused = (args.path == "fused" or (args.path == "auto" and B >= 192)) and \
+            bool(L.dgcnn_fused_fits(max(b.max_nodes for b in batches_cpu), max(b.max_edges for b in batches_cpu), F))
         nprof = min(args.steps, 300)
         for i in range(nprof):
             a, bb = ev(), ev()
@@ -207,19 +223,22 @@ def main():
         for a, bb, n_, e_ in pairs:
             _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
-            tot_bytes += algorithmic_bytes_agg(n_, e_)          # synthetic graphs have no self loops
+            tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, B, F) if fused else algorithmic_bytes_agg(n_, e_)
             L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
         avg_us = max(tot_us / len(pairs), 1e-3)
         bytes_per_launch = tot_bytes / len(pairs)
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_gcn_fwd32 (32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA)",
+        roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup: conv1..conv4 + SortPooling + tail, LDS-resident)" if fused
+                    else "k_gcn_fwd32 (32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_us, "launches_measured": len(pairs),
                     "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
-                    "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at B=50 the launch "
-                            "moves ~1.5 MB and is latency-bound, see DESIGN.md for the batch-size sweep"}
+                    "note": ("compulsory traffic of the fused forward (every array once: x, CSR, dinv in; x1..x4, pooled, "
+                             "tail activations out), see DESIGN.md") if fused else
+                            ("compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at B=50 the launch "
+                             "moves ~1.5 MB and is latency-bound, see DESIGN.md for the batch-size sweep")}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 4
 FLAG_COALESCED_UNDIRECTED = 1
+FLAG_FORCE_FUSED = 2
+FLAG_FORCE_TILED = 4
 
 K = 30
 CAT = 97
@@ -38,6 +40,7 @@ SIGNATURES = {
                                     ctypes.c_uint32, c_void_p]),
     "dgcnn_debug_phase_clocks": (c_int, [c_void_p]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
+    "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
                                 c_void_p]),

@@ -41,6 +41,11 @@ int dgcnn_debug_phase_clocks(void* dev_u64x16) {
   return DGCNN_OK;
 }
 
+int dgcnn_fused_fits(int max_nodes, int max_edges, int F) {
+  if (F < 1 || F > DGCNN_MAX_F) return 0;
+  return dg_fused_fits(max_nodes, max_edges, F);
+}
+
 int dgcnn_fused_max_nodes(int F) {
   if (F < 1 || F > DGCNN_MAX_F) return 0;
   return dg_fused_max_nodes(F);
@@ -138,7 +143,11 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
-  if (max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F)) {
+  // Path choice.  One workgroup per graph only pays when there are enough graphs to occupy the chip
+  // (256 CUs): at the reference's batch of 50 the tiled kernels spread each graph's nodes over all CUs
+  // and are faster; from a few hundred graphs per batch the LDS-resident kernel wins (no L2 gathers).
+  const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) || (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
+  if (want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F)) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
     DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,

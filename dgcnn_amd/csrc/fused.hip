@@ -169,10 +169,10 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
       const float4 acc = fg_gather_row32(H, cl, rp[i], rp[i + 1], i, lane);
       const float di = dv[i];
       float4 val;
-      val.x = tanhf(fmaf(di, acc.x, b4.x));
-      val.y = tanhf(fmaf(di, acc.y, b4.y));
-      val.z = tanhf(fmaf(di, acc.z, b4.z));
-      val.w = tanhf(fmaf(di, acc.w, b4.w));
+      val.x = dg_tanh(fmaf(di, acc.x, b4.x));
+      val.y = dg_tanh(fmaf(di, acc.y, b4.y));
+      val.z = dg_tanh(fmaf(di, acc.z, b4.z));
+      val.w = dg_tanh(fmaf(di, acc.w, b4.w));
       if (g == 0) {
         *reinterpret_cast<float4*>(X + i * FG_RS + 4 * q) = val;
         *reinterpret_cast<float4*>(xout + (size_t)(n0 + i) * 32 + 4 * q) = val;
@@ -221,7 +221,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
       for (int e = start + lane; e < end; e += 64) s += h4s[cl[e]];
       s = dg_wave_sum(s) + h4s[i];
       if (lane == 0) {
-        const float v4 = tanhf(fmaf(dv[i], s, b4s));
+        const float v4 = dg_tanh(fmaf(dv[i], s, b4s));
         x4s[i] = v4;
         x4[n0 + i] = v4;
       }

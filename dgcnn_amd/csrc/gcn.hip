@@ -141,10 +141,10 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
       const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane);
       const float di = dinv[i];
       float4 val;
-      val.x = tanhf(fmaf(di, acc.x, b4.x));
-      val.y = tanhf(fmaf(di, acc.y, b4.y));
-      val.z = tanhf(fmaf(di, acc.z, b4.z));
-      val.w = tanhf(fmaf(di, acc.w, b4.w));
+      val.x = dg_tanh(fmaf(di, acc.x, b4.x));
+      val.y = dg_tanh(fmaf(di, acc.y, b4.y));
+      val.z = dg_tanh(fmaf(di, acc.z, b4.z));
+      val.w = dg_tanh(fmaf(di, acc.w, b4.w));
       if (g == 0) {
         *reinterpret_cast<float4*>(xout + (size_t)i * 32 + 4 * q) = val;
         if (MODE == 0) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = val;
@@ -222,7 +222,7 @@ k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx
   for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
     const int start = rowptr[i], end = rowptr[i + 1];
     const float s = dg_gather_row1(h4s, colidx, start, end, lane) + h4s[i];
-    if (lane == 0) x4[i] = tanhf(fmaf(dinv[i], s, b));
+    if (lane == 0) x4[i] = dg_tanh(fmaf(dinv[i], s, b));
   }
 }
 

@@ -214,14 +214,17 @@ class Model(nn.Module):
         self._epoch = (self._epoch % 0x7FFFFFFE) + 1
         return self._epoch
 
-    @staticmethod
-    def _flags_of(data) -> int:
-        return _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
+    def _flags_of(self, data) -> int:
+        f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
+        uf = getattr(self, "use_fused", None)       # None: library heuristic; True/False: force (tests, sweeps)
+        if uf is True:
+            f |= _lib.FLAG_FORCE_FUSED
+        elif uf is False:
+            f |= _lib.FLAG_FORCE_TILED
+        return f
 
     def _max_nodes_of(self, data) -> int:
-        """per-graph node bound for the fused path; honours ``self.use_fused`` (tests flip it)."""
-        if not getattr(self, "use_fused", True):
-            return 0
+        """per-graph node bound (host-known hint) for the graph-per-workgroup path"""
         return int(getattr(data, "max_nodes", 0) or 0)
 
     def check_errors(self) -> None:

@@ -57,6 +57,9 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
 
 /* flags of dgcnn_graph_prep / dgcnn_model_forward */
 #define DGCNN_FLAG_COALESCED_UNDIRECTED 1
+#define DGCNN_FLAG_FORCE_FUSED 2    /* use the graph-per-workgroup kernel whenever the hints allow it */
+#define DGCNN_FLAG_FORCE_TILED 4    /* never use it */
+#define DGCNN_FUSED_MIN_GRAPHS 192  /* default: fused path only for batches of at least this many graphs */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
  * duplicates, no self loops, every edge present in both directions -- what a TU dataset file (and
  * PyG coalesce/to_undirected) holds, i.e. what the reference's loader feeds model.py:27.  Graph
@@ -151,9 +154,10 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *            from `seed` (mask is exported in the workspace region "drop_mask" [B,128] u8)
  *   flags  : 0 or DGCNN_FLAG_COALESCED_UNDIRECTED
  *   max_nodes: host-known upper bound of the node count of any single graph of the batch
- *            (PyG's collate knows it; 0 = unknown).  When 0 < max_nodes <= dgcnn_fused_max_nodes(F)
- *            the graph-per-workgroup fused kernel runs (whole forward in one launch, activations in
- *            LDS); otherwise the general tiled kernels.  Both give bit-identical results.  A hint
+ *            (PyG's collate knows it; 0 = unknown).  With max_nodes/max_edges given, a batch of at least
+ *            DGCNN_FUSED_MIN_GRAPHS graphs whose largest graph fits the LDS plan runs the
+ *            graph-per-workgroup fused kernel (whole forward in one launch, activations and adjacency
+ *            in LDS); otherwise the tiled kernels.  Both give bit-identical results.  A hint
  *            that is too small is detected on the device and reported through the error words.
  *   max_edges: host-known upper bound of the directed-edge count of any single graph (0 = unknown);
  *            lets the fused kernel also keep each graph's neighbour ids in LDS when they fit.
@@ -168,6 +172,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                         int max_edges, uint32_t epoch, dgcnn_stream_t stream);
 int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
+int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batch fits the fused LDS plan */
 
 /* ------------------------------------------------------------------------------------
  * Whole-model backward: what `loss.backward()` (/root/reference/train.py:40) executes for

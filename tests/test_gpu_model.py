@@ -130,6 +130,7 @@ def test_fused_path_flags_bad_hints():
     sh = synth.SHAPES["PROTEINS"]
     b = synth.make_batch("PROTEINS", 6, start=20)
     m = make_model(sh.num_features, sh.num_classes).eval()
+    m.use_fused = True
     # max_nodes hint smaller than the largest graph
     assert b.max_nodes > 16
     small = Batch(b.x, b.edge_index, b.batch, b.y, coalesced_undirected=True, max_nodes=16, max_edges=b.max_edges)
