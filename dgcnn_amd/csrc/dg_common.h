@@ -159,6 +159,18 @@ __device__ __forceinline__ float dg_half_sum(float v) {
   const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
   return (threadIdx.x & 32) ? hi : lo;
 }
+// XCD-aware tile order (MI355X: 8 XCDs, private 4 MiB L2 each, workgroup b is observed to run on XCD
+// b % 8): give each XCD a CONTIGUOUS range of node tiles so the rows a tile gathers (its own graph's,
+// i.e. nearby tiles') are served by that XCD's L2 instead of being fetched into all eight.  Bijective
+// for any tile count; placement only affects speed, never results.
+__device__ __forceinline__ int dg_xcd_tile(int t, int numTiles) {
+  const int q = numTiles >> 3, r = numTiles & 7;
+  const int xcd = t & 7, k = t >> 3;
+  // XCD x owns q+1 tiles if x < r else q tiles; tiles with k beyond the owner's share wrap to the tail
+  const int share = xcd < r ? q + 1 : q;
+  if (k < share) return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  return t;   // unreachable for t < numTiles when iterated as below; keeps the map total
+}
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {

@@ -133,7 +133,8 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
   if (MODE == 1) w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
   const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
 
-  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+  for (int tl = blockIdx.x; tl < numTiles; tl += gridDim.x) {
+    const int tile = (gridDim.x == (unsigned)numTiles) ? dg_xcd_tile(tl, numTiles) : tl;
     const int i = tile * DG_TILE + wave;
     if (i < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
@@ -187,7 +188,7 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
-  const int grid = tiles > 8192 ? 8192 : tiles;
+  const int grid = tiles;          // one workgroup per tile (XCD-aware order inside the kernel)
   // hipExtLaunchKernelGGL attaches the events to THIS dispatch (its own start/end timestamps, the
   // same ones rocprofv3 reports); with null events it is a plain launch.
   if (mode == 0)
@@ -323,7 +324,11 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + wave * 16 + (lane & 15)];
   }
 
-  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+  // each workgroup owns a CONTIGUOUS chunk of tiles, and chunks are laid out XCD-contiguously
+  const int chunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = dg_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tile_end = min(numTiles, (wg + 1) * chunk);
+  for (int tile = wg * chunk; tile < tile_end; ++tile) {
     const int j = tile * DG_TILE + wave;
     if (j < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
