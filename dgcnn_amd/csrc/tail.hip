@@ -369,7 +369,9 @@ int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* 
   const float* pb2 = dg_cptr<float>(ws, wl->pb2);
   const float* pb3 = dg_cptr<float>(ws, wl->pb3);
   const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, 8, B, grads + pl->off[12], nullptr, 0);
+  // small batches: 8 lanes per output hide the latency of the short reduction; large batches: one lane per
+  // output so consecutive lanes read consecutive addresses of a6[b][:] (coalesced) for every b
+  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, B <= 128 ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
   add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
   add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
   add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);

@@ -41,6 +41,8 @@ class Trainer:
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.pg = process_group
+        from .dist import GradAllReduce
+        self._allreduce = GradAllReduce(process_group) if process_group is not None else None
         self.step_count = 0
         flat = model.flat_params
         self.exp_avg = torch.zeros_like(flat)
@@ -104,9 +106,8 @@ class Trainer:
     def train_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
         """One iteration of the body of the reference ``train()`` loop (train.py:36-45)."""
         logp = self.forward_backward(data, y, global_batch)
-        if self.pg is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+        if self._allreduce is not None:
+            self._allreduce(self.grads)          # ONE flat-bucket RCCL all-reduce per step (dgcnn_amd/dist.py)
         self.optimizer_step()
         return logp
 
