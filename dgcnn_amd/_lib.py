@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -42,6 +42,8 @@ SIGNATURES = {
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "dgcnn_model_backward_step": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
                                 c_void_p]),
     "dgcnn_accumulate_metrics": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -8,6 +8,23 @@ static thread_local hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
 #define DG_PROF_A(idx) (g_prof_which == (idx) ? g_prof_a : nullptr)
 #define DG_PROF_B(idx) (g_prof_which == (idx) ? g_prof_b : nullptr)
 
+// Helper stream for work that is independent of the GCN backward chain (tail weight gradients): created
+// once per host thread and device on first use, together with the two events that fork/join it.
+struct DgSide { hipStream_t stream; hipEvent_t fork, join; int dev; };
+static thread_local DgSide g_side = {nullptr, nullptr, nullptr, -1};
+static int dg_side_get(DgSide** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return DGCNN_ELAUNCH;
+  if (g_side.stream == nullptr || g_side.dev != dev) {
+    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return DGCNN_ELAUNCH;
+    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess) return DGCNN_ELAUNCH;
+    if (hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) return DGCNN_ELAUNCH;
+    g_side.dev = dev;
+  }
+  *out = &g_side;
+  return DGCNN_OK;
+}
+
 extern "C" {
 
 int dgcnn_profile_next_forward(int which, void* ev_start, void* ev_stop) {
@@ -181,7 +198,8 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
-                                  float loss_scale, int training, float* grads, float* metrics, hipStream_t s) {
+                                  float loss_scale, int training, float* grads, float* metrics,
+                                  const DgAdam* adam, hipStream_t s) {
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -199,6 +217,14 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), s));
+  // fork: the tail weight gradients (and their optional Adam update, and the loss/accuracy bookkeeping) depend
+  // only on k_tail_bwd; they run on the helper stream while the latency-bound GCN chain runs here
+  DgSide* side = nullptr;
+  DG_TRY(dg_side_get(&side));
+  if (hipEventRecord(side->fork, s) != hipSuccess) return DGCNN_ELAUNCH;
+  if (hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return DGCNN_ELAUNCH;
+  DG_TRY(dg_launch_wgrad(1, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, side->stream));
+  if (hipEventRecord(side->join, side->stream) != hipSuccess) return DGCNN_ELAUNCH;
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s));
@@ -211,8 +237,9 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
   DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                              dg_ptr<float>(ws, wl.pb1), wl.P32, s));
-  // every weight gradient, fixed-order reductions
-  DG_TRY(dg_launch_wgrad(N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, s));
+  // GCN weight gradients: fixed-order reductions of the per-workgroup partials; then join the helper stream
+  DG_TRY(dg_launch_wgrad(2, N, B, F, C, &pl, &wl, ws, grads, nullptr, adam, s));
+  if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) return DGCNN_ELAUNCH;
   return DGCNN_OK;
 }
 
@@ -223,7 +250,20 @@ int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
   if (!params || !x || !ws || !logp || !grads || N <= 0 || B <= 0) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, glogp, y, loss_scale, training ? 1 : 0,
-                                grads, metrics, (hipStream_t)stream);
+                                grads, metrics, nullptr, (hipStream_t)stream);
+}
+
+int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, const float* x, void* ws,
+                              const float* logp, const int64_t* y, float loss_scale, int training, float* grads,
+                              float* metrics, float* exp_avg, float* exp_avg_sq, int64_t step, float lr,
+                              float beta1, float beta2, float eps, dgcnn_stream_t stream) {
+  if (!params || !x || !ws || !logp || !y || !grads || !exp_avg || !exp_avg_sq || N <= 0 || B <= 0 || step < 1)
+    return DGCNN_EINVAL;
+  DgAdam ad;
+  ad.params = params; ad.exp_avg = exp_avg; ad.exp_avg_sq = exp_avg_sq;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step = step;
+  return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, nullptr, y, loss_scale, training ? 1 : 0,
+                                grads, metrics, &ad, (hipStream_t)stream);
 }
 
 int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,

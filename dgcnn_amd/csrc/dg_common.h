@@ -276,8 +276,13 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                        hipStream_t s);
-int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, hipStream_t s);
+struct DgAdam {          // optional optimizer step fused into the weight-gradient kernel
+  float *params, *exp_avg, *exp_avg_sq;
+  float lr, beta1, beta2, eps;
+  int64_t step;
+};
+int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s);
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);
 int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s);

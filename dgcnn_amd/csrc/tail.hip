@@ -288,6 +288,10 @@ struct WgSeg {
 struct WgArgs {
   int nseg, B, C;
   const float *dlogit, *a1d, *gz1, *a6, *gz6, *a5, *gz5, *pooled;
+  // optional fused Adam (torch.optim.Adam defaults semantics): applied by the lane that owns the output
+  float *adam_p, *adam_m, *adam_v;     // flat buffers (same layout as grads); null = no optimizer step here
+  const float* grads_base;             // to turn an output pointer into a flat index
+  float lr, b1, b2, eps, bc1, bc2_sqrt;
   WgSeg seg[WG_MAX_SEG];
 };
 
@@ -329,29 +333,42 @@ k_wgrad(WgArgs A) {
   const int lpo = sg.lpo;
   const int i = gid / lpo, r0 = gid - i * lpo;
   const bool live = i < sg.count;
-  // 4 independent accumulators -> 4 loads in flight per lane; combined in a fixed order
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // 8 independent accumulators -> 8 loads in flight per lane; combined in a fixed order
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (live) {
     const int R = sg.R;
     int r = r0;
-    for (; r + 3 * lpo < R; r += 4 * lpo) {
-      a0 += dg_wg_term(A, sg, i, r);
-      a1 += dg_wg_term(A, sg, i, r + lpo);
-      a2 += dg_wg_term(A, sg, i, r + 2 * lpo);
-      a3 += dg_wg_term(A, sg, i, r + 3 * lpo);
+    for (; r + 7 * lpo < R; r += 8 * lpo) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
     }
-    for (; r < R; r += lpo) a0 += dg_wg_term(A, sg, i, r);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r + u * lpo < R) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
   }
-  float acc = (a0 + a1) + (a2 + a3);
+  float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   for (int o = 1; o < lpo; o <<= 1) acc += __shfl_xor(acc, o);
   if (live && r0 == 0) {
-    if (sg.type == WG_METRIC) sg.out[i] += acc;     // running loss / #correct accumulators
-    else sg.out[i] = acc;
+    if (sg.type == WG_METRIC) {
+      sg.out[i] += acc;     // running loss / #correct accumulators
+    } else {
+      sg.out[i] = acc;
+      if (A.adam_p) {       // optimizer.step() for this element (train.py:41), same formula as k_adam
+        const size_t k = (size_t)(sg.out - A.grads_base) + i;
+        const float mi = A.b1 * A.adam_m[k] + (1.f - A.b1) * acc;
+        const float vi = A.b2 * A.adam_v[k] + (1.f - A.b2) * acc * acc;
+        A.adam_m[k] = mi; A.adam_v[k] = vi;
+        const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+        A.adam_p[k] = A.adam_p[k] - (A.lr / A.bc1) * (mi / denom);
+      }
+    }
   }
 }
 
-int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, hipStream_t s) {
+// which: bit 0 = tail parameters (depend on k_tail_bwd only), bit 1 = GCN parameters (depend on the GCN
+// backward kernels).  The two halves can run on different streams.
+int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s) {
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
@@ -359,36 +376,50 @@ int dg_launch_wgrad(int N, int B, int F, int C, const DgParams* pl, const DgWs* 
   A.gz1 = dg_cptr<float>(ws, wl->gz1); A.a6 = dg_cptr<float>(ws, wl->a6);
   A.gz6 = dg_cptr<float>(ws, wl->gz6); A.a5 = dg_cptr<float>(ws, wl->a5);
   A.gz5 = dg_cptr<float>(ws, wl->gz5); A.pooled = dg_cptr<float>(ws, wl->pooled);
+  A.grads_base = grads;
+  if (adam && adam->params) {
+    A.adam_p = adam->params; A.adam_m = adam->exp_avg; A.adam_v = adam->exp_avg_sq;
+    A.lr = adam->lr; A.b1 = adam->beta1; A.b2 = adam->beta2; A.eps = adam->eps;
+    A.bc1 = (float)(1.0 - pow((double)adam->beta1, (double)adam->step));
+    A.bc2_sqrt = (float)sqrt(1.0 - pow((double)adam->beta2, (double)adam->step));
+  }
   int nb = 0, ns = 0;
   auto add = [&](int type, int count, int lpo, int R, float* out, const float* src, int stride) {
     WgSeg& g = A.seg[ns++];
     g.type = type; g.count = count; g.lpo = lpo; g.R = R; g.block0 = nb; g.stride = stride; g.src = src; g.out = out;
     nb += dg_cdiv(count * lpo, 256);
   };
-  const float* pb1 = dg_cptr<float>(ws, wl->pb1);
-  const float* pb2 = dg_cptr<float>(ws, wl->pb2);
-  const float* pb3 = dg_cptr<float>(ws, wl->pb3);
-  const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-  // small batches: 8 lanes per output hide the latency of the short reduction; large batches: one lane per
-  // output so consecutive lanes read consecutive addresses of a6[b][:] (coalesced) for every b
-  add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, B <= 128 ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
-  add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
-  add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
-  add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
-  add(WG_C6B, DGCNN_C6, 64, B * DGCNN_T6, grads + pl->off[11], nullptr, 0);
-  add(WG_C5B, DGCNN_C5, 64, B * DGCNN_K, grads + pl->off[9], nullptr, 0);
-  add(WG_FC2W, C * DGCNN_HID1, 8, B, grads + pl->off[14], nullptr, 0);
-  add(WG_FC2B, C, 64, B, grads + pl->off[15], nullptr, 0);
-  add(WG_REDUCE, 32 * F, 16, wl->P32, grads + pl->off[0], pb1, 32 * F);          // dW1
-  add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
-  add(WG_REDUCE, 1024, 16, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
-  add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
-  add(WG_REDUCE, 1024, 16, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
-  add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
-  add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
-  add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
-  if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
+  if (which & 1) {
+    // small batches: several lanes per output keep each lane's reduction to one or two rounds of 8 loads;
+    // large batches: one lane per output so consecutive lanes read consecutive addresses (coalesced)
+    const bool small = B <= 128;
+    add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, small ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
+    add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
+    add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, small ? 64 : 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
+    add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
+    add(WG_C6B, DGCNN_C6, 64, B * DGCNN_T6, grads + pl->off[11], nullptr, 0);
+    add(WG_C5B, DGCNN_C5, 64, B * DGCNN_K, grads + pl->off[9], nullptr, 0);
+    add(WG_FC2W, C * DGCNN_HID1, 8, B, grads + pl->off[14], nullptr, 0);
+    add(WG_FC2B, C, 64, B, grads + pl->off[15], nullptr, 0);
+    if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
+  }
+  if (which & 2) {
+    const float* pb1 = dg_cptr<float>(ws, wl->pb1);
+    const float* pb2 = dg_cptr<float>(ws, wl->pb2);
+    const float* pb3 = dg_cptr<float>(ws, wl->pb3);
+    const float* pa4 = dg_cptr<float>(ws, wl->pa4);
+    const int lp = wl->P32 <= 512 ? 64 : 16;
+    add(WG_REDUCE, 32 * F, lp, wl->P32, grads + pl->off[0], pb1, 32 * F);           // dW1
+    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
+    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
+    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
+    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
+    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
+    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
+    add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
+  }
   A.nseg = ns;
+  if (nb == 0) return DGCNN_OK;
   hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
   DG_CHECK_LAUNCH();
   (void)N;

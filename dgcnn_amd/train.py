@@ -68,9 +68,10 @@ class Trainer:
         Model._check_inputs(x, ei, data.batch)
         return x.shape[0], ei.shape[1], _batch_size_of(data), x.shape[1], self.model.num_classes
 
-    def forward_backward(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
+    def forward_backward(self, data, y, global_batch: Optional[int] = None, fuse_adam: bool = False) -> torch.Tensor:
         """forward + NLL(mean) + backward into ``self.grads``; returns the log-probs view [B,C].
-        No optimizer step, no sync."""
+        No sync.  ``fuse_adam``: the weight-gradient kernel also applies the Adam update
+        (``dgcnn_model_backward_step``) -- single-GPU only."""
         L = _lib.lib()
         m = self.model
         N, E, B, F, C = self._dims(data)
@@ -86,10 +87,19 @@ class Trainer:
                                          logp.data_ptr(), training, seed, m._flags_of(data), m._max_nodes_of(data),
                                          int(getattr(data, "max_edges", 0) or 0), m._next_epoch(), stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
-        _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
-                                          logp.data_ptr(), None, y.data_ptr(), scale, training,
-                                          self.grads.data_ptr(), self.metrics.data_ptr(), stream),
-                   "dgcnn_model_backward")
+        if fuse_adam:
+            self.step_count += 1
+            _lib.check(L.dgcnn_model_backward_step(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
+                                                   logp.data_ptr(), y.data_ptr(), scale, training,
+                                                   self.grads.data_ptr(), self.metrics.data_ptr(),
+                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                   self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                   stream), "dgcnn_model_backward_step")
+        else:
+            _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
+                                              logp.data_ptr(), None, y.data_ptr(), scale, training,
+                                              self.grads.data_ptr(), self.metrics.data_ptr(), stream),
+                       "dgcnn_model_backward")
         m._last_ws, m._last_dims = ws, (N, E, B, F, C)
         return logp[:B]
 
@@ -105,9 +115,11 @@ class Trainer:
 
     def train_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
         """One iteration of the body of the reference ``train()`` loop (train.py:36-45)."""
+        if self._allreduce is None:
+            # single GPU: optimizer fused into the weight-gradient kernel (no separate Adam launch)
+            return self.forward_backward(data, y, global_batch, fuse_adam=True)
         logp = self.forward_backward(data, y, global_batch)
-        if self._allreduce is not None:
-            self._allreduce(self.grads)          # ONE flat-bucket RCCL all-reduce per step (dgcnn_amd/dist.py)
+        self._allreduce(self.grads)              # ONE flat-bucket RCCL all-reduce per step (dgcnn_amd/dist.py)
         self.optimizer_step()
         return logp
 

@@ -13,10 +13,13 @@
  *
  * Conventions (all entry points):
  *   - returns 0 on success, a negative DGCNN_E* code on a bad argument or a HIP launch error;
- *   - never allocates, never synchronises, never throws; all buffers are caller-owned
- *     DEVICE memory (the caller is PyTorch-ROCm's allocator); work is enqueued on `stream`
- *     (pass torch.cuda.current_stream().cuda_stream);
- *   - stateless and re-entrant across streams (no globals besides read-only tables);
+ *   - never allocates device memory, never synchronises, never throws; all buffers are
+ *     caller-owned DEVICE memory (the caller is PyTorch-ROCm's allocator); work is enqueued on
+ *     `stream` (pass torch.cuda.current_stream().cuda_stream) and is complete, in stream order,
+ *     when later work on `stream` runs;
+ *   - the only hidden state: dgcnn_model_backward* creates, once per host thread and device, a
+ *     helper stream + two events on which the tail weight gradients overlap the GCN backward
+ *     chain (forked from and joined back into `stream` inside the call); otherwise re-entrant;
  *   - fp32 arithmetic, int64 graph indices in (as the reference), int32 indices inside;
  *   - results are run-to-run bit-reproducible: no floating-point atomics anywhere.
  */
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 4
+#define DGCNN_ABI_VERSION 5
 
 /* error codes */
 #define DGCNN_OK            0
@@ -192,6 +195,19 @@ int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
                          const float* glogp, const int64_t* y, float loss_scale, int training,
                          float* grads, float* metrics, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward + optimizer in one call (single-GPU training step): as dgcnn_model_backward in label
+ * mode, and every weight-gradient lane immediately applies the Adam update of its element
+ * (`optimizer.step()`, train.py:41, torch.optim.Adam defaults semantics; `step` is 1-based), so no
+ * separate optimizer launch exists.  `grads` still receives the gradient (`zero_grad` is moot: every
+ * call overwrites it).  Not for data-parallel runs (the all-reduce sits between gradient and update).
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, const float* x, void* ws,
+                              const float* logp, const int64_t* y, float loss_scale, int training,
+                              float* grads, float* metrics, float* exp_avg, float* exp_avg_sq,
+                              int64_t step, float lr, float beta1, float beta2, float eps,
+                              dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam step over the flat buffer: replaces `optimizer.step(); optimizer.zero_grad()`

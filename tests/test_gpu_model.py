@@ -211,6 +211,13 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     assert abs(lsum - float(loss.detach().cpu())) < 1e-5
     assert correct == float((pred.argmax(1) == b.y).sum().item())
     assert float(tr.grads.abs().max()) == 0.0           # zero_grad fused into the Adam kernel
+    # route C: optimizer fused into the weight-gradient kernel (dgcnn_model_backward_step)
+    m3 = make_model(sh.num_features, sh.num_classes)
+    m3.train(); m3._seed_base, m3._fwd_count = 11, 0
+    tr3 = Trainer(m3)
+    tr3.train_step(b, b.y)
+    assert torch.equal(tr3.grads, gradB)
+    assert torch.equal(m3.flat_params, m2.flat_params)   # same Adam arithmetic, element for element
     # and the loss agrees with the oracle on the kernel's own mask/perm
     mask = m2.last_workspace_view("drop_mask").cpu(); perm = m2.last_workspace_view("perm").cpu()
     _, loss_ref, _, _ = ref_dense.loss_and_grads_dense(sd, b_cpu.x, b_cpu.edge_index, b_cpu.batch, b_cpu.y,
