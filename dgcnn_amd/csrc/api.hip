@@ -8,23 +8,6 @@ static thread_local hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
 #define DG_PROF_A(idx) (g_prof_which == (idx) ? g_prof_a : nullptr)
 #define DG_PROF_B(idx) (g_prof_which == (idx) ? g_prof_b : nullptr)
 
-// Helper stream for work that is independent of the GCN backward chain (tail weight gradients): created
-// once per host thread and device on first use, together with the two events that fork/join it.
-struct DgSide { hipStream_t stream; hipEvent_t fork, join; int dev; };
-static thread_local DgSide g_side = {nullptr, nullptr, nullptr, -1};
-static int dg_side_get(DgSide** out) {
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return DGCNN_ELAUNCH;
-  if (g_side.stream == nullptr || g_side.dev != dev) {
-    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return DGCNN_ELAUNCH;
-    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess) return DGCNN_ELAUNCH;
-    if (hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) return DGCNN_ELAUNCH;
-    g_side.dev = dev;
-  }
-  *out = &g_side;
-  return DGCNN_OK;
-}
-
 extern "C" {
 
 int dgcnn_profile_next_forward(int which, void* ev_start, void* ev_stop) {
@@ -217,14 +200,6 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), s));
-  // fork: the tail weight gradients (and their optional Adam update, and the loss/accuracy bookkeeping) depend
-  // only on k_tail_bwd; they run on the helper stream while the latency-bound GCN chain runs here
-  DgSide* side = nullptr;
-  DG_TRY(dg_side_get(&side));
-  if (hipEventRecord(side->fork, s) != hipSuccess) return DGCNN_ELAUNCH;
-  if (hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return DGCNN_ELAUNCH;
-  DG_TRY(dg_launch_wgrad(1, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, side->stream));
-  if (hipEventRecord(side->join, side->stream) != hipSuccess) return DGCNN_ELAUNCH;
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s));
@@ -237,9 +212,10 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
   DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                              dg_ptr<float>(ws, wl.pb1), wl.P32, s));
-  // GCN weight gradients: fixed-order reductions of the per-workgroup partials; then join the helper stream
-  DG_TRY(dg_launch_wgrad(2, N, B, F, C, &pl, &wl, ws, grads, nullptr, adam, s));
-  if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) return DGCNN_ELAUNCH;
+  // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
+  // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
+  // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
+  DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s));
   return DGCNN_OK;
 }
 

@@ -395,7 +395,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     const bool small = B <= 128;
     add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, small ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
     add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
-    add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, small ? 64 : 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
+    add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
     add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
     add(WG_C6B, DGCNN_C6, 64, B * DGCNN_T6, grads + pl->off[11], nullptr, 0);
     add(WG_C5B, DGCNN_C5, 64, B * DGCNN_K, grads + pl->off[9], nullptr, 0);
@@ -408,7 +408,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     const float* pb2 = dg_cptr<float>(ws, wl->pb2);
     const float* pb3 = dg_cptr<float>(ws, wl->pb3);
     const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-    const int lp = wl->P32 <= 512 ? 64 : 16;
+    const int lp = 16;
     add(WG_REDUCE, 32 * F, lp, wl->P32, grads + pl->off[0], pb1, 32 * F);           // dW1
     add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
     add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2

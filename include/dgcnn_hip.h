@@ -17,9 +17,8 @@
  *     caller-owned DEVICE memory (the caller is PyTorch-ROCm's allocator); work is enqueued on
  *     `stream` (pass torch.cuda.current_stream().cuda_stream) and is complete, in stream order,
  *     when later work on `stream` runs;
- *   - the only hidden state: dgcnn_model_backward* creates, once per host thread and device, a
- *     helper stream + two events on which the tail weight gradients overlap the GCN backward
- *     chain (forked from and joined back into `stream` inside the call); otherwise re-entrant;
+ *   - stateless and re-entrant across streams (the only state is the one-shot, thread-local
+ *     profiling/debug request of the measurement helpers at the end of this file);
  *   - fp32 arithmetic, int64 graph indices in (as the reference), int32 indices inside;
  *   - results are run-to-run bit-reproducible: no floating-point atomics anywhere.
  */
