@@ -199,7 +199,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_cptr<float>(ws, wl.a1d), logp, glogp, y, loss_scale, training,
                             dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
-                            dg_ptr<float>(ws, wl.lossv), s));
+                            dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
+                            dg_cptr<float>(ws, wl.pooled), s));
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s));

@@ -9,6 +9,13 @@
 #define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
 #define DG_TILE_THREADS 1024  // 16 waves: one wave per destination node
 #define DG_MAX_PART 1024      // cap on per-workgroup partial-gradient slots
+// per-graph partial weight gradients written by k_tail_bwd: conv5 W|b, conv6 W|b, classifier_2 W|b
+#define DG_PT_W5 0
+#define DG_PT_B5 (DGCNN_C5 * DGCNN_CAT)
+#define DG_PT_W6 (DG_PT_B5 + DGCNN_C5)
+#define DG_PT_B6 (DG_PT_W6 + DGCNN_C6 * DGCNN_C5 * DGCNN_KW6)
+#define DG_PT_WF2 (DG_PT_B6 + DGCNN_C6)
+#define DG_PTAIL(C) (DG_PT_WF2 + (C) * DGCNN_HID1 + (C))
 #define DG_LDS_PAD 36         // row stride (floats) of 16x32 LDS tiles: 16-B aligned rows
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,7 +59,7 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
   X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
-  X(pa4) X(pb3) X(pb2) X(pb1)
+  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail)
 
 struct DgWs {
 #define X(n) int64_t n;
@@ -118,6 +125,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(pb3, 4 * (int64_t)w->P32 * 1056);
   R(pb2, 4 * (int64_t)w->P32 * 1056);
   R(pb1, 4 * (int64_t)w->P32 * 32 * F);
+  R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
 #undef R
   w->total = o;
   return DGCNN_OK;
@@ -274,8 +282,8 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
-                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
-                       hipStream_t s);
+                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
+                       const float* pooled, hipStream_t s);
 struct DgAdam {          // optional optimizer step fused into the weight-gradient kernel
   float *params, *exp_avg, *exp_avg_sq;
   float lr, beta1, beta2, eps;

@@ -196,13 +196,13 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float* wr = w.Wf1 + (size_t)(wv * 8 + u) * DGCNN_FLAT;
+      const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + u) * DGCNN_FLAT;   // row blocks rotated per graph:
       wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
       wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int j = wv * 8 + u;
+      const int j = ((wv + b) & 15) * 8 + u;    // 50 CUs do not hit the same Wf1 lines in lockstep
       float a = wv0[u] * f0;
       a = fmaf(wv1[u], f1, a);
       a = fmaf(wv2[u], f2, a);

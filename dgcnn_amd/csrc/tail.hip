@@ -16,6 +16,7 @@
 //   n <= 4096 : bitonic network in LDS
 //   n  > 4096 : k rounds of workgroup-wide arg-min selection (keys stay in HBM/L2)
 #include "dg_common.h"
+#include <stdlib.h>
 #include "dg_readout.h"
 
 __global__ void __launch_bounds__(SP_THREADS)
@@ -119,8 +120,11 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
            float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
-           float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv) {
+           float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
+           float* __restrict__ ptail, const float* __restrict__ pooled) {
   __shared__ float W5s[NW5];
+  __shared__ float a1ds[DGCNN_HID1];
+  __shared__ float p5s[DGCNN_C5 * DGCNN_T5];
   __shared__ float W6s[NW6];
   __shared__ float dl[DGCNN_MAX_C];
   __shared__ float gz1s[DGCNN_HID1];
@@ -172,9 +176,17 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     const float a = a1dg[(size_t)b * DGCNN_HID1 + tid];
     const float gz = (a != 0.f) ? (training ? ga * 2.0f : ga) : 0.f;
     gz1s[tid] = gz;
+    a1ds[tid] = a;
     gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
   }
   __syncthreads();
+  // per-graph partial of classifier_2's weight gradient: dl[c] * a1d[j]  (and bias = dl[c])
+  float* pt = ptail + (size_t)b * DG_PTAIL(C);
+  for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
+    const int c = t / DGCNN_HID1, j = t - c * DGCNN_HID1;
+    pt[DG_PT_WF2 + t] = dl[c] * a1ds[j];
+  }
+  if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
   // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads)
   if (tid < 2 * DGCNN_FLAT) {
     const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
@@ -217,6 +229,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
     const float a0 = a5g[base], a1 = a5g[base + 1];
+    p5s[tid] = fmaxf(a0, a1);                      // MaxPool1d output, needed for conv6's weight gradient
     const float gp = gp5[tid];
     const bool first = !(a1 > a0);
     const float g0 = (first && a0 > 0.f) ? gp : 0.f;
@@ -227,6 +240,37 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz5g[base + 1] = g1;
   }
   __syncthreads();
+  // 5b. per-graph partial weight gradients of conv6 and conv5 (everything they need is in LDS / this graph's
+  //     pooled rows); k_wgrad then only sums B contiguous partials per element (coalesced)
+  for (int t = tid; t < NW6; t += RD_THREADS) {       // t = (oc*16 + c)*5 + d
+    const int d = t % DGCNN_KW6, c = (t / DGCNN_KW6) % DGCNN_C5, oc = t / (DGCNN_KW6 * DGCNN_C5);
+    float acc = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < DGCNN_T6; ++tt) acc = fmaf(gz6s[oc * DGCNN_T6 + tt], p5s[c * DGCNN_T5 + tt + d], acc);
+    pt[DG_PT_W6 + t] = acc;
+  }
+  if (tid < DGCNN_C6) {
+    float acc = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < DGCNN_T6; ++tt) acc += gz6s[tid * DGCNN_T6 + tt];
+    pt[DG_PT_B6 + tid] = acc;
+  }
+  {
+    const float* prow = pooled + (size_t)b * KCAT;
+    for (int t = tid; t < NW5; t += RD_THREADS) {     // t = o*97 + m
+      const int o = t / DGCNN_CAT, m = t - o * DGCNN_CAT;
+      float acc = 0.f;
+#pragma unroll 6
+      for (int sl = 0; sl < DGCNN_K; ++sl) acc = fmaf(gz5s[o * DGCNN_K + sl], prow[sl * DGCNN_CAT + m], acc);
+      pt[DG_PT_W5 + t] = acc;
+    }
+    if (tid >= 512 && tid < 512 + DGCNN_C5) {
+      const int o = tid - 512;
+      float acc = 0.f;
+      for (int sl = 0; sl < DGCNN_K; ++sl) acc += gz5s[o * DGCNN_K + sl];
+      pt[DG_PT_B5 + o] = acc;
+    }
+  }
   // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
   for (int o = tid; o < msel * DGCNN_CAT; o += RD_THREADS) {
     const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
@@ -256,13 +300,13 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
-                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
-                       hipStream_t s) {
+                       float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
+                       const float* pooled, hipStream_t s) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
                      x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
-                     gas4, gb4p, lossv);
+                     gas4, gb4p, lossv, ptail, pooled);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -394,13 +438,17 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     // large batches: one lane per output so consecutive lanes read consecutive addresses (coalesced)
     const bool small = B <= 128;
     add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, small ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
-    add(WG_C5W, DGCNN_C5 * DGCNN_CAT, 64, B * DGCNN_K, grads + pl->off[8], nullptr, 0);
-    add(WG_C6W, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, 16, B * DGCNN_T6, grads + pl->off[10], nullptr, 0);
+    // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum B contiguous partials per element
+    const float* pt = dg_cptr<float>(ws, wl->ptail);
+    const int st = DG_PTAIL(C);
+    const int lpr = small ? 8 : 1;
+    add(WG_REDUCE, DGCNN_C5 * DGCNN_CAT, lpr, B, grads + pl->off[8], pt + DG_PT_W5, st);
+    add(WG_REDUCE, DGCNN_C5, 64, B, grads + pl->off[9], pt + DG_PT_B5, st);
+    add(WG_REDUCE, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, lpr, B, grads + pl->off[10], pt + DG_PT_W6, st);
+    add(WG_REDUCE, DGCNN_C6, 64, B, grads + pl->off[11], pt + DG_PT_B6, st);
+    add(WG_REDUCE, C * DGCNN_HID1, lpr, B, grads + pl->off[14], pt + DG_PT_WF2, st);
+    add(WG_REDUCE, C, 64, B, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
     add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
-    add(WG_C6B, DGCNN_C6, 64, B * DGCNN_T6, grads + pl->off[11], nullptr, 0);
-    add(WG_C5B, DGCNN_C5, 64, B * DGCNN_K, grads + pl->off[9], nullptr, 0);
-    add(WG_FC2W, C * DGCNN_HID1, 8, B, grads + pl->off[14], nullptr, 0);
-    add(WG_FC2B, C, 64, B, grads + pl->off[15], nullptr, 0);
     if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
   }
   if (which & 2) {
@@ -420,6 +468,16 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
   }
   A.nseg = ns;
   if (nb == 0) return DGCNN_OK;
+  static const bool split = getenv("DG_WGRAD_SPLIT") != nullptr;     // diagnostic: one launch per segment
+  if (split) {
+    for (int k = 0; k < ns; ++k) {
+      WgArgs One = A;
+      One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
+      hipLaunchKernelGGL(k_wgrad, dim3(dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256)), dim3(256), 0, s, One);
+    }
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
   hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
   DG_CHECK_LAUNCH();
   (void)N;
