@@ -125,6 +125,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   __shared__ float W5s[NW5];
   __shared__ float a1ds[DGCNN_HID1];
   __shared__ float p5s[DGCNN_C5 * DGCNN_T5];
+  __shared__ float sps[KCAT];            // this graph's pooled rows (conv5's weight-gradient operand)
   __shared__ float W6s[NW6];
   __shared__ float dl[DGCNN_MAX_C];
   __shared__ float gz1s[DGCNN_HID1];
@@ -139,6 +140,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
 
   for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
   for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  for (int t = tid; t < KCAT; t += RD_THREADS) sps[t] = pooled[(size_t)blockIdx.x * KCAT + t];
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
   for (int t = tid; t < n * 32; t += RD_THREADS) {
     gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
@@ -256,7 +258,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     pt[DG_PT_B6 + tid] = acc;
   }
   {
-    const float* prow = pooled + (size_t)b * KCAT;
+    const float* prow = sps;
     for (int t = tid; t < NW5; t += RD_THREADS) {     // t = o*97 + m
       const int o = t / DGCNN_CAT, m = t - o * DGCNN_CAT;
       float acc = 0.f;
@@ -317,7 +319,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
 // with a fixed xor-butterfly -> no floating-point atomics, bit-reproducible, and the long
 // reductions (bias sums over B*30 terms, per-workgroup partials) are no longer serial chains.
 // ---------------------------------------------------------------------------------------------
-enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC };
+enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC, WG_FC1W_MFMA };
 #define WG_MAX_SEG 20
 struct WgSeg {
   int type;
@@ -368,44 +370,84 @@ __device__ __forceinline__ float dg_wg_term(const WgArgs& A, const WgSeg& sg, in
   return 0.f;
 }
 
+__device__ __forceinline__ void dg_wg_store(const WgArgs& A, const WgSeg& sg, int i, float acc) {
+  sg.out[i] = acc;
+  if (A.adam_p) {       // optimizer.step() for this element (train.py:41), same formula as k_adam
+    const size_t k = (size_t)(sg.out - A.grads_base) + i;
+    const float mi = A.b1 * A.adam_m[k] + (1.f - A.b1) * acc;
+    const float vi = A.b2 * A.adam_v[k] + (1.f - A.b2) * acc * acc;
+    A.adam_m[k] = mi; A.adam_v[k] = vi;
+    const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+    A.adam_p[k] = A.adam_p[k] - (A.lr / A.bc1) * (mi / denom);
+  }
+}
+
+// classifier_1 weight gradient as a small GEMM on the fp32 matrix cores:
+//   dW[j][m] = sum_b gz1[b][j] * a6[b][m]  = (gz1^T [128 x B]) . (a6 [B x 352]),  K = B (zero-padded to 4)
+// one wave per 16x16 output tile (8 x 22 tiles), v_mfma_f32_16x16x4_f32: a k-ordered fma chain over b.
+__device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg, int tile, int lane) {
+  const int rb = tile / 22, cb = tile - rb * 22;
+  const int B = A.B;
+  const int jr = rb * 16 + (lane & 15), mc = cb * 16 + (lane & 15), kq = lane >> 4;
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < B; k0 += 32) {          // 8 MFMAs (32 graphs) per round: 16 loads in flight per lane
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = k0 + 4 * u + kq;
+      av[u] = bb < B ? A.gz1[(size_t)bb * DGCNN_HID1 + jr] : 0.f;
+      bv[u] = bb < B ? A.a6[(size_t)bb * DGCNN_FLAT + mc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 4 * u < B) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = rb * 16 + kq * 4 + r, m = cb * 16 + (lane & 15);
+    dg_wg_store(A, sg, j * DGCNN_FLAT + m, d[r]);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_wgrad(WgArgs A) {
   int si = 0;
   for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
   const WgSeg sg = A.seg[si];
+  if (sg.type == WG_FC1W_MFMA) {      // block-uniform branch: 4 waves = 4 tiles per workgroup
+    const int tile = ((int)blockIdx.x - sg.block0) * 4 + (threadIdx.x >> 6);
+    if (tile < 8 * 22) dg_wg_fc1w_mfma(A, sg, tile, threadIdx.x & 63);
+    return;
+  }
   const int gid = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
   const int lpo = sg.lpo;
   const int i = gid / lpo, r0 = gid - i * lpo;
   const bool live = i < sg.count;
-  // 8 independent accumulators -> 8 loads in flight per lane; combined in a fixed order
-  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // 16 independent accumulators -> 16 loads in flight per lane (one memory round trip for the usual
+  // reduction lengths); combined in a fixed order
+  float a[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) a[u] = 0.f;
   if (live) {
     const int R = sg.R;
     int r = r0;
-    for (; r + 7 * lpo < R; r += 8 * lpo) {
+    for (; r + 15 * lpo < R; r += 16 * lpo) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
+      for (int u = 0; u < 16; ++u) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 16; ++u)
       if (r + u * lpo < R) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
   }
-  float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) a[u] += a[u + w];
+  float acc = a[0];
   for (int o = 1; o < lpo; o <<= 1) acc += __shfl_xor(acc, o);
   if (live && r0 == 0) {
-    if (sg.type == WG_METRIC) {
-      sg.out[i] += acc;     // running loss / #correct accumulators
-    } else {
-      sg.out[i] = acc;
-      if (A.adam_p) {       // optimizer.step() for this element (train.py:41), same formula as k_adam
-        const size_t k = (size_t)(sg.out - A.grads_base) + i;
-        const float mi = A.b1 * A.adam_m[k] + (1.f - A.b1) * acc;
-        const float vi = A.b2 * A.adam_v[k] + (1.f - A.b2) * acc * acc;
-        A.adam_m[k] = mi; A.adam_v[k] = vi;
-        const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
-        A.adam_p[k] = A.adam_p[k] - (A.lr / A.bc1) * (mi / denom);
-      }
-    }
+    if (sg.type == WG_METRIC) sg.out[i] += acc;     // running loss / #correct accumulators
+    else dg_wg_store(A, sg, i, acc);
   }
 }
 
@@ -433,11 +475,30 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     g.type = type; g.count = count; g.lpo = lpo; g.R = R; g.block0 = nb; g.stride = stride; g.src = src; g.out = out;
     nb += dg_cdiv(count * lpo, 256);
   };
+  auto add_tiles = [&](int type, int tiles, float* out) {     // one wave per tile, 4 tiles per workgroup
+    WgSeg& g = A.seg[ns++];
+    g.type = type; g.count = tiles; g.lpo = 64; g.R = B; g.block0 = nb; g.stride = 0; g.src = nullptr; g.out = out;
+    nb += dg_cdiv(tiles, 4);
+  };
+  // segments with the longest dependent latency first: their workgroups are dispatched first
+  if (which & 2) {
+    const float* pb1 = dg_cptr<float>(ws, wl->pb1);
+    const float* pb2 = dg_cptr<float>(ws, wl->pb2);
+    const float* pb3 = dg_cptr<float>(ws, wl->pb3);
+    const float* pa4 = dg_cptr<float>(ws, wl->pa4);
+    const int lp = 16;
+    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
+    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
+    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
+    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
+    add(WG_REDUCE, 32 * F, lp, wl->P32, grads + pl->off[0], pb1, 32 * F);           // dW1
+    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
+    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
+    add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
+  }
   if (which & 1) {
-    // small batches: several lanes per output keep each lane's reduction to one or two rounds of 8 loads;
-    // large batches: one lane per output so consecutive lanes read consecutive addresses (coalesced)
     const bool small = B <= 128;
-    add(WG_FC1W, DGCNN_HID1 * DGCNN_FLAT, small ? 8 : 1, B, grads + pl->off[12], nullptr, 0);
+    add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                           // classifier_1 weight: MFMA GEMM
     // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum B contiguous partials per element
     const float* pt = dg_cptr<float>(ws, wl->ptail);
     const int st = DG_PTAIL(C);
@@ -451,21 +512,6 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
     if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
   }
-  if (which & 2) {
-    const float* pb1 = dg_cptr<float>(ws, wl->pb1);
-    const float* pb2 = dg_cptr<float>(ws, wl->pb2);
-    const float* pb3 = dg_cptr<float>(ws, wl->pb3);
-    const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-    const int lp = 16;
-    add(WG_REDUCE, 32 * F, lp, wl->P32, grads + pl->off[0], pb1, 32 * F);           // dW1
-    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
-    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
-    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
-    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
-    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
-    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
-    add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
-  }
   A.nseg = ns;
   if (nb == 0) return DGCNN_OK;
   static const bool split = getenv("DG_WGRAD_SPLIT") != nullptr;     // diagnostic: one launch per segment
@@ -473,7 +519,8 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     for (int k = 0; k < ns; ++k) {
       WgArgs One = A;
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
-      hipLaunchKernelGGL(k_wgrad, dim3(dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256)), dim3(256), 0, s, One);
+      const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256);
+      hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One);
     }
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
