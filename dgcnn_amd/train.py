@@ -43,6 +43,8 @@ class Trainer:
         self.pg = process_group
         from .dist import GradAllReduce
         self._allreduce = GradAllReduce(process_group) if process_group is not None else None
+        if self._allreduce is not None and self._allreduce.world_size == 1 and not __import__('os').environ.get('BENCH_FORCE_DIST'):
+            self._allreduce = None           # a 1-rank group needs no collective
         self.step_count = 0
         flat = model.flat_params
         self.exp_avg = torch.zeros_like(flat)
