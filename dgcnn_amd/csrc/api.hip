@@ -138,16 +138,21 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   float *x1 = dg_ptr<float>(ws, wl.x1), *x2 = dg_ptr<float>(ws, wl.x2), *x3 = dg_ptr<float>(ws, wl.x3),
         *x4 = dg_ptr<float>(ws, wl.x4);
 
+  // Path choice.  One workgroup per graph only pays when there are enough graphs to occupy the chip
+  // (256 CUs): at the reference's batch of 50 the tiled kernels spread each graph's nodes over all CUs
+  // and are faster; from a few hundred graphs per batch the LDS-resident kernel wins (no L2 gathers).
+  const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) ||
+                          (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
+  const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
+  DgLinFirst lf; lf.x = x; lf.W = params + pl.off[0]; lf.hs = hsA; lf.F = F;
+  const bool use_lf = !fused;          // tiled path: conv1's linear rides on the second prep launch
+  int lin_done = 0;
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
-                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s));
-  // Path choice.  One workgroup per graph only pays when there are enough graphs to occupy the chip
-  // (256 CUs): at the reference's batch of 50 the tiled kernels spread each graph's nodes over all CUs
-  // and are faster; from a few hundred graphs per batch the LDS-resident kernel wins (no L2 gathers).
-  const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) || (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
-  if (want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F)) {
+                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done));
+  if (fused) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
     DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,
@@ -162,7 +167,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
+  if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
                              DG_PROF_A(0), DG_PROF_B(0)));
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,

@@ -240,11 +240,13 @@ __device__ void dg_block_bitonic(PTR data, int n) {
 }
 #endif
 
+struct DgLinFirst { const float* x; const float* W; float* hs; int F; };   // optional conv1 linear riding on the prep launch
 // kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
-                   int32_t* err, int flags, uint32_t epoch, hipStream_t s);
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
+                   int* lin_done = nullptr);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
                         int Fout, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step

@@ -97,8 +97,9 @@ struct RdSmem {
   float* flat;                   // [352]
   float* a1s;                    // [128]
   float* lg;                     // [MAX_C]
+  float* lg2;                    // [2*16*30] conv5 half sums
 };
-#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C) * 4)
+#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (3 * DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C) * 4)
 __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   RdSmem m;
   m.region0 = reinterpret_cast<unsigned long long*>(region0);
@@ -109,7 +110,8 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   m.p5 = reinterpret_cast<float*>(p); p += DGCNN_C5 * DGCNN_T5 * 4;
   m.flat = reinterpret_cast<float*>(p); p += DGCNN_FLAT * 4;
   m.a1s = reinterpret_cast<float*>(p); p += DGCNN_HID1 * 4;
-  m.lg = reinterpret_cast<float*>(p);
+  m.lg = reinterpret_cast<float*>(p); p += DGCNN_MAX_C * 4;
+  m.lg2 = reinterpret_cast<float*>(p);
   return m;
 }
 
@@ -127,7 +129,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float* W5s = sp + 2912;                                 // [1552]
   float* W6s = W5s + NW5;                                 // [2560]   (2912+1552+2560)*4 = 28096 <= 32768
   int* sel = M.sel;
-  float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg;
+  float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg, *lg2 = M.lg2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
@@ -153,15 +155,23 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(9);
-  // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s  ([B,16,30])
-  if (tid < DGCNN_C5 * DGCNN_K) {
-    const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
-    float acc = w.b5[o];
+  // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s ([B,16,30]); the 97-term chain is split in
+  // two halves (49 + 48 terms) over 960 threads and combined in a fixed order
+  if (tid < 2 * DGCNN_C5 * DGCNN_K) {
+    const int hh = tid / (DGCNN_C5 * DGCNN_K), t = tid - hh * (DGCNN_C5 * DGCNN_K);
+    const int o = t / DGCNN_K, s = t - o * DGCNN_K;
     const float* wr = W5s + o * DGCNN_CAT;
     const float* xr = sp + s * DGCNN_CAT;
+    float acc = 0.f;
+    const int m0 = hh ? 49 : 0, m1 = hh ? DGCNN_CAT : 49;
 #pragma unroll 8
-    for (int m = 0; m < DGCNN_CAT; ++m) acc = fmaf(wr[m], xr[m], acc);
-    acc = fmaxf(acc, 0.f);
+    for (int m = m0; m < m1; ++m) acc = fmaf(wr[m], xr[m], acc);
+    lg2[hh * (DGCNN_C5 * DGCNN_K) + t] = acc;
+  }
+  __syncthreads();
+  if (tid < DGCNN_C5 * DGCNN_K) {
+    const int o = tid / DGCNN_K;
+    const float acc = fmaxf((lg2[tid] + lg2[DGCNN_C5 * DGCNN_K + tid]) + w.b5[o], 0.f);
     a5s[tid] = acc;
     a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
   }

@@ -163,6 +163,14 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
     } else if (MODE == 0 && g == 0) {
       *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float dpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && wave < 2) {      // dst scales of the MFMA epilogue rows: issue the loads before the barrier
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+        dpre[r] = node < N ? dinv[node] : 0.f;
+      }
+    }
     if (MODE == 0) {
       __syncthreads();
       if (wave < 2) {   // [16 nodes x 32] . W^T -> 16x16 block `wave` of the [16 x 32] result
@@ -175,7 +183,7 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
-          if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dinv[node] * d[r];
+          if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dpre[r] * d[r];
         }
       }
       __syncthreads();

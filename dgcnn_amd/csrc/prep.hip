@@ -211,10 +211,32 @@ k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __res
 
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
 // search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.
+// The same launch also carries conv1's linear (hs1[i] = dinv[i] * x[i] W1^T) in a second block range:
+// it only needs the row pointers that kernel A completed (dinv is recomputed locally, bit-identically),
+// so the separate k_lin_first32 launch disappears from the step.
 __global__ void __launch_bounds__(256)
 k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
-              float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch) {
+              float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int nblk_b,
+              int F, const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ hs) {
+  extern __shared__ __attribute__((aligned(16))) float Wt[];   // lin range only: [F][32]
+  if ((int)blockIdx.x >= nblk_b) {      // ---- conv1 linear block range (same arithmetic as k_lin_first32) ----
+    for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
+      const int c = t / F, k = t - c * F;
+      Wt[k * 32 + c] = W1[t];
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int nlin = (int)gridDim.x - nblk_b;
+    for (int i = ((int)blockIdx.x - nblk_b) * 8 + r; i < N; i += nlin * 8) {
+      const float di = 1.0f / sqrtf((float)(rowptr[i + 1] - rowptr[i] + 1));
+      const float* xr = x + (size_t)i * F;
+      float acc = 0.f;
+      for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
+      hs[(size_t)i * 32 + c] = di * acc;
+    }
+    return;
+  }
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < N) dinv[t] = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
   if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
@@ -235,8 +257,9 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
-                   int32_t* err, int flags, uint32_t epoch, hipStream_t s) {
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done) {
   if (N <= 0 || E < 0 || B <= 0) return DGCNN_EINVAL;
+  if (lin_done) *lin_done = 0;
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
     int work = E > N + 1 ? E : N + 1;
@@ -244,8 +267,16 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
     DG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr,
-                       colidx, graph_ptr, graph_eptr, dinv, uerr, epoch);
+    const int nblk_b = dg_cdiv(work, 256);
+    int nlin = 0;
+    if (lf && lf->x && lf->F >= 1 && lf->F <= DGCNN_MAX_F) {
+      nlin = dg_cdiv(N, 8);
+      if (nlin > 4096) nlin = 4096;
+    }
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(nblk_b + nlin), dim3(256), nlin ? sizeof(float) * 32 * lf->F : 0, s,
+                       edge_index, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv, uerr, epoch, nblk_b,
+                       nlin ? lf->F : 0, nlin ? lf->x : nullptr, nlin ? lf->W : nullptr, nlin ? lf->hs : nullptr);
+    if (nlin && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }

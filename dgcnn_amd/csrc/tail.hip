@@ -132,6 +132,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   __shared__ float gfh[2][DGCNN_FLAT];
   __shared__ float gz6s[DGCNN_FLAT];
   __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
+  __shared__ float gp5q[4][DGCNN_C5 * DGCNN_T5];
   __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
   __shared__ float ga4s[DGCNN_K];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -211,20 +212,26 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
   __syncthreads();
-  // 4. conv6 data gradient -> [16,15]
-  if (tid < DGCNN_C5 * DGCNN_T5) {
-    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+  // 4. conv6 data gradient -> [16,15]: 240 outputs x 160 terms, split over 4 groups of 8 output channels
+  //    (960 threads, 40-term chains) and combined in a fixed order
+  if (tid < 4 * DGCNN_C5 * DGCNN_T5) {
+    const int grp = tid / (DGCNN_C5 * DGCNN_T5), o = tid - grp * (DGCNN_C5 * DGCNN_T5);
+    const int c = o / DGCNN_T5, u = o - c * DGCNN_T5;
     float acc = 0.f;
-#pragma unroll 4
-    for (int oc = 0; oc < DGCNN_C6; ++oc)
+#pragma unroll
+    for (int oo = 0; oo < 8; ++oo) {
+      const int oc = grp * 8 + oo;
 #pragma unroll
       for (int d = 0; d < DGCNN_KW6; ++d) {
         const int tt = u - d;
         if (tt >= 0 && tt < DGCNN_T6)
           acc = fmaf(gz6s[oc * DGCNN_T6 + tt], W6s[(oc * DGCNN_C5 + c) * DGCNN_KW6 + d], acc);
       }
-    gp5[tid] = acc;
+    }
+    gp5q[grp][o] = acc;
   }
+  __syncthreads();
+  if (tid < DGCNN_C5 * DGCNN_T5) gp5[tid] = (gp5q[0][tid] + gp5q[1][tid]) + (gp5q[2][tid] + gp5q[3][tid]);
   __syncthreads();
   // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
   if (tid < DGCNN_C5 * DGCNN_T5) {
