@@ -1,8 +1,6 @@
 // api.hip -- extern "C" entry points of libdgcnn_hip.so (see include/dgcnn_hip.h) and the
 // orchestration of the whole-model forward / backward as a chain of launches on one stream.
 #include "dg_common.h"
-#include "dg_wgrad.h"
-#include <stdlib.h>
 
 // one-shot, thread-local profiling request (see dgcnn_profile_next_forward)
 static thread_local int g_prof_which = -1;
@@ -212,33 +210,21 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_cptr<float>(ws, wl.pooled), s));
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   const int32_t* colpad_t = dg_cptr<int32_t>(ws, wl.colpad_t);
-  // Weight-gradient stages ride as extra block ranges on the NEXT backward launch (their inputs are complete
-  // by then), so they overlap the latency-bound GCN chain without a second stream and without a launch of
-  // their own; only dW1's reduction is left for a final small launch.  (DG_NO_RIDERS=1: one launch at the end.)
-  static const bool no_riders = getenv("DG_NO_RIDERS") != nullptr;
-  float* mt = (y != nullptr) ? metrics : nullptr;
-  WgArgs r0, r1, r2, r3;
-  int nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
-  if (!no_riders) {
-    nb0 = dg_wgrad_build(&r0, 1, B, F, C, &pl, &wl, ws, grads, mt, adam);       // tail + db4 + metrics  [after tail_bwd]
-    nb1 = dg_wgrad_build(&r1, 2, B, F, C, &pl, &wl, ws, grads, nullptr, adam);  // dW4, db3              [after bwd1]
-    nb2 = dg_wgrad_build(&r2, 4, B, F, C, &pl, &wl, ws, grads, nullptr, adam);  // dW3, db2              [after layer-3 bwd]
-    nb3 = dg_wgrad_build(&r3, 8, B, F, C, &pl, &wl, ws, grads, nullptr, adam);  // dW2, db1              [after layer-2 bwd]
-  }
-  // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, colpad_t, nb0 ? &r0 : nullptr, nb0));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, colpad_t));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
-                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, colpad_t, nb1 ? &r1 : nullptr, nb1));
+                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, colpad_t));
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
-                             dg_ptr<float>(ws, wl.pb2), wl.P32, s, colpad_t, nb2 ? &r2 : nullptr, nb2));
+                             dg_ptr<float>(ws, wl.pb2), wl.P32, s, colpad_t));
   // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
   DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
-                             dg_ptr<float>(ws, wl.pb1), wl.P32, s, colpad_t, nb3 ? &r3 : nullptr, nb3));
-  // what is left: dW1 (or everything when riders are off), fixed-order reductions, optional Adam
-  DG_TRY(dg_launch_wgrad(no_riders ? 31 : 16, N, B, F, C, &pl, &wl, ws, grads, no_riders ? mt : nullptr, adam, s));
+                             dg_ptr<float>(ws, wl.pb1), wl.P32, s, colpad_t));
+  // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
+  // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
+  // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
+  DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s));
   return DGCNN_OK;
 }
 

@@ -261,13 +261,12 @@ int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, cons
                        const float* h4s, const float* bias, float* x4, hipStream_t s, const int32_t* colpad = nullptr);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t = nullptr,
-                       const struct WgArgs* rider = nullptr, int rider_blocks = 0);
+                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t = nullptr);
 // which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const int32_t* colpad_t = nullptr, const struct WgArgs* rider = nullptr, int rider_blocks = 0);
+                        const int32_t* colpad_t = nullptr);
 int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
                            const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s);
 int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
@@ -285,7 +284,6 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
 int dg_fused_max_nodes(int F);
 int dg_fused_fits(int nmax, int emax, int F);
 void dg_fused_set_debug(unsigned long long* p);
-unsigned long long* dg_debug_buffer();
 #define DG_GATHER_UNROLL 8
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,

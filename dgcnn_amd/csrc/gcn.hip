@@ -23,7 +23,6 @@
 // with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
 #include "dg_common.h"
 #include <hip/hip_ext.h>
-#include "dg_wgrad.h"
 
 // ---------------------------------------------------------------------------------------------
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
@@ -123,10 +122,8 @@ __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
             float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next,
-            const int* __restrict__ colpad, unsigned long long* dbg) {
-#define GF_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+            const int* __restrict__ colpad) {
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
-  GF_MARK(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 3, q = lane & 7;
@@ -148,9 +145,7 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
       const int pad0 = colpad ? colpad[(size_t)i * DG_COLPAD + lane] : 0;     // independent of the row pointers
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
-      GF_MARK(1);
       const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane, pad0, colpad != nullptr);
-      GF_MARK(2);
       const float di = dinv[i];
       float4 val;
       val.x = dg_tanh(fmaf(di, acc.x, b4.x));
@@ -182,10 +177,8 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
         dpre[r] = node < N ? dinv[node] : 0.f;
       }
     }
-    GF_MARK(3);
     if (MODE == 0) {
       __syncthreads();
-      GF_MARK(4);
       if (wave < 2) {   // [16 nodes x 32] . W^T -> 16x16 block `wave` of the [16 x 32] result
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -199,12 +192,9 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
           if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dpre[r] * d[r];
         }
       }
-      GF_MARK(5);
       __syncthreads();
     }
   }
-  GF_MARK(6);
-#undef GF_MARK
 }
 
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
@@ -217,13 +207,13 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
   // same ones rocprofv3 reports); with null events it is a plain launch.
   if (mode == 0)
     hipExtLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad, dg_debug_buffer());
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
   else if (mode == 1)
     hipExtLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad, dg_debug_buffer());
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
   else
     hipExtLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad, dg_debug_buffer());
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -274,17 +264,13 @@ __global__ void __launch_bounds__(256)
 k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
-           float* __restrict__ pa4, const int* __restrict__ colpad_t, int own_blocks, WgArgs rider) {
-  if ((int)blockIdx.x >= own_blocks) {       // rider block range: weight-gradient stages whose inputs are complete
-    dg_wgrad_body(rider, (int)blockIdx.x - own_blocks, (int)threadIdx.x);
-    return;
-  }
+           float* __restrict__ pa4, const int* __restrict__ colpad_t) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & 31;
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
-  for (int j = blockIdx.x * 4 + w; j < N; j += own_blocks * 4) {
+  for (int j = blockIdx.x * 4 + w; j < N; j += gridDim.x * 4) {
     const int pad0 = colpad_t ? colpad_t[(size_t)j * DG_COLPAD + lane] : 0;
     const int start = rowptr_t[j], end = rowptr_t[j + 1];
     const float s = dg_gather_row1(gas4, colidx_t, start, end, lane, pad0, colpad_t != nullptr) + gas4[j];
@@ -309,13 +295,10 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
 
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t, const WgArgs* rider,
-                       int rider_blocks) {
+                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
-  static WgArgs none;     // zero-initialised: nseg = 0
-  const int rb = rider ? rider_blocks : 0;
-  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rb), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
-                     pa4, colpad_t, P1, rider ? *rider : none);
+  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
+                     pa4, colpad_t);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -336,13 +319,7 @@ __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
-            float* __restrict__ part, const int* __restrict__ colpad_t, int own_blocks, int rider_vblocks,
-            WgArgs rider) {
-  if ((int)blockIdx.x >= own_blocks) {       // rider block range: 4 virtual 256-thread blocks per workgroup
-    const int vb = ((int)blockIdx.x - own_blocks) * 4 + (int)(threadIdx.x >> 8);
-    if (vb < rider_vblocks) dg_wgrad_body(rider, vb, (int)(threadIdx.x & 255));
-    return;
-  }
+            float* __restrict__ part, const int* __restrict__ colpad_t) {
   __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
   extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
@@ -364,8 +341,8 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   }
 
   // each workgroup owns a CONTIGUOUS chunk of tiles, and chunks are laid out XCD-contiguously
-  const int chunk = (numTiles + own_blocks - 1) / own_blocks;
-  const int wg = dg_xcd_tile((int)blockIdx.x, own_blocks);
+  const int chunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = dg_xcd_tile((int)blockIdx.x, (int)gridDim.x);
   const int tile_end = min(numTiles, (wg + 1) * chunk);
   for (int tile = wg * chunk; tile < tile_end; ++tile) {
     const int j = tile * DG_TILE + wave;
@@ -472,20 +449,16 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const int32_t* colpad_t, const WgArgs* rider, int rider_blocks) {
+                        const int32_t* colpad_t) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
-  static WgArgs none;
-  const int rvb = rider ? rider_blocks : 0;
-  const int rb = (rvb + 3) / 4;
   const int tiles = dg_cdiv(N, DG_TILE);
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
-    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32 + rb), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
-                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t, P32, rvb,
-                       rider ? *rider : none);
+    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
+                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t);
   } else {
-    hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32 + rb), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,
-                       dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t, P32, rvb, rider ? *rider : none);
+    hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,
+                       dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t);
   }
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
