@@ -151,9 +151,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
-                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
-                        dg_ptr<int32_t>(ws, wl.colpad), dg_ptr<int32_t>(ws, wl.colpad_t)));
-  const int32_t* colpad = dg_cptr<int32_t>(ws, wl.colpad);
+                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done));
   if (fused) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
@@ -171,13 +169,13 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
-                             DG_PROF_A(0), DG_PROF_B(0), colpad));
+                             DG_PROF_A(0), DG_PROF_B(0)));
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,
-                             DG_PROF_A(1), DG_PROF_B(1), colpad));
+                             DG_PROF_A(1), DG_PROF_B(1)));
   DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
-                             DG_PROF_A(2), DG_PROF_B(2), colpad));
+                             DG_PROF_A(2), DG_PROF_B(2)));
   g_prof_which = -1;
-  DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s, colpad));
+  DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
   // SortPooling + the whole dense tail: one launch, one workgroup per graph
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
@@ -209,18 +207,17 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
                             dg_cptr<float>(ws, wl.pooled), s));
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
-  const int32_t* colpad_t = dg_cptr<int32_t>(ws, wl.colpad_t);
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, colpad_t));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
-                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, colpad_t));
+                             dg_ptr<float>(ws, wl.pb3), wl.P32, s));
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
-                             dg_ptr<float>(ws, wl.pb2), wl.P32, s, colpad_t));
+                             dg_ptr<float>(ws, wl.pb2), wl.P32, s));
   // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
   DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
-                             dg_ptr<float>(ws, wl.pb1), wl.P32, s, colpad_t));
+                             dg_ptr<float>(ws, wl.pb1), wl.P32, s));
   // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)

@@ -16,7 +16,6 @@
 #define DG_PT_B6 (DG_PT_W6 + DGCNN_C6 * DGCNN_C5 * DGCNN_KW6)
 #define DG_PT_WF2 (DG_PT_B6 + DGCNN_C6)
 #define DG_PTAIL(C) (DG_PT_WF2 + (C) * DGCNN_HID1 + (C))
-#define DG_COLPAD 64           // padded neighbour table: first 64 sorted neighbours of every row at [i*64 .. )
 #define DG_LDS_PAD 36         // row stride (floats) of 16x32 LDS tiles: 16-B aligned rows
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +59,7 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
   X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
-  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(colpad) X(colpad_t)
+  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail)
 
 struct DgWs {
 #define X(n) int64_t n;
@@ -127,8 +126,6 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(pb2, 4 * (int64_t)w->P32 * 1056);
   R(pb1, 4 * (int64_t)w->P32 * 32 * F);
   R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
-  R(colpad, 4 * n * DG_COLPAD);
-  R(colpad_t, 4 * n * DG_COLPAD);
 #undef R
   w->total = o;
   return DGCNN_OK;
@@ -249,24 +246,22 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
-                   int* lin_done = nullptr, int32_t* colpad = nullptr, int32_t* colpad_t = nullptr);
+                   int* lin_done = nullptr);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
                         int Fout, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                        const int32_t* colpad = nullptr);
+                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                       const float* h4s, const float* bias, float* x4, hipStream_t s, const int32_t* colpad = nullptr);
+                       const float* h4s, const float* bias, float* x4, hipStream_t s);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t = nullptr);
+                       float* gas3, float* pa4, int P1, hipStream_t s);
 // which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
-                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const int32_t* colpad_t = nullptr);
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s);
 int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
                            const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s);
 int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,

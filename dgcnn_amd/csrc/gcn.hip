@@ -81,17 +81,13 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 // gather of one destination row: returns (in every lane with g==0, and in fact all lanes) the
 // float4 chunk q of   sum_{e in [start,end)} src[col[e]]  +  src[self]
 // ---------------------------------------------------------------------------------------------
-// `padrow` (nullable) = this row's slice of the padded neighbour table: its address depends only on the node
-// id, so the load of the first 64 neighbour ids is issued TOGETHER with the row-pointer load instead of
-// after it (one dependent memory hop less per kernel); the caller loads it before it knows start/end.
 __device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src, const int* __restrict__ col,
-                                                  int start, int end, int self, int lane, int pad0 = 0,
-                                                  bool have_pad = false) {
+                                                  int start, int end, int self, int lane) {
   const int g = lane >> 3, q = lane & 7;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
-    const int cj = (have_pad && base == start) ? pad0 : (lane < cnt ? col[base + lane] : 0);
+    const int cj = lane < cnt ? col[base + lane] : 0;
     const int iters = (cnt + 7) >> 3;
     for (int it = 0; it < iters; ++it) {
       const int idx = it * 8 + g;
@@ -121,8 +117,7 @@ template <int MODE>
 __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
-            float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next,
-            const int* __restrict__ colpad) {
+            float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next) {
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -142,10 +137,9 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
     const int tile = (gridDim.x == (unsigned)numTiles) ? dg_xcd_tile(tl, numTiles) : tl;
     const int i = tile * DG_TILE + wave;
     if (i < N) {
-      const int pad0 = colpad ? colpad[(size_t)i * DG_COLPAD + lane] : 0;     // independent of the row pointers
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
-      const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane, pad0, colpad != nullptr);
+      const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane);
       const float di = dinv[i];
       float4 val;
       val.x = dg_tanh(fmaf(di, acc.x, b4.x));
@@ -199,7 +193,7 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
 
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* colpad) {
+                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   const int grid = tiles;          // one workgroup per tile (XCD-aware order inside the kernel)
@@ -207,13 +201,13 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
   // same ones rocprofv3 reports); with null events it is a plain launch.
   if (mode == 0)
     hipExtLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   else if (mode == 1)
     hipExtLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   else
     hipExtLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next, colpad);
+                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -222,32 +216,31 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 // forward, F = 1 (conv4): wave per node, lanes across neighbours.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dg_gather_row1(const float* __restrict__ src, const int* __restrict__ col,
-                                                int start, int end, int lane, int pad0 = 0, bool have_pad = false) {
+                                                int start, int end, int lane) {
   float s = 0.f;
-  for (int e = start + lane; e < end; e += 64) s += src[(have_pad && e - lane == start) ? pad0 : col[e]];
+  for (int e = start + lane; e < end; e += 64) s += src[col[e]];
   return dg_wave_sum(s);
 }
 
 __global__ void __launch_bounds__(256)
 k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx,
            const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
-           float* __restrict__ x4, const int* __restrict__ colpad) {
+           float* __restrict__ x4) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float b = bias[0];
   for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
-    const int pad0 = colpad ? colpad[(size_t)i * DG_COLPAD + lane] : 0;
     const int start = rowptr[i], end = rowptr[i + 1];
-    const float s = dg_gather_row1(h4s, colidx, start, end, lane, pad0, colpad != nullptr) + h4s[i];
+    const float s = dg_gather_row1(h4s, colidx, start, end, lane) + h4s[i];
     if (lane == 0) x4[i] = dg_tanh(fmaf(dinv[i], s, b));
   }
 }
 
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                       const float* h4s, const float* bias, float* x4, hipStream_t s, const int32_t* colpad) {
+                       const float* h4s, const float* bias, float* x4, hipStream_t s) {
   if (N <= 0) return DGCNN_EINVAL;
   int grid = dg_cdiv(N, 4);
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4, colpad);
+  hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -264,16 +257,15 @@ __global__ void __launch_bounds__(256)
 k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
-           float* __restrict__ pa4, const int* __restrict__ colpad_t) {
+           float* __restrict__ pa4) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & 31;
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
   for (int j = blockIdx.x * 4 + w; j < N; j += gridDim.x * 4) {
-    const int pad0 = colpad_t ? colpad_t[(size_t)j * DG_COLPAD + lane] : 0;
     const int start = rowptr_t[j], end = rowptr_t[j + 1];
-    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane, pad0, colpad_t != nullptr) + gas4[j];
+    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
     const float dj = dinv[j];
     const float gh = dj * s;
     if (lane < 32) {
@@ -295,10 +287,10 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
 
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const int32_t* colpad_t) {
+                       float* gas3, float* pa4, int P1, hipStream_t s) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
-                     pa4, colpad_t);
+                     pa4);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -319,7 +311,7 @@ __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
-            float* __restrict__ part, const int* __restrict__ colpad_t) {
+            float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
   extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
@@ -347,10 +339,9 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   for (int tile = wg * chunk; tile < tile_end; ++tile) {
     const int j = tile * DG_TILE + wave;
     if (j < N) {
-      const int pad0 = colpad_t ? colpad_t[(size_t)j * DG_COLPAD + lane] : 0;
       const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr_t[j + 1]);
-      float4 acc = dg_gather_row32(gas, colidx_t, start, end, j, lane, pad0, colpad_t != nullptr);
+      float4 acc = dg_gather_row32(gas, colidx_t, start, end, j, lane);
       const float dj = dinv[j];
       acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
       if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = acc;
@@ -448,17 +439,16 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
 
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
-                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const int32_t* colpad_t) {
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
     hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
-                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t);
+                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part);
   } else {
     hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,
-                       dinv, gas, Wl, xprev, gpprev, gas_prev, part, colpad_t);
+                       dinv, gas, Wl, xprev, gpprev, gas_prev, part);
   }
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

@@ -105,8 +105,7 @@ k_prep_fill(const int64_t* __restrict__ ei, int E, int N, int B, int* __restrict
 
 __global__ void __launch_bounds__(256)
 k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx,
-                 const int* __restrict__ rowptr_t, int* __restrict__ colidx_t, int* __restrict__ colpad,
-                 int* __restrict__ colpad_t) {
+                 const int* __restrict__ rowptr_t, int* __restrict__ colidx_t) {
   __shared__ int buf[DG_SORT_LDS];
   __shared__ int long_row[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -115,13 +114,10 @@ k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx
   if (r < 2 * N) {
     const int* rp = r < N ? rowptr : rowptr_t;
     int* col = r < N ? colidx : colidx_t;
-    int* pad = r < N ? colpad : colpad_t;
     const int i = r < N ? r : r - N;
     const int start = rp[i], d = rp[i + 1] - start;
     if (d > 64) {
       if (lane == 0) long_row[w] = r;
-    } else if (d == 1) {
-      if (pad && lane == 0) pad[(size_t)i * DG_COLPAD] = col[start];
     } else if (d > 1) {
       const int v = lane < d ? col[start + lane] : 0x7fffffff;
       int rank = 0;
@@ -129,7 +125,7 @@ k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx
         const int u = __shfl(v, m);
         rank += (u < v || (u == v && m < lane)) ? 1 : 0;
       }
-      if (lane < d) { col[start + rank] = v; if (pad) pad[(size_t)i * DG_COLPAD + rank] = v; }
+      if (lane < d) col[start + rank] = v;
     }
   }
   __syncthreads();
@@ -138,7 +134,6 @@ k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx
     if (rr < 0) continue;
     const int* rp = rr < N ? rowptr : rowptr_t;
     int* col = rr < N ? colidx : colidx_t;
-    int* pad = rr < N ? colpad : colpad_t;
     const int i = rr < N ? rr : rr - N;
     const int start = rp[i], d = rp[i + 1] - start;
     if (d <= DG_SORT_LDS) {
@@ -146,12 +141,9 @@ k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx
       __syncthreads();
       dg_block_bitonic<int>(buf, d);
       for (int t = threadIdx.x; t < d; t += blockDim.x) col[start + t] = buf[t];
-      if (pad && threadIdx.x < DG_COLPAD) pad[(size_t)i * DG_COLPAD + threadIdx.x] = buf[threadIdx.x];
       __syncthreads();
     } else {
       dg_block_bitonic<int>(col + start, d);   // rare: in place in global memory (same workgroup only)
-      if (pad && threadIdx.x < DG_COLPAD) pad[(size_t)i * DG_COLPAD + threadIdx.x] = col[start + threadIdx.x];
-      __syncthreads();
     }
   }
 }
@@ -226,8 +218,7 @@ __global__ void __launch_bounds__(256)
 k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
               float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int nblk_b,
-              int F, const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ hs,
-              int* __restrict__ colpad, int* __restrict__ colpad_t) {
+              int F, const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ hs) {
   extern __shared__ __attribute__((aligned(16))) float Wt[];   // lin range only: [F][32]
   if ((int)blockIdx.x >= nblk_b) {      // ---- conv1 linear block range (same arithmetic as k_lin_first32) ----
     for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
@@ -252,13 +243,6 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
   if (t < E) {
     const int64_t s = ei[t], d = ei[(int64_t)E + t];
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
-      if (colpad) {          // padded table: the first DG_COLPAD neighbours of row s (list is already sorted)
-        const int pos = t - rowptr[s];
-        if ((unsigned)pos < (unsigned)DG_COLPAD) {
-          colpad[(size_t)s * DG_COLPAD + pos] = (int)d;
-          colpad_t[(size_t)s * DG_COLPAD + pos] = (int)d;     // symmetric graph: CSR by source == CSR by target
-        }
-      }
       const int end = rowptr[d + 1];
       int a = rowptr[d], b = end;
       while (a < b) {
@@ -273,8 +257,7 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
-                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done,
-                   int32_t* colpad, int32_t* colpad_t) {
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done) {
   if (N <= 0 || E < 0 || B <= 0) return DGCNN_EINVAL;
   if (lin_done) *lin_done = 0;
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
@@ -292,8 +275,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     }
     hipLaunchKernelGGL(k_prep_fast_b, dim3(nblk_b + nlin), dim3(256), nlin ? sizeof(float) * 32 * lf->F : 0, s,
                        edge_index, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv, uerr, epoch, nblk_b,
-                       nlin ? lf->F : 0, nlin ? lf->x : nullptr, nlin ? lf->W : nullptr, nlin ? lf->hs : nullptr,
-                       colpad, colpad_t);
+                       nlin ? lf->F : 0, nlin ? lf->x : nullptr, nlin ? lf->W : nullptr, nlin ? lf->hs : nullptr);
     if (nlin && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
@@ -311,7 +293,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
   DG_CHECK_LAUNCH();
   if (E > 0) {
     hipLaunchKernelGGL(k_prep_sort_rows, dim3(dg_cdiv(2 * N, 4)), dim3(256), 0, s, N, rowptr, colidx, rowptr_t,
-                       colidx_t, colpad, colpad_t);
+                       colidx_t);
     DG_CHECK_LAUNCH();
   }
   return DGCNN_OK;

@@ -8,7 +8,6 @@ sh = synth.SHAPES["COLLAB"]
 b = synth.make_batch("COLLAB", 50, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda").eval()
-m.use_fused = True
 dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 names = ["start", "stage+lin1", "layer1", "layer2", "layer3", "conv4", "-", "-", "topk", "gather+Wstage", "conv5",
