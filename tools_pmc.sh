@@ -4,7 +4,7 @@
 # usage: tools_pmc.sh <tag> [bench args]
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   rocprofv3 --pmc $C --kernel-trace --truncate-kernels --output-format csv -d $OUT/pmc_${TAG}_$C -o p -- \
       python $R/bench.py "$@" --no-cpu-baseline --no-roofline > $OUT/pmc_${TAG}_$C.log 2>&1
 done
@@ -12,7 +12,8 @@ python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, json, collections
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
+import os
+for c in os.environ.get("PMC_COUNTERS", "FETCH_SIZE WRITE_SIZE").split():
     f = glob.glob(f"{out}/pmc_{tag}_{c}/**/*counter_collection.csv", recursive=True)
     if not f:
         print("no counter file for", c); continue
@@ -25,7 +26,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         res[k]["dispatches"] = n
 json.dump(res, open(f"{out}/pmc_{tag}.json", "w"), indent=1)
 for k, d in sorted(res.items()):
-    fs, wsz = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
-    print(f"{k:22s} n={d['dispatches']:5d} FETCH_SIZE={fs:10.1f} KB  WRITE_SIZE={wsz:10.1f} KB  -> (2*F+W)*1024 = {(2*fs+wsz)*1024/1e6:8.2f} MB")
+    if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+        fs, wsz = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
+        print(f"{k:22s} n={d['dispatches']:5d} FETCH_SIZE={fs:10.1f} KB  WRITE_SIZE={wsz:10.1f} KB  -> (2*F+W)*1024 = {(2*fs+wsz)*1024/1e6:8.2f} MB")
+    else:
+        print(f"{k:22s} " + " ".join(f"{c}={v:.1f}" for c, v in d.items()))
 PY
-rm -rf $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do rm -rf $OUT/pmc_${TAG}_$C; done
