@@ -51,19 +51,60 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.grads = torch.zeros_like(flat)
         self.metrics = torch.zeros(2, dtype=torch.float32, device=flat.device)
-        self._ws = None
-        self._ws_bytes = 0
         self._logp = None
+        # two workspace slots: the step runs in slot `_cur`; `prefetch` prepares the next batch's graph structure
+        # in the other slot on a side stream (software pipelining of graph prep across steps)
+        self._slots = [{"ws": None, "bytes": 0, "free": None}, {"ws": None, "bytes": 0, "free": None}]
+        self._cur = 0
+        self._side = None
+        self._ready_evt = None
+        self._pf = None          # (data, N, E, B, F, C, flags, epoch, ...) of the batch prepared in slot 1-_cur
 
     # ---- buffers reused across steps (sizes only grow) -------------------------------------
+    def _slot_ws(self, k, need, device):
+        sl = self._slots[k]
+        if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != device:
+            sl["ws"] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+            sl["bytes"] = sl["ws"].numel()
+        return sl["ws"]
+
     def _buffers(self, N, E, B, F, C, device):
         need = _lib.workspace_bytes(N, E, B, F, C)
-        if self._ws is None or need > self._ws_bytes or self._ws.device != device:
-            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
-            self._ws_bytes = self._ws.numel()
+        self._ws = self._slot_ws(self._cur, need, device)
         if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != device:
             self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=device)
         return self._ws, self._logp
+
+    def prefetch(self, data) -> None:
+        """Prepare ``data``'s graph structure (CSR, degrees, graph ranges) NOW, on a side stream, into the spare
+        workspace, so that the next ``train_step(data)`` / ``forward_backward(data)`` skips graph prep.
+        Graph prep depends on the batch only (not on the parameters), so a training loop calls this for batch
+        i+1 right after launching step i -- what a DataLoader with prefetching does on the host, done here on
+        the device.  Purely an overlap: every step's prep is still executed, once."""
+        L = _lib.lib()
+        m = self.model
+        N, E, B, F, C = self._dims(data)
+        dev = data.x.device
+        need = _lib.workspace_bytes(N, E, B, F, C)
+        cur = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+            self._ready_evt = torch.cuda.Event()
+        o = 1 - self._cur
+        ws = self._slot_ws(o, need, dev)
+        flags = m._flags_of(data)
+        epoch = m._next_epoch()
+        sl = self._slots[o]
+        if sl["free"] is not None:
+            self._side.wait_event(sl["free"])            # that slot's previous consumer (step i-1) is done
+        else:
+            self._side.wait_stream(cur)                  # first use: order after whatever allocated/queued so far
+        ei, bt = data.edge_index.contiguous(), data.batch.contiguous()
+        _lib.check(L.dgcnn_model_prepare(N, E, B, F, C, ei.data_ptr() if E else None, bt.data_ptr(),
+                                         ws.data_ptr(), flags, epoch, self._side.cuda_stream),
+                   "dgcnn_model_prepare")
+        self._ready_evt.record(self._side)
+        self._pf = (data, N, E, B, F, C, flags, epoch, ei, bt)
 
     def _dims(self, data):
         x, ei = data.x, data.edge_index
@@ -80,14 +121,29 @@ class Trainer:
         dev = data.x.device
         ws, logp = self._buffers(N, E, B, F, C, dev)
         flat = m.flat_params
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        cur = torch.cuda.current_stream(dev)
+        stream = cur.cuda_stream
         training = 1 if m.training else 0
         seed = m._next_seed() if training else 0
         x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+        flags = m._flags_of(data)
+        if self._pf is not None and self._pf[0] is data and self._pf[1:6] == (N, E, B, F, C):
+            # consume the prefetched graph structure: swap workspaces, wait for the side stream, skip prep
+            _, _, _, _, _, _, pflags, epoch, _, _ = self._pf
+            self._pf = None
+            self._cur = 1 - self._cur
+            ws = self._ws = self._slots[self._cur]["ws"]
+            cur.wait_event(self._ready_evt)
+            flags = pflags | _lib.FLAG_PREPARED
+            m._epoch = epoch
+            swapped = True
+        else:
+            epoch = m._next_epoch()
+            swapped = False
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
-                                         logp.data_ptr(), training, seed, m._flags_of(data), m._max_nodes_of(data),
-                                         int(getattr(data, "max_edges", 0) or 0), m._next_epoch(), stream), "dgcnn_model_forward")
+                                         logp.data_ptr(), training, seed, flags, m._max_nodes_of(data),
+                                         int(getattr(data, "max_edges", 0) or 0), epoch, stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam:
             self.step_count += 1
@@ -103,6 +159,11 @@ class Trainer:
                                               self.grads.data_ptr(), self.metrics.data_ptr(), stream),
                        "dgcnn_model_backward")
         m._last_ws, m._last_dims = ws, (N, E, B, F, C)
+        if self._side is not None:      # prefetching in use: mark when this step's slot becomes reusable
+            sl = self._slots[self._cur]
+            if sl["free"] is None:
+                sl["free"] = torch.cuda.Event()
+            sl["free"].record(cur)
         return logp[:B]
 
     def optimizer_step(self) -> None:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 5
+#define DGCNN_ABI_VERSION 6
 
 /* error codes */
 #define DGCNN_OK            0
@@ -61,6 +61,8 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
 #define DGCNN_FLAG_COALESCED_UNDIRECTED 1
 #define DGCNN_FLAG_FORCE_FUSED 2    /* use the graph-per-workgroup kernel whenever the hints allow it */
 #define DGCNN_FLAG_FORCE_TILED 4    /* never use it */
+#define DGCNN_FLAG_PREPARED    8    /* dgcnn_model_forward: the workspace already holds this batch's graph structure
+                                       (dgcnn_model_prepare with the SAME sizes, flags and epoch): skip graph prep */
 #define DGCNN_FUSED_MIN_GRAPHS 192  /* default: fused path only for batches of at least this many graphs */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
  * duplicates, no self loops, every edge present in both directions -- what a TU dataset file (and
@@ -173,6 +175,11 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                         int max_edges, uint32_t epoch, dgcnn_stream_t stream);
+/* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: lets a
+ * training loop prepare batch i+1 on another stream while step i computes (it depends on the batch only, not
+ * on the parameters).  Follow with dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, same epoch). */
+int dgcnn_model_prepare(int N, int E, int B, int F, int C, const int64_t* edge_index, const int64_t* batch,
+                        void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream);
 int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
 int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batch fits the fused LDS plan */
 

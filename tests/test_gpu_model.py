@@ -225,6 +225,27 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     assert abs(lsum - float(loss_ref)) < 1e-5
 
 
+def test_prefetched_graph_prep_gives_identical_training():
+    """Trainer.prefetch (graph prep of batch i+1 on a side stream during step i) must not change a single bit."""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    batches = [b.to("cuda") for b in synth.make_batches("COLLAB", 60, 12, start=4000)]
+    outs = []
+    for use_pf in (False, True):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 3, 0
+        tr = Trainer(m)
+        for it in range(12):
+            b = batches[it % len(batches)]
+            tr.train_step(b, b.y)
+            if use_pf:
+                tr.prefetch(batches[(it + 1) % len(batches)])
+        torch.cuda.synchronize()
+        m.check_errors()
+        outs.append((m.flat_params.clone(), tr.metrics.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_training_reduces_loss_like_reference_loop():
     """Overfit 3 fixed batches with the fused Trainer; mean loss must drop (the qualitative
     behaviour of /root/reference/results/*.png), and eval mode must be deterministic."""
