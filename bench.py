@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-prefetch", action="store_true", help="do graph prep inside each step's own launch chain")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="software-pipeline graph prep (batch i+1 on a side stream during step i); off by default: "
+                         "measured host-bound (see DESIGN.md)")
     ap.add_argument("--path", choices=["auto", "fused", "tiled"], default="auto",
                     help="forward kernel family: library heuristic, graph-per-workgroup fused, or tiled")
     return ap.parse_args()
@@ -165,7 +167,7 @@ def main():
     def step(i):
         b = batches[i % nb]
         tr.train_step(b, b.y, global_batch=gb)
-        if not args.no_prefetch:
+        if args.prefetch:
             # software-pipelined graph prep: batch i+1's CSR build runs on a side stream during step i
             tr.prefetch(batches[(i + 1) % nb])
 
@@ -279,7 +281,7 @@ def main():
                        if args.workload == "COLLAB" else f"{args.workload}-shape synthetic graphs, batch_size={B} per GPU",
                        "global_batch": gb, "avg_nodes_per_batch": avgN, "avg_directed_edges_per_batch": avgE,
                        "parallelism": f"dp{world}", "step": "forward + NLL(mean) + backward + fused Adam + zero_grad "
-                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) of every batch inside the timed region" + ("" if args.no_prefetch else ", software-pipelined: prep of batch i+1 runs on a side stream during step i")},
+                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) of every batch inside the timed region" + (", software-pipelined: prep of batch i+1 runs on a side stream during step i" if args.prefetch else "")},
             "train_loss_mean": loss_sum / max(args.steps + args.warmup, 1), "correct_frac_rank0": correct / ((args.steps + args.warmup) * B),
         }
         out.update(extra)

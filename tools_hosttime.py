@@ -1,0 +1,26 @@
+"""GPU-box helper: host enqueue time vs device time per training step (is the loop host-bound?)."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from dgcnn_amd import synth
+from dgcnn_amd.model import Model
+from dgcnn_amd.train import Trainer
+sh = synth.SHAPES["COLLAB"]
+batches = [b.to("cuda") for b in synth.make_batches("COLLAB", 500, 50)]
+torch.manual_seed(324)
+m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
+tr = Trainer(m)
+for pf in (False, True):
+    for i in range(50):
+        tr.train_step(batches[i % 10], batches[i % 10].y)
+        if pf: tr.prefetch(batches[(i + 1) % 10])
+    torch.cuda.synchronize()
+    K = 400
+    t0 = time.perf_counter()
+    for i in range(K):
+        b = batches[i % 10]
+        tr.train_step(b, b.y)
+        if pf: tr.prefetch(batches[(i + 1) % 10])
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"prefetch={pf}: host enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
