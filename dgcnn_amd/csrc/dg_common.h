@@ -179,6 +179,25 @@ __device__ __forceinline__ int dg_xcd_tile(int t, int numTiles) {
   if (k < share) return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   return t;   // unreachable for t < numTiles when iterated as below; keeps the map total
 }
+// One 16x16 output tile of C = A.B on the fp32 matrix cores, one wavefront, v_mfma_f32_16x16x4_f32:
+//   fa(m, k) -> A[m][k],  fb(k, n) -> B[k][n]   (lane-callable, return 0 outside the real extents = padding)
+//   st(m, n, v) receives the 4 elements this lane owns.   K is rounded up to a multiple of 4 by the padding.
+// The sum over k is a k-ordered fma chain (deterministic).  Operands typically come from LDS: a scalar
+// VALU formulation of these small products is LDS-read-bound (2 reads per FMA), the matrix unit needs 2
+// reads per 64x4x... block of FMAs.
+template <typename FA, typename FB, typename ST>
+__device__ __forceinline__ void dg_mfma_tile16(int m0, int n0, int K, int lane, FA fa, FB fb, ST st) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  const int mi = lane & 15, kq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const float a = fa(m0 + mi, k0 + kq);
+    const float b = fb(k0 + kq, n0 + mi);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) st(m0 + kq * 4 + r, n0 + mi, d[r]);
+}
+
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {
@@ -279,6 +298,7 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
 int dg_fused_max_nodes(int F);
 int dg_fused_fits(int nmax, int emax, int F);
 void dg_fused_set_debug(unsigned long long* p);
+unsigned long long* dg_debug_buffer();
 #define DG_GATHER_UNROLL 8
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,

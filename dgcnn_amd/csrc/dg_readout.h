@@ -97,9 +97,8 @@ struct RdSmem {
   float* flat;                   // [352]
   float* a1s;                    // [128]
   float* lg;                     // [MAX_C]
-  float* lg2;                    // [2*16*30] conv5 half sums
 };
-#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (3 * DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C) * 4)
+#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C) * 4)
 __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   RdSmem m;
   m.region0 = reinterpret_cast<unsigned long long*>(region0);
@@ -110,8 +109,7 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   m.p5 = reinterpret_cast<float*>(p); p += DGCNN_C5 * DGCNN_T5 * 4;
   m.flat = reinterpret_cast<float*>(p); p += DGCNN_FLAT * 4;
   m.a1s = reinterpret_cast<float*>(p); p += DGCNN_HID1 * 4;
-  m.lg = reinterpret_cast<float*>(p); p += DGCNN_MAX_C * 4;
-  m.lg2 = reinterpret_cast<float*>(p);
+  m.lg = reinterpret_cast<float*>(p);
   return m;
 }
 
@@ -129,7 +127,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float* W5s = sp + 2912;                                 // [1552]
   float* W6s = W5s + NW5;                                 // [2560]   (2912+1552+2560)*4 = 28096 <= 32768
   int* sel = M.sel;
-  float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg, *lg2 = M.lg2;
+  float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
@@ -155,25 +153,20 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(9);
-  // conv5: per-slot 97 -> 16 linear, ReLU.  output index o*30+s ([B,16,30]); the 97-term chain is split in
-  // two halves (49 + 48 terms) over 960 threads and combined in a fixed order
-  if (tid < 2 * DGCNN_C5 * DGCNN_K) {
-    const int hh = tid / (DGCNN_C5 * DGCNN_K), t = tid - hh * (DGCNN_C5 * DGCNN_K);
-    const int o = t / DGCNN_K, s = t - o * DGCNN_K;
-    const float* wr = W5s + o * DGCNN_CAT;
-    const float* xr = sp + s * DGCNN_CAT;
-    float acc = 0.f;
-    const int m0 = hh ? 49 : 0, m1 = hh ? DGCNN_CAT : 49;
-#pragma unroll 8
-    for (int m = m0; m < m1; ++m) acc = fmaf(wr[m], xr[m], acc);
-    lg2[hh * (DGCNN_C5 * DGCNN_K) + t] = acc;
-  }
-  __syncthreads();
-  if (tid < DGCNN_C5 * DGCNN_K) {
-    const int o = tid / DGCNN_K;
-    const float acc = fmaxf((lg2[tid] + lg2[DGCNN_C5 * DGCNN_K + tid]) + w.b5[o], 0.f);
-    a5s[tid] = acc;
-    a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
+  // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16],
+  // two 16x16 tiles, one wave each; ReLU + bias in the store.  output index o*30+s ([B,16,30])
+  if (wv < 2) {
+    dg_mfma_tile16(
+        wv * 16, 0, 100, lane,
+        [&](int s, int m) { return (s < DGCNN_K && m < DGCNN_CAT) ? sp[s * DGCNN_CAT + m] : 0.f; },
+        [&](int m, int o) { return m < DGCNN_CAT ? W5s[o * DGCNN_CAT + m] : 0.f; },
+        [&](int s, int o, float v) {
+          if (s < DGCNN_K) {
+            const float acc = fmaxf(v + w.b5[o], 0.f);
+            a5s[o * DGCNN_K + s] = acc;
+            a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K + s] = acc;
+          }
+        });
   }
   __syncthreads();
   RD_MARK(10);
@@ -183,18 +176,20 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     p5[tid] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
   }
   __syncthreads();
-  // conv6: [16,15] -> [32,11], kernel 5, ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
-  if (tid < DGCNN_FLAT) {
-    const int oc = tid / DGCNN_T6, tt = tid - oc * DGCNN_T6;
-    float acc = w.b6[oc];
-    const float* wr = W6s + oc * (DGCNN_C5 * DGCNN_KW6);
-#pragma unroll 4
-    for (int c = 0; c < DGCNN_C5; ++c)
-#pragma unroll
-      for (int d = 0; d < DGCNN_KW6; ++d) acc = fmaf(wr[c * DGCNN_KW6 + d], p5[c * DGCNN_T5 + tt + d], acc);
-    acc = fmaxf(acc, 0.f);
-    flat[tid] = acc;
-    a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
+  // conv6 on the matrix cores: z6[oc][t] = sum_{c,d} W6[oc][c][d] p5[c][t+d]  ->  [32 x 16(11)] = [32 x 80] . [80 x 16],
+  // two 16x16 tiles, one wave each; flat index oc*11+t (x.view(B,-1), model.py:40)
+  if (wv < 2) {
+    dg_mfma_tile16(
+        wv * 16, 0, DGCNN_C5 * DGCNN_KW6, lane,
+        [&](int oc, int k) { return W6s[oc * (DGCNN_C5 * DGCNN_KW6) + k]; },
+        [&](int k, int t) { return t < DGCNN_T6 ? p5[(k / DGCNN_KW6) * DGCNN_T5 + t + (k % DGCNN_KW6)] : 0.f; },
+        [&](int oc, int t, float v) {
+          if (t < DGCNN_T6) {
+            const float acc = fmaxf(v + w.b6[oc], 0.f);
+            flat[oc * DGCNN_T6 + t] = acc;
+            a6g[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + t] = acc;
+          }
+        });
   }
   __syncthreads();
   RD_MARK(11);

@@ -239,6 +239,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
 
 static thread_local unsigned long long* g_fg_dbg = nullptr;
 void dg_fused_set_debug(unsigned long long* p) { g_fg_dbg = p; }
+unsigned long long* dg_debug_buffer() { return g_fg_dbg; }
 
 // does a batch with per-graph bounds (nmax nodes, emax directed edges) fit the fused kernel's LDS plan?
 int dg_fused_fits(int nmax, int emax, int F) {

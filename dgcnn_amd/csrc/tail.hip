@@ -121,7 +121,9 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-           float* __restrict__ ptail, const float* __restrict__ pooled) {
+           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg) {
+#define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+  TB_MARK(0);
   __shared__ float W5s[NW5];
   __shared__ float a1ds[DGCNN_HID1];
   __shared__ float p5s[DGCNN_C5 * DGCNN_T5];
@@ -172,6 +174,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     if (lane < C) { dl[lane] = d; dlogit[(size_t)b * C + lane] = d; }
   }
   __syncthreads();
+  TB_MARK(1);
   // 2. through classifier_2, dropout, ReLU
   if (tid < DGCNN_HID1) {
     float ga = 0.f;
@@ -190,6 +193,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     pt[DG_PT_WF2 + t] = dl[c] * a1ds[j];
   }
   if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
+  TB_MARK(2);
   // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads)
   if (tid < 2 * DGCNN_FLAT) {
     const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
@@ -212,27 +216,25 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
   __syncthreads();
-  // 4. conv6 data gradient -> [16,15]: 240 outputs x 160 terms, split over 4 groups of 8 output channels
-  //    (960 threads, 40-term chains) and combined in a fixed order
-  if (tid < 4 * DGCNN_C5 * DGCNN_T5) {
-    const int grp = tid / (DGCNN_C5 * DGCNN_T5), o = tid - grp * (DGCNN_C5 * DGCNN_T5);
-    const int c = o / DGCNN_T5, u = o - c * DGCNN_T5;
-    float acc = 0.f;
-#pragma unroll
-    for (int oo = 0; oo < 8; ++oo) {
-      const int oc = grp * 8 + oo;
-#pragma unroll
-      for (int d = 0; d < DGCNN_KW6; ++d) {
-        const int tt = u - d;
-        if (tt >= 0 && tt < DGCNN_T6)
-          acc = fmaf(gz6s[oc * DGCNN_T6 + tt], W6s[(oc * DGCNN_C5 + c) * DGCNN_KW6 + d], acc);
-      }
-    }
-    gp5q[grp][o] = acc;
+  TB_MARK(3);
+  // 4. conv6 data gradient on the matrix cores: gp5[c][u] = sum_{oc,d} W6[oc][c][d] gz6[oc][u-d]
+  //    -> [16 x 16(15)] = [16 x 160] . [160 x 16]; K split over 4 waves (40 each), combined in a fixed order
+  if (wv < 4) {
+    const int kbase = wv * 40;
+    dg_mfma_tile16(
+        0, 0, 40, lane,
+        [&](int c, int kk) { const int k = kbase + kk; return W6s[((k / DGCNN_KW6) * DGCNN_C5 + c) * DGCNN_KW6 + (k % DGCNN_KW6)]; },
+        [&](int kk, int u) {
+          const int k = kbase + kk;
+          const int tt = u - (k % DGCNN_KW6);
+          return (u < DGCNN_T5 && tt >= 0 && tt < DGCNN_T6) ? gz6s[(k / DGCNN_KW6) * DGCNN_T6 + tt] : 0.f;
+        },
+        [&](int c, int u, float v) { if (u < DGCNN_T5) gp5q[wv][c * DGCNN_T5 + u] = v; });
   }
   __syncthreads();
   if (tid < DGCNN_C5 * DGCNN_T5) gp5[tid] = (gp5q[0][tid] + gp5q[1][tid]) + (gp5q[2][tid] + gp5q[3][tid]);
   __syncthreads();
+  TB_MARK(4);
   // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
@@ -249,14 +251,27 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz5g[base + 1] = g1;
   }
   __syncthreads();
+  TB_MARK(5);
   // 5b. per-graph partial weight gradients of conv6 and conv5 (everything they need is in LDS / this graph's
   //     pooled rows); k_wgrad then only sums B contiguous partials per element (coalesced)
-  for (int t = tid; t < NW6; t += RD_THREADS) {       // t = (oc*16 + c)*5 + d
-    const int d = t % DGCNN_KW6, c = (t / DGCNN_KW6) % DGCNN_C5, oc = t / (DGCNN_KW6 * DGCNN_C5);
-    float acc = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < DGCNN_T6; ++tt) acc = fmaf(gz6s[oc * DGCNN_T6 + tt], p5s[c * DGCNN_T5 + tt + d], acc);
-    pt[DG_PT_W6 + t] = acc;
+  // conv6: pW6[oc][(c,d)] = sum_t gz6[oc][t] p5[c][t+d]   -> [32 x 80] = [32 x 12(11)] . [12 x 80]   (10 tiles)
+  // conv5: pW5[o][m]      = sum_s gz5[o][s] sp[s][m]       -> [16 x 112(97)] = [16 x 32(30)] . [32 x 112] (7 tiles)
+  for (int job = wv; job < 17; job += RD_THREADS / 64) {
+    if (job < 10) {
+      const int mt = job / 5, nt = job - mt * 5;
+      dg_mfma_tile16(
+          mt * 16, nt * 16, 12, lane,
+          [&](int oc, int t) { return t < DGCNN_T6 ? gz6s[oc * DGCNN_T6 + t] : 0.f; },
+          [&](int t, int n) { return t < DGCNN_T6 ? p5s[(n / DGCNN_KW6) * DGCNN_T5 + t + (n % DGCNN_KW6)] : 0.f; },
+          [&](int oc, int n, float v) { pt[DG_PT_W6 + oc * (DGCNN_C5 * DGCNN_KW6) + n] = v; });
+    } else {
+      const int nt = job - 10;
+      dg_mfma_tile16(
+          0, nt * 16, 32, lane,
+          [&](int o, int sl) { return sl < DGCNN_K ? gz5s[o * DGCNN_K + sl] : 0.f; },
+          [&](int sl, int m) { return (sl < DGCNN_K && m < DGCNN_CAT) ? sps[sl * DGCNN_CAT + m] : 0.f; },
+          [&](int o, int m, float v) { if (m < DGCNN_CAT) pt[DG_PT_W5 + o * DGCNN_CAT + m] = v; });
+    }
   }
   if (tid < DGCNN_C6) {
     float acc = 0.f;
@@ -264,40 +279,38 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     for (int tt = 0; tt < DGCNN_T6; ++tt) acc += gz6s[tid * DGCNN_T6 + tt];
     pt[DG_PT_B6 + tid] = acc;
   }
-  {
-    const float* prow = sps;
-    for (int t = tid; t < NW5; t += RD_THREADS) {     // t = o*97 + m
-      const int o = t / DGCNN_CAT, m = t - o * DGCNN_CAT;
-      float acc = 0.f;
-#pragma unroll 6
-      for (int sl = 0; sl < DGCNN_K; ++sl) acc = fmaf(gz5s[o * DGCNN_K + sl], prow[sl * DGCNN_CAT + m], acc);
-      pt[DG_PT_W5 + t] = acc;
-    }
-    if (tid >= 512 && tid < 512 + DGCNN_C5) {
-      const int o = tid - 512;
-      float acc = 0.f;
-      for (int sl = 0; sl < DGCNN_K; ++sl) acc += gz5s[o * DGCNN_K + sl];
-      pt[DG_PT_B5 + o] = acc;
-    }
+  if (tid >= 512 && tid < 512 + DGCNN_C5) {
+    const int o = tid - 512;
+    float acc = 0.f;
+    for (int sl = 0; sl < DGCNN_K; ++sl) acc += gz5s[o * DGCNN_K + sl];
+    pt[DG_PT_B5 + o] = acc;
   }
+  TB_MARK(6);
   // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
-  for (int o = tid; o < msel * DGCNN_CAT; o += RD_THREADS) {
-    const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
-    const int node = perm[b * DGCNN_K + s];
-    float v = 0.f;
-#pragma unroll
-    for (int oc = 0; oc < DGCNN_C5; ++oc) v = fmaf(gz5s[oc * DGCNN_K + s], W5s[oc * DGCNN_CAT + c], v);
-    if (c < 32) gp1[(size_t)node * 32 + c] = v;
-    else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
-    else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
-    else {
-      const float xv = x4[node];
-      const float ga = v * (1.f - xv * xv);      // tanh'
-      gas4[node] = dinv[node] * ga;
-      ga4s[s] = ga;
-    }
+  // gsp[s][c] = sum_oc gz5[oc][s] W5[oc][c]  -> [32(30) x 112(97)] = [32 x 16] . [16 x 112]  (14 tiles, one wave each)
+  for (int job = wv; job < 14; job += RD_THREADS / 64) {
+    const int mt = job / 7, nt = job - mt * 7;
+    dg_mfma_tile16(
+        mt * 16, nt * 16, DGCNN_C5, lane,
+        [&](int sl, int oc) { return sl < DGCNN_K ? gz5s[oc * DGCNN_K + sl] : 0.f; },
+        [&](int oc, int c) { return c < DGCNN_CAT ? W5s[oc * DGCNN_CAT + c] : 0.f; },
+        [&](int sl, int c, float v) {
+          if (sl < msel && c < DGCNN_CAT) {
+            const int node = perm[b * DGCNN_K + sl];
+            if (c < 32) gp1[(size_t)node * 32 + c] = v;
+            else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
+            else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
+            else {
+              const float xv = x4[node];
+              const float ga = v * (1.f - xv * xv);      // tanh'
+              gas4[node] = dinv[node] * ga;
+              ga4s[sl] = ga;
+            }
+          }
+        });
   }
   __syncthreads();
+  TB_MARK(7);
   if (tid == 0) {     // db4 partial of this graph, fixed order
     float sum = 0.f;
     for (int s = 0; s < DGCNN_K; ++s) sum += ga4s[s];
@@ -315,7 +328,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
                      x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
-                     gas4, gb4p, lossv, ptail, pooled);
+                     gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer());
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
