@@ -189,10 +189,19 @@ template <typename FA, typename FB, typename ST>
 __device__ __forceinline__ void dg_mfma_tile16(int m0, int n0, int K, int lane, FA fa, FB fb, ST st) {
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
   const int mi = lane & 15, kq = lane >> 4;
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const float a = fa(m0 + mi, k0 + kq);
-    const float b = fb(k0 + kq, n0 + mi);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
+  // operands of 8 k-steps are fetched together (16 LDS reads in flight), then the 8 dependent MFMAs issue
+  // back to back: one LDS round trip per 8 MFMAs instead of one per MFMA
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 4 * u + kq;
+      av[u] = (k0 + 4 * u < K) ? fa(m0 + mi, k) : 0.f;
+      bv[u] = (k0 + 4 * u < K) ? fb(k, n0 + mi) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 4 * u < K) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) st(m0 + kq * 4 + r, n0 + mi, d[r]);

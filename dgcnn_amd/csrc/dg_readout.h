@@ -97,8 +97,9 @@ struct RdSmem {
   float* flat;                   // [352]
   float* a1s;                    // [128]
   float* lg;                     // [MAX_C]
+  float* cpart;                  // [4][32][16] conv5 K-split partial tiles
 };
-#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C) * 4)
+#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C + 4 * 32 * 16) * 4)
 __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   RdSmem m;
   m.region0 = reinterpret_cast<unsigned long long*>(region0);
@@ -109,7 +110,8 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   m.p5 = reinterpret_cast<float*>(p); p += DGCNN_C5 * DGCNN_T5 * 4;
   m.flat = reinterpret_cast<float*>(p); p += DGCNN_FLAT * 4;
   m.a1s = reinterpret_cast<float*>(p); p += DGCNN_HID1 * 4;
-  m.lg = reinterpret_cast<float*>(p);
+  m.lg = reinterpret_cast<float*>(p); p += DGCNN_MAX_C * 4;
+  m.cpart = reinterpret_cast<float*>(p);
   return m;
 }
 
@@ -153,20 +155,29 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(9);
-  // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16],
-  // two 16x16 tiles, one wave each; ReLU + bias in the store.  output index o*30+s ([B,16,30])
-  if (wv < 2) {
-    dg_mfma_tile16(
-        wv * 16, 0, 100, lane,
-        [&](int s, int m) { return (s < DGCNN_K && m < DGCNN_CAT) ? sp[s * DGCNN_CAT + m] : 0.f; },
-        [&](int m, int o) { return m < DGCNN_CAT ? W5s[o * DGCNN_CAT + m] : 0.f; },
-        [&](int s, int o, float v) {
-          if (s < DGCNN_K) {
-            const float acc = fmaxf(v + w.b5[o], 0.f);
-            a5s[o * DGCNN_K + s] = acc;
-            a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K + s] = acc;
-          }
-        });
+  // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16]:
+  // two 16x16 tiles, K split over 4 waves each (28 + 24 + 24 + 24 columns), partial tiles combined in a fixed
+  // order; ReLU + bias at the combine.  output index o*30+s ([B,16,30])
+  {
+    float* part = M.cpart;                       // [4][32][16]
+    if (wv < 8) {
+      const int mt = wv >> 2, kc = wv & 3;
+      const int kb = kc == 0 ? 0 : 28 + (kc - 1) * 24, kl = kc == 0 ? 28 : 24;
+      dg_mfma_tile16(
+          mt * 16, 0, kl, lane,
+          [&](int s, int kk) { const int m = kb + kk; return (s < DGCNN_K && m < DGCNN_CAT) ? sp[s * DGCNN_CAT + m] : 0.f; },
+          [&](int kk, int o) { const int m = kb + kk; return m < DGCNN_CAT ? W5s[o * DGCNN_CAT + m] : 0.f; },
+          [&](int s, int o, float v) { part[(kc * 32 + s) * 16 + o] = v; });
+    }
+    __syncthreads();
+    if (tid < DGCNN_C5 * DGCNN_K) {
+      const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
+      const float v = (part[(0 * 32 + s) * 16 + o] + part[(1 * 32 + s) * 16 + o]) +
+                      (part[(2 * 32 + s) * 16 + o] + part[(3 * 32 + s) * 16 + o]);
+      const float acc = fmaxf(v + w.b5[o], 0.f);
+      a5s[tid] = acc;
+      a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
+    }
   }
   __syncthreads();
   RD_MARK(10);

@@ -87,14 +87,15 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
               float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
-              uint64_t seed) {
+              uint64_t seed, unsigned long long* dbg) {
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[7] = clock64();
   __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
   __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
   const RdSmem M = dg_rd_carve(region0, small);
   const int b = blockIdx.x;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   dg_readout_fwd_body(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
-                      training, seed);
+                      training, seed, dbg);
 }
 
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
@@ -103,7 +104,7 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           int training, uint64_t seed, hipStream_t s) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_readout_fwd, dim3(B), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2,
-                     x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed);
+                     x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer());
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
