@@ -132,6 +132,17 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
+  // classifier_1's weights (180 KB, rewritten by the optimizer every step, so never cache-warm) are this
+  // kernel's longest memory wait: issue this wave's 48 row loads NOW, into registers; they land while the sort,
+  // the gather and the two convolutions run.  Row blocks are rotated per graph so that the ~50 concurrent
+  // workgroups do not request the same lines in lockstep.
+  float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + u) * DGCNN_FLAT;
+    wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
+    wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
+  }
   // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
   // the first n*8 <= 4096*8 bytes of region0 only when n > 1456; W5s starts at byte 11648)
   const bool early_w = n * 8 <= 11648;
@@ -204,18 +215,11 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(11);
-  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows: all 44 weight loads of a lane are
-  // issued before the first reduction (one L2 round trip), reductions on the DPP path.
+  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; the weights were prefetched at kernel
+  // start, reductions on the DPP path.
   {
     const float f0 = flat[lane], f1 = flat[lane + 64], f2 = flat[lane + 128], f3 = flat[lane + 192],
                 f4 = flat[lane + 256], f5 = lane < 32 ? flat[lane + 320] : 0.f;
-    float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + u) * DGCNN_FLAT;   // row blocks rotated per graph:
-      wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
-      wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
-    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = ((wv + b) & 15) * 8 + u;    // 50 CUs do not hit the same Wf1 lines in lockstep

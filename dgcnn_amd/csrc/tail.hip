@@ -142,6 +142,15 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
+  // classifier_1's weights for step 3 (this thread's column m, 64 rows): the longest memory wait of the kernel
+  // (180 KB per workgroup, rewritten by the optimizer every step) -> issue the loads first, consume them later
+  float wpre[64];
+  if (tid < 2 * DGCNN_FLAT) {
+    const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
+    const float* wc = w.Wf1 + (size_t)(h * 64) * DGCNN_FLAT + m;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wpre[j] = wc[(size_t)j * DGCNN_FLAT];
+  }
   for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
   for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
   for (int t = tid; t < KCAT; t += RD_THREADS) sps[t] = pooled[(size_t)blockIdx.x * KCAT + t];
@@ -195,17 +204,17 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   }
   if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
   TB_MARK(2);
-  // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads)
+  // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads); the
+  //    weights were prefetched into registers at kernel start
   if (tid < 2 * DGCNN_FLAT) {
     const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
-    const float* wc = w.Wf1 + (size_t)(h * 64) * DGCNN_FLAT + m;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < 64; j += 4) {
-      g0 = fmaf(gz1s[h * 64 + j], wc[(size_t)j * DGCNN_FLAT], g0);
-      g1 = fmaf(gz1s[h * 64 + j + 1], wc[(size_t)(j + 1) * DGCNN_FLAT], g1);
-      g2 = fmaf(gz1s[h * 64 + j + 2], wc[(size_t)(j + 2) * DGCNN_FLAT], g2);
-      g3 = fmaf(gz1s[h * 64 + j + 3], wc[(size_t)(j + 3) * DGCNN_FLAT], g3);
+      g0 = fmaf(gz1s[h * 64 + j], wpre[j], g0);
+      g1 = fmaf(gz1s[h * 64 + j + 1], wpre[j + 1], g1);
+      g2 = fmaf(gz1s[h * 64 + j + 2], wpre[j + 2], g2);
+      g3 = fmaf(gz1s[h * 64 + j + 3], wpre[j + 3], g3);
     }
     gfh[h][m] = (g0 + g1) + (g2 + g3);
   }
