@@ -98,8 +98,9 @@ struct RdSmem {
   float* a1s;                    // [128]
   float* lg;                     // [MAX_C]
   float* cpart;                  // [4][32][16] conv5 K-split partial tiles
+  float* bias;                   // b5[16] | b6[32] | bf1[128] | bf2[MAX_C]
 };
-#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C + 4 * 32 * 16) * 4)
+#define RD_SMALL_BYTES (16 * 8 + 32 * 4 + (DGCNN_C5 * DGCNN_K + DGCNN_C5 * DGCNN_T5 + DGCNN_FLAT + DGCNN_HID1 + DGCNN_MAX_C + 4 * 32 * 16 + 16 + 32 + 128 + DGCNN_MAX_C) * 4)
 __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   RdSmem m;
   m.region0 = reinterpret_cast<unsigned long long*>(region0);
@@ -111,7 +112,8 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
   m.flat = reinterpret_cast<float*>(p); p += DGCNN_FLAT * 4;
   m.a1s = reinterpret_cast<float*>(p); p += DGCNN_HID1 * 4;
   m.lg = reinterpret_cast<float*>(p); p += DGCNN_MAX_C * 4;
-  m.cpart = reinterpret_cast<float*>(p);
+  m.cpart = reinterpret_cast<float*>(p); p += 4 * 32 * 16 * 4;
+  m.bias = reinterpret_cast<float*>(p);
   return m;
 }
 
@@ -132,19 +134,13 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float *a5s = M.a5s, *p5 = M.p5, *flat = M.flat, *a1s = M.a1s, *lg = M.lg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-  // classifier_1's weights (180 KB, rewritten by the optimizer every step, so never cache-warm) are this
-  // kernel's longest memory wait: issue this wave's 48 row loads NOW, into registers; they land while the sort,
-  // the gather and the two convolutions run.  Row blocks are rotated per graph so that the ~50 concurrent
-  // workgroups do not request the same lines in lockstep.
-  float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + u) * DGCNN_FLAT;
-    wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
-    wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
-  }
   // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
   // the first n*8 <= 4096*8 bytes of region0 only when n > 1456; W5s starts at byte 11648)
+  float* bs = M.bias;        // every bias of the tail in LDS: no global load between the prefetch and its use
+  if (tid < 16) bs[tid] = w.b5[tid];
+  else if (tid < 48) bs[tid] = w.b6[tid - 16];
+  else if (tid < 176) bs[tid] = w.bf1[tid - 48];
+  else if (tid < 176 + C) bs[tid] = w.bf2[tid - 176];
   const bool early_w = n * 8 <= 11648;
   if (early_w) {
     for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
@@ -166,6 +162,18 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   __syncthreads();
   RD_MARK(9);
+  // classifier_1's weights (180 KB, rewritten by the optimizer every step, so never cache-warm) are this
+  // kernel's longest memory wait.  VMEM loads complete in order, so they are issued only NOW -- after every
+  // other global load of the kernel has been consumed -- into registers; until their use in classifier_1
+  // there is no further global load and only LDS-only barriers, so they land while conv5 / pool / conv6 run.
+  // Row blocks are rotated per graph so that the ~50 concurrent workgroups do not request the same lines.
+  float wv0[8], wv1[8], wv2[8], wv3[8], wv4[8], wv5[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + u) * DGCNN_FLAT;
+    wv0[u] = wr[lane]; wv1[u] = wr[lane + 64]; wv2[u] = wr[lane + 128]; wv3[u] = wr[lane + 192];
+    wv4[u] = wr[lane + 256]; wv5[u] = lane < 32 ? wr[lane + 320] : 0.f;
+  }
   // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16]:
   // two 16x16 tiles, K split over 4 waves each (28 + 24 + 24 + 24 columns), partial tiles combined in a fixed
   // order; ReLU + bias at the combine.  output index o*30+s ([B,16,30])
@@ -180,24 +188,24 @@ __device__ __forceinline__ void dg_readout_fwd_body(
           [&](int kk, int o) { const int m = kb + kk; return m < DGCNN_CAT ? W5s[o * DGCNN_CAT + m] : 0.f; },
           [&](int s, int o, float v) { part[(kc * 32 + s) * 16 + o] = v; });
     }
-    __syncthreads();
+    dg_lds_barrier();
     if (tid < DGCNN_C5 * DGCNN_K) {
       const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
       const float v = (part[(0 * 32 + s) * 16 + o] + part[(1 * 32 + s) * 16 + o]) +
                       (part[(2 * 32 + s) * 16 + o] + part[(3 * 32 + s) * 16 + o]);
-      const float acc = fmaxf(v + w.b5[o], 0.f);
+      const float acc = fmaxf(v + bs[o], 0.f);
       a5s[tid] = acc;
       a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
     }
   }
-  __syncthreads();
+  dg_lds_barrier();
   RD_MARK(10);
   // MaxPool1d(2,2): [16,30] -> [16,15]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     p5[tid] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
   }
-  __syncthreads();
+  dg_lds_barrier();
   // conv6 on the matrix cores: z6[oc][t] = sum_{c,d} W6[oc][c][d] p5[c][t+d]  ->  [32 x 16(11)] = [32 x 80] . [80 x 16],
   // two 16x16 tiles, one wave each; flat index oc*11+t (x.view(B,-1), model.py:40)
   if (wv < 2) {
@@ -207,16 +215,16 @@ __device__ __forceinline__ void dg_readout_fwd_body(
         [&](int k, int t) { return t < DGCNN_T6 ? p5[(k / DGCNN_KW6) * DGCNN_T5 + t + (k % DGCNN_KW6)] : 0.f; },
         [&](int oc, int t, float v) {
           if (t < DGCNN_T6) {
-            const float acc = fmaxf(v + w.b6[oc], 0.f);
+            const float acc = fmaxf(v + bs[16 + oc], 0.f);
             flat[oc * DGCNN_T6 + t] = acc;
             a6g[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + t] = acc;
           }
         });
   }
-  __syncthreads();
+  dg_lds_barrier();
   RD_MARK(11);
-  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; the weights were prefetched at kernel
-  // start, reductions on the DPP path.
+  // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; the weights were prefetched before conv5,
+  // reductions on the DPP path.
   {
     const float f0 = flat[lane], f1 = flat[lane + 64], f2 = flat[lane + 128], f3 = flat[lane + 192],
                 f4 = flat[lane + 256], f5 = lane < 32 ? flat[lane + 320] : 0.f;
@@ -231,7 +239,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
       a = fmaf(wv5[u], f5, a);
       const float tot = dg_wave_sum(a);
       if (lane == 0) {
-        float av = fmaxf(tot + w.bf1[j], 0.f);
+        float av = fmaxf(tot + bs[48 + j], 0.f);
         uint8_t keep = 1;
         if (training) {
           keep = dg_keep(seed, (uint64_t)b * DGCNN_HID1 + j) ? 1 : 0;
@@ -251,7 +259,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     float acc = wr[lane] * a1s[lane];
     acc = fmaf(wr[lane + 64], a1s[lane + 64], acc);
     acc = dg_wave_sum(acc);
-    if (lane == 0) lg[c] = acc + w.bf2[c];
+    if (lane == 0) lg[c] = acc + bs[176 + c];
   }
   __syncthreads();
   // log_softmax over C (C <= 64): wave 0

@@ -142,8 +142,28 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
-  // classifier_1's weights for step 3 (this thread's column m, 64 rows): the longest memory wait of the kernel
-  // (180 KB per workgroup, rewritten by the optimizer every step) -> issue the loads first, consume them later
+  // ---- every small global load of steps 0-2 first (VMEM loads complete in order) ----
+  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
+  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
+  for (int t = tid; t < KCAT; t += RD_THREADS) sps[t] = pooled[(size_t)blockIdx.x * KCAT + t];
+  float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
+  int yb_ = 0;
+  if (wv == 0) {
+    lp_ = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
+    if (glogp) g_ = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
+    else yb_ = (int)y[b];
+  }
+  float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
+  if (tid < DGCNN_HID1) {
+    a1_ = a1dg[(size_t)b * DGCNN_HID1 + tid];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
+  }
+  // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
+  // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only
+  // LDS-only barriers and no further global load, so they land while steps 1-2 run. ----
   float wpre[64];
   if (tid < 2 * DGCNN_FLAT) {
     const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
@@ -151,9 +171,6 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
 #pragma unroll
     for (int j = 0; j < 64; ++j) wpre[j] = wc[(size_t)j * DGCNN_FLAT];
   }
-  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
-  for (int t = tid; t < KCAT; t += RD_THREADS) sps[t] = pooled[(size_t)blockIdx.x * KCAT + t];
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
   for (int t = tid; t < n * 32; t += RD_THREADS) {
     gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
@@ -163,13 +180,11 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
 
   // 1. d(loss)/d(logits) from the upstream gradient wrt log-probs (or from labels: NLL mean)
   if (wv == 0) {
-    const float lp = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
-    float g = 0.f;
-    if (glogp) {
-      g = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
-    } else {
+    const float lp = lp_;
+    float g = g_;
+    if (!glogp) {
       const float sc = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;
-      const int yb = (int)y[b];
+      const int yb = yb_;
       g = (lane == yb) ? -sc : 0.f;
       // loss and accuracy bookkeeping (train.py:44-45): first max index like torch.argmax
       float mx = lp;
@@ -183,19 +198,21 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     const float d = lane < C ? g - expf(lp) * sg : 0.f;
     if (lane < C) { dl[lane] = d; dlogit[(size_t)b * C + lane] = d; }
   }
-  __syncthreads();
+  dg_lds_barrier();
   TB_MARK(1);
   // 2. through classifier_2, dropout, ReLU
   if (tid < DGCNN_HID1) {
     float ga = 0.f;
-    for (int c = 0; c < C; ++c) ga = fmaf(dl[c], w.Wf2[c * DGCNN_HID1 + tid], ga);
-    const float a = a1dg[(size_t)b * DGCNN_HID1 + tid];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) ga = fmaf(dl[c], wf2_[c], ga);
+    for (int c = 8; c < C; ++c) ga = fmaf(dl[c], w.Wf2[c * DGCNN_HID1 + tid], ga);
+    const float a = a1_;
     const float gz = (a != 0.f) ? (training ? ga * 2.0f : ga) : 0.f;
     gz1s[tid] = gz;
     a1ds[tid] = a;
     gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
   }
-  __syncthreads();
+  dg_lds_barrier();
   // per-graph partial of classifier_2's weight gradient: dl[c] * a1d[j]  (and bias = dl[c])
   float* pt = ptail + (size_t)b * DG_PTAIL(C);
   for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
