@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic counters of the hot kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slot limits,
 # /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"), kernel-trace only.
-# usage: tools_pmc.sh <tag> [bench args]
+# usage: tools/pmc.sh <tag> [bench args]
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do

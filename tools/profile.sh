@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line + rocprofv3 kernel-trace stats of the same command.
-# usage: tools_profile.sh <tag> [bench args...]
+# usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
