@@ -222,7 +222,9 @@ def main():
         nprof = min(args.steps, 300)
         for i in range(nprof):
             a, bb = ev(), ev()
-            which = i % 3                       # conv1 / conv2 / conv3 aggregation, round robin
+            # the 32-wide aggregation launches, round robin: conv2 / conv3 (conv1 is the F-wide aggregate-first
+            # kernel k_gcn_fwd_af when F <= 32, a different kernel) or conv1 / conv2 / conv3 when F > 32
+            which = 1 + i % 2 if F <= 32 else i % 3
             # the events are attached to that ONE dispatch (hipExtLaunchKernelGGL): their elapsed time
             # is the kernel's own start->end, the same timestamps rocprofv3 reports
             _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")

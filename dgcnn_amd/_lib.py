@@ -144,7 +144,7 @@ def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
         "a5": (torch.float32, (B, 16, K)), "a6": (torch.float32, (B, FLAT)), "a1d": (torch.float32, (B, HID1)),
         "drop_mask": (torch.uint8, (B, HID1)), "dlogit": (torch.float32, (B, C)),
         "gp1": (torch.float32, (N, 32)), "gp2": (torch.float32, (N, 32)), "gp3": (torch.float32, (N, 32)),
-        "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)),
+        "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)), "ax": (torch.float32, (N, F)),
     }
     dt, shape = shapes[name]
     off = workspace_offset(name, N, E, B, F, C)

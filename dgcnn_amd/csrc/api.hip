@@ -158,7 +158,8 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                           (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
   const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
   DgLinFirst lf; lf.x = x; lf.W = params + pl.off[0]; lf.hs = hsA; lf.F = F;
-  const bool use_lf = !fused;          // tiled path: conv1's linear rides on the second prep launch
+  const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: no stand-alone linear at all
+  const bool use_lf = !fused && !af;   // wide raw features: conv1's linear rides on the second prep launch
   int lin_done = 0;
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   if (!(flags & DGCNN_FLAG_PREPARED))
@@ -170,7 +171,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
     DG_TRY(dg_launch_fused_fwd(N, B, F, C, nmax, max_edges > 0 ? max_edges : 0, params, &pl, x, rowptr, colidx, dinv,
-                               dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr), x1, x2, x3, x4,
+                               dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled),
                                dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
                                dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,
@@ -181,9 +182,14 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
-  DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
-                             DG_PROF_A(0), DG_PROF_B(0)));
+  if (af) {
+    DG_TRY(dg_launch_gcn_fwd_af(N, F, rowptr, colidx, dinv, x, params + pl.off[0], params + pl.off[1],
+                                dg_ptr<float>(ws, wl.ax), x1, params + pl.off[2], hsB, s, DG_PROF_A(0), DG_PROF_B(0)));
+  } else {
+    if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
+    DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
+                               DG_PROF_A(0), DG_PROF_B(0)));
+  }
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,
                              DG_PROF_A(1), DG_PROF_B(1)));
   DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
@@ -227,11 +233,18 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
                              dg_ptr<float>(ws, wl.pb3), wl.P32, s));
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
-  DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
-                             dg_ptr<float>(ws, wl.pb2), wl.P32, s));
-  // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
-  DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
-                             dg_ptr<float>(ws, wl.pb1), wl.P32, s));
+  if (F <= DG_AF_MAX_F) {
+    // ... carrying conv1's whole backward: dW1 = ga1^T . (A_hat x), from the ax slab the forward saved
+    DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
+                               dg_ptr<float>(ws, wl.pb2), wl.P32, s, dg_cptr<float>(ws, wl.ax), F,
+                               dg_ptr<float>(ws, wl.pb1)));
+  } else {
+    DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
+                               dg_ptr<float>(ws, wl.pb2), wl.P32, s));
+    // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
+    DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
+                               dg_ptr<float>(ws, wl.pb1), wl.P32, s));
+  }
   // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)

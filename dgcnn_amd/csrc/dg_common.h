@@ -59,7 +59,14 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
   X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
-  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail)
+  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(ax)
+
+// conv1 is evaluated aggregate-first, (A_hat X) W1^T instead of A_hat (X W1^T), whenever the raw feature width is
+// <= 32: the gather then moves F floats per edge instead of 32, conv1 needs no stand-alone linear (so graph prep
+// depends on the batch only, never on the weights), and its weight gradient dW1 = ga1^T (A_hat X) needs NO
+// gather at all in backward -- it rides on conv2's backward kernel from the saved A_hat X.
+#define DG_AF_MAX_F 32
+static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
 
 struct DgWs {
 #define X(n) int64_t n;
@@ -126,6 +133,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(pb2, 4 * (int64_t)w->P32 * 1056);
   R(pb1, 4 * (int64_t)w->P32 * 32 * F);
   R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
+  R(ax, F <= DG_AF_MAX_F ? 4 * n * F : 0);      // aggregated raw input (aggregate-first conv1), saved for dW1
 #undef R
   w->total = o;
   return DGCNN_OK;
@@ -266,6 +274,55 @@ __device__ void dg_block_bitonic(PTR data, int n) {
     }
   }
 }
+// ---- aggregate-first conv1 (F <= DG_AF_MAX_F) -------------------------------------------------------
+// One wavefront, one destination row.  Lane = (g = lane >> lfp neighbour group, q = lane & (2^lfp - 1) feature):
+// 64 >> lfp neighbours in flight per wave-instruction.  Returns, in every lane with q < F,
+//     sum_{e in [start,end)} dinv[col[e]] * x[col[e]][q]  +  dinv[self] * x[self][q]        (self term last, group 0)
+// combined over the groups by a fixed xor butterfly.  PRESCALED: xsrc already holds dinv*x (LDS copy, stride F).
+// The product is rounded on its own (never contracted into the add) so both variants are bit-identical.
+__device__ __forceinline__ int dg_af_lfp_dev(int F) { return F <= 1 ? 0 : 32 - __builtin_clz(F - 1); }
+template <bool PRESCALED>
+__device__ __forceinline__ float dg_af_gather(const float* __restrict__ xsrc, const float* __restrict__ dsrc, int F,
+                                              int lfp, const int* __restrict__ col, int start, int end, int self,
+                                              int lane) {
+  const int q = lane & ((1 << lfp) - 1), g = lane >> lfp, sh = 6 - lfp;
+  const bool qa = q < F;
+  float acc = 0.f;
+  for (int base = start; base < end; base += 64) {
+    const int cnt = min(64, end - base);
+    const int cj = lane < cnt ? col[base + lane] : 0;
+    const int iters = (cnt + (1 << sh) - 1) >> sh;
+    for (int it = 0; it < iters; ++it) {
+      const int idx = (it << sh) + g;
+      const int j = __shfl(cj, idx);
+      if (idx < cnt && qa) {
+        float v;
+        if (PRESCALED) v = xsrc[j * F + q];
+        else { v = dsrc[j] * xsrc[(size_t)j * F + q]; asm volatile("" : "+v"(v)); }
+        acc += v;
+      }
+    }
+  }
+  if (g == 0 && qa) {
+    float v;
+    if (PRESCALED) v = xsrc[self * F + q];
+    else { v = dsrc[self] * xsrc[(size_t)self * F + q]; asm volatile("" : "+v"(v)); }
+    acc += v;
+  }
+  for (int off = 1 << lfp; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+  return acc;
+}
+// conv1's dense step on the aggregated row: lane c = lane & 31 returns sum_f ax[f] * W1[c][f] (k-ordered fma chain);
+// ax[f] lives in lane f of the wave (group 0), Wt = W1 transposed [F][32] in LDS.
+__device__ __forceinline__ float dg_af_transform(float ax, int F, const float* __restrict__ Wt, int lane) {
+  const int c = lane & 31;
+  float pre = 0.f;
+  for (int f = 0; f < F; ++f) {
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), f));
+    pre = fmaf(a, Wt[f * 32 + c], pre);
+  }
+  return pre;
+}
 #endif
 
 struct DgLinFirst { const float* x; const float* W; float* hs; int F; };   // optional conv1 linear riding on the prep launch
@@ -289,7 +346,12 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
 // which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
-                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s);
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
+                        const float* ax = nullptr, int Fa = 0, float* part1 = nullptr);
+// conv1 aggregate-first forward (F <= DG_AF_MAX_F): ax = A_hat x saved, x1 = tanh(ax W1^T + b1), hs_next = dinv*(x1 Wnext^T)
+int dg_launch_gcn_fwd_af(int N, int F, const int32_t* rowptr, const int32_t* colidx, const float* dinv, const float* x,
+                         const float* W1, const float* bias, float* ax, float* xout, const float* Wnext,
+                         float* hs_next, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
                            const float* x3, const float* x4, float* pooled, int32_t* perm, hipStream_t s);
 int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* perm, const float* gpooled,
@@ -300,9 +362,9 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
                           int training, uint64_t seed, hipStream_t s);
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* x1, float* x2, float* x3, float* x4,
-                        float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
-                        int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
+                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* ax, float* x1, float* x2, float* x3,
+                        float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask,
+                        float* logp, int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_fused_max_nodes(int F);
 int dg_fused_fits(int nmax, int emax, int F);

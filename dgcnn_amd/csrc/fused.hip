@@ -35,7 +35,8 @@ __device__ __forceinline__ size_t fg_a16_dev(size_t x) { return (x + 15) & ~(siz
 // LDS layout (bytes), dynamic:
 //   region0 : max(2*(nmax+1)*RS*4, (nmax+1)*RS*4 + 32*F*4, RD_REGION0_BYTES)   H | X  (aliased later by the readout)
 //             row nmax of H is an all-zero row: padded / invalid neighbour slots point at it
-//   dv, h4s, x4s : (nmax+1)*4 each ;  rp : (nmax+1)*4 ;  cl : emax_lds*4 (+32 slack) ;  prm : 160*4 ;  small
+//   dv, h4s, x4s : (nmax+1)*4 each ;  rp : (nmax+1)*4 ;  cl : emax_lds*4 (+32 slack) ;  prm : 160*4 ;
+//   wta : 32*F*4 (aggregate-first conv1 only: W1^T) ;  small
 static inline size_t fg_a16(size_t x) { return (x + 15) & ~(size_t)15; }
 static inline size_t fg_region0_bytes(int nmax, int F) {
   const size_t row = (size_t)(nmax + 1) * FG_RS * 4;
@@ -47,7 +48,7 @@ static inline size_t fg_region0_bytes(int nmax, int F) {
 }
 static inline size_t fg_lds_bytes(int nmax, int F, int emax_lds) {
   return fg_region0_bytes(nmax, F) + 4 * fg_a16((size_t)(nmax + 1) * 4) + fg_a16((size_t)emax_lds * 4 + 32) +
-         160 * 4 + RD_SMALL_BYTES + 16;
+         160 * 4 + (F <= DG_AF_MAX_F ? (size_t)32 * F * 4 : 0) + RD_SMALL_BYTES + 16;
 }
 #define FG_LDS_CAP (160 * 1024)
 
@@ -87,8 +88,8 @@ __global__ void __launch_bounds__(FG_THREADS)
 k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, TailW tw,
             const float* __restrict__ xin, const int* __restrict__ rowptr, const int* __restrict__ colidx,
             const float* __restrict__ dinv, const int* __restrict__ graph_ptr, const int* __restrict__ graph_eptr,
-            float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
-            float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
+            float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3,
+            float* __restrict__ x4, float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
             float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
             uint64_t seed, unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg) {
 #define FG_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
@@ -111,6 +112,8 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
   int* rp = reinterpret_cast<int*>(p);      p += nb4;
   int* cl = reinterpret_cast<int*>(p);      p += fg_a16_dev((size_t)emax_lds * 4 + 32);
   float* prm = reinterpret_cast<float*>(p); p += 160 * 4;   // b1|b2|b3 (96) W4 (32) b4 (1)
+  const bool af = F <= DG_AF_MAX_F;                         // conv1 aggregate-first (see dg_common.h)
+  float* wta = reinterpret_cast<float*>(p); p += af ? (size_t)32 * F * 4 : 0;
   char* small = p;
   FG_MARK(0);
 
@@ -140,14 +143,22 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     cl[t] = ok ? j : 0;            // flagged below; clamp keeps LDS reads in range
   }
   if (bad) { err[1] = epoch; err[3] = ~epoch; }     // an edge left its graph: batch is not block-diagonal
-  float* Wt = X;                       // [F][32], X is free until the first gather
+  float* Wt = af ? wta : X;            // [F][32]; (linear-first: X is free until the first gather)
   for (int t = tid; t < 32 * F; t += FG_THREADS) {
     const int cc = t / F, k = t - cc * F;
     Wt[k * 32 + cc] = gw.W1[t];
   }
+  if (af) {   // pre-scaled raw features dinv[j]*x[j] -> H (as [n][F]); H proper is first written by the MFMA post-step
+    for (int t = tid; t < n * F; t += FG_THREADS) {
+      const int i = t / F;
+      float v = dinv[n0 + i] * xin[(size_t)n0 * F + t];
+      asm volatile("" : "+v"(v));
+      H[t] = v;
+    }
+  }
   __syncthreads();
   // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (same fma chain as k_lin_first32) ----
-  {
+  if (!af) {
     const int c = tid & 31;
     for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
       const float* xr = xin + (size_t)(n0 + i) * F;
@@ -165,6 +176,21 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     float* xout = layer == 0 ? x1 : (layer == 1 ? x2 : x3);
     const float4 b4 = *reinterpret_cast<const float4*>(prm + layer * 32 + 4 * q);
     const float4 w4 = *reinterpret_cast<const float4*>(prm + 96 + 4 * q);
+    if (layer == 0 && af) {
+      // conv1 aggregate-first: same lane mapping / order as k_gcn_fwd_af (gcn.hip), rows from the LDS copy
+      const int lfp = dg_af_lfp_dev(F);
+      const float bc = prm[lane & 31];
+      for (int i = wave; i < n; i += FG_WAVES) {
+        const float acc = dg_af_gather<true>(H, nullptr, F, lfp, cl, rp[i], rp[i + 1], i, lane);
+        const float ax = dv[i] * acc;
+        if (lane < F) axg[(size_t)(n0 + i) * F + lane] = ax;
+        const float val = dg_tanh(dg_af_transform(ax, F, wta, lane) + bc);
+        if (lane < 32) {
+          X[i * FG_RS + lane] = val;
+          xout[(size_t)(n0 + i) * 32 + lane] = val;
+        }
+      }
+    } else
     for (int i = wave; i < n; i += FG_WAVES) {
       const float4 acc = fg_gather_row32(H, cl, rp[i], rp[i + 1], i, lane);
       const float di = dv[i];
@@ -250,9 +276,9 @@ int dg_fused_fits(int nmax, int emax, int F) {
 
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* x1, float* x2, float* x3, float* x4,
-                        float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
-                        int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
+                        const int32_t* graph_ptr, const int32_t* graph_eptr, float* ax, float* x1, float* x2, float* x3,
+                        float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask,
+                        float* logp, int training, uint64_t seed, int32_t* err, uint32_t epoch, hipStream_t s,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0 || B <= 0 || nmax <= 0 || nmax > DGCNN_FUSED_MAX_NODES) return DGCNN_EINVAL;
   const int emax_lds = emax;
@@ -272,7 +298,7 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5];
   gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   hipExtLaunchKernelGGL(k_fused_fwd, dim3(B), dim3(FG_THREADS), lds, s, ev_start, ev_stop, 0, F, C, nmax, emax_lds, r0,
-                        gw, dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, graph_eptr, x1, x2, x3, x4, pooled, perm,
+                        gw, dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, graph_eptr, ax, x1, x2, x3, x4, pooled, perm,
                         a5, a6, a1d, drop_mask, logp, training, seed, reinterpret_cast<unsigned int*>(err), epoch,
                         g_fg_dbg);
   DG_CHECK_LAUNCH();

@@ -213,6 +213,93 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward of conv1, aggregate-first (raw feature width F <= DG_AF_MAX_F):
+//     ax[i]  = dinv[i] * ( sum_j dinv[j] x[j] + dinv[i] x[i] )      (F-wide gather, saved for backward)
+//     x1[i]  = tanh( ax[i] W1^T + b1 )                               (F fmas per channel)
+//     hs2[i] = dinv[i] * ( x1[i] W2^T )                              (MFMA on the LDS tile, as k_gcn_fwd32<0>)
+// Same tile shape as k_gcn_fwd32: wave per destination node, 16 nodes per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DG_TILE_THREADS)
+k_gcn_fwd_af(int N, int F, int lfp, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+             const float* __restrict__ dinv, const float* __restrict__ x, const float* __restrict__ W1,
+             const float* __restrict__ bias, float* __restrict__ axout, float* __restrict__ xout,
+             const float* __restrict__ Wn, float* __restrict__ hs_next) {
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  __shared__ float Wt[DG_AF_MAX_F * 32];     // W1 transposed [F][32]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31;
+
+  float wreg[8];
+  if (wave < 2) {
+    const int cc = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[cc * 32 + 4 * kk + (lane >> 4)];
+  }
+  const float bc = bias[c];
+  for (int t = threadIdx.x; t < 32 * F; t += DG_TILE_THREADS) {
+    const int cc = t / F, k = t - cc * F;
+    Wt[k * 32 + cc] = W1[t];
+  }
+  bool wt_ready = false;
+
+  for (int tl = blockIdx.x; tl < numTiles; tl += gridDim.x) {
+    const int tile = (gridDim.x == (unsigned)numTiles) ? dg_xcd_tile(tl, numTiles) : tl;
+    const int i = tile * DG_TILE + wave;
+    float ax = 0.f, di = 0.f;
+    if (i < N) {
+      const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
+      const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
+      const float acc = dg_af_gather<false>(x, dinv, F, lfp, colidx, start, end, i, lane);
+      di = dinv[i];
+      ax = di * acc;
+      if (lane < F) axout[(size_t)i * F + lane] = ax;
+    }
+    float dpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+        dpre[r] = node < N ? dinv[node] : 0.f;
+      }
+    }
+    if (!wt_ready) { __syncthreads(); wt_ready = true; }     // W1^T staged (its load overlapped the gather)
+    float val = 0.f;
+    if (i < N) {
+      val = dg_tanh(dg_af_transform(ax, F, Wt, lane) + bc);
+      if (lane < 32) xout[(size_t)i * 32 + c] = val;
+    }
+    if (lane < 32) xt[wave][c] = val;
+    __syncthreads();
+    if (wave < 2) {
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float a = xt[lane & 15][4 * kk + (lane >> 4)];
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+        if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dpre[r] * d[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int dg_launch_gcn_fwd_af(int N, int F, const int32_t* rowptr, const int32_t* colidx, const float* dinv, const float* x,
+                         const float* W1, const float* bias, float* ax, float* xout, const float* Wnext,
+                         float* hs_next, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (N <= 0 || F < 1 || F > DG_AF_MAX_F) return DGCNN_EINVAL;
+  const int tiles = dg_cdiv(N, DG_TILE);
+  hipExtLaunchKernelGGL(k_gcn_fwd_af, dim3(tiles), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, F,
+                        dg_af_lfp(F), tiles, rowptr, colidx, dinv, x, W1, bias, ax, xout, Wnext, hs_next);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward, F = 1 (conv4): wave per node, lanes across neighbours.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dg_gather_row1(const float* __restrict__ src, const int* __restrict__ col,
@@ -306,14 +393,20 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
 // FIRST = true (layer 1): x_{l-1} is the raw input x [N,F]; only dW_1 [32,F] is produced
 // (data.x needs no gradient, /root/reference/train.py:36-40).  part[P][32*F].
 // ---------------------------------------------------------------------------------------------
-template <bool FIRST>
+//
+// AF = true (layer 2 when conv1 ran aggregate-first): additionally dW_1 += ga_1^T . ax  with ax = A_hat X [N,Fa]
+// saved by k_gcn_fwd_af -- conv1's whole backward, no gather needed.  part1[P][32*Fa] in W1's own layout.
+template <bool FIRST, bool AF>
 __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
-            float* __restrict__ part) {
+            float* __restrict__ part, const float* __restrict__ axin, int Fa, float* __restrict__ part1) {
   __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  __shared__ float gat[AF ? DG_TILE : 1][DG_LDS_PAD];          // AF: ga_1 tile
+  __shared__ float axs[AF ? DG_TILE * DG_AF_MAX_F : 1];        // AF: ax tile [16][Fa]
+  float accA = 0.f;                                            // AF: dW1[c][k], thread t = k*32 + c
   extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -350,7 +443,9 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
             *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
       if (FIRST)
         for (int k = lane; k < F; k += 64) xs[wave * F + k] = xprev[(size_t)j * F + k];
+      if (AF && lane < Fa) axs[wave * Fa + lane] = axin[(size_t)j * Fa + lane];
     } else {
+      if (AF && lane < Fa) axs[wave * Fa + lane] = 0.f;
       if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!FIRST && g == 1) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
       if (FIRST)
@@ -384,13 +479,15 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
         for (int r = 0; r < 4; ++r) {
           const int row = (lane >> 4) * 4 + r;
           const int node = tile * DG_TILE + row;
+          float ga = 0.f;
           if (node < N) {
             const float xv = xt[row][c];
             const float gx = d[r] + gpprev[(size_t)node * 32 + c];
-            const float ga = gx * (1.f - xv * xv);
-            gas_prev[(size_t)node * 32 + c] = dinv[node] * ga;
+            ga = gx * (1.f - xv * xv);
+            if (!AF) gas_prev[(size_t)node * 32 + c] = dinv[node] * ga;   // AF: conv1 needs no propagated gradient
             pb += ga;
           }
+          if (AF) gat[row][c] = ga;
         }
       } else if (wave < 6) {   // dW block (mb, nb): A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n]
         const int mb = (wave - 2) >> 1, nb = (wave - 2) & 1;
@@ -404,9 +501,23 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
       }
     }
     __syncthreads();
+    if (AF) {
+      if ((int)threadIdx.x < 32 * Fa) {
+        const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
+        float a = accA;
+#pragma unroll
+        for (int nd = 0; nd < DG_TILE; ++nd) a = fmaf(gat[nd][c], axs[nd * Fa + k], a);
+        accA = a;
+      }
+      if (tile + 1 < tile_end) __syncthreads();
+    }
   }
 
   // write this workgroup's partials
+  if (AF && (int)threadIdx.x < 32 * Fa) {
+    const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
+    part1[(size_t)blockIdx.x * 32 * Fa + c * Fa + k] = accA;
+  }
   if (FIRST) {
     const int total = 32 * F;
     float* dst = part + (size_t)blockIdx.x * total;
@@ -439,16 +550,21 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
 
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
-                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s) {
+                        const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
+                        const float* ax, int Fa, float* part1) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
-    hipLaunchKernelGGL(k_gcn_bwd32<true>, dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N, F,
-                       tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part);
+    hipLaunchKernelGGL((k_gcn_bwd32<true, false>), dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N,
+                       F, tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, nullptr, 0, nullptr);
+  } else if (ax) {     // conv2 backward carrying conv1's weight gradient (aggregate-first conv1)
+    if (Fa < 1 || Fa > DG_AF_MAX_F || !part1) return DGCNN_EINVAL;
+    hipLaunchKernelGGL((k_gcn_bwd32<false, true>), dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t,
+                       colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, ax, Fa, part1);
   } else {
-    hipLaunchKernelGGL(k_gcn_bwd32<false>, dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t, colidx_t,
-                       dinv, gas, Wl, xprev, gpprev, gas_prev, part);
+    hipLaunchKernelGGL((k_gcn_bwd32<false, false>), dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t,
+                       colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, nullptr, 0, nullptr);
   }
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

@@ -50,6 +50,30 @@ def test_workload_forward_and_backward(name, bs, force):
     check_backward_parity(m, b, sd)
 
 
+@pytest.mark.parametrize("F", [1, 2, 3, 7, 13, 16, 19, 32, 33, 40])
+@pytest.mark.parametrize("fused", [False, True])
+def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
+    """conv1 runs aggregate-first ((A x) W) for F <= 32 and linear-first (A (x W)) above: every lanes-per-row
+    shape of the F-wide gather, both sides of the switch, forward + gradients (dW1 comes from the saved A x)."""
+    base = synth.make_batch("COLLAB" if F % 2 else "PROTEINS", 12, start=77)
+    g = torch.Generator().manual_seed(F)
+    from dgcnn_amd.batch import Batch
+    b = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
+              base.coalesced_undirected, base.max_nodes, base.max_edges)
+    m = make_model(F, 3)
+    m.use_fused = fused
+    sd = cpu_state_dict(m)
+    check_forward_parity(m, b, sd)
+    if F <= 32:     # the slab saved for backward is exactly A_hat x
+        ax = m.last_workspace_view("ax").cpu().double()
+        ptr = torch.searchsorted(b.batch, torch.arange(b.num_graphs + 1))
+        for gi in range(b.num_graphs):
+            n0, n1 = int(ptr[gi]), int(ptr[gi + 1])
+            A = ref_dense.dense_norm_adj(b.edge_index, n0, n1)
+            np.testing.assert_allclose(ax[n0:n1].numpy(), (A @ b.x[n0:n1].double()).numpy(), rtol=0, atol=2e-5)
+    check_backward_parity(m, b, sd)
+
+
 def test_edge_cases_isolated_selfloops_single_graph_empty_edges():
     # one graph, n < k, isolated nodes, input self loops, duplicate edge
     x = torch.randn(7, 5)
