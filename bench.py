@@ -50,9 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="software-pipeline graph prep (batch i+1 on a side stream during step i); off by default: "
-                         "measured host-bound (see DESIGN.md)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="do not software-pipeline graph prep (default: batch i+1's CSR build runs on the library's "
+                         "side stream during step i, one dgcnn_pipeline_train_step call per step)")
     ap.add_argument("--path", choices=["auto", "fused", "tiled"], default="auto",
                     help="forward kernel family: library heuristic, graph-per-workgroup fused, or tiled")
     return ap.parse_args()
@@ -168,10 +168,9 @@ def main():
 
     def step(i):
         b = batches[i % nb]
-        tr.train_step(b, b.y, global_batch=gb)
-        if args.prefetch:
-            # software-pipelined graph prep: batch i+1's CSR build runs on a side stream during step i
-            tr.prefetch(batches[(i + 1) % nb])
+        # software-pipelined graph prep (default): the loop tells the step which batch comes next, whose CSR build
+        # then runs on the library's side stream during this step; every batch's prep still runs once per step
+        tr.train_step(b, b.y, global_batch=gb, next_data=batches[(i + 1) % nb] if args.pipeline else None)
 
     def barrier():
         if use_dist:
@@ -285,7 +284,7 @@ def main():
                        if args.workload == "COLLAB" else f"{args.workload}-shape synthetic graphs, batch_size={B} per GPU",
                        "global_batch": gb, "avg_nodes_per_batch": avgN, "avg_directed_edges_per_batch": avgE,
                        "parallelism": f"dp{world}", "step": "forward + NLL(mean) + backward + fused Adam + zero_grad "
-                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) of every batch inside the timed region" + (", software-pipelined: prep of batch i+1 runs on a side stream during step i" if args.prefetch else "")},
+                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) of every batch inside the timed region" + (", software-pipelined: prep of batch i+1 runs on a side stream during step i" if args.pipeline else "")},
             "train_loss_mean": loss_sum / max(args.steps + args.warmup, 1), "correct_frac_rank0": correct / ((args.steps + args.warmup) * B),
         }
         out.update(extra)

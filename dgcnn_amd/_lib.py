@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -26,8 +26,23 @@ HID1 = 128
 FLAT = 352
 NUM_SEG = 16
 
+class StepArgs(ctypes.Structure):
+    """``dgcnn_step_args`` of include/dgcnn_hip.h (field order and types must match)."""
+    _fields_ = [("N", ctypes.c_int32), ("E", ctypes.c_int32), ("B", ctypes.c_int32), ("F", ctypes.c_int32),
+                ("C", ctypes.c_int32), ("training", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("max_nodes", ctypes.c_int32), ("max_edges", ctypes.c_int32), ("epoch", ctypes.c_uint32),
+                ("seed", c_uint64), ("step", c_int64), ("lr", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("eps", c_float), ("loss_scale", c_float), ("reserved_", ctypes.c_int32),
+                ("params", c_void_p), ("x", c_void_p), ("edge_index", c_void_p), ("batch", c_void_p),
+                ("y", c_void_p), ("ws", c_void_p), ("logp", c_void_p), ("grads", c_void_p), ("metrics", c_void_p),
+                ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/dgcnn_hip.h declares
 SIGNATURES = {
+    "dgcnn_pipeline_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "dgcnn_pipeline_destroy": (c_int, [c_void_p]),
+    "dgcnn_pipeline_train_step": (c_int, [c_void_p, ctypes.POINTER(StepArgs), ctypes.POINTER(StepArgs), c_void_p]),
     "dgcnn_version": (c_int, []),
     "dgcnn_param_layout": (c_int64, [c_int, c_int, ctypes.POINTER(c_int64)]),
     "dgcnn_workspace_bytes": (c_int64, [c_int] * 5),

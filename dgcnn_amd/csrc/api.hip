@@ -1,6 +1,8 @@
 // api.hip -- extern "C" entry points of libdgcnn_hip.so (see include/dgcnn_hip.h) and the
 // orchestration of the whole-model forward / backward as a chain of launches on one stream.
 #include "dg_common.h"
+#include "dg_prep.h"
+#include <cstdlib>
 
 // one-shot, thread-local profiling request (see dgcnn_profile_next_forward)
 static thread_local int g_prof_which = -1;
@@ -132,10 +134,13 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const int64_t* edge_i
                         flags, epoch, (hipStream_t)stream, nullptr, nullptr);
 }
 
-int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
-                        const float* x, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
-                        int max_edges, uint32_t epoch, dgcnn_stream_t stream) {
+// rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
+// *rode = 1 when it was attached)
+static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float* params,
+                                 const float* x, const int64_t* edge_index, const int64_t* batch,
+                                 void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
+                                 int max_edges, uint32_t epoch, dgcnn_stream_t stream, const DgPrepRider* rider_a,
+                                 int* rode) {
   if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   DgParams pl; DgWs wl;
@@ -200,14 +205,23 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
                                dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
-                               dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s));
+                               dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s, rider_a));
+  if (rider_a && rode) *rode = 1;
   return DGCNN_OK;
+}
+
+int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
+                        const float* x, const int64_t* edge_index, const int64_t* batch,
+                        void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
+                        int max_edges, uint32_t epoch, dgcnn_stream_t stream) {
+  return dg_model_forward_impl(N, E, B, F, C, params, x, edge_index, batch, ws, logp, training, seed, flags, max_nodes,
+                               max_edges, epoch, stream, nullptr, nullptr);
 }
 
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
                                   float loss_scale, int training, float* grads, float* metrics,
-                                  const DgAdam* adam, hipStream_t s) {
+                                  const DgAdam* adam, hipStream_t s, const DgPrepRider* rider_b = nullptr) {
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -225,7 +239,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
-                            dg_cptr<float>(ws, wl.pooled), s));
+                            dg_cptr<float>(ws, wl.pooled), s, rider_b));
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s));
@@ -273,6 +287,90 @@ int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, 
   ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step = step;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, nullptr, y, loss_scale, training ? 1 : 0,
                                 grads, metrics, &ad, (hipStream_t)stream);
+}
+
+// ---- pipelined training step ------------------------------------------------------------------------
+// The next batch's graph preparation rides on this step's two graph-per-workgroup launches (k_readout_fwd carries
+// phase A, k_tail_bwd phase B; see dg_prep.h): same stream, no events, no second queue.  (A side stream + events
+// was measured SLOWER than no overlap at all -- 97 vs 86 us/step: each cross-queue dependency costs ~5 us here.)
+struct DgPipeline {
+  const void* prep_ws = nullptr;         // workspace holding a prepared-but-not-yet-consumed graph structure
+  int pN = 0, pE = 0, pB = 0, pflags = 0;
+  uint32_t pepoch = 0;
+};
+
+int dgcnn_pipeline_create(void** handle) {
+  if (!handle) return DGCNN_EINVAL;
+  *handle = new DgPipeline();
+  return DGCNN_OK;
+}
+
+int dgcnn_pipeline_destroy(void* handle) {
+  if (!handle) return DGCNN_EINVAL;
+  delete static_cast<DgPipeline*>(handle);
+  return DGCNN_OK;
+}
+
+int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
+                              dgcnn_stream_t stream) {
+  if (!handle || !cur) return DGCNN_EINVAL;
+  DgPipeline* h = static_cast<DgPipeline*>(handle);
+  hipStream_t s = (hipStream_t)stream;
+  if (!cur->params || !cur->x || !cur->batch || !cur->y || !cur->ws || !cur->logp || !cur->grads || cur->N <= 0 ||
+      cur->B <= 0 || cur->E < 0 || cur->epoch == 0)
+    return DGCNN_EINVAL;
+  if (cur->exp_avg && (!cur->exp_avg_sq || cur->step < 1)) return DGCNN_EINVAL;
+  if (next && (next->ws == cur->ws || !next->ws || !next->batch || next->N <= 0 || next->B <= 0 || next->E < 0 ||
+               next->epoch == 0 || (next->E > 0 && !next->edge_index)))
+    return DGCNN_EINVAL;
+  const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B;
+  const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;     // the host says so explicitly ...
+  if (prepared && !match) return DGCNN_EINVAL;                       // ... and it must be the batch we prepared
+  int flags = cur->flags;
+  uint32_t epoch = cur->epoch;
+  if (prepared) {
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED));
+    epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
+  }
+  h->prep_ws = nullptr;
+
+  DgPrepRider rd{};
+  const DgPrepRider* rider = nullptr;
+  if (next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
+    DgWs nl;
+    DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
+    rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
+    rd.rowptr = dg_ptr<int32_t>(next->ws, nl.rowptr); rd.colidx = dg_ptr<int32_t>(next->ws, nl.colidx);
+    rd.rowptr_t = dg_ptr<int32_t>(next->ws, nl.rowptr_t); rd.colidx_t = dg_ptr<int32_t>(next->ws, nl.colidx_t);
+    rd.graph_ptr = dg_ptr<int32_t>(next->ws, nl.graph_ptr); rd.graph_eptr = dg_ptr<int32_t>(next->ws, nl.graph_eptr);
+    rd.dinv = dg_ptr<float>(next->ws, nl.dinv); rd.err = dg_ptr<unsigned int>(next->ws, nl.err);
+    rd.epoch = next->epoch;
+    rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B), 1024);
+    rider = &rd;
+  }
+  int rode = 0;
+  DG_TRY(dg_model_forward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->edge_index, cur->batch,
+                               cur->ws, cur->logp, cur->training, cur->seed, flags, cur->max_nodes, cur->max_edges,
+                               epoch, stream, rider, &rode));
+  DgAdam ad;
+  const DgAdam* adam = nullptr;
+  if (cur->exp_avg) {
+    ad.params = cur->params; ad.exp_avg = cur->exp_avg; ad.exp_avg_sq = cur->exp_avg_sq;
+    ad.lr = cur->lr; ad.beta1 = cur->beta1; ad.beta2 = cur->beta2; ad.eps = cur->eps; ad.step = cur->step;
+    adam = &ad;
+  }
+  DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
+                                cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
+                                rode ? rider : nullptr));
+  if (next) {
+    // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
+    if (!rode)
+      DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->edge_index, next->batch, next->ws,
+                                 next->flags, next->epoch, stream));
+    h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;
+    h->pepoch = next->epoch;
+  }
+  return DGCNN_OK;
 }
 
 int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,

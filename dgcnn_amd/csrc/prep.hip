@@ -11,6 +11,7 @@
 // All integer work: HBM/latency-bound, int32 atomics only (order-independent results because
 // every row is sorted afterwards).
 #include "dg_common.h"
+#include "dg_prep.h"
 
 // ---- 1. count degrees (skipping self loops) + graph_ptr by binary search on sorted batch ----
 __global__ void __launch_bounds__(256)
@@ -173,40 +174,8 @@ k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __res
               int* __restrict__ rowptr, int* __restrict__ colidx, int* __restrict__ rowptr_t,
               int* __restrict__ colidx_t, int* __restrict__ graph_ptr, unsigned int* __restrict__ err,
               unsigned int epoch) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t* src = ei;
-  const int64_t* dst = ei + E;
-  if (t < E) {
-    const int64_t s = src[t], d = dst[t];
-    const bool range = (uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N;
-    bool bad = range || s == d;
-    int64_t ps = -1;
-    if (t > 0) {
-      ps = src[t - 1];
-      const int64_t pd = dst[t - 1];
-      bad = bad || !(ps < s || (ps == s && pd < d));
-    }
-    if (bad) { err[range ? 0 : 1] = epoch; err[range ? 2 : 3] = ~epoch; }
-    // memory safety even when the promise is broken: clamp everything that later indexes memory, so a
-    // flagged batch yields garbage numbers but never an out-of-bounds access
-    const int dc = (uint64_t)d < (uint64_t)N ? (int)d : 0;
-    const int sc = s < 0 ? 0 : (s >= N ? N - 1 : (int)s);
-    const int pc = ps < 0 ? -1 : (ps >= N ? N - 1 : (int)ps);
-    colidx[t] = dc;
-    colidx_t[t] = dc;
-    if (pc < sc || t == 0)
-      for (int k = pc + 1; k <= sc; ++k) { rowptr[k] = t; rowptr_t[k] = t; }
-    if (t == E - 1)
-      for (int k = sc + 1; k <= N; ++k) { rowptr[k] = E; rowptr_t[k] = E; }
-  }
-  if (t <= B) {
-    int lo = 0, hi = N;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (batch[mid] < (int64_t)t) lo = mid + 1; else hi = mid;
-    }
-    graph_ptr[t] = lo;
-  }
+  dg_prep_fast_a_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, batch, B, rowptr, colidx, rowptr_t, colidx_t,
+                      graph_ptr, err, epoch);
 }
 
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
@@ -237,21 +206,8 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
     }
     return;
   }
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < N) dinv[t] = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
-  if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
-  if (t < E) {
-    const int64_t s = ei[t], d = ei[(int64_t)E + t];
-    if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
-      const int end = rowptr[d + 1];
-      int a = rowptr[d], b = end;
-      while (a < b) {
-        const int mid = (a + b) >> 1;
-        if (colidx[mid] < (int)s) a = mid + 1; else b = mid;
-      }
-      if (!(a < end && colidx[a] == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
-    }
-  }
+  dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
+                      err, epoch);
 }
 
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
@@ -262,8 +218,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
   if (lin_done) *lin_done = 0;
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
-    int work = E > N + 1 ? E : N + 1;
-    if (B + 1 > work) work = B + 1;
+    const int work = dg_prep_fast_work(E, N, B);
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
     DG_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 #include "dg_common.h"
 #include <stdlib.h>
 #include "dg_readout.h"
+#include "dg_prep.h"
 
 __global__ void __launch_bounds__(SP_THREADS)
 k_sortpool_fwd(const int* __restrict__ graph_ptr, const float* __restrict__ x1, const float* __restrict__ x2,
@@ -87,7 +88,12 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
               float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
-              uint64_t seed, unsigned long long* dbg) {
+              uint64_t seed, unsigned long long* dbg, int B, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {    // rider range: phase A of the NEXT batch's graph preparation (dg_prep.h)
+    dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
+                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch);
+    return;
+  }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[7] = clock64();
   __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
   __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
@@ -101,10 +107,12 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
-                          int training, uint64_t seed, hipStream_t s) {
+                          int training, uint64_t seed, hipStream_t s, const DgPrepRider* rider) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_readout_fwd, dim3(B), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2,
-                     x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer());
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  hipLaunchKernelGGL(k_readout_fwd, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1,
+                     x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -122,7 +130,13 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg) {
+           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {    // rider range: phase B of the NEXT batch's graph preparation (phase A rode on the
+                                 // readout launch of this step's forward, complete by now)
+    dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
+                        rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch);
+    return;
+  }
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
   __shared__ float W5s[NW5];
@@ -350,12 +364,14 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
-                       const float* pooled, hipStream_t s) {
+                       const float* pooled, hipStream_t s, const DgPrepRider* rider) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_tail_bwd, dim3(B), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm, dinv,
-                     x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
-                     gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer());
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  hipLaunchKernelGGL(k_tail_bwd, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm,
+                     dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
+                     gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

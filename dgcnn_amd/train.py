@@ -52,13 +52,22 @@ class Trainer:
         self.grads = torch.zeros_like(flat)
         self.metrics = torch.zeros(2, dtype=torch.float32, device=flat.device)
         self._logp = None
-        # two workspace slots: the step runs in slot `_cur`; `prefetch` prepares the next batch's graph structure
-        # in the other slot on a side stream (software pipelining of graph prep across steps)
-        self._slots = [{"ws": None, "bytes": 0, "free": None}, {"ws": None, "bytes": 0, "free": None}]
+        # two workspace slots: the step runs in slot `_cur` while the pipelined step prepares the NEXT batch's graph
+        # structure in the other slot on the library's side stream (software pipelining of graph prep across steps)
+        self._slots = [{"ws": None, "bytes": 0}, {"ws": None, "bytes": 0}]
         self._cur = 0
-        self._side = None
-        self._ready_evt = None
-        self._pf = None          # (data, N, E, B, F, C, flags, epoch, ...) of the batch prepared in slot 1-_cur
+        self._pipe = None        # dgcnn_pipeline handle (side stream + events), created on first pipelined step
+        self._args_cache = {}    # id(batch) -> (batch, y, StepArgs, ws bytes, keep-alive tensors, dims)
+        self._prep_ent = None    # cache entry of the batch whose graph structure the last pipelined call prepared
+        self._prep_slot = 0
+
+    def __del__(self):
+        try:
+            if self._pipe is not None:
+                _lib.lib().dgcnn_pipeline_destroy(self._pipe)
+                self._pipe = None
+        except Exception:
+            pass
 
     # ---- buffers reused across steps (sizes only grow) -------------------------------------
     def _slot_ws(self, k, need, device):
@@ -70,41 +79,12 @@ class Trainer:
 
     def _buffers(self, N, E, B, F, C, device):
         need = _lib.workspace_bytes(N, E, B, F, C)
+        if self._prep_ent is not None:       # an unpipelined call interleaved: keep the prepared slot intact
+            self._cur = 1 - self._prep_slot
         self._ws = self._slot_ws(self._cur, need, device)
         if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != device:
             self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=device)
         return self._ws, self._logp
-
-    def prefetch(self, data) -> None:
-        """Prepare ``data``'s graph structure (CSR, degrees, graph ranges) NOW, on a side stream, into the spare
-        workspace, so that the next ``train_step(data)`` / ``forward_backward(data)`` skips graph prep.
-        Graph prep depends on the batch only (not on the parameters), so a training loop calls this for batch
-        i+1 right after launching step i -- what a DataLoader with prefetching does on the host, done here on
-        the device.  Purely an overlap: every step's prep is still executed, once."""
-        L = _lib.lib()
-        m = self.model
-        N, E, B, F, C = self._dims(data)
-        dev = data.x.device
-        need = _lib.workspace_bytes(N, E, B, F, C)
-        cur = torch.cuda.current_stream(dev)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-            self._ready_evt = torch.cuda.Event()
-        o = 1 - self._cur
-        ws = self._slot_ws(o, need, dev)
-        flags = m._flags_of(data)
-        epoch = m._next_epoch()
-        sl = self._slots[o]
-        if sl["free"] is not None:
-            self._side.wait_event(sl["free"])            # that slot's previous consumer (step i-1) is done
-        else:
-            self._side.wait_stream(cur)                  # first use: order after whatever allocated/queued so far
-        ei, bt = data.edge_index.contiguous(), data.batch.contiguous()
-        _lib.check(L.dgcnn_model_prepare(N, E, B, F, C, ei.data_ptr() if E else None, bt.data_ptr(),
-                                         ws.data_ptr(), flags, epoch, self._side.cuda_stream),
-                   "dgcnn_model_prepare")
-        self._ready_evt.record(self._side)
-        self._pf = (data, N, E, B, F, C, flags, epoch, ei, bt)
 
     def _dims(self, data):
         x, ei = data.x, data.edge_index
@@ -127,19 +107,7 @@ class Trainer:
         seed = m._next_seed() if training else 0
         x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
         flags = m._flags_of(data)
-        if self._pf is not None and self._pf[0] is data and self._pf[1:6] == (N, E, B, F, C):
-            # consume the prefetched graph structure: swap workspaces, wait for the side stream, skip prep
-            _, _, _, _, _, _, pflags, epoch, _, _ = self._pf
-            self._pf = None
-            self._cur = 1 - self._cur
-            ws = self._ws = self._slots[self._cur]["ws"]
-            cur.wait_event(self._ready_evt)
-            flags = pflags | _lib.FLAG_PREPARED
-            m._epoch = epoch
-            swapped = True
-        else:
-            epoch = m._next_epoch()
-            swapped = False
+        epoch = m._next_epoch()
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
                                          logp.data_ptr(), training, seed, flags, m._max_nodes_of(data),
@@ -159,11 +127,6 @@ class Trainer:
                                               self.grads.data_ptr(), self.metrics.data_ptr(), stream),
                        "dgcnn_model_backward")
         m._last_ws, m._last_dims = ws, (N, E, B, F, C)
-        if self._side is not None:      # prefetching in use: mark when this step's slot becomes reusable
-            sl = self._slots[self._cur]
-            if sl["free"] is None:
-                sl["free"] = torch.cuda.Event()
-            sl["free"].record(cur)
         return logp[:B]
 
     def optimizer_step(self) -> None:
@@ -176,8 +139,94 @@ class Trainer:
                                      self.exp_avg_sq.data_ptr(), flat.numel(), self.step_count, self.lr,
                                      self.betas[0], self.betas[1], self.eps, 1, stream), "dgcnn_adam_step")
 
-    def train_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
-        """One iteration of the body of the reference ``train()`` loop (train.py:36-45)."""
+    # ---- pipelined step: ONE C-ABI call per batch, next batch's graph prep on the library's side stream ----
+    def _step_args(self, data, y):
+        """cached ``dgcnn_step_args`` of a batch object (pointers + sizes are per-batch constants)"""
+        ent = self._args_cache.get(id(data))
+        if ent is not None and ent[0] is data and ent[1] is y:
+            return ent
+        N, E, B, F, C = self._dims(data)
+        x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+        yy = y.contiguous()
+        a = _lib.StepArgs()
+        a.N, a.E, a.B, a.F, a.C = N, E, B, F, C
+        a.max_nodes = self.model._max_nodes_of(data)
+        a.max_edges = int(getattr(data, "max_edges", 0) or 0)
+        a.x, a.edge_index, a.batch, a.y = x.data_ptr(), (ei.data_ptr() if E else None), bt.data_ptr(), yy.data_ptr()
+        a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        need = _lib.workspace_bytes(N, E, B, F, C)
+        if len(self._args_cache) >= 1024:
+            self._args_cache.clear()
+        ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C))
+        self._args_cache[id(data)] = ent
+        return ent
+
+    def pipelined_step(self, data, y, next_data=None, next_y=None, global_batch: Optional[int] = None,
+                       fuse_adam: bool = True) -> torch.Tensor:
+        """``dgcnn_pipeline_train_step``: forward + backward (+ fused Adam) of ``data`` as one call; when
+        ``next_data`` is given its graph structure is prepared concurrently on the library's side stream and the
+        following ``pipelined_step(next_data, ...)`` skips its own preparation.  Bit-identical to ``train_step``."""
+        L = _lib.lib()
+        m = self.model
+        dev = data.x.device
+        if self._pipe is None:
+            h = _lib.c_void_p()
+            _lib.check(L.dgcnn_pipeline_create(_lib.ctypes.byref(h)), "dgcnn_pipeline_create")
+            self._pipe = h
+        _, _, a, need, _, dims = ent = self._step_args(data, y)
+        prepared = self._prep_ent is not None and self._prep_ent[0] is data
+        if prepared:
+            slot = self._prep_slot               # its workspace was sized when it was handed in as `next`
+            m._epoch = a.epoch
+        else:
+            # (a prepared-but-abandoned batch keeps its slot untouched: use the other one)
+            slot = self._cur if self._prep_ent is None else 1 - self._prep_slot
+            a.epoch = m._next_epoch()
+        self._prep_ent = None
+        ws = self._slot_ws(slot, need, dev)
+        B, C = dims[2], dims[4]
+        if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != dev:
+            self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
+        flat = m.flat_params
+        training = 1 if m.training else 0
+        a.ws, a.logp, a.params, a.grads, a.metrics = ws.data_ptr(), self._logp.data_ptr(), flat.data_ptr(), \
+            self.grads.data_ptr(), self.metrics.data_ptr()
+        a.training = training
+        a.seed = m._next_seed() if training else 0
+        a.flags = m._flags_of(data) | (_lib.FLAG_PREPARED if prepared else 0)
+        a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
+        if fuse_adam:
+            self.step_count += 1
+            a.step = self.step_count
+            a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        else:
+            a.exp_avg = a.exp_avg_sq = None
+        nref = None
+        if next_data is not None and next_data is not data:
+            nent = self._step_args(next_data, next_y if next_y is not None else next_data.y)
+            na = nent[2]
+            nws = self._slot_ws(1 - slot, nent[3], dev)
+            na.ws, na.flags, na.epoch = nws.data_ptr(), m._flags_of(next_data), m._next_epoch()
+            nref = _lib.ctypes.byref(na)
+            self._prep_ent, self._prep_slot = nent, 1 - slot
+        self._cur = 1 - slot if nref is not None else slot
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(L.dgcnn_pipeline_train_step(self._pipe, _lib.ctypes.byref(a), nref, stream),
+                   "dgcnn_pipeline_train_step")
+        self._ws = ws
+        m._last_ws, m._last_dims = ws, dims
+        return self._logp[:B]
+
+    def train_step(self, data, y, global_batch: Optional[int] = None, next_data=None) -> torch.Tensor:
+        """One iteration of the body of the reference ``train()`` loop (train.py:36-45).  ``next_data``: the batch the
+        NEXT call will be given (optional) -- its graph preparation then overlaps this step."""
+        if next_data is not None or self._prep_ent is not None:
+            if self._allreduce is None:
+                return self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=True)
+            logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
+            self._allreduce(self.grads)
+            self.optimizer_step()
+            return logp
         if self._allreduce is None:
             # single GPU: optimizer fused into the weight-gradient kernel (no separate Adam launch)
             return self.forward_backward(data, y, global_batch, fuse_adam=True)
@@ -230,9 +279,13 @@ class Trainer:
         self.model.train()
         self.reset_metrics()
         nb = 0
-        for b in batches:
-            self.train_step(b, b.y)
+        it = iter(batches)
+        cur = next(it, None)
+        while cur is not None:          # one batch of look-ahead: batch i+1's graph prep overlaps step i
+            nxt = next(it, None)
+            self.train_step(cur, cur.y, next_data=nxt)
             nb += 1
+            cur = nxt
         loss, correct = self.read_metrics()
         return loss / max(nb, 1), correct / max(num_samples, 1) * 100.0
 

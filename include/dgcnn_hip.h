@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 6
+#define DGCNN_ABI_VERSION 7
 
 /* error codes */
 #define DGCNN_OK            0
@@ -224,6 +224,59 @@ int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, 
 int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                     int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
                     int zero_grads, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pipelined training step: the body of the reference's `train()` loop (/root/reference/train.py:36-45)
+ * for one batch as ONE call, with the NEXT batch's graph preparation overlapped with it.
+ *
+ * dgcnn_step_args describes one batch (fields as the same-named arguments of dgcnn_model_forward /
+ * dgcnn_model_backward[_step]); host code fills it once per batch object and only touches seed / epoch /
+ * step between calls.  exp_avg == NULL selects "forward + backward only" (data parallel: the caller
+ * all-reduces `grads` and then calls dgcnn_adam_step); otherwise the Adam update is fused as in
+ * dgcnn_model_backward_step.
+ *
+ * dgcnn_pipeline_train_step(h, cur, next, stream), everything on `stream`:
+ *   1. forward + backward (+Adam) of `cur`.  With DGCNN_FLAG_PREPARED in cur->flags (the host states that `cur`
+ *      is the batch the previous call was given as `next`: same ws, N, E, B -- anything else is DGCNN_EINVAL)
+ *      the step skips its own graph preparation, else it prepares in-stream first.
+ *   2. if `next` != NULL: its graph structure (what dgcnn_model_prepare builds: CSR by target / by source, dinv,
+ *      graph ranges -- a function of the batch only, never of the weights) is built DURING this step, by extra
+ *      workgroups appended to the step's two graph-per-workgroup launches (SortPooling+tail forward carries
+ *      phase A, its backward phase B): those launches occupy only B of the 256 CUs, the preparation runs on the
+ *      idle ones.  Same stream, no events.  next->ws must differ from cur->ws.  (General edge lists without
+ *      DGCNN_FLAG_COALESCED_UNDIRECTED, or a step that took the fused forward, are prepared in-stream after
+ *      the step instead: same results, no overlap.)
+ * Every batch's preparation still runs exactly once inside the training loop; only its position changes.
+ * No host synchronisation.  Results are bit-identical to the unpipelined calls.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dgcnn_step_args {
+  int32_t N, E, B, F, C;
+  int32_t training;            /* dropout on/off, as model.train() / model.eval() */
+  int32_t flags;               /* DGCNN_FLAG_* layout promises / path overrides */
+  int32_t max_nodes, max_edges;
+  uint32_t epoch;              /* error-word tag of this forward (non-zero, unique per forward on this ws) */
+  uint64_t seed;               /* dropout stream of this step */
+  int64_t step;                /* Adam step, 1-based (ignored when exp_avg == NULL) */
+  float lr, beta1, beta2, eps; /* Adam hyper-parameters */
+  float loss_scale;            /* 0 = 1/B, else 1/B_global */
+  int32_t reserved_;
+  float* params;               /* flat parameters (updated in place when exp_avg != NULL) */
+  const float* x;              /* [N,F] */
+  const int64_t* edge_index;   /* [2,E] */
+  const int64_t* batch;        /* [N] */
+  const int64_t* y;            /* [B] labels */
+  void* ws;                    /* workspace of dgcnn_workspace_bytes(N,E,B,F,C) bytes */
+  float* logp;                 /* [B,C] out */
+  float* grads;                /* flat gradient out */
+  float* metrics;              /* optional 2-float accumulator */
+  float* exp_avg;              /* Adam moments, or NULL */
+  float* exp_avg_sq;
+} dgcnn_step_args;
+
+int dgcnn_pipeline_create(void** handle);     /* one per training loop: remembers which workspace holds a prepared batch */
+int dgcnn_pipeline_destroy(void* handle);
+int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
+                              dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Metrics (stand-alone form of the `metrics` argument above): folds the per-graph loss /

@@ -249,25 +249,74 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     assert abs(lsum - float(loss_ref)) < 1e-5
 
 
-def test_prefetched_graph_prep_gives_identical_training():
-    """Trainer.prefetch (graph prep of batch i+1 on a side stream during step i) must not change a single bit."""
+def test_pipelined_step_gives_identical_training():
+    """dgcnn_pipeline_train_step (one call per step; graph prep of batch i+1 on the library's side stream during
+    step i) must not change a single bit, whether or not the promised next batch actually comes next."""
     from dgcnn_amd.train import Trainer
     sh = synth.SHAPES["COLLAB"]
     batches = [b.to("cuda") for b in synth.make_batches("COLLAB", 60, 12, start=4000)]
     outs = []
-    for use_pf in (False, True):
+    for mode in ("plain", "pipelined", "pipelined_no_lookahead", "broken_promise", "interleaved_eval"):
         m = make_model(sh.num_features, sh.num_classes)
         m.train(); m._seed_base, m._fwd_count = 3, 0
         tr = Trainer(m)
         for it in range(12):
             b = batches[it % len(batches)]
-            tr.train_step(b, b.y)
-            if use_pf:
-                tr.prefetch(batches[(it + 1) % len(batches)])
+            nxt = batches[(it + 1) % len(batches)]
+            if mode == "plain":
+                tr.train_step(b, b.y)
+            elif mode == "pipelined":
+                tr.train_step(b, b.y, next_data=nxt)
+            elif mode == "pipelined_no_lookahead":
+                tr.pipelined_step(b, b.y)
+            elif mode == "broken_promise":        # promise a batch that does not come next
+                tr.train_step(b, b.y, next_data=batches[(it + 2) % len(batches)])
+            else:
+                tr.train_step(b, b.y, next_data=nxt)
+                if it % 3 == 0:                   # an unpipelined call in between must not clobber the prepared slot
+                    keep = tr.metrics.clone()
+                    fc = m._fwd_count
+                    tr.eval_step(batches[-1], batches[-1].y)
+                    tr.metrics.copy_(keep); m._fwd_count = fc; m.train()
         torch.cuda.synchronize()
         m.check_errors()
         outs.append((m.flat_params.clone(), tr.metrics.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
+def test_pipelined_step_data_parallel_route_matches_fused_adam():
+    """exp_avg == NULL selects forward+backward only (DP: all-reduce, then dgcnn_adam_step): same update."""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["MUTAG"]
+    batches = [b.to("cuda") for b in synth.make_batches("MUTAG", 40, 10, start=10)]
+    res = []
+    for fuse in (True, False):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 5, 0
+        tr = Trainer(m)
+        for it in range(6):
+            b = batches[it % 4]
+            tr.pipelined_step(b, b.y, batches[(it + 1) % 4], fuse_adam=fuse)
+            if not fuse:
+                tr.optimizer_step()
+        torch.cuda.synchronize()
+        res.append(m.flat_params.clone())
+    torch.testing.assert_close(res[0], res[1], rtol=1e-6, atol=1e-7)
+
+
+def test_pipeline_refuses_unprepared_batch_claimed_as_prepared():
+    from dgcnn_amd import _lib
+    from dgcnn_amd.train import Trainer
+    b = synth.make_batch("MUTAG", 5).to("cuda")
+    m = make_model(8, 2); m.train()
+    tr = Trainer(m)
+    tr.pipelined_step(b, b.y)                       # creates the pipeline, nothing prepared
+    ent = tr._step_args(b, b.y)
+    ent[2].flags |= _lib.FLAG_PREPARED
+    rc = _lib.lib().dgcnn_pipeline_train_step(tr._pipe, _lib.ctypes.byref(ent[2]), None,
+                                              torch.cuda.current_stream().cuda_stream)
+    assert rc == -1
 
 
 def test_training_reduces_loss_like_reference_loop():

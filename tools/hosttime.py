@@ -11,16 +11,14 @@ m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
 tr = Trainer(m)
 for pf in (False, True):
     for i in range(50):
-        tr.train_step(batches[i % 10], batches[i % 10].y)
-        if pf: tr.prefetch(batches[(i + 1) % 10])
+        tr.train_step(batches[i % 10], batches[i % 10].y, next_data=batches[(i + 1) % 10] if pf else None)
     torch.cuda.synchronize()
     K = 400
     t0 = time.perf_counter()
     for i in range(K):
         b = batches[i % 10]
-        tr.train_step(b, b.y)
-        if pf: tr.prefetch(batches[(i + 1) % 10])
+        tr.train_step(b, b.y, next_data=batches[(i + 1) % 10] if pf else None)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"prefetch={pf}: host enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
+    print(f"pipelined={pf}: host enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
