@@ -59,13 +59,16 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
   X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
-  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(ax)
+  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(ax) X(wg_t1) X(wg_t2)
 
 // conv1 is evaluated aggregate-first, (A_hat X) W1^T instead of A_hat (X W1^T), whenever the raw feature width is
 // <= 32: the gather then moves F floats per edge instead of 32, conv1 needs no stand-alone linear (so graph prep
 // depends on the batch only, never on the weights), and its weight gradient dW1 = ga1^T (A_hat X) needs NO
 // gather at all in backward -- it rides on conv2's backward kernel from the saved A_hat X.
 #define DG_AF_MAX_F 32
+#define DG_WG_TWO_STAGE_B 128       // batches above this reduce the per-graph weight-gradient partials in two stages
+#define DG_WG_ROWS_PER_CHUNK 32
+#define DG_WG_FC1_KCHUNK 128
 static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
 
 struct DgWs {
@@ -134,6 +137,9 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(pb1, 4 * (int64_t)w->P32 * 32 * F);
   R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
   R(ax, F <= DG_AF_MAX_F ? 4 * n * F : 0);      // aggregated raw input (aggregate-first conv1), saved for dW1
+  // large batches only: stage-1 buffers of the two-stage weight-gradient reduction (tail.hip, dg_launch_wgrad)
+  R(wg_t1, B > DG_WG_TWO_STAGE_B ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * DG_PTAIL(C) : 0);
+  R(wg_t2, B > DG_WG_TWO_STAGE_B ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
 #undef R
   w->total = o;
   return DGCNN_OK;

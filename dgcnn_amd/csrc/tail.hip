@@ -382,7 +382,8 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
 // with a fixed xor-butterfly -> no floating-point atomics, bit-reproducible, and the long
 // reductions (bias sums over B*30 terms, per-workgroup partials) are no longer serial chains.
 // ---------------------------------------------------------------------------------------------
-enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC, WG_FC1W_MFMA };
+enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC, WG_FC1W_MFMA,
+       WG_REDUCE_CHUNK, WG_FC1W_MFMA_CHUNK };
 #define WG_MAX_SEG 20
 struct WgSeg {
   int type;
@@ -390,7 +391,8 @@ struct WgSeg {
   int lpo;           // lanes per output
   int R;             // reduction length
   int block0;        // first block of this segment
-  int stride;        // WG_REDUCE: floats between partial slots ; WG_METRIC: 2
+  int stride;        // WG_REDUCE: floats between partial slots ; WG_METRIC: 2 ; *_CHUNK: row width
+  int aux;           // *_CHUNK: total number of rows (graphs) being reduced, R = rows per chunk
   const float* src;  // WG_REDUCE / WG_SUMB / WG_METRIC source
   float* out;
 };
@@ -408,6 +410,9 @@ __device__ __forceinline__ float dg_wg_term(const WgArgs& A, const WgSeg& sg, in
   const int C = A.C;
   switch (sg.type) {
     case WG_REDUCE: return sg.src[(size_t)r * sg.stride + i];
+    case WG_REDUCE_CHUNK: {   // output i = chunk * width + column: partial sum of rows [chunk*R, chunk*R + R)
+      const int ch = i / sg.stride, col = i - ch * sg.stride, row = ch * sg.R + r;
+      return row < sg.aux ? sg.src[(size_t)row * sg.stride + col] : 0.f; }
     case WG_SUMB:   return sg.src[r];
     case WG_METRIC: return sg.src[(size_t)r * 2 + i];
     case WG_FC2W: { const int c = i / DGCNN_HID1, j = i - c * DGCNN_HID1;
@@ -448,12 +453,14 @@ __device__ __forceinline__ void dg_wg_store(const WgArgs& A, const WgSeg& sg, in
 // classifier_1 weight gradient as a small GEMM on the fp32 matrix cores:
 //   dW[j][m] = sum_b gz1[b][j] * a6[b][m]  = (gz1^T [128 x B]) . (a6 [B x 352]),  K = B (zero-padded to 4)
 // one wave per 16x16 output tile (8 x 22 tiles), v_mfma_f32_16x16x4_f32: a k-ordered fma chain over b.
-__device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg, int tile, int lane) {
+// Large batches: the K range is cut into chunks (one wave per (chunk, tile)); chunk partials are then summed by a
+// WG_REDUCE segment of the second launch.
+__device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg, int tile, int lane, int kbeg, int B,
+                                                float* pout) {
   const int rb = tile / 22, cb = tile - rb * 22;
-  const int B = A.B;
   const int jr = rb * 16 + (lane & 15), mc = cb * 16 + (lane & 15), kq = lane >> 4;
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < B; k0 += 32) {          // 8 MFMAs (32 graphs) per round: 16 loads in flight per lane
+  for (int k0 = kbeg; k0 < B; k0 += 32) {       // 8 MFMAs (32 graphs) per round: 16 loads in flight per lane
     float av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -468,7 +475,8 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = rb * 16 + kq * 4 + r, m = cb * 16 + (lane & 15);
-    dg_wg_store(A, sg, j * DGCNN_FLAT + m, d[r]);
+    if (pout) pout[j * DGCNN_FLAT + m] = d[r];
+    else dg_wg_store(A, sg, j * DGCNN_FLAT + m, d[r]);
   }
 }
 
@@ -479,7 +487,16 @@ k_wgrad(WgArgs A) {
   const WgSeg sg = A.seg[si];
   if (sg.type == WG_FC1W_MFMA) {      // block-uniform branch: 4 waves = 4 tiles per workgroup
     const int tile = ((int)blockIdx.x - sg.block0) * 4 + (threadIdx.x >> 6);
-    if (tile < 8 * 22) dg_wg_fc1w_mfma(A, sg, tile, threadIdx.x & 63);
+    if (tile < 8 * 22) dg_wg_fc1w_mfma(A, sg, tile, threadIdx.x & 63, 0, A.B, nullptr);
+    return;
+  }
+  if (sg.type == WG_FC1W_MFMA_CHUNK) {   // task = chunk * 176 + tile ; K range of sg.R graphs per chunk
+    const int task = ((int)blockIdx.x - sg.block0) * 4 + (threadIdx.x >> 6);
+    if (task < sg.count) {
+      const int ch = task / (8 * 22), tile = task - ch * (8 * 22);
+      const int kbeg = ch * sg.R, kend = min(A.B, kbeg + sg.R);
+      dg_wg_fc1w_mfma(A, sg, tile, threadIdx.x & 63, kbeg, kend, sg.out + (size_t)ch * (DGCNN_HID1 * DGCNN_FLAT));
+    }
     return;
   }
   const int gid = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
@@ -560,18 +577,43 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
   }
   if (which & 1) {
-    const bool small = B <= 128;
-    add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                           // classifier_1 weight: MFMA GEMM
-    // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum B contiguous partials per element
-    const float* pt = dg_cptr<float>(ws, wl->ptail);
+    const bool small = B <= DG_WG_TWO_STAGE_B;
     const int st = DG_PTAIL(C);
-    const int lpr = small ? 8 : 1;
-    add(WG_REDUCE, DGCNN_C5 * DGCNN_CAT, lpr, B, grads + pl->off[8], pt + DG_PT_W5, st);
-    add(WG_REDUCE, DGCNN_C5, 64, B, grads + pl->off[9], pt + DG_PT_B5, st);
-    add(WG_REDUCE, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, lpr, B, grads + pl->off[10], pt + DG_PT_W6, st);
-    add(WG_REDUCE, DGCNN_C6, 64, B, grads + pl->off[11], pt + DG_PT_B6, st);
-    add(WG_REDUCE, C * DGCNN_HID1, lpr, B, grads + pl->off[14], pt + DG_PT_WF2, st);
-    add(WG_REDUCE, C, 64, B, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
+    const float* pt = dg_cptr<float>(ws, wl->ptail);
+    int Rt = B;                      // rows the final reduction of the per-graph tail partials runs over
+    if (!small) {
+      // ---- large batches, stage 1 (own launch): per-graph partials -> per-chunk partials, fully coalesced and
+      // with (columns x chunks) parallelism; classifier_1's GEMM split over K.  Fixed chunking -> deterministic.
+      WgArgs S = A;
+      S.adam_p = nullptr; S.adam_m = nullptr; S.adam_v = nullptr;
+      int nb1 = 0;
+      const int nch = dg_cdiv(B, DG_WG_ROWS_PER_CHUNK), nk = dg_cdiv(B, DG_WG_FC1_KCHUNK);
+      float* t1 = const_cast<float*>(dg_cptr<float>(ws, wl->wg_t1));
+      float* t2 = const_cast<float*>(dg_cptr<float>(ws, wl->wg_t2));
+      WgSeg& g0 = S.seg[0];
+      g0.type = WG_FC1W_MFMA_CHUNK; g0.count = nk * 8 * 22; g0.lpo = 64; g0.R = DG_WG_FC1_KCHUNK; g0.block0 = 0;
+      g0.stride = 0; g0.aux = B; g0.src = nullptr; g0.out = t2;
+      nb1 += dg_cdiv(g0.count, 4);
+      WgSeg& g1 = S.seg[1];
+      g1.type = WG_REDUCE_CHUNK; g1.count = nch * st; g1.lpo = 1; g1.R = DG_WG_ROWS_PER_CHUNK; g1.block0 = nb1;
+      g1.stride = st; g1.aux = B; g1.src = pt; g1.out = t1;
+      nb1 += dg_cdiv(g1.count, 256);
+      S.nseg = 2;
+      hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S);
+      DG_CHECK_LAUNCH();
+      pt = t1; Rt = nch;
+      add(WG_REDUCE, DGCNN_HID1 * DGCNN_FLAT, 1, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
+    } else {
+      add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                         // classifier_1 weight: MFMA GEMM
+    }
+    // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum the partials per element
+    const int lpr = Rt <= 128 ? 8 : 1;
+    add(WG_REDUCE, DGCNN_C5 * DGCNN_CAT, lpr, Rt, grads + pl->off[8], pt + DG_PT_W5, st);
+    add(WG_REDUCE, DGCNN_C5, 64, Rt, grads + pl->off[9], pt + DG_PT_B5, st);
+    add(WG_REDUCE, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, lpr, Rt, grads + pl->off[10], pt + DG_PT_W6, st);
+    add(WG_REDUCE, DGCNN_C6, 64, Rt, grads + pl->off[11], pt + DG_PT_B6, st);
+    add(WG_REDUCE, C * DGCNN_HID1, lpr, Rt, grads + pl->off[14], pt + DG_PT_WF2, st);
+    add(WG_REDUCE, C, 64, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
     add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
     if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
   }

@@ -74,6 +74,18 @@ def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
     check_backward_parity(m, b, sd)
 
 
+@pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 700), ("PROTEINS", 260)])
+def test_large_batch_two_stage_weight_gradients(name, bs):
+    """B > 128 switches the weight-gradient reduction to two stages (chunk partials, then the final sum) and, from
+    192 graphs, the forward to the graph-per-workgroup kernel: same parity bar as the reference-sized batches."""
+    sh = synth.SHAPES[name]
+    b = synth.make_batch(name, bs, start=300)
+    m = make_model(sh.num_features, sh.num_classes)
+    sd = cpu_state_dict(m)
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
+
+
 def test_edge_cases_isolated_selfloops_single_graph_empty_edges():
     # one graph, n < k, isolated nodes, input self loops, duplicate edge
     x = torch.randn(7, 5)
