@@ -293,28 +293,33 @@ __device__ __forceinline__ float dg_af_gather(const float* __restrict__ xsrc, co
                                               int lane) {
   const int q = lane & ((1 << lfp) - 1), g = lane >> lfp, sh = 6 - lfp;
   const bool qa = q < F;
-  float acc = 0.f;
+  float acc = 0.f, vself = 0.f;
+  if (g == 0 && qa) {
+    if (PRESCALED) vself = xsrc[self * F + q];
+    else { vself = dsrc[self] * xsrc[(size_t)self * F + q]; asm volatile("" : "+v"(vself)); }
+  }
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int cj = lane < cnt ? col[base + lane] : 0;
     const int iters = (cnt + (1 << sh) - 1) >> sh;
-    for (int it = 0; it < iters; ++it) {
-      const int idx = (it << sh) + g;
-      const int j = __shfl(cj, idx);
-      if (idx < cnt && qa) {
-        float v;
-        if (PRESCALED) v = xsrc[j * F + q];
-        else { v = dsrc[j] * xsrc[(size_t)j * F + q]; asm volatile("" : "+v"(v)); }
-        acc += v;
+    for (int it0 = 0; it0 < iters; it0 += 8) {      // 8 neighbour rounds in flight, summed in round order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = ((it0 + u) << sh) + g;
+        const int j = __shfl(cj, idx & 63);
+        v[u] = 0.f;
+        if (idx < cnt && qa) {
+          if (PRESCALED) v[u] = xsrc[j * F + q];
+          else { v[u] = dsrc[j] * xsrc[(size_t)j * F + q]; asm volatile("" : "+v"(v[u])); }
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if ((((it0 + u) << sh) + g) < cnt && qa) acc += v[u];
     }
   }
-  if (g == 0 && qa) {
-    float v;
-    if (PRESCALED) v = xsrc[self * F + q];
-    else { v = dsrc[self] * xsrc[(size_t)self * F + q]; asm volatile("" : "+v"(v)); }
-    acc += v;
-  }
+  if (g == 0 && qa) acc += vself;
   for (int off = 1 << lfp; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
   return acc;
 }

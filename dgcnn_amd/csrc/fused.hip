@@ -61,23 +61,26 @@ __device__ __forceinline__ float4 fg_gather_row32(const float* __restrict__ H, c
                                                   int start, int end, int self, int lane) {
   const int g = lane >> 3, q = lane & 7;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 vself = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g == 0) vself = *reinterpret_cast<const float4*>(H + self * FG_RS + 4 * q);
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int cj = lane < cnt ? cl[base + lane] : 0;
-    const int iters = (cnt + 7) >> 3;
-    for (int it = 0; it < iters; ++it) {
-      const int idx = it * 8 + g;
-      const int j = __shfl(cj, idx);
-      if (idx < cnt) {
-        const float4 v = *reinterpret_cast<const float4*>(H + j * FG_RS + 4 * q);
-        acc = dg_add4(acc, v);
-      }
+    float4 v[8];
+    int j[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) j[u] = __shfl(cj, u * 8 + g);     // the 8 index broadcasts first (one LDS round trip)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u * 8 + g < cnt) v[u] = *reinterpret_cast<const float4*>(H + j[u] * FG_RS + 4 * q);
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u * 8 + g < cnt) acc = dg_add4(acc, v[u]);
   }
-  if (g == 0) {
-    const float4 v = *reinterpret_cast<const float4*>(H + self * FG_RS + 4 * q);
-    acc = dg_add4(acc, v);
-  }
+  if (g == 0) acc = dg_add4(acc, vself);
   acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
   acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
   acc = dg_add4(acc, dg_shfl_xor4(acc, 32));

@@ -23,6 +23,18 @@
 // with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
 #include "dg_common.h"
 #include <hip/hip_ext.h>
+// Gather depth = row loads in flight per wavefront.  Few tiles (the reference's batch of 50: one workgroup per CU,
+// latency-bound): deepest batching, 8 -> one memory round trip per 64 neighbours.  Many tiles (large batches,
+// throughput-bound): shallower batching keeps the VGPR count low enough for two 1024-thread workgroups per CU,
+// whose gathers then hide each other's epilogues (measured: profiles/r01_sweep.txt).
+#define DG_DEPTH_SMALL 8
+#ifndef DG_DEPTH_FWD_BIG
+#define DG_DEPTH_FWD_BIG 4
+#endif
+#ifndef DG_DEPTH_BWD_BIG
+#define DG_DEPTH_BWD_BIG 2
+#endif
+#define DG_SMALL_GRID_TILES 512
 
 // ---------------------------------------------------------------------------------------------
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
@@ -81,27 +93,38 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 // gather of one destination row: returns (in every lane with g==0, and in fact all lanes) the
 // float4 chunk q of   sum_{e in [start,end)} src[col[e]]  +  src[self]
 // ---------------------------------------------------------------------------------------------
+template <int DG_GATHER_DEPTH>
 __device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src, const int* __restrict__ col,
                                                   int start, int end, int self, int lane) {
   const int g = lane >> 3, q = lane & 7;
+  const float* sq = src + 4 * q;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 vself = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g == 0) vself = *reinterpret_cast<const float4*>(sq + (size_t)self * 32);   // issued first, added last
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
     const int cj = lane < cnt ? col[base + lane] : 0;
-    const int iters = (cnt + 7) >> 3;
-    for (int it = 0; it < iters; ++it) {
-      const int idx = it * 8 + g;
-      const int j = __shfl(cj, idx);
-      if (idx < cnt) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)j * 32 + 4 * q);
-        acc = dg_add4(acc, v);
+    // DG_GATHER_DEPTH row loads are issued back to back and only then summed, in the same order as a
+    // one-at-a-time loop would: one memory round trip per DEPTH*8 neighbours instead of one per 8
+#pragma unroll
+    for (int u0 = 0; u0 < 8; u0 += DG_GATHER_DEPTH) {
+      if (u0 * 8 >= cnt) break;
+      float4 v[DG_GATHER_DEPTH];
+      int j[DG_GATHER_DEPTH];
+#pragma unroll
+      for (int u = 0; u < DG_GATHER_DEPTH; ++u) j[u] = __shfl(cj, (u0 + u) * 8 + g);   // index broadcasts first
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < DG_GATHER_DEPTH; ++u) {
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((u0 + u) * 8 + g < cnt) v[u] = *reinterpret_cast<const float4*>(sq + (size_t)j[u] * 32);
       }
+#pragma unroll
+      for (int u = 0; u < DG_GATHER_DEPTH; ++u)
+        if ((u0 + u) * 8 + g < cnt) acc = dg_add4(acc, v[u]);
     }
   }
-  if (g == 0) {   // self loop term, added last in group 0 (PyG appends self loops at the end)
-    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)self * 32 + 4 * q);
-    acc = dg_add4(acc, v);
-  }
+  if (g == 0) acc = dg_add4(acc, vself);   // self loop term, added last in group 0 (PyG appends self loops at the end)
   acc = dg_add4(acc, dg_shfl_xor4(acc, 8));
   acc = dg_add4(acc, dg_shfl_xor4(acc, 16));
   acc = dg_add4(acc, dg_shfl_xor4(acc, 32));
@@ -113,7 +136,7 @@ __device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src,
 //                   MODE 1: fused next 32->1 linear (dot)   -> hs_next [N]
 //                   MODE 2: no post-step (stand-alone layer)
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int DEPTH>
 __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
@@ -139,7 +162,7 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
     if (i < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
-      const float4 acc = dg_gather_row32(hs, colidx, start, end, i, lane);
+      const float4 acc = dg_gather_row32<DEPTH>(hs, colidx, start, end, i, lane);
       const float di = dinv[i];
       float4 val;
       val.x = dg_tanh(fmaf(di, acc.x, b4.x));
@@ -199,15 +222,13 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
   const int grid = tiles;          // one workgroup per tile (XCD-aware order inside the kernel)
   // hipExtLaunchKernelGGL attaches the events to THIS dispatch (its own start/end timestamps, the
   // same ones rocprofv3 reports); with null events it is a plain launch.
-  if (mode == 0)
-    hipExtLaunchKernelGGL(k_gcn_fwd32<0>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
-  else if (mode == 1)
-    hipExtLaunchKernelGGL(k_gcn_fwd32<1>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
-  else
-    hipExtLaunchKernelGGL(k_gcn_fwd32<2>, dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, ev_stop, 0, N, tiles,
-                          rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next);
+#define DG_FWD32_LAUNCH(M, D) hipExtLaunchKernelGGL((k_gcn_fwd32<M, D>), dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, \
+                                                    ev_stop, 0, N, tiles, rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
+  const bool small = tiles <= DG_SMALL_GRID_TILES;
+  if (mode == 0) { if (small) DG_FWD32_LAUNCH(0, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(0, DG_DEPTH_FWD_BIG); }
+  else if (mode == 1) { if (small) DG_FWD32_LAUNCH(1, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(1, DG_DEPTH_FWD_BIG); }
+  else { if (small) DG_FWD32_LAUNCH(2, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(2, DG_DEPTH_FWD_BIG); }
+#undef DG_FWD32_LAUNCH
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -396,7 +417,7 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
 //
 // AF = true (layer 2 when conv1 ran aggregate-first): additionally dW_1 += ga_1^T . ax  with ax = A_hat X [N,Fa]
 // saved by k_gcn_fwd_af -- conv1's whole backward, no gather needed.  part1[P][32*Fa] in W1's own layout.
-template <bool FIRST, bool AF>
+template <bool FIRST, bool AF, int DEPTH>
 __global__ void __launch_bounds__(DG_TILE_THREADS)
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
@@ -434,7 +455,7 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     if (j < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr_t[j + 1]);
-      float4 acc = dg_gather_row32(gas, colidx_t, start, end, j, lane);
+      float4 acc = dg_gather_row32<DEPTH>(gas, colidx_t, start, end, j, lane);
       const float dj = dinv[j];
       acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
       if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = acc;
@@ -554,18 +575,23 @@ int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const 
                         const float* ax, int Fa, float* part1) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
+  const bool small = tiles <= DG_SMALL_GRID_TILES;
+#define DG_BWD32_LAUNCH(FI, AFV, D, LDS, FF, AX, FA, P1)                                                                 \
+  hipLaunchKernelGGL((k_gcn_bwd32<FI, AFV, D>), dim3(P32), dim3(DG_TILE_THREADS), LDS, s, N, FF, tiles, rowptr_t, colidx_t, \
+                     dinv, gas, Wl, xprev, gpprev, gas_prev, part, AX, FA, P1)
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
-    hipLaunchKernelGGL((k_gcn_bwd32<true, false>), dim3(P32), dim3(DG_TILE_THREADS), sizeof(float) * DG_TILE * F, s, N,
-                       F, tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, nullptr, 0, nullptr);
+    if (small) DG_BWD32_LAUNCH(true, false, DG_DEPTH_SMALL, sizeof(float) * DG_TILE * F, F, nullptr, 0, nullptr);
+    else DG_BWD32_LAUNCH(true, false, DG_DEPTH_BWD_BIG, sizeof(float) * DG_TILE * F, F, nullptr, 0, nullptr);
   } else if (ax) {     // conv2 backward carrying conv1's weight gradient (aggregate-first conv1)
     if (Fa < 1 || Fa > DG_AF_MAX_F || !part1) return DGCNN_EINVAL;
-    hipLaunchKernelGGL((k_gcn_bwd32<false, true>), dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t,
-                       colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, ax, Fa, part1);
+    if (small) DG_BWD32_LAUNCH(false, true, DG_DEPTH_SMALL, 0, 32, ax, Fa, part1);
+    else DG_BWD32_LAUNCH(false, true, DG_DEPTH_BWD_BIG, 0, 32, ax, Fa, part1);
   } else {
-    hipLaunchKernelGGL((k_gcn_bwd32<false, false>), dim3(P32), dim3(DG_TILE_THREADS), 0, s, N, 32, tiles, rowptr_t,
-                       colidx_t, dinv, gas, Wl, xprev, gpprev, gas_prev, part, nullptr, 0, nullptr);
+    if (small) DG_BWD32_LAUNCH(false, false, DG_DEPTH_SMALL, 0, 32, nullptr, 0, nullptr);
+    else DG_BWD32_LAUNCH(false, false, DG_DEPTH_BWD_BIG, 0, 32, nullptr, 0, nullptr);
   }
+#undef DG_BWD32_LAUNCH
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

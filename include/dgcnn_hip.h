@@ -63,7 +63,8 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
 #define DGCNN_FLAG_FORCE_TILED 4    /* never use it */
 #define DGCNN_FLAG_PREPARED    8    /* dgcnn_model_forward: the workspace already holds this batch's graph structure
                                        (dgcnn_model_prepare with the SAME sizes, flags and epoch): skip graph prep */
-#define DGCNN_FUSED_MIN_GRAPHS 192  /* default: fused path only for batches of at least this many graphs */
+#define DGCNN_FUSED_MIN_GRAPHS 4096 /* default: fused path only for batches of at least this many graphs (measured:
+                                       the tiled kernels are faster below, see profiles/r01_sweep.txt) */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
  * duplicates, no self loops, every edge present in both directions -- what a TU dataset file (and
  * PyG coalesce/to_undirected) holds, i.e. what the reference's loader feeds model.py:27.  Graph
