@@ -84,8 +84,8 @@ static inline int dg_grid32(int N) {
   int tiles = dg_cdiv(N, DG_TILE);
   return tiles < 1 ? 1 : (tiles > DG_MAX_PART ? DG_MAX_PART : tiles);
 }
-static inline int dg_grid1(int N) {   // F=1 kernels: 4 waves (256 threads) per workgroup, wave per node
-  int b = dg_cdiv(N, 4);
+static inline int dg_grid1(int N) {   // conv4 backward: 16 waves (1024 threads) per workgroup, wave per node
+  int b = dg_cdiv(N, 16);
   return b < 1 ? 1 : (b > DG_MAX_PART ? DG_MAX_PART : b);
 }
 

@@ -361,24 +361,26 @@ int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, cons
 //   partials: dW4 += gh4[j] * x3[j]   (32)  ,  db3 += ga3[j]   (32)
 // wave per node; lanes 0..31 = channel.  pa4[P1][64] = per-workgroup partial {dW4, db3}.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
            float* __restrict__ pa4) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & 31;
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
-  for (int j = blockIdx.x * 4 + w; j < N; j += gridDim.x * 4) {
+  for (int j = blockIdx.x * 16 + w; j < N; j += gridDim.x * 16) {
     const int start = rowptr_t[j], end = rowptr_t[j + 1];
-    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
+    // issue everything that does not depend on the gather before it
+    float xv = 0.f, gpv = 0.f;
+    if (lane < 32) { xv = x3[(size_t)j * 32 + c]; gpv = gp3[(size_t)j * 32 + c]; }
     const float dj = dinv[j];
+    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
     const float gh = dj * s;
     if (lane < 32) {
-      const float xv = x3[(size_t)j * 32 + c];
-      const float gx = fmaf(gh, w4c, gp3[(size_t)j * 32 + c]);
+      const float gx = fmaf(gh, w4c, gpv);
       const float ga = gx * (1.f - xv * xv);
       gas3[(size_t)j * 32 + c] = dj * ga;
       pW = fmaf(gh, xv, pW);
@@ -387,9 +389,15 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
   }
   if (lane < 32) { red[w][c] = pW; red[w][32 + c] = pb; }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = v;
+  if (threadIdx.x < 64) {     // fixed-order tree over the 16 waves
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = red[u][threadIdx.x];
+#pragma unroll
+    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+      for (int u = 0; u < st; ++u) v[u] += v[u + st];
+    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = v[0];
   }
 }
 
@@ -397,7 +405,7 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
                        float* gas3, float* pa4, int P1, hipStream_t s) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
+  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
                      pa4);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

@@ -383,7 +383,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
 // reductions (bias sums over B*30 terms, per-workgroup partials) are no longer serial chains.
 // ---------------------------------------------------------------------------------------------
 enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC, WG_FC1W_MFMA,
-       WG_REDUCE_CHUNK, WG_FC1W_MFMA_CHUNK };
+       WG_REDUCE_CHUNK, WG_FC1W_MFMA_CHUNK, WG_REDUCE_COL };
 #define WG_MAX_SEG 20
 struct WgSeg {
   int type;
@@ -499,6 +499,49 @@ k_wgrad(WgArgs A) {
     }
     return;
   }
+  if (sg.type == WG_REDUCE_COL) {
+    // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS (every load instruction reads 256 contiguous bytes
+    // of one partial row), rows dealt round-robin to the 4 waves, up to 64 loads in flight per lane, then a
+    // fixed-order combine through LDS.  Lanes-along-rows (WG_REDUCE) touches one 128-B line per 16 useful bytes.
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - sg.block0) * 64 + lane;
+    const bool live = c < sg.count;
+    const bool owner = live && w == 0;
+    float pm = 0.f, pv = 0.f, pp = 0.f;
+    const size_t k = (size_t)(sg.out - A.grads_base) + (live ? c : 0);
+    if (owner && A.adam_p) { pm = A.adam_m[k]; pv = A.adam_v[k]; pp = A.adam_p[k]; }   // optimizer state: same round trip
+    const float* sp = sg.src + (live ? c : 0);
+    const int R = sg.R, stride = sg.stride;
+    float acc = 0.f;
+    for (int rb = w; rb < R; rb += 4 * 64) {
+      float a[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        const int r = rb + 4 * u;
+        a[u] = (live && r < R) ? sp[(size_t)r * stride] : 0.f;
+      }
+#pragma unroll
+      for (int st = 32; st >= 1; st >>= 1)
+#pragma unroll
+        for (int u = 0; u < st; ++u) a[u] += a[u + st];
+      acc += a[0];
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (owner) {
+      const float g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      sg.out[c] = g;
+      if (A.adam_p) {
+        const float mi = A.b1 * pm + (1.f - A.b1) * g;
+        const float vi = A.b2 * pv + (1.f - A.b2) * g * g;
+        A.adam_m[k] = mi; A.adam_v[k] = vi;
+        const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+        A.adam_p[k] = pp - (A.lr / A.bc1) * (mi / denom);
+      }
+    }
+    return;
+  }
   const int gid = ((int)blockIdx.x - sg.block0) * 256 + threadIdx.x;
   const int lpo = sg.lpo;
   const int i = gid / lpo, r0 = gid - i * lpo;
@@ -555,6 +598,12 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     g.type = type; g.count = count; g.lpo = lpo; g.R = R; g.block0 = nb; g.stride = stride; g.src = src; g.out = out;
     nb += dg_cdiv(count * lpo, 256);
   };
+  auto add_col = [&](int count, int R, float* out, const float* src, int stride) {   // column-coalesced reduction
+    WgSeg& g = A.seg[ns++];
+    g.type = WG_REDUCE_COL; g.count = count; g.lpo = 1; g.R = R; g.block0 = nb; g.stride = stride; g.aux = 0;
+    g.src = src; g.out = out;
+    nb += dg_cdiv(count, 64);
+  };
   auto add_tiles = [&](int type, int tiles, float* out) {     // one wave per tile, 4 tiles per workgroup
     WgSeg& g = A.seg[ns++];
     g.type = type; g.count = tiles; g.lpo = 64; g.R = B; g.block0 = nb; g.stride = 0; g.src = nullptr; g.out = out;
@@ -566,14 +615,13 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     const float* pb2 = dg_cptr<float>(ws, wl->pb2);
     const float* pb3 = dg_cptr<float>(ws, wl->pb3);
     const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-    const int lp = 16;
-    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[5], pa4 + 32, 64);               // db3 (from conv4 backward)
-    add(WG_REDUCE, 32, 64, wl->P1, grads + pl->off[6], pa4, 64);                    // dW4
-    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[2], pb2, 1056);               // dW2
-    add(WG_REDUCE, 1024, lp, wl->P32, grads + pl->off[4], pb3, 1056);               // dW3
-    add(WG_REDUCE, 32 * F, lp, wl->P32, grads + pl->off[0], pb1, 32 * F);           // dW1
-    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);          // db1 (from layer-2 backward)
-    add(WG_REDUCE, 32, 64, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);          // db2 (from layer-3 backward)
+    add_col(32, wl->P1, grads + pl->off[5], pa4 + 32, 64);                          // db3 (from conv4 backward)
+    add_col(32, wl->P1, grads + pl->off[6], pa4, 64);                               // dW4
+    add_col(1024, wl->P32, grads + pl->off[2], pb2, 1056);                          // dW2
+    add_col(1024, wl->P32, grads + pl->off[4], pb3, 1056);                          // dW3
+    add_col(32 * F, wl->P32, grads + pl->off[0], pb1, 32 * F);                      // dW1
+    add_col(32, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);                     // db1 (from layer-2 backward)
+    add_col(32, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);                     // db2 (from layer-3 backward)
     add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
   }
   if (which & 1) {
@@ -602,18 +650,17 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S);
       DG_CHECK_LAUNCH();
       pt = t1; Rt = nch;
-      add(WG_REDUCE, DGCNN_HID1 * DGCNN_FLAT, 1, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
+      add_col(DGCNN_HID1 * DGCNN_FLAT, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
     } else {
       add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                         // classifier_1 weight: MFMA GEMM
     }
     // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum the partials per element
-    const int lpr = Rt <= 128 ? 8 : 1;
-    add(WG_REDUCE, DGCNN_C5 * DGCNN_CAT, lpr, Rt, grads + pl->off[8], pt + DG_PT_W5, st);
-    add(WG_REDUCE, DGCNN_C5, 64, Rt, grads + pl->off[9], pt + DG_PT_B5, st);
-    add(WG_REDUCE, DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, lpr, Rt, grads + pl->off[10], pt + DG_PT_W6, st);
-    add(WG_REDUCE, DGCNN_C6, 64, Rt, grads + pl->off[11], pt + DG_PT_B6, st);
-    add(WG_REDUCE, C * DGCNN_HID1, lpr, Rt, grads + pl->off[14], pt + DG_PT_WF2, st);
-    add(WG_REDUCE, C, 64, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
+    add_col(DGCNN_C5 * DGCNN_CAT, Rt, grads + pl->off[8], pt + DG_PT_W5, st);
+    add_col(DGCNN_C5, Rt, grads + pl->off[9], pt + DG_PT_B5, st);
+    add_col(DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, Rt, grads + pl->off[10], pt + DG_PT_W6, st);
+    add_col(DGCNN_C6, Rt, grads + pl->off[11], pt + DG_PT_B6, st);
+    add_col(C * DGCNN_HID1, Rt, grads + pl->off[14], pt + DG_PT_WF2, st);
+    add_col(C, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
     add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
     if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
   }
@@ -624,7 +671,8 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     for (int k = 0; k < ns; ++k) {
       WgArgs One = A;
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
-      const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256);
+      const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4)
+                     : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 64) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
       hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One);
     }
     DG_CHECK_LAUNCH();
