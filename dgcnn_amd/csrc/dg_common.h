@@ -280,6 +280,29 @@ __device__ void dg_block_bitonic(PTR data, int n) {
     }
   }
 }
+// Cooperative global -> LDS staging of N floats by THREADS threads, split in two steps so that EVERY load is in
+// flight before the first LDS store waits for one: a plain `for (t = tid; t < N; t += THREADS) lds[t] = g[t]` is
+// compiled as load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. one full memory round trip per iteration.
+template <int N, int THREADS>
+struct DgStage {
+  static constexpr int IT = (N + THREADS - 1) / THREADS;
+  float v[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int t = tid + i * THREADS;
+      v[i] = t < N ? src[t] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int t = tid + i * THREADS;
+      if (t < N) dst[t] = v[i];
+    }
+  }
+};
+
 // ---- aggregate-first conv1 (F <= DG_AF_MAX_F) -------------------------------------------------------
 // One wavefront, one destination row.  Lane = (g = lane >> lfp neighbour group, q = lane & (2^lfp - 1) feature):
 // 64 >> lfp neighbours in flight per wave-instruction.  Returns, in every lane with q < F,

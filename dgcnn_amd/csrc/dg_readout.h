@@ -141,25 +141,34 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   else if (tid < 48) bs[tid] = w.b6[tid - 16];
   else if (tid < 176) bs[tid] = w.bf1[tid - 48];
   else if (tid < 176 + C) bs[tid] = w.bf2[tid - 176];
-  const bool early_w = n * 8 <= 11648;
-  if (early_w) {
-    for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-    for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
-  }
+  // conv5 / conv6 weights: loads issued now, held in registers over the sort (the key area may overlap W5s/W6s),
+  // stored to LDS afterwards -- no memory round trip of theirs is left on the critical path
+  DgStage<NW5, RD_THREADS> st5;
+  DgStage<NW6, RD_THREADS> st6;
+  st5.load(w.W5, tid); st6.load(w.W6, tid);
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
-  for (int o = tid; o < KCAT; o += RD_THREADS) {
-    const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
-    const int ln = sel[s];
-    const float v = ln >= 0 ? dg_cat_load(x1, x2, x3, x4, n0 + ln, c) : 0.f;
-    sp[o] = v;
-    pooled[(size_t)b * KCAT + o] = v;
+  {   // SortPooling gather: all row loads in flight, then the LDS / global stores
+    constexpr int IT = (KCAT + RD_THREADS - 1) / RD_THREADS;
+    float gv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int o = tid + i * RD_THREADS;
+      gv[i] = 0.f;
+      if (o < KCAT) {
+        const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
+        const int ln = sel[s];
+        if (ln >= 0) gv[i] = dg_cat_load(x1, x2, x3, x4, n0 + ln, c);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int o = tid + i * RD_THREADS;
+      if (o < KCAT) { sp[o] = gv[i]; pooled[(size_t)b * KCAT + o] = gv[i]; }
+    }
   }
-  if (!early_w) {
-    for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-    for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
-  }
+  st5.store(W5s, tid); st6.store(W6s, tid);
   __syncthreads();
   RD_MARK(9);
   // classifier_1's weights (180 KB, rewritten by the optimizer every step, so never cache-warm) are this

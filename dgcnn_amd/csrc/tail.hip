@@ -146,7 +146,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   __shared__ float W6s[NW6];
   __shared__ float dl[DGCNN_MAX_C];
   __shared__ float gz1s[DGCNN_HID1];
-  __shared__ float gfh[2][DGCNN_FLAT];
+  __shared__ __attribute__((aligned(16))) float gfh[8][DGCNN_FLAT];
   __shared__ float gz6s[DGCNN_FLAT];
   __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
   __shared__ float gp5q[4][DGCNN_C5 * DGCNN_T5];
@@ -157,9 +157,10 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
   // ---- every small global load of steps 0-2 first (VMEM loads complete in order) ----
-  for (int t = tid; t < NW5; t += RD_THREADS) W5s[t] = w.W5[t];
-  for (int t = tid; t < NW6; t += RD_THREADS) W6s[t] = w.W6[t];
-  for (int t = tid; t < KCAT; t += RD_THREADS) sps[t] = pooled[(size_t)blockIdx.x * KCAT + t];
+  DgStage<NW5, RD_THREADS> st5;
+  DgStage<NW6, RD_THREADS> st6;
+  DgStage<KCAT, RD_THREADS> stp;
+  st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)blockIdx.x * KCAT, tid);
   float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
   int yb_ = 0;
   if (wv == 0) {
@@ -178,13 +179,16 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
   // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only
   // LDS-only barriers and no further global load, so they land while steps 1-2 run. ----
-  float wpre[64];
+  // 704 threads = 8 row groups (16 rows each) x 88 column quads: 16 x 16-byte loads per thread (one quarter of the
+  // vector-memory instructions a dword-per-lane mapping needs for the same 180 KB)
+  float4 wpre[16];
   if (tid < 2 * DGCNN_FLAT) {
-    const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
-    const float* wc = w.Wf1 + (size_t)(h * 64) * DGCNN_FLAT + m;
+    const int rg = tid / 88, mq = tid - rg * 88;
+    const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) wpre[j] = wc[(size_t)j * DGCNN_FLAT];
+    for (int j = 0; j < 16; ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
   }
+  st5.store(W5s, tid); st6.store(W6s, tid); stp.store(sps, tid);     // (waits only for the small loads above)
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
   for (int t = tid; t < n * 32; t += RD_THREADS) {
     gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
@@ -238,20 +242,20 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads); the
   //    weights were prefetched into registers at kernel start
   if (tid < 2 * DGCNN_FLAT) {
-    const int h = tid / DGCNN_FLAT, m = tid - h * DGCNN_FLAT;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    const int rg = tid / 88, mq = tid - rg * 88;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 64; j += 4) {
-      g0 = fmaf(gz1s[h * 64 + j], wpre[j], g0);
-      g1 = fmaf(gz1s[h * 64 + j + 1], wpre[j + 1], g1);
-      g2 = fmaf(gz1s[h * 64 + j + 2], wpre[j + 2], g2);
-      g3 = fmaf(gz1s[h * 64 + j + 3], wpre[j + 3], g3);
+    for (int j = 0; j < 16; ++j) {
+      const float z = gz1s[rg * 16 + j];
+      g.x = fmaf(z, wpre[j].x, g.x); g.y = fmaf(z, wpre[j].y, g.y);
+      g.z = fmaf(z, wpre[j].z, g.z); g.w = fmaf(z, wpre[j].w, g.w);
     }
-    gfh[h][m] = (g0 + g1) + (g2 + g3);
+    *reinterpret_cast<float4*>(&gfh[rg][4 * mq]) = g;
   }
   __syncthreads();
-  if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6
-    const float gf = gfh[0][tid] + gfh[1][tid];
+  if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
+    const float gf = ((gfh[0][tid] + gfh[1][tid]) + (gfh[2][tid] + gfh[3][tid])) +
+                     ((gfh[4][tid] + gfh[5][tid]) + (gfh[6][tid] + gfh[7][tid]));
     const float g6 = a6g[(size_t)b * DGCNN_FLAT + tid] > 0.f ? gf : 0.f;
     gz6s[tid] = g6;
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
