@@ -196,6 +196,25 @@ class Model(nn.Module):
             self.flatten_parameters()
         return self._flat
 
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.cuda()`` / ``.float()`` replace parameter storage: drop the flat buffer (rebuilt lazily)."""
+        self._flat = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def flat_params_fast(self) -> torch.Tensor:
+        """``flat_params`` for the per-step hot path: instead of checking all 16 parameters (~15 us of Python per
+        call) it probes the first and the last one; ``_apply`` (``.to()`` & co) and ``load_state_dict`` are covered
+        exactly (``_apply`` drops the buffer, ``load_state_dict`` copies in place).  Replacing a single
+        ``param.data`` by hand between steps needs a ``flatten_parameters()`` call."""
+        flat = self._flat
+        if flat is not None:
+            base = flat.data_ptr()
+            offs = self._offsets
+            if self.conv1.lin.weight.data_ptr() == base + 4 * offs[0] and \
+                    self.classifier_2.bias.data_ptr() == base + 4 * offs[15]:
+                return flat
+        return self.flat_params
+
     @property
     def flat_numel(self) -> int:
         if self._offsets is None:

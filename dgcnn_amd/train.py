@@ -54,9 +54,13 @@ class Trainer:
         self._logp = None
         # two workspace slots: the step runs in slot `_cur` while the pipelined step prepares the NEXT batch's graph
         # structure in the other slot on the library's side stream (software pipelining of graph prep across steps)
-        self._slots = [{"ws": None, "bytes": 0}, {"ws": None, "bytes": 0}]
+        self._slots = [{"ws": None, "bytes": 0, "ptr": 0}, {"ws": None, "bytes": 0, "ptr": 0}]
         self._cur = 0
-        self._pipe = None        # dgcnn_pipeline handle (side stream + events), created on first pipelined step
+        self._pipe = None        # dgcnn_pipeline handle, created on first pipelined step
+        self._pipe_fn = None
+        self._p_flat = 0         # cached data_ptr()s of the trainer-lifetime buffers (pipelined step)
+        self._p_grads = self._p_metrics = self._p_m = self._p_v = 0
+        self._logp_views = {}
         self._args_cache = {}    # id(batch) -> (batch, y, StepArgs, ws bytes, keep-alive tensors, dims)
         self._prep_ent = None    # cache entry of the batch whose graph structure the last pipelined call prepared
         self._prep_slot = 0
@@ -75,6 +79,7 @@ class Trainer:
         if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != device:
             sl["ws"] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
             sl["bytes"] = sl["ws"].numel()
+            sl["ptr"] = sl["ws"].data_ptr()
         return sl["ws"]
 
     def _buffers(self, N, E, B, F, C, device):
@@ -141,97 +146,123 @@ class Trainer:
 
     # ---- pipelined step: ONE C-ABI call per batch, next batch's graph prep on the library's side stream ----
     def _step_args(self, data, y):
-        """cached ``dgcnn_step_args`` of a batch object (pointers + sizes are per-batch constants)"""
+        """cached ``dgcnn_step_args`` of a batch object: sizes, input pointers, layout flags and the optimizer's
+        constants are filled ONCE per batch object; a step only touches epoch / seed / step / ws."""
         ent = self._args_cache.get(id(data))
         if ent is not None and ent[0] is data and ent[1] is y:
             return ent
+        m = self.model
         N, E, B, F, C = self._dims(data)
         x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
         yy = y.contiguous()
         a = _lib.StepArgs()
         a.N, a.E, a.B, a.F, a.C = N, E, B, F, C
-        a.max_nodes = self.model._max_nodes_of(data)
+        a.max_nodes = m._max_nodes_of(data)
         a.max_edges = int(getattr(data, "max_edges", 0) or 0)
         a.x, a.edge_index, a.batch, a.y = x.data_ptr(), (ei.data_ptr() if E else None), bt.data_ptr(), yy.data_ptr()
         a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
         need = _lib.workspace_bytes(N, E, B, F, C)
         if len(self._args_cache) >= 1024:
             self._args_cache.clear()
-        ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C))
+        ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C), _lib.ctypes.byref(a), x.device,
+               _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0)
         self._args_cache[id(data)] = ent
         return ent
+
+    def _bind_static(self, a) -> None:
+        """pointers that are constant for this trainer (re-bound only if a buffer was re-allocated)"""
+        a.params, a.grads, a.metrics = self._p_flat, self._p_grads, self._p_metrics
 
     def pipelined_step(self, data, y, next_data=None, next_y=None, global_batch: Optional[int] = None,
                        fuse_adam: bool = True) -> torch.Tensor:
         """``dgcnn_pipeline_train_step``: forward + backward (+ fused Adam) of ``data`` as one call; when
-        ``next_data`` is given its graph structure is prepared concurrently on the library's side stream and the
-        following ``pipelined_step(next_data, ...)`` skips its own preparation.  Bit-identical to ``train_step``."""
-        L = _lib.lib()
+        ``next_data`` is given its graph structure is prepared during this step (extra workgroups on the step's
+        two graph-per-workgroup launches) and the following ``pipelined_step(next_data, ...)`` skips its own
+        preparation.  Bit-identical to ``train_step`` without look-ahead.  The Python side of a step is a dict
+        lookup and a handful of field stores (the host must stay ahead of a ~60 us GPU step)."""
         m = self.model
-        dev = data.x.device
+        ent = self._args_cache.get(id(data))
+        if ent is None or ent[0] is not data or ent[1] is not y:
+            ent = self._step_args(data, y)
+        a, need, dims, aref, dev = ent[2], ent[3], ent[5], ent[6], ent[7]
         if self._pipe is None:
+            L = _lib.lib()
             h = _lib.c_void_p()
             _lib.check(L.dgcnn_pipeline_create(_lib.ctypes.byref(h)), "dgcnn_pipeline_create")
             self._pipe = h
-        _, _, a, need, _, dims = ent = self._step_args(data, y)
-        prepared = self._prep_ent is not None and self._prep_ent[0] is data
+            self._pipe_fn = L.dgcnn_pipeline_train_step
+        flat = m.flat_params_fast()
+        if flat.data_ptr() != self._p_flat:         # model moved / re-flattened: refresh the cached pointers
+            self._p_flat, self._p_grads, self._p_metrics = flat.data_ptr(), self.grads.data_ptr(), self.metrics.data_ptr()
+            self._p_m, self._p_v = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        pe = self._prep_ent
+        prepared = pe is not None and pe[0] is data
         if prepared:
             slot = self._prep_slot               # its workspace was sized when it was handed in as `next`
             m._epoch = a.epoch
         else:
             # (a prepared-but-abandoned batch keeps its slot untouched: use the other one)
-            slot = self._cur if self._prep_ent is None else 1 - self._prep_slot
+            slot = self._cur if pe is None else 1 - self._prep_slot
             a.epoch = m._next_epoch()
         self._prep_ent = None
-        ws = self._slot_ws(slot, need, dev)
+        sl = self._slots[slot]
+        if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
+            self._slot_ws(slot, need, dev)
+        ws = sl["ws"]
         B, C = dims[2], dims[4]
-        if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != dev:
-            self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
-        flat = m.flat_params
+        lp = self._logp
+        if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
+            lp = self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
+            self._logp_views = {}
         training = 1 if m.training else 0
-        a.ws, a.logp, a.params, a.grads, a.metrics = ws.data_ptr(), self._logp.data_ptr(), flat.data_ptr(), \
-            self.grads.data_ptr(), self.metrics.data_ptr()
+        a.ws, a.logp, a.params, a.grads, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_grads, self._p_metrics
         a.training = training
         a.seed = m._next_seed() if training else 0
-        a.flags = m._flags_of(data) | (_lib.FLAG_PREPARED if prepared else 0)
+        uf = getattr(m, "use_fused", None)
+        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | \
+            (0 if uf is None else (_lib.FLAG_FORCE_FUSED if uf else _lib.FLAG_FORCE_TILED))
         a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam:
             self.step_count += 1
             a.step = self.step_count
-            a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+            a.exp_avg, a.exp_avg_sq = self._p_m, self._p_v
         else:
             a.exp_avg = a.exp_avg_sq = None
         nref = None
         if next_data is not None and next_data is not data:
-            nent = self._step_args(next_data, next_y if next_y is not None else next_data.y)
+            ny = next_y if next_y is not None else next_data.y
+            nent = self._args_cache.get(id(next_data))
+            if nent is None or nent[0] is not next_data or nent[1] is not ny:
+                nent = self._step_args(next_data, ny)
             na = nent[2]
-            nws = self._slot_ws(1 - slot, nent[3], dev)
-            na.ws, na.flags, na.epoch = nws.data_ptr(), m._flags_of(next_data), m._next_epoch()
-            nref = _lib.ctypes.byref(na)
+            nsl = self._slots[1 - slot]
+            if nsl["ws"] is None or nent[3] > nsl["bytes"] or nsl["ws"].device != dev:
+                self._slot_ws(1 - slot, nent[3], dev)
+            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8], m._next_epoch()
+            nref = nent[6]
             self._prep_ent, self._prep_slot = nent, 1 - slot
-        self._cur = 1 - slot if nref is not None else slot
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.dgcnn_pipeline_train_step(self._pipe, _lib.ctypes.byref(a), nref, stream),
-                   "dgcnn_pipeline_train_step")
+            self._cur = 1 - slot
+        else:
+            self._cur = slot
+        rc = self._pipe_fn(self._pipe, aref, nref, torch._C._cuda_getCurrentRawStream(dev.index))
+        if rc != 0:
+            _lib.check(rc, "dgcnn_pipeline_train_step")
         self._ws = ws
         m._last_ws, m._last_dims = ws, dims
-        return self._logp[:B]
+        v = self._logp_views.get(B)
+        if v is None:
+            v = self._logp_views[B] = lp[:B]
+        return v
 
     def train_step(self, data, y, global_batch: Optional[int] = None, next_data=None) -> torch.Tensor:
-        """One iteration of the body of the reference ``train()`` loop (train.py:36-45).  ``next_data``: the batch the
-        NEXT call will be given (optional) -- its graph preparation then overlaps this step."""
-        if next_data is not None or self._prep_ent is not None:
-            if self._allreduce is None:
-                return self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=True)
-            logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
-            self._allreduce(self.grads)
-            self.optimizer_step()
-            return logp
+        """One iteration of the body of the reference ``train()`` loop (train.py:36-45), one C-ABI call.
+        ``next_data``: the batch the NEXT call will be given (optional) -- its graph preparation then overlaps
+        this step.  Data parallel: forward+backward, ONE flat-bucket RCCL all-reduce (dgcnn_amd/dist.py), Adam."""
         if self._allreduce is None:
             # single GPU: optimizer fused into the weight-gradient kernel (no separate Adam launch)
-            return self.forward_backward(data, y, global_batch, fuse_adam=True)
-        logp = self.forward_backward(data, y, global_batch)
-        self._allreduce(self.grads)              # ONE flat-bucket RCCL all-reduce per step (dgcnn_amd/dist.py)
+            return self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=True)
+        logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
+        self._allreduce(self.grads)
         self.optimizer_step()
         return logp
 

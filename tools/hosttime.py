@@ -22,3 +22,22 @@ for pf in (False, True):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"pipelined={pf}: host enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
+
+# pure C-side enqueue cost of one pipelined step (same argument block re-submitted; results are not meaningful)
+import ctypes
+from dgcnn_amd import _lib
+L = _lib.lib()
+b = batches[0]
+ent = tr._step_args(b, b.y)
+a = ent[2]
+a.flags &= ~_lib.FLAG_PREPARED
+stream = torch.cuda.current_stream().cuda_stream
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(K):
+    a.epoch = (i % 1000) + 1
+    L.dgcnn_pipeline_train_step(tr._pipe, ctypes.byref(a), None, stream)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"C call only (unpipelined, 12 launches): host {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
