@@ -162,8 +162,8 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
     if (i < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
+      const float di = dinv[i];                       // issued before the gather, consumed after it
       const float4 acc = dg_gather_row32<DEPTH>(hs, colidx, start, end, i, lane);
-      const float di = dinv[i];
       float4 val;
       val.x = dg_tanh(fmaf(di, acc.x, b4.x));
       val.y = dg_tanh(fmaf(di, acc.y, b4.y));
@@ -271,8 +271,8 @@ k_gcn_fwd_af(int N, int F, int lfp, int numTiles, const int* __restrict__ rowptr
     if (i < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
-      const float acc = dg_af_gather<false>(x, dinv, F, lfp, colidx, start, end, i, lane);
       di = dinv[i];
+      const float acc = dg_af_gather<false>(x, dinv, F, lfp, colidx, start, end, i, lane);
       ax = di * acc;
       if (lane < F) axout[(size_t)i * F + lane] = ax;
     }
@@ -325,8 +325,19 @@ int dg_launch_gcn_fwd_af(int N, int F, const int32_t* rowptr, const int32_t* col
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dg_gather_row1(const float* __restrict__ src, const int* __restrict__ col,
                                                 int start, int end, int lane) {
+  // 128 neighbours per round: both index loads, then both value loads, in flight together; the per-lane order of
+  // the additions (e, e+64, e+128, ...) is that of the plain loop
   float s = 0.f;
-  for (int e = start + lane; e < end; e += 64) s += src[col[e]];
+  for (int base = start + lane; base < end; base += 128) {
+    const int e1 = base + 64;
+    const bool h1 = e1 < end;
+    const int c0 = col[base];
+    const int c1 = h1 ? col[e1] : 0;
+    const float v0 = src[c0];
+    const float v1 = h1 ? src[c1] : 0.f;
+    s += v0;
+    if (h1) s += v1;
+  }
   return dg_wave_sum(s);
 }
 
@@ -338,8 +349,9 @@ k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx
   const float b = bias[0];
   for (int i = blockIdx.x * 4 + w; i < N; i += gridDim.x * 4) {
     const int start = rowptr[i], end = rowptr[i + 1];
-    const float s = dg_gather_row1(h4s, colidx, start, end, lane) + h4s[i];
-    if (lane == 0) x4[i] = dg_tanh(fmaf(dinv[i], s, b));
+    const float hself = h4s[i], di = dinv[i];          // issued before the gather, not after it
+    const float s = dg_gather_row1(h4s, colidx, start, end, lane) + hself;
+    if (lane == 0) x4[i] = dg_tanh(fmaf(di, s, b));
   }
 }
 
@@ -376,8 +388,8 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
     // issue everything that does not depend on the gather before it
     float xv = 0.f, gpv = 0.f;
     if (lane < 32) { xv = x3[(size_t)j * 32 + c]; gpv = gp3[(size_t)j * 32 + c]; }
-    const float dj = dinv[j];
-    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gas4[j];
+    const float dj = dinv[j], gself = gas4[j];
+    const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gself;
     const float gh = dj * s;
     if (lane < 32) {
       const float gx = fmaf(gh, w4c, gpv);
@@ -463,22 +475,37 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     if (j < N) {
       const int start = __builtin_amdgcn_readfirstlane(rowptr_t[j]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr_t[j + 1]);
-      float4 acc = dg_gather_row32<DEPTH>(gas, colidx_t, start, end, j, lane);
+      // everything that does not depend on the gather is loaded before it
       const float dj = dinv[j];
+      float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!FIRST && g == 1) xrow = *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
+      float axv = 0.f;
+      if (AF && lane < Fa) axv = axin[(size_t)j * Fa + lane];
+      float4 acc = dg_gather_row32<DEPTH>(gas, colidx_t, start, end, j, lane);
       acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
       if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = acc;
-      if (!FIRST && g == 1)
-        *reinterpret_cast<float4*>(&xt[wave][4 * q]) =
-            *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
+      if (!FIRST && g == 1) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = xrow;
       if (FIRST)
         for (int k = lane; k < F; k += 64) xs[wave * F + k] = xprev[(size_t)j * F + k];
-      if (AF && lane < Fa) axs[wave * Fa + lane] = axin[(size_t)j * Fa + lane];
+      if (AF && lane < Fa) axs[wave * Fa + lane] = axv;
     } else {
       if (AF && lane < Fa) axs[wave * Fa + lane] = 0.f;
       if (g == 0) *reinterpret_cast<float4*>(&ght[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!FIRST && g == 1) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
       if (FIRST)
         for (int k = lane; k < F; k += 64) xs[wave * F + k] = 0.f;
+    }
+    // operands of the MFMA epilogue (SortPooling gradient rows, dst scales): loads issued before the barrier
+    float gpp[4] = {0.f, 0.f, 0.f, 0.f}, dnn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!FIRST && wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+        if (node < N) {
+          gpp[r] = gpprev[(size_t)node * 32 + wave * 16 + (lane & 15)];
+          dnn[r] = dinv[node];
+        }
+      }
     }
     __syncthreads();
     if (FIRST) {
@@ -511,9 +538,9 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
           float ga = 0.f;
           if (node < N) {
             const float xv = xt[row][c];
-            const float gx = d[r] + gpprev[(size_t)node * 32 + c];
+            const float gx = d[r] + gpp[r];
             ga = gx * (1.f - xv * xv);
-            if (!AF) gas_prev[(size_t)node * 32 + c] = dinv[node] * ga;   // AF: conv1 needs no propagated gradient
+            if (!AF) gas_prev[(size_t)node * 32 + c] = dnn[r] * ga;       // AF: conv1 needs no propagated gradient
             pb += ga;
           }
           if (AF) gat[row][c] = ga;
