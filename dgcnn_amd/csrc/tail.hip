@@ -152,6 +152,8 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   __shared__ float gp5q[4][DGCNN_C5 * DGCNN_T5];
   __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
   __shared__ float ga4s[DGCNN_K];
+  __shared__ int selS[DGCNN_K];
+  __shared__ float x4S[DGCNN_K], dvS[DGCNN_K];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
@@ -168,6 +170,16 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     if (glogp) g_ = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
     else yb_ = (int)y[b];
   }
+  // operands of the later steps that live in global memory: loaded NOW (their round trips overlap steps 1-2)
+  float a6_ = 0.f, a5a_ = 0.f, a5b_ = 0.f;
+  if (tid < DGCNN_FLAT) a6_ = a6g[(size_t)b * DGCNN_FLAT + tid];                       // step 3: ReLU mask of conv6
+  if (tid < DGCNN_C5 * DGCNN_T5) {                                                     // step 5: MaxPool argmax
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+    const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
+    a5a_ = a5g[base]; a5b_ = a5g[base + 1];
+  }
+  int node_ = -1;                                                                      // step 6: scatter targets
+  if (tid >= 64 && tid < 64 + DGCNN_K) node_ = perm[b * DGCNN_K + (tid - 64)];
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
 #pragma unroll
   for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
@@ -218,6 +230,8 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   }
   dg_lds_barrier();
   TB_MARK(1);
+  float x4n_ = 0.f, dvn_ = 0.f;             // conv4 output / dst scale of the selected nodes (wave 1; used in step 6)
+  if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
   // 2. through classifier_2, dropout, ReLU
   if (tid < DGCNN_HID1) {
     float ga = 0.f;
@@ -256,7 +270,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
     const float gf = ((gfh[0][tid] + gfh[1][tid]) + (gfh[2][tid] + gfh[3][tid])) +
                      ((gfh[4][tid] + gfh[5][tid]) + (gfh[6][tid] + gfh[7][tid]));
-    const float g6 = a6g[(size_t)b * DGCNN_FLAT + tid] > 0.f ? gf : 0.f;
+    const float g6 = a6_ > 0.f ? gf : 0.f;
     gz6s[tid] = g6;
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
@@ -284,7 +298,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
-    const float a0 = a5g[base], a1 = a5g[base + 1];
+    const float a0 = a5a_, a1 = a5b_;
     p5s[tid] = fmaxf(a0, a1);                      // MaxPool1d output, needed for conv6's weight gradient
     const float gp = gp5[tid];
     const bool first = !(a1 > a0);
@@ -295,6 +309,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gz5g[base] = g0;
     gz5g[base + 1] = g1;
   }
+  if (tid >= 64 && tid < 64 + DGCNN_K) { selS[tid - 64] = node_; x4S[tid - 64] = x4n_; dvS[tid - 64] = dvn_; }
   __syncthreads();
   TB_MARK(5);
   // 5b. per-graph partial weight gradients of conv6 and conv5 (everything they need is in LDS / this graph's
@@ -341,14 +356,14 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
         [&](int oc, int c) { return c < DGCNN_CAT ? W5s[oc * DGCNN_CAT + c] : 0.f; },
         [&](int sl, int c, float v) {
           if (sl < msel && c < DGCNN_CAT) {
-            const int node = perm[b * DGCNN_K + sl];
+            const int node = selS[sl];
             if (c < 32) gp1[(size_t)node * 32 + c] = v;
             else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
             else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
             else {
-              const float xv = x4[node];
+              const float xv = x4S[sl];
               const float ga = v * (1.f - xv * xv);      // tanh'
-              gas4[node] = dinv[node] * ga;
+              gas4[node] = dvS[sl] * ga;
               ga4s[sl] = ga;
             }
           }
@@ -464,6 +479,17 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
   const int rb = tile / 22, cb = tile - rb * 22;
   const int jr = rb * 16 + (lane & 15), mc = cb * 16 + (lane & 15), kq = lane >> 4;
   f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  // optimizer state of the 4 elements this lane owns: same memory round trip as the operands
+  float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool adam = !pout && A.adam_p;
+  const size_t kbase_ = (size_t)(sg.out - A.grads_base);
+  if (adam) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t k = kbase_ + (size_t)(rb * 16 + kq * 4 + r) * DGCNN_FLAT + cb * 16 + (lane & 15);
+      pm[r] = A.adam_m[k]; pv[r] = A.adam_v[k]; pp[r] = A.adam_p[k];
+    }
+  }
   for (int k0 = kbeg; k0 < B; k0 += 32) {       // 8 MFMAs (32 graphs) per round: 16 loads in flight per lane
     float av[8], bv[8];
 #pragma unroll
@@ -480,7 +506,16 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
   for (int r = 0; r < 4; ++r) {
     const int j = rb * 16 + kq * 4 + r, m = cb * 16 + (lane & 15);
     if (pout) pout[j * DGCNN_FLAT + m] = d[r];
-    else dg_wg_store(A, sg, j * DGCNN_FLAT + m, d[r]);
+    else if (adam) {
+      const size_t k = kbase_ + (size_t)j * DGCNN_FLAT + m;
+      const float g = d[r];
+      sg.out[j * DGCNN_FLAT + m] = g;
+      const float mi = A.b1 * pm[r] + (1.f - A.b1) * g;
+      const float vi = A.b2 * pv[r] + (1.f - A.b2) * g * g;
+      A.adam_m[k] = mi; A.adam_v[k] = vi;
+      const float denom = sqrtf(vi) / A.bc2_sqrt + A.eps;
+      A.adam_p[k] = pp[r] - (A.lr / A.bc1) * (mi / denom);
+    } else dg_wg_store(A, sg, j * DGCNN_FLAT + m, d[r]);
   }
 }
 
