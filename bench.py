@@ -216,7 +216,7 @@ def main():
         pairs = []
         ms = ctypes.c_float()
         b0 = batches_cpu[0]
-        fused = (args.path == "fused" or (args.path == "auto" and B >= 4096)) and \
+        fused = (args.path == "fused" or (args.path == "auto" and B >= (1 << 30))) and \
             bool(L.dgcnn_fused_fits(max(b.max_nodes for b in batches_cpu), max(b.max_edges for b in batches_cpu), F))
         nprof = min(args.steps, 300)
         for i in range(nprof):

@@ -63,8 +63,8 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
 #define DGCNN_FLAG_FORCE_TILED 4    /* never use it */
 #define DGCNN_FLAG_PREPARED    8    /* dgcnn_model_forward: the workspace already holds this batch's graph structure
                                        (dgcnn_model_prepare with the SAME sizes, flags and epoch): skip graph prep */
-#define DGCNN_FUSED_MIN_GRAPHS 4096 /* default: fused path only for batches of at least this many graphs (measured:
-                                       the tiled kernels are faster below, see profiles/r01_sweep.txt) */
+#define DGCNN_FUSED_MIN_GRAPHS (1 << 30) /* the fused path is never chosen automatically: the tiled kernels measured
+                                            faster at every batch size (profiles/r01_sweep.txt); FORCE_FUSED selects it */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
  * duplicates, no self loops, every edge present in both directions -- what a TU dataset file (and
  * PyG coalesce/to_undirected) holds, i.e. what the reference's loader feeds model.py:27.  Graph
@@ -159,11 +159,12 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *            from `seed` (mask is exported in the workspace region "drop_mask" [B,128] u8)
  *   flags  : 0 or DGCNN_FLAG_COALESCED_UNDIRECTED
  *   max_nodes: host-known upper bound of the node count of any single graph of the batch
- *            (PyG's collate knows it; 0 = unknown).  With max_nodes/max_edges given, a batch of at least
- *            DGCNN_FUSED_MIN_GRAPHS graphs whose largest graph fits the LDS plan runs the
+ *            (PyG's collate knows it; 0 = unknown).  With max_nodes/max_edges given and
+ *            DGCNN_FLAG_FORCE_FUSED, a batch whose largest graph fits the LDS plan runs the
  *            graph-per-workgroup fused kernel (whole forward in one launch, activations and adjacency
- *            in LDS); otherwise the tiled kernels.  Both give bit-identical results.  A hint
- *            that is too small is detected on the device and reported through the error words.
+ *            in LDS); otherwise the tiled kernels (measured faster at every batch size, hence the default).
+ *            Both give bit-identical results.  A hint that is too small is detected on the device and
+ *            reported through the error words.
  *   max_edges: host-known upper bound of the directed-edge count of any single graph (0 = unknown);
  *            lets the fused kernel also keep each graph's neighbour ids in LDS when they fit.
  *   epoch  : non-zero tag of this call.  Input errors are reported WITHOUT any host sync or

@@ -76,8 +76,8 @@ def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
 
 @pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 700), ("PROTEINS", 260)])
 def test_large_batch_two_stage_weight_gradients(name, bs):
-    """B > 128 switches the weight-gradient reduction to two stages (chunk partials, then the final sum) and, from
-    192 graphs, the forward to the graph-per-workgroup kernel: same parity bar as the reference-sized batches."""
+    """B > 128 switches the weight-gradient reduction to two stages (chunk partials, then the final sum), and large
+    grids use the shallower gather depth: same parity bar as the reference-sized batches."""
     sh = synth.SHAPES[name]
     b = synth.make_batch(name, bs, start=300)
     m = make_model(sh.num_features, sh.num_classes)
