@@ -297,6 +297,32 @@ def test_pipelined_step_gives_identical_training():
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
 
 
+def test_pipelined_step_without_rider_fast_path_prepares_in_stream():
+    """general edge lists (no coalesced_undirected promise) and edge-less batches cannot ride; the next batch is then
+    prepared in-stream after the step -- same results as the unpipelined calls."""
+    from dgcnn_amd.batch import Batch
+    from dgcnn_amd.train import Trainer
+    base = [b for b in synth.make_batches("MUTAG", 40, 10, start=50)]
+    general = []
+    for b in base:
+        perm = torch.randperm(b.edge_index.shape[1], generator=torch.Generator().manual_seed(1))
+        general.append(Batch(b.x, b.edge_index[:, perm], b.batch, b.y, b.num_graphs, False, b.max_nodes, b.max_edges))
+    noedge = Batch(base[0].x, torch.zeros(2, 0, dtype=torch.int64), base[0].batch, base[0].y, base[0].num_graphs)
+    seq = [g.to("cuda") for g in general] + [noedge.to("cuda")]
+    outs = []
+    for look in (False, True):
+        m = make_model(8, 2)
+        m.train(); m._seed_base, m._fwd_count = 9, 0
+        tr = Trainer(m)
+        for it in range(10):
+            b = seq[it % len(seq)]
+            tr.train_step(b, b.y, next_data=seq[(it + 1) % len(seq)] if look else None)
+        torch.cuda.synchronize()
+        m.check_errors()
+        outs.append(m.flat_params.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_pipelined_step_data_parallel_route_matches_fused_adam():
     """exp_avg == NULL selects forward+backward only (DP: all-reduce, then dgcnn_adam_step): same update."""
     from dgcnn_amd.train import Trainer
