@@ -437,8 +437,9 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
 //
 // AF = true (layer 2 when conv1 ran aggregate-first): additionally dW_1 += ga_1^T . ax  with ax = A_hat X [N,Fa]
 // saved by k_gcn_fwd_af -- conv1's whole backward, no gather needed.  part1[P][32*Fa] in W1's own layout.
+// large grids (DEPTH <= 4): cap the registers at 64 so that TWO 1024-thread workgroups fit a CU (8 waves per SIMD)
 template <bool FIRST, bool AF, int DEPTH>
-__global__ void __launch_bounds__(DG_TILE_THREADS)
+__global__ void __launch_bounds__(DG_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(DEPTH <= 4 ? 8 : 4)))
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
