@@ -121,17 +121,19 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 
 #define DG_TRY(expr) do { const int rc__ = (expr); if (rc__ != DGCNN_OK) return rc__; } while (0)
 
-int dgcnn_model_prepare(int N, int E, int B, int F, int C, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream) {
+int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
+                        const int64_t* batch, void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream) {
   if (!batch || !ws || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
+  if (F <= DG_AF_MAX_F && !x) return DGCNN_EINVAL;       // the pre-scaled features are part of the preparation
   DgWs wl;
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
+  DgLinFirst lf; lf.x = x; lf.W = nullptr; lf.hs = dg_ptr<float>(ws, wl.hsA); lf.F = F;
   return dg_launch_prep(edge_index, E, batch, N, B, dg_ptr<int32_t>(ws, wl.rowptr), dg_ptr<int32_t>(ws, wl.colidx),
                         dg_ptr<int32_t>(ws, wl.rowptr_t), dg_ptr<int32_t>(ws, wl.colidx_t), dg_ptr<float>(ws, wl.dinv),
                         dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out), dg_ptr<int32_t>(ws, wl.err),
-                        flags, epoch, (hipStream_t)stream, nullptr, nullptr);
+                        flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr);
 }
 
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
@@ -162,9 +164,9 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) ||
                           (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
   const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
-  DgLinFirst lf; lf.x = x; lf.W = params + pl.off[0]; lf.hs = hsA; lf.F = F;
-  const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: no stand-alone linear at all
-  const bool use_lf = !fused && !af;   // wide raw features: conv1's linear rides on the second prep launch
+  const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: prep leaves xs = dinv*x in hsA, no linear at all
+  DgLinFirst lf; lf.x = x; lf.W = af ? nullptr : params + pl.off[0]; lf.hs = hsA; lf.F = F;
+  const bool use_lf = !fused || af;    // wide raw features: conv1's linear rides on the second prep launch
   int lin_done = 0;
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   if (!(flags & DGCNN_FLAG_PREPARED))
@@ -188,7 +190,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   if (af) {
-    DG_TRY(dg_launch_gcn_fwd_af(N, F, rowptr, colidx, dinv, x, params + pl.off[0], params + pl.off[1],
+    DG_TRY(dg_launch_gcn_fwd_af(N, F, rowptr, colidx, dinv, hsA, params + pl.off[0], params + pl.off[1],
                                 dg_ptr<float>(ws, wl.ax), x1, params + pl.off[2], hsB, s, DG_PROF_A(0), DG_PROF_B(0)));
   } else {
     if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
@@ -320,8 +322,8 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
       cur->B <= 0 || cur->E < 0 || cur->epoch == 0)
     return DGCNN_EINVAL;
   if (cur->exp_avg && (!cur->exp_avg_sq || cur->step < 1)) return DGCNN_EINVAL;
-  if (next && (next->ws == cur->ws || !next->ws || !next->batch || next->N <= 0 || next->B <= 0 || next->E < 0 ||
-               next->epoch == 0 || (next->E > 0 && !next->edge_index)))
+  if (next && (next->ws == cur->ws || !next->ws || !next->batch || !next->x || next->N <= 0 || next->B <= 0 ||
+               next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index)))
     return DGCNN_EINVAL;
   const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B;
   const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;     // the host says so explicitly ...
@@ -344,6 +346,8 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     rd.rowptr_t = dg_ptr<int32_t>(next->ws, nl.rowptr_t); rd.colidx_t = dg_ptr<int32_t>(next->ws, nl.colidx_t);
     rd.graph_ptr = dg_ptr<int32_t>(next->ws, nl.graph_ptr); rd.graph_eptr = dg_ptr<int32_t>(next->ws, nl.graph_eptr);
     rd.dinv = dg_ptr<float>(next->ws, nl.dinv); rd.err = dg_ptr<unsigned int>(next->ws, nl.err);
+    const bool naf = next->F <= DG_AF_MAX_F;
+    rd.x = naf ? next->x : nullptr; rd.xs = naf ? dg_ptr<float>(next->ws, nl.hsA) : nullptr; rd.F = next->F;
     rd.epoch = next->epoch;
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B), 1024);
     rider = &rd;
@@ -365,8 +369,8 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   if (next) {
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
     if (!rode)
-      DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->edge_index, next->batch, next->ws,
-                                 next->flags, next->epoch, stream));
+      DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
+                                 next->ws, next->flags, next->epoch, stream));
     h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;
     h->pepoch = next->epoch;
   }

@@ -11,6 +11,7 @@ struct DgPrepRider {
   int E, N, B;
   int *rowptr, *colidx, *rowptr_t, *colidx_t, *graph_ptr, *graph_eptr;
   float* dinv;
+  const float* x; float* xs; int F;      // aggregate-first conv1: xs[i] = dinv[i]*x[i] ([N,F]); x == nullptr: none
   unsigned int* err;
   unsigned int epoch;
   int nblk;        // rider workgroups appended to the host kernel's grid (0 = none)
@@ -68,8 +69,15 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                     const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
                                                     float* __restrict__ dinv, unsigned int* __restrict__ err,
-                                                    unsigned int epoch) {
-  if (t < N) dinv[t] = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
+                                                    unsigned int epoch, const float* __restrict__ x = nullptr,
+                                                    float* __restrict__ xs = nullptr, int F = 0) {
+  if (t < N) {
+    const float di = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
+    dinv[t] = di;
+    if (x) {      // pre-scaled raw features for the aggregate-first conv1 gather (one row load per edge, no dinv[j] load)
+      for (int f = 0; f < F; ++f) xs[(size_t)t * F + f] = di * x[(size_t)t * F + f];
+    }
+  }
   if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
   if (t < E) {
     const int64_t s = ei[t], d = ei[(int64_t)E + t];

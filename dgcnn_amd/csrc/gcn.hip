@@ -235,7 +235,7 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 
 // ---------------------------------------------------------------------------------------------
 // forward of conv1, aggregate-first (raw feature width F <= DG_AF_MAX_F):
-//     ax[i]  = dinv[i] * ( sum_j dinv[j] x[j] + dinv[i] x[i] )      (F-wide gather, saved for backward)
+//     ax[i]  = dinv[i] * ( sum_j xs[j] + xs[i] ),  xs = dinv*x from graph prep   (F-wide gather, saved for backward)
 //     x1[i]  = tanh( ax[i] W1^T + b1 )                               (F fmas per channel)
 //     hs2[i] = dinv[i] * ( x1[i] W2^T )                              (MFMA on the LDS tile, as k_gcn_fwd32<0>)
 // Same tile shape as k_gcn_fwd32: wave per destination node, 16 nodes per workgroup.
@@ -272,7 +272,7 @@ k_gcn_fwd_af(int N, int F, int lfp, int numTiles, const int* __restrict__ rowptr
       const int start = __builtin_amdgcn_readfirstlane(rowptr[i]);
       const int end = __builtin_amdgcn_readfirstlane(rowptr[i + 1]);
       di = dinv[i];
-      const float acc = dg_af_gather<false>(x, dinv, F, lfp, colidx, start, end, i, lane);
+      const float acc = dg_af_gather<true>(x, nullptr, F, lfp, colidx, start, end, i, lane);   // x = xs = dinv*x
       ax = di * acc;
       if (lane < F) axout[(size_t)i * F + lane] = ax;
     }

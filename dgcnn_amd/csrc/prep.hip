@@ -206,8 +206,17 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
     }
     return;
   }
+  // W1 == nullptr with x given: "scale mode" for the aggregate-first conv1, hs receives xs = dinv*x [N,F]
+  const bool scale = x != nullptr && W1 == nullptr;
   dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
-                      err, epoch);
+                      err, epoch, scale ? x : nullptr, hs, F);
+}
+
+// xs[i][f] = dinv[i] * x[i][f]  (general prep path; the fast path does it inside k_prep_fast_b)
+__global__ void __launch_bounds__(256)
+k_scale_x(int N, int F, const float* __restrict__ x, const float* __restrict__ dinv, float* __restrict__ xs) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < (int64_t)N * F) xs[t] = dinv[t / F] * x[t];
 }
 
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
@@ -224,14 +233,15 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     DG_CHECK_LAUNCH();
     const int nblk_b = dg_cdiv(work, 256);
     int nlin = 0;
-    if (lf && lf->x && lf->F >= 1 && lf->F <= DGCNN_MAX_F) {
+    const bool have = lf && lf->x && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
+    if (have && lf->W) {          // conv1 linear block range (raw features wider than DG_AF_MAX_F)
       nlin = dg_cdiv(N, 8);
       if (nlin > 4096) nlin = 4096;
     }
     hipLaunchKernelGGL(k_prep_fast_b, dim3(nblk_b + nlin), dim3(256), nlin ? sizeof(float) * 32 * lf->F : 0, s,
                        edge_index, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv, uerr, epoch, nblk_b,
-                       nlin ? lf->F : 0, nlin ? lf->x : nullptr, nlin ? lf->W : nullptr, nlin ? lf->hs : nullptr);
-    if (nlin && lin_done) *lin_done = 1;
+                       have ? lf->F : 0, have ? lf->x : nullptr, have ? lf->W : nullptr, have ? lf->hs : nullptr);
+    if (have && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
@@ -250,6 +260,12 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     hipLaunchKernelGGL(k_prep_sort_rows, dim3(dg_cdiv(2 * N, 4)), dim3(256), 0, s, N, rowptr, colidx, rowptr_t,
                        colidx_t);
     DG_CHECK_LAUNCH();
+  }
+  if (lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F) {     // scale mode on the general path
+    const int64_t tot = (int64_t)N * lf->F;
+    hipLaunchKernelGGL(k_scale_x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, N, lf->F, lf->x, dinv, lf->hs);
+    DG_CHECK_LAUNCH();
+    if (lin_done) *lin_done = 1;
   }
   return DGCNN_OK;
 }

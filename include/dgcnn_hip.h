@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 7
+#define DGCNN_ABI_VERSION 8
 
 /* error codes */
 #define DGCNN_OK            0
@@ -177,11 +177,12 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                         int max_edges, uint32_t epoch, dgcnn_stream_t stream);
-/* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: lets a
- * training loop prepare batch i+1 on another stream while step i computes (it depends on the batch only, not
- * on the parameters).  Follow with dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, same epoch). */
-int dgcnn_model_prepare(int N, int E, int B, int F, int C, const int64_t* edge_index, const int64_t* batch,
-                        void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream);
+/* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
+ * forward that depends on the batch only, not on the parameters -- CSR by target / by source, dinv, graph ranges and
+ * (for F <= 32, where conv1 runs aggregate-first) the pre-scaled raw features dinv*x, which is why `x` is an input
+ * (may be NULL only when F > 32).  Follow with dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, same epoch). */
+int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
+                        const int64_t* batch, void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream);
 int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
 int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batch fits the fused LDS plan */
 
