@@ -23,6 +23,7 @@
 // with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
 #include "dg_common.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 // Gather depth = row loads in flight per wavefront.  Few tiles (the reference's batch of 50: one workgroup per CU,
 // latency-bound): deepest batching, 8 -> one memory round trip per 64 neighbours.  Many tiles (large batches,
 // throughput-bound): shallower batching keeps the VGPR count low enough for two 1024-thread workgroups per CU,
@@ -35,6 +36,7 @@
 #define DG_DEPTH_BWD_BIG 2
 #endif
 #define DG_SMALL_GRID_TILES 512
+#define DG_PERSIST_WGS 512           // persistent large-grid kernels: 2 workgroups per CU
 
 // ---------------------------------------------------------------------------------------------
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
@@ -93,9 +95,10 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
 // gather of one destination row: returns (in every lane with g==0, and in fact all lanes) the
 // float4 chunk q of   sum_{e in [start,end)} src[col[e]]  +  src[self]
 // ---------------------------------------------------------------------------------------------
-template <int DG_GATHER_DEPTH>
+// HAVE0: the first batch of neighbour ids (col[start + lane], 0 beyond the row) was loaded by the caller (cj0).
+template <int DG_GATHER_DEPTH, bool HAVE0 = false>
 __device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src, const int* __restrict__ col,
-                                                  int start, int end, int self, int lane) {
+                                                  int start, int end, int self, int lane, int cj0 = 0) {
   const int g = lane >> 3, q = lane & 7;
   const float* sq = src + 4 * q;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,7 +106,7 @@ __device__ __forceinline__ float4 dg_gather_row32(const float* __restrict__ src,
   if (g == 0) vself = *reinterpret_cast<const float4*>(sq + (size_t)self * 32);   // issued first, added last
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
-    const int cj = lane < cnt ? col[base + lane] : 0;
+    const int cj = (HAVE0 && base == start) ? cj0 : (lane < cnt ? col[base + lane] : 0);
     // DG_GATHER_DEPTH row loads are issued back to back and only then summed, in the same order as a
     // one-at-a-time loop would: one memory round trip per DEPTH*8 neighbours instead of one per 8
 #pragma unroll
@@ -214,6 +217,113 @@ k_gcn_fwd32(int N, int numTiles, const int* __restrict__ rowptr, const int* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large grids: PERSISTENT, software-pipelined form of k_gcn_fwd32.  With one tile per workgroup a wave's life is a
+// chain of three dependent round trips (row pointers -> neighbour ids -> neighbour rows) and then it retires; at
+// thousands of tiles the chip is latency-bound on that chain.  Here 2 workgroups per CU each walk a contiguous,
+// XCD-contiguous chunk of tiles and every load a tile needs except the rows themselves is issued one or two tiles
+// AHEAD (row pointers of tile t+2, first 64 ids of tile t+1) -- per tile only the row round trip is exposed.
+// Same lane mapping and summation order as k_gcn_fwd32: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int DEPTH>
+__global__ void __launch_bounds__(DG_TILE_THREADS)
+k_gcn_fwd32p(int N, int numTiles, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
+             float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next) {
+  __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+
+  float wreg[8];
+  if (MODE == 0 && wave < 2) {
+    const int c = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[c * 32 + 4 * kk + (lane >> 4)];
+  }
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1) w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+
+  const int chunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = dg_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int t0 = wg * chunk, t1 = min(numTiles, t0 + chunk);
+  if (t0 >= t1) return;
+  // pipeline state: (rs0,re0,cj0) = this tile; (rs1,re1) = next tile's row pointers (vector registers until used)
+  int rs0 = 0, re0 = 0, cj0 = 0, rs1v = 0, re1v = 0;
+  {
+    const int i0 = t0 * DG_TILE + wave, i1 = i0 + DG_TILE;
+    if (i0 < N) { rs0 = rowptr[i0]; re0 = rowptr[i0 + 1]; }
+    if (t0 + 1 < t1 && i1 < N) { rs1v = rowptr[i1]; re1v = rowptr[i1 + 1]; }
+    rs0 = __builtin_amdgcn_readfirstlane(rs0); re0 = __builtin_amdgcn_readfirstlane(re0);
+    cj0 = lane < min(64, re0 - rs0) ? colidx[rs0 + lane] : 0;
+  }
+  for (int tile = t0; tile < t1; ++tile) {
+    const int i = tile * DG_TILE + wave;
+    // stage A: row pointers of tile + 2
+    int rs2v = 0, re2v = 0;
+    {
+      const int i2 = i + 2 * DG_TILE;
+      if (tile + 2 < t1 && i2 < N) { rs2v = rowptr[i2]; re2v = rowptr[i2 + 1]; }
+    }
+    // stage B: first neighbour ids of tile + 1 (its row pointers were requested one tile ago)
+    const int rs1 = __builtin_amdgcn_readfirstlane(rs1v), re1 = __builtin_amdgcn_readfirstlane(re1v);
+    const int cj1 = lane < min(64, re1 - rs1) ? colidx[rs1 + lane] : 0;
+    // stage C: this tile
+    if (i < N) {
+      const float di = dinv[i];
+      const float4 acc = dg_gather_row32<DEPTH, true>(hs, colidx, rs0, re0, i, lane, cj0);
+      float4 val;
+      val.x = dg_tanh(fmaf(di, acc.x, b4.x));
+      val.y = dg_tanh(fmaf(di, acc.y, b4.y));
+      val.z = dg_tanh(fmaf(di, acc.z, b4.z));
+      val.w = dg_tanh(fmaf(di, acc.w, b4.w));
+      if (g == 0) {
+        *reinterpret_cast<float4*>(xout + (size_t)i * 32 + 4 * q) = val;
+        if (MODE == 0) *reinterpret_cast<float4*>(&xt[wave][4 * q]) = val;
+      }
+      if (MODE == 1) {
+        float p = val.x * w4.x;
+        p = fmaf(val.y, w4.y, p);
+        p = fmaf(val.z, w4.z, p);
+        p = fmaf(val.w, w4.w, p);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        if (lane == 0) hs_next[i] = di * p;
+      }
+    } else if (MODE == 0 && g == 0) {
+      *reinterpret_cast<float4*>(&xt[wave][4 * q]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float dpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+        dpre[r] = node < N ? dinv[node] : 0.f;
+      }
+    }
+    if (MODE == 0) {
+      __syncthreads();
+      if (wave < 2) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float a = xt[lane & 15][4 * kk + (lane >> 4)];
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
+          if (node < N) hs_next[(size_t)node * 32 + wave * 16 + (lane & 15)] = dpre[r] * d[r];
+        }
+      }
+      __syncthreads();
+    }
+    rs0 = rs1; re0 = re1; cj0 = cj1; rs1v = rs2v; re1v = re2v;
+  }
+}
+
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
                         hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -224,11 +334,16 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
   // same ones rocprofv3 reports); with null events it is a plain launch.
 #define DG_FWD32_LAUNCH(M, D) hipExtLaunchKernelGGL((k_gcn_fwd32<M, D>), dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, \
                                                     ev_stop, 0, N, tiles, rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
+#define DG_FWD32P_LAUNCH(M, D) hipExtLaunchKernelGGL((k_gcn_fwd32p<M, D>), dim3(DG_PERSIST_WGS), dim3(DG_TILE_THREADS), 0, s, \
+                                                     ev_start, ev_stop, 0, N, tiles, rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
   const bool small = tiles <= DG_SMALL_GRID_TILES;
-  if (mode == 0) { if (small) DG_FWD32_LAUNCH(0, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(0, DG_DEPTH_FWD_BIG); }
-  else if (mode == 1) { if (small) DG_FWD32_LAUNCH(1, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(1, DG_DEPTH_FWD_BIG); }
-  else { if (small) DG_FWD32_LAUNCH(2, DG_DEPTH_SMALL); else DG_FWD32_LAUNCH(2, DG_DEPTH_FWD_BIG); }
+  static const bool nopersist = getenv("DG_NO_PERSIST") != nullptr;     // A/B switch (measurement only)
+  const bool persist = tiles >= 4 * DG_PERSIST_WGS && !nopersist;   // pays from ~4 tiles per workgroup (measured)
+  if (mode == 0) { if (small) DG_FWD32_LAUNCH(0, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(0, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(0, DG_DEPTH_FWD_BIG); }
+  else if (mode == 1) { if (small) DG_FWD32_LAUNCH(1, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(1, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(1, DG_DEPTH_FWD_BIG); }
+  else { if (small) DG_FWD32_LAUNCH(2, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(2, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(2, DG_DEPTH_FWD_BIG); }
 #undef DG_FWD32_LAUNCH
+#undef DG_FWD32P_LAUNCH
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
