@@ -86,6 +86,27 @@ def test_large_batch_two_stage_weight_gradients(name, bs):
     check_backward_parity(m, b, sd)
 
 
+def test_persistent_aggregation_kernel_is_bit_identical_to_the_tiled_one():
+    """>= 2048 node tiles select the persistent, software-pipelined 32-wide aggregation kernel.  A graph's result must
+    not depend on the batch it travels in, so 2400 graphs in one batch (persistent kernel) must reproduce, bit for bit,
+    the log-probabilities of the same graphs in 4 batches of 600 (one tile per workgroup)."""
+    from dgcnn_amd.batch import collate
+    sh = synth.SHAPES["MUTAG"]
+    graphs = synth.make_graphs("MUTAG", 2400, start=9000)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.eval()
+    with torch.no_grad():
+        big = collate(graphs).to("cuda")
+        assert (big.x.shape[0] + 15) // 16 >= 2048
+        lp_big = m(big).clone()
+        m.check_errors()
+        parts = []
+        for k in range(4):
+            parts.append(m(collate(graphs[600 * k:600 * (k + 1)]).to("cuda")).clone())
+            m.check_errors()
+    assert torch.equal(lp_big, torch.cat(parts))
+
+
 def test_edge_cases_isolated_selfloops_single_graph_empty_edges():
     # one graph, n < k, isolated nodes, input self loops, duplicate edge
     x = torch.randn(7, 5)
