@@ -106,7 +106,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(dinv, 4 * n);
   R(graph_ptr, 4 * (b + 1));
   R(graph_eptr, 4 * (b + 1));
-  R(hsA, 4 * n * 32);
+  R(hsA, 4 * n * 32);   // pre-scaled linear outputs, ping; before conv1 (F <= 32) it holds xs = dinv*x [N,F] from graph prep
   R(hsB, 4 * n * 32);
   R(h4s, 4 * n);
   R(x1, 4 * n * 32);

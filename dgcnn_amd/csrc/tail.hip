@@ -396,13 +396,16 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients.  out[i] = sum_{r<R} term(i, r): every output is owned by a group of LPO
-// consecutive lanes (LPO in {1,8,16,64}) that stride over the reduction index r and then combine
-// with a fixed xor-butterfly -> no floating-point atomics, bit-reproducible, and the long
-// reductions (bias sums over B*30 terms, per-workgroup partials) are no longer serial chains.
+// weight gradients: ONE launch whose workgroups are partitioned into segments (WgSeg), one per parameter tensor.
+//   WG_REDUCE_COL       out[c] = sum of R partial rows (per-workgroup partials of the GCN backward kernels, per-graph
+//                       partials of k_tail_bwd), read column-coalesced
+//   WG_FC1W_MFMA        classifier_1's weight gradient, a [128 x B].[B x 352] GEMM on the fp32 matrix cores
+//   WG_FC1B / WG_SUMB / WG_METRIC   short sums with 64 lanes per output (strided over r, fixed xor butterfly)
+//   *_CHUNK             stage 1 of the two-stage form used for batches of more than DG_WG_TWO_STAGE_B graphs
+// No floating-point atomics anywhere: fixed reduction orders, bit-reproducible.  The lane that owns an output also
+// applies the Adam update when the optimizer is fused.
 // ---------------------------------------------------------------------------------------------
-enum { WG_REDUCE = 0, WG_FC2W, WG_FC2B, WG_FC1W, WG_FC1B, WG_C6W, WG_C6B, WG_C5W, WG_C5B, WG_SUMB, WG_METRIC, WG_FC1W_MFMA,
-       WG_REDUCE_CHUNK, WG_FC1W_MFMA_CHUNK, WG_REDUCE_COL };
+enum { WG_FC1B = 0, WG_SUMB, WG_METRIC, WG_FC1W_MFMA, WG_REDUCE_CHUNK, WG_FC1W_MFMA_CHUNK, WG_REDUCE_COL };
 #define WG_MAX_SEG 20
 struct WgSeg {
   int type;
@@ -410,14 +413,14 @@ struct WgSeg {
   int lpo;           // lanes per output
   int R;             // reduction length
   int block0;        // first block of this segment
-  int stride;        // WG_REDUCE: floats between partial slots ; WG_METRIC: 2 ; *_CHUNK: row width
+  int stride;        // WG_REDUCE_COL: floats between partial rows ; WG_METRIC: 2 ; *_CHUNK: row width
   int aux;           // *_CHUNK: total number of rows (graphs) being reduced, R = rows per chunk
-  const float* src;  // WG_REDUCE / WG_SUMB / WG_METRIC source
+  const float* src;  // partial rows / per-graph values being summed
   float* out;
 };
 struct WgArgs {
   int nseg, B, C;
-  const float *dlogit, *a1d, *gz1, *a6, *gz6, *a5, *gz5, *pooled;
+  const float *gz1, *a6;               // classifier_1 operands: d(loss)/d(pre-activation) [B,128], input [B,352]
   // optional fused Adam (torch.optim.Adam defaults semantics): applied by the lane that owns the output
   float *adam_p, *adam_m, *adam_v;     // flat buffers (same layout as grads); null = no optimizer step here
   const float* grads_base;             // to turn an output pointer into a flat index
@@ -426,33 +429,13 @@ struct WgArgs {
 };
 
 __device__ __forceinline__ float dg_wg_term(const WgArgs& A, const WgSeg& sg, int i, int r) {
-  const int C = A.C;
   switch (sg.type) {
-    case WG_REDUCE: return sg.src[(size_t)r * sg.stride + i];
     case WG_REDUCE_CHUNK: {   // output i = chunk * width + column: partial sum of rows [chunk*R, chunk*R + R)
       const int ch = i / sg.stride, col = i - ch * sg.stride, row = ch * sg.R + r;
       return row < sg.aux ? sg.src[(size_t)row * sg.stride + col] : 0.f; }
     case WG_SUMB:   return sg.src[r];
     case WG_METRIC: return sg.src[(size_t)r * 2 + i];
-    case WG_FC2W: { const int c = i / DGCNN_HID1, j = i - c * DGCNN_HID1;
-                    return A.dlogit[(size_t)r * C + c] * A.a1d[(size_t)r * DGCNN_HID1 + j]; }
-    case WG_FC2B:   return A.dlogit[(size_t)r * C + i];
-    case WG_FC1W: { const int j = i / DGCNN_FLAT, m = i - j * DGCNN_FLAT;
-                    return A.gz1[(size_t)r * DGCNN_HID1 + j] * A.a6[(size_t)r * DGCNN_FLAT + m]; }
     case WG_FC1B:   return A.gz1[(size_t)r * DGCNN_HID1 + i];
-    case WG_C6W: {  // i = (oc*16 + c)*5 + d ; r = b*11 + t
-      const int d = i % DGCNN_KW6, c = (i / DGCNN_KW6) % DGCNN_C5, oc = i / (DGCNN_KW6 * DGCNN_C5);
-      const int b = r / DGCNN_T6, t = r - b * DGCNN_T6;
-      const float* a5b = A.a5 + (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * (t + d);
-      return A.gz6[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + t] * fmaxf(a5b[0], a5b[1]); }
-    case WG_C6B: {  const int b = r / DGCNN_T6, t = r - b * DGCNN_T6;
-                    return A.gz6[(size_t)b * DGCNN_FLAT + i * DGCNN_T6 + t]; }
-    case WG_C5W: {  // i = o*97 + m ; r = b*30 + s
-      const int o = i / DGCNN_CAT, m = i - o * DGCNN_CAT;
-      const int b = r / DGCNN_K, s = r - b * DGCNN_K;
-      return A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + o * DGCNN_K + s] * A.pooled[(size_t)b * KCAT + s * DGCNN_CAT + m]; }
-    case WG_C5B: {  const int b = r / DGCNN_K, s = r - b * DGCNN_K;
-                    return A.gz5[(size_t)b * (DGCNN_C5 * DGCNN_K) + i * DGCNN_K + s]; }
   }
   return 0.f;
 }
@@ -620,10 +603,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
-  A.dlogit = dg_cptr<float>(ws, wl->dlogit); A.a1d = dg_cptr<float>(ws, wl->a1d);
   A.gz1 = dg_cptr<float>(ws, wl->gz1); A.a6 = dg_cptr<float>(ws, wl->a6);
-  A.gz6 = dg_cptr<float>(ws, wl->gz6); A.a5 = dg_cptr<float>(ws, wl->a5);
-  A.gz5 = dg_cptr<float>(ws, wl->gz5); A.pooled = dg_cptr<float>(ws, wl->pooled);
   A.grads_base = grads;
   if (adam && adam->params) {
     A.adam_p = adam->params; A.adam_m = adam->exp_avg; A.adam_v = adam->exp_avg_sq;
