@@ -473,16 +473,16 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
       pm[r] = A.adam_m[k]; pv[r] = A.adam_v[k]; pp[r] = A.adam_p[k];
     }
   }
-  for (int k0 = kbeg; k0 < B; k0 += 32) {       // 8 MFMAs (32 graphs) per round: 16 loads in flight per lane
-    float av[8], bv[8];
+  for (int k0 = kbeg; k0 < B; k0 += 64) {       // 16 MFMAs (64 graphs) per round: 32 loads in flight per lane, so the
+    float av[16], bv[16];                        // reference's batch of 50 is ONE memory round trip
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int bb = k0 + 4 * u + kq;
       av[u] = bb < B ? A.gz1[(size_t)bb * DGCNN_HID1 + jr] : 0.f;
       bv[u] = bb < B ? A.a6[(size_t)bb * DGCNN_FLAT + mc] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 16; ++u)
       if (k0 + 4 * u < B) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
   }
 #pragma unroll
