@@ -85,7 +85,7 @@ class _DGCNNFunction(torch.autograd.Function):
         N, F = x.shape
         E = edge_index.shape[1]
         C = model.num_classes
-        flat = model.flat_params
+        flat = model.flat_params_fast()
         ws = torch.empty(_lib.workspace_bytes(N, E, B, F, C), dtype=torch.uint8, device=x.device)
         logp = torch.empty(B, C, dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -108,15 +108,17 @@ class _DGCNNFunction(torch.autograd.Function):
         N, E, B, F, C, training = ctx.dims
         x, ws, logp = ctx.saved_tensors
         glogp = glogp.contiguous()
-        flat = model.flat_params
+        flat = model.flat_params_fast()
         grads = torch.zeros_like(flat)       # fresh buffer: p.grad views stay valid until dropped
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), glogp.data_ptr(), None, 0.0, training,
                                           grads.data_ptr(), None, stream), "dgcnn_model_backward")
         model._last_flat_grad = grads
-        views = model._views_of(grads)
-        return (None, None, None, None, None, None, None, None, None, None, *views)
+        # the 16 gradients handed to autograd are views of ONE flat buffer in the parameter layout: autograd keeps them
+        # as they are (no copies), so an optimizer that recognises the layout (dgcnn_amd.optim.Adam) updates the
+        # whole model with one kernel
+        return (None, None, None, None, None, None, None, None, None, None, *model._grad_views(grads))
 
 
 class Model(nn.Module):
@@ -149,12 +151,37 @@ class Model(nn.Module):
 
     # ---- flat parameter buffer ---------------------------------------------------------
     def _param_list(self) -> List[nn.Parameter]:
-        """Parameters in the order of the C-ABI flat layout (include/dgcnn_hip.h)."""
-        return [self.conv1.lin.weight, self.conv1.bias, self.conv2.lin.weight, self.conv2.bias,
-                self.conv3.lin.weight, self.conv3.bias, self.conv4.lin.weight, self.conv4.bias,
-                self.conv5.weight, self.conv5.bias, self.conv6.weight, self.conv6.bias,
-                self.classifier_1.weight, self.classifier_1.bias,
-                self.classifier_2.weight, self.classifier_2.bias]
+        """Parameters in the order of the C-ABI flat layout (include/dgcnn_hip.h).  The Parameter OBJECTS never change
+        (``.to()`` / ``load_state_dict`` replace or fill their data), so the list is built once: 16 ``nn.Module``
+        attribute look-ups cost ~20 us, too much for a per-step path."""
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = [self.conv1.lin.weight, self.conv1.bias, self.conv2.lin.weight, self.conv2.bias,
+                  self.conv3.lin.weight, self.conv3.bias, self.conv4.lin.weight, self.conv4.bias,
+                  self.conv5.weight, self.conv5.bias, self.conv6.weight, self.conv6.bias,
+                  self.classifier_1.weight, self.classifier_1.bias,
+                  self.classifier_2.weight, self.classifier_2.bias]
+            self.__dict__["_plist"] = pl
+        return pl
+
+    def _grad_views(self, flat_grad: torch.Tensor):
+        """the 16 per-parameter views of a flat gradient buffer: ONE split call + reshapes of the matrices"""
+        sp = self.__dict__.get("_gsplit")
+        if sp is None:
+            offs, plist = self._offsets, self._param_list()
+            sizes, keep, shapes, pos = [], [], [], 0
+            for p, off in zip(plist, offs):
+                if off > pos:
+                    sizes.append(off - pos)          # alignment gap
+                sizes.append(p.numel()); keep.append(len(sizes) - 1); shapes.append(tuple(p.shape))
+                pos = off + p.numel()
+            if self._total > pos:
+                sizes.append(self._total - pos)
+            sp = (sizes, keep, shapes)
+            self.__dict__["_gsplit"] = sp
+        sizes, keep, shapes = sp
+        parts = flat_grad.split_with_sizes(sizes)
+        return [parts[k] if len(sh) == 1 else parts[k].view(sh) for k, sh in zip(keep, shapes)]
 
     def _views_of(self, flat: torch.Tensor) -> List[torch.Tensor]:
         out = []
@@ -199,6 +226,7 @@ class Model(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         """``.to()`` / ``.cuda()`` / ``.float()`` replace parameter storage: drop the flat buffer (rebuilt lazily)."""
         self._flat = None
+        self.__dict__.pop("_gsplit", None)
         return super()._apply(fn, *args, **kwargs)
 
     def flat_params_fast(self) -> torch.Tensor:
@@ -284,7 +312,7 @@ class Model(nn.Module):
             raise _lib.DgcnnError(f"data.x has {x.shape[1]} features, model expects {self.num_features}")
         x, edge_index, batch = x.contiguous(), edge_index.contiguous(), batch.contiguous()
         B = _batch_size_of(data)
-        flat = self.flat_params
+        flat = self.flat_params_fast()
         if flat.device != x.device:
             raise _lib.DgcnnError(f"model on {flat.device}, data on {x.device}")
         training = self.training

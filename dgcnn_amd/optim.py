@@ -1,0 +1,150 @@
+"""``Adam`` with the call signature of ``torch.optim.Adam`` that updates a :class:`dgcnn_amd.Model` with ONE kernel.
+
+The reference builds its optimizer as ``Adam(model.parameters())`` (/root/reference/train.py:11,99).  With this
+build's ``Model`` all 16 parameters are views of one flat buffer and ``loss.backward()`` leaves their ``.grad`` as views
+of one flat gradient buffer in the same layout, so ``optimizer.step()`` can be a single ``dgcnn_adam_step`` launch over
+the flat buffers instead of torch's multi-tensor path (~10 launches and ~190 us of host time per step for 16 small
+tensors).  Changing the import is the only edit to the reference loop::
+
+    from dgcnn_amd.optim import Adam          # instead of: from torch.optim import Adam
+
+Semantics are those of ``torch.optim.Adam`` defaults (no weight decay, no amsgrad; `step`, `exp_avg`, `exp_avg_sq`
+per parameter in ``state_dict()``).  Whenever the flat layout is NOT recognised (other modules' parameters, gradients
+that are not views of one buffer, a parameter without gradient, ...) the step falls back to torch's own implementation
+for that call -- same numbers, just slower.  GPU tensors only take the fused route.
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim import Optimizer
+
+from . import _lib
+
+
+class Adam(Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False):
+        if weight_decay != 0.0 or amsgrad:
+            raise ValueError("dgcnn_amd.optim.Adam implements torch.optim.Adam's defaults (weight_decay=0, amsgrad=False); "
+                             "use torch.optim.Adam for the other variants")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._flat = {}          # id(group) -> [params_flat, exp_avg, exp_avg_sq, offsets, step tensor, step] once recognised
+
+    # ---- layout recognition ---------------------------------------------------------------------------
+    @staticmethod
+    def _flat_of(tensors):
+        """the 1-D tensor spanning the storage range [min offset, max end) that all `tensors` are views of, plus
+        each tensor's offset inside it -- or None when they do not share one storage / overlap / are not dense"""
+        t0 = tensors[0]
+        st = t0.untyped_storage()
+        base, spans = st.data_ptr(), []
+        for t in tensors:
+            if t.untyped_storage().data_ptr() != base or not t.is_contiguous() or t.dtype != torch.float32 \
+                    or t.device != t0.device:
+                return None
+            spans.append((t.storage_offset(), t.numel()))
+        lo = min(o for o, _ in spans)
+        hi = max(o + n for o, n in spans)
+        order = sorted(spans)
+        for (o1, n1), (o2, _) in zip(order, order[1:]):
+            if o1 + n1 > o2:
+                return None
+        if (hi - lo) > 2 * sum(n for _, n in spans) + 64:        # not one packed buffer
+            return None
+        flat = torch.empty(0, dtype=torch.float32, device=t0.device).set_(st, lo, (hi - lo,))
+        return flat, [o - lo for o, _ in spans]
+
+    def _state_views(self, group, pflat, offs):
+        m = torch.zeros_like(pflat)
+        v = torch.zeros_like(pflat)
+        for p, off in zip(group["params"], offs):
+            stt = self.state[p]
+            prev_m, prev_v = stt.get("exp_avg"), stt.get("exp_avg_sq")
+            mv = m[off:off + p.numel()].view(p.shape)
+            vv = v[off:off + p.numel()].view(p.shape)
+            if prev_m is not None:                     # continue from a loaded / torch-produced state
+                mv.copy_(prev_m); vv.copy_(prev_v)
+            stt["exp_avg"], stt["exp_avg_sq"] = mv, vv
+        # ONE step counter object shared by the group's parameters (torch keeps one per parameter; a state_dict saved
+        # from here holds 16 equal values and loads back either way)
+        prev = self.state[group["params"][0]].get("step")
+        shared = torch.tensor(float(prev) if prev is not None else 0.0, dtype=torch.float32)
+        for p in group["params"]:
+            self.state[p]["step"] = shared
+        return m, v, shared
+
+    # ---- step -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = group["params"]
+            if not self._fused_step(group, params):
+                self._torch_step(group, params)
+        return loss
+
+    def _fused_step(self, group, params) -> bool:
+        if not params or not params[0].is_cuda or any(p.grad is None for p in params):
+            return False
+        key = id(group)
+        ent = self._flat.get(key)
+        if ent is None or ent[0].untyped_storage().data_ptr() != params[0].untyped_storage().data_ptr():
+            rec = self._flat_of(params)
+            if rec is None:
+                return False
+            pflat, offs = rec
+            m, v, shared = self._state_views(group, pflat, offs)
+            ent = self._flat[key] = [pflat, m, v, offs, shared, int(shared.item())]
+        pflat, m, v, offs, shared, nstep = ent
+        if self.state[params[0]]["step"] is not shared:       # a state_dict was loaded: adopt its counter
+            shared.fill_(float(self.state[params[0]]["step"]))
+            nstep = ent[5] = int(shared.item())
+            for p in params:
+                self.state[p]["step"] = shared
+        g0 = params[0].grad
+        gst = g0.untyped_storage().data_ptr()
+        gbase = g0.storage_offset() - offs[0]
+        if gbase < 0:
+            return False
+        for p, off in zip(params, offs):                # gradients must mirror the parameter layout in ONE buffer
+            g = p.grad
+            if g.untyped_storage().data_ptr() != gst or g.storage_offset() - gbase != off or not g.is_contiguous() \
+                    or g.dtype != torch.float32:
+                return False
+        n = pflat.numel()
+        if gbase + n > g0.untyped_storage().nbytes() // 4:
+            return False
+        gflat = torch.empty(0, dtype=torch.float32, device=pflat.device).set_(g0.untyped_storage(), gbase, (n,))
+        step = nstep + 1
+        b1, b2 = group["betas"]
+        stream = torch.cuda.current_stream(pflat.device).cuda_stream
+        # the gaps between segments hold zeros in both buffers (zero gradient -> zero update), so one launch over the
+        # whole span is exact
+        _lib.check(_lib.lib().dgcnn_adam_step(pflat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), n, step,
+                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]), 0, stream),
+                   "dgcnn_adam_step")
+        shared += 1
+        ent[5] = step
+        return True
+
+    def _torch_step(self, group, params) -> None:
+        """torch's own multi-tensor Adam on this group (layout not recognised)"""
+        from torch.optim.adam import adam as _adam
+        with_grad = [p for p in params if p.grad is not None]
+        if not with_grad:
+            return
+        grads, ms, vs, steps = [], [], [], []
+        for p in with_grad:
+            stt = self.state[p]
+            if "exp_avg" not in stt:
+                stt["step"] = torch.tensor(0.0, dtype=torch.float32)
+                stt["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                stt["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            grads.append(p.grad); ms.append(stt["exp_avg"]); vs.append(stt["exp_avg_sq"]); steps.append(stt["step"])
+        b1, b2 = group["betas"]
+        _adam(with_grad, grads, ms, vs, [], steps, amsgrad=False, beta1=b1, beta2=b2, lr=group["lr"], weight_decay=0.0,
+              eps=group["eps"], maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+              grad_scale=None, found_inf=None, has_complex=False)
