@@ -4,6 +4,7 @@ Public surface (mirrors what the reference exposes for this path):
   Model            -- nn.Module drop-in of /root/reference/model.py:9-45
   Batch, collate   -- the input container the model consumes (PyG Batch stand-in)
   Trainer          -- the per-batch step of /root/reference/train.py:27-66 on fused kernels
+  optim.Adam       -- torch.optim.Adam drop-in that updates the flat parameter buffer with one kernel (train.py:11,99)
   tudataset        -- TU-format reader + Indegree + fold files + GraphLoader (train.py:81-109, utils.py:18-33)
   cli              -- the 10-fold driver (train.py:69-148), also reachable as ``python train.py``
 """

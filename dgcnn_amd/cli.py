@@ -38,7 +38,8 @@ def get_args(argv=None):
     p.add_argument('--num_epochs', default=100, type=int, help='train epochs number')
     p.add_argument('--seed', default=324, type=int, help='random seed')
     p.add_argument('--data_root', default='data', type=str, help='directory holding <data_type>/raw/*.txt and 10fold_idx')
-    p.add_argument('--synthetic', default=0, type=int, help='use N synthetic graphs of that shape instead of TU files')
+    p.add_argument('--synthetic', default=0, type=int,
+                   help='use N synthetic graphs of that shape (class = edge-density level) instead of TU files')
     p.add_argument('--folds', default=10, type=int, help='number of folds to run (<= 10)')
     p.add_argument('--out_dir', default='.', type=str, help='where epochs/ and statistics/ are written')
     p.add_argument('--device', default='cuda', type=str)
@@ -57,7 +58,7 @@ def set_determ(seed: int) -> None:
 def load_dataset(opt) -> TUData:
     if opt.synthetic > 0:
         shape = synth.SHAPES[SYNTH_SHAPE[opt.data_type]]
-        graphs = synth.make_graphs(shape.name, opt.synthetic, seed=opt.seed)
+        graphs = synth.make_graphs(shape.name, opt.synthetic, seed=opt.seed, labels="structure")   # learnable
         return TUData(graphs, shape.num_classes, opt.data_type)
     return read_tu_dataset(os.path.join(opt.data_root, opt.data_type), opt.data_type, use_node_attr=True)
 

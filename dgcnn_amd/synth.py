@@ -94,11 +94,21 @@ def _gnp_edges(rng: np.random.Generator, n: int, p: float) -> np.ndarray:
     return arr
 
 
-def make_graph(shape: Shape, g: int, seed: int = BASE_SEED, force_n: Optional[int] = None) -> Graph:
+def make_graph(shape: Shape, g: int, seed: int = BASE_SEED, force_n: Optional[int] = None,
+               labels: str = "random") -> Graph:
+    """``labels="random"``: class drawn independently of the graph (throughput workloads; nothing to learn).
+    ``labels="structure"``: the class sets the edge density (class c -> mean degree x (0.6 + 0.8 c)), a task DGCNN
+    learns quickly from the degree feature -- used by the end-to-end training tests and the driver's synthetic mode."""
     rng = np.random.default_rng(seed + g)
     n = int(force_n) if force_n is not None else shape.draw_n(rng)
     n = max(n, 2)
     deg = shape.mean_deg if shape.mean_deg > 0 else min(-shape.mean_deg, n - 1)
+    y_struct = None
+    if labels == "structure":
+        y_struct = int(np.random.default_rng(seed * 7919 + g).integers(0, shape.num_classes))
+        deg = deg * (0.6 + 0.8 * y_struct)
+    elif labels != "random":
+        raise ValueError("labels must be 'random' or 'structure'")
     p = deg / (n - 1)
     und = _gnp_edges(rng, n, p)
     tries = 0
@@ -121,16 +131,18 @@ def make_graph(shape: Shape, g: int, seed: int = BASE_SEED, force_n: Optional[in
     x = indegree_feature(ei, n, feat).contiguous()
     assert x.shape[1] == shape.num_features, (x.shape, shape)
     y = int(rng.integers(0, shape.num_classes))
+    if y_struct is not None:
+        y = y_struct
     return Graph(x=x, edge_index=ei, y=y, coalesced_undirected=True)
 
 
 def make_graphs(name: str, count: int, start: int = 0, seed: int = BASE_SEED,
-                force_first_n: Optional[int] = None) -> List[Graph]:
+                force_first_n: Optional[int] = None, labels: str = "random") -> List[Graph]:
     shape = SHAPES[name]
     out = []
     for g in range(start, start + count):
         fn = force_first_n if (force_first_n is not None and g == start) else None
-        out.append(make_graph(shape, g, seed, fn))
+        out.append(make_graph(shape, g, seed, fn, labels))
     return out
 
 
