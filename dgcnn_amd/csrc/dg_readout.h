@@ -179,12 +179,13 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // Mapping: a wave owns 8 output rows; lane = (row r = lane >> 3, part p = lane & 7); a 352-float row is 8 parts
   // x 11 float4, so the whole 8-row block is 11 x 16-byte loads per lane (vs 48 dword loads with lanes along
   // the row): 4.4x fewer vector-memory instructions through the CU's address unit for the same 180 KB.
+  // The 180 KB stream keeps the CU's address unit busy for ~2900 cycles (64 B/clk); a barrier cannot complete before
+  // every wave has ISSUED the loads that precede it in its instruction stream, so the prefetch is cut in three and
+  // spread over conv5's MFMA, conv5's combine and pool/conv6 instead of standing in front of the first barrier.
   float4 wf[11];
-  {
-    const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + (lane >> 3)) * DGCNN_FLAT + 4 * (lane & 7);
+  const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + (lane >> 3)) * DGCNN_FLAT + 4 * (lane & 7);
 #pragma unroll
-    for (int jq = 0; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
-  }
+  for (int jq = 0; jq < 4; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16]:
   // two 16x16 tiles, K split over 4 waves each (28 + 24 + 24 + 24 columns), partial tiles combined in a fixed
   // order; ReLU + bias at the combine.  output index o*30+s ([B,16,30])
@@ -200,6 +201,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
           [&](int s, int o, float v) { part[(kc * 32 + s) * 16 + o] = v; });
     }
     dg_lds_barrier();
+#pragma unroll
+    for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
     if (tid < DGCNN_C5 * DGCNN_K) {
       const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
       const float v = (part[(0 * 32 + s) * 16 + o] + part[(1 * 32 + s) * 16 + o]) +
@@ -211,6 +214,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   dg_lds_barrier();
   RD_MARK(10);
+#pragma unroll
+  for (int jq = 8; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   // MaxPool1d(2,2): [16,30] -> [16,15]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
@@ -218,19 +223,27 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   dg_lds_barrier();
   // conv6 on the matrix cores: z6[oc][t] = sum_{c,d} W6[oc][c][d] p5[c][t+d]  ->  [32 x 16(11)] = [32 x 80] . [80 x 16],
-  // two 16x16 tiles, one wave each; flat index oc*11+t (x.view(B,-1), model.py:40)
-  if (wv < 2) {
-    dg_mfma_tile16(
-        wv * 16, 0, DGCNN_C5 * DGCNN_KW6, lane,
-        [&](int oc, int k) { return W6s[oc * (DGCNN_C5 * DGCNN_KW6) + k]; },
-        [&](int k, int t) { return t < DGCNN_T6 ? p5[(k / DGCNN_KW6) * DGCNN_T5 + t + (k % DGCNN_KW6)] : 0.f; },
-        [&](int oc, int t, float v) {
-          if (t < DGCNN_T6) {
-            const float acc = fmaxf(v + bs[16 + oc], 0.f);
-            flat[oc * DGCNN_T6 + t] = acc;
-            a6g[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + t] = acc;
-          }
-        });
+  // two 16x16 tiles, K split over 4 waves each (20 columns = 5 MFMA steps per wave instead of 20), partial tiles
+  // combined in a fixed order with bias + ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
+  {
+    float* part = M.cpart;                       // [4][32][16], free again after conv5's combine
+    if (wv < 8) {
+      const int mt = wv >> 2, kc = wv & 3, kb = kc * 20;
+      dg_mfma_tile16(
+          mt * 16, 0, 20, lane,
+          [&](int oc, int kk) { return W6s[oc * (DGCNN_C5 * DGCNN_KW6) + kb + kk]; },
+          [&](int kk, int t) { const int k = kb + kk; return t < DGCNN_T6 ? p5[(k / DGCNN_KW6) * DGCNN_T5 + t + (k % DGCNN_KW6)] : 0.f; },
+          [&](int oc, int t, float v) { part[(kc * 32 + oc) * 16 + t] = v; });
+    }
+    dg_lds_barrier();
+    if (tid < DGCNN_FLAT) {
+      const int oc = tid / DGCNN_T6, t = tid - oc * DGCNN_T6;
+      const float v = (part[(0 * 32 + oc) * 16 + t] + part[(1 * 32 + oc) * 16 + t]) +
+                      (part[(2 * 32 + oc) * 16 + t] + part[(3 * 32 + oc) * 16 + t]);
+      const float acc = fmaxf(v + bs[16 + oc], 0.f);
+      flat[tid] = acc;
+      a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
+    }
   }
   dg_lds_barrier();
   RD_MARK(11);
