@@ -146,6 +146,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   DgStage<NW5, RD_THREADS> st5;
   DgStage<NW6, RD_THREADS> st6;
   st5.load(w.W5, tid); st6.load(w.W6, tid);
+  float wf2a = 0.f, wf2b = 0.f;                   // classifier_2 row of class `wv` (used at the very end: no cold load there)
+  if (wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
@@ -280,8 +282,9 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // classifier_2: 128 -> C, wave per class
   for (int c = wv; c < C; c += RD_THREADS / 64) {
     const float* wr = w.Wf2 + c * DGCNN_HID1;
-    float acc = wr[lane] * a1s[lane];
-    acc = fmaf(wr[lane + 64], a1s[lane + 64], acc);
+    const bool pre = c == wv;                     // first class of this wave: row prefetched with the conv weights
+    float acc = (pre ? wf2a : wr[lane]) * a1s[lane];
+    acc = fmaf(pre ? wf2b : wr[lane + 64], a1s[lane + 64], acc);
     acc = dg_wave_sum(acc);
     if (lane == 0) lg[c] = acc + bs[176 + c];
   }
