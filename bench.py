@@ -248,7 +248,8 @@ def main():
         kname = "k_fused_fwd" if fused else "k_gcn_fwd32"
         if args.workload == "COLLAB" and os.path.exists(pmc_file):
             try:
-                pm = json.load(open(pmc_file)).get(kname)
+                pmj = json.load(open(pmc_file))
+                pm = pmj.get(kname + "p") or pmj.get(kname)     # k_gcn_fwd32p: persistent form used from 2048 node tiles
                 if pm:
                     traffic = (2.0 * pm.get("FETCH_SIZE", 0.0) + pm.get("WRITE_SIZE", 0.0)) * 1024.0
             except Exception:
