@@ -5,6 +5,7 @@ Public surface (mirrors what the reference exposes for this path):
   Batch, collate   -- the input container the model consumes (PyG Batch stand-in)
   Trainer          -- the per-batch step of /root/reference/train.py:27-66 on fused kernels
   optim.Adam       -- torch.optim.Adam drop-in that updates the flat parameter buffer with one kernel (train.py:11,99)
+  device_data      -- DeviceDataset / DeviceLoader: dataset resident in HBM, batches assembled on the device
   tudataset        -- TU-format reader + Indegree + fold files + GraphLoader (train.py:81-109, utils.py:18-33)
   cli              -- the 10-fold driver (train.py:69-148), also reachable as ``python train.py``
 """

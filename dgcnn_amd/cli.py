@@ -24,6 +24,7 @@ import torch
 from . import synth
 from .model import Model
 from .train import Trainer
+from .device_data import DeviceDataset, DeviceLoader
 from .tudataset import GraphLoader, TUData, make_fold_indices, read_fold_indices, read_tu_dataset
 
 CHOICES = ['DD', 'PTC_MR', 'NCI1', 'PROTEINS', 'IMDB-BINARY', 'IMDB-MULTI', 'MUTAG', 'COLLAB']
@@ -43,6 +44,9 @@ def get_args(argv=None):
     p.add_argument('--folds', default=10, type=int, help='number of folds to run (<= 10)')
     p.add_argument('--out_dir', default='.', type=str, help='where epochs/ and statistics/ are written')
     p.add_argument('--device', default='cuda', type=str)
+    p.add_argument('--host_loader', dest='device_loader', action='store_false',
+                   help='collate every batch on the host like the reference DataLoader (default: dataset resident in HBM, '
+                        'batches assembled on the device)')
     return p.parse_args(argv)
 
 
@@ -71,6 +75,7 @@ def run(opt) -> dict:
     os.makedirs(os.path.join(opt.out_dir, 'statistics'), exist_ok=True)
     over = {'train_accuracy': [], 'test_accuracy': []}
     gen = torch.Generator().manual_seed(opt.seed)
+    dev_set = DeviceDataset(data_set, opt.device) if (opt.device_loader and str(opt.device).startswith('cuda')) else None
     for fold in range(1, opt.folds + 1):
         model = Model(data_set.num_features, data_set.num_classes).to(opt.device)
         trainer = Trainer(model)                        # Adam defaults, as Adam(model.parameters()) at train.py:99
@@ -79,8 +84,12 @@ def run(opt) -> dict:
             tr_idx, te_idx = read_fold_indices(idx_dir, fold)
         else:
             tr_idx, te_idx = make_fold_indices(len(data_set), fold, max(opt.folds, 2), opt.seed)
-        train_loader = GraphLoader(data_set[tr_idx], opt.batch_size, shuffle=True, generator=gen, device=opt.device)
-        test_loader = GraphLoader(data_set[te_idx], opt.batch_size, shuffle=False, device=opt.device)
+        if dev_set is not None:       # dataset resident in HBM, batches assembled by one kernel launch each
+            train_loader = DeviceLoader(dev_set, opt.batch_size, tr_idx, shuffle=True, generator=gen)
+            test_loader = DeviceLoader(dev_set, opt.batch_size, te_idx, shuffle=False)
+        else:
+            train_loader = GraphLoader(data_set[tr_idx], opt.batch_size, shuffle=True, generator=gen, device=opt.device)
+            test_loader = GraphLoader(data_set[te_idx], opt.batch_size, shuffle=False, device=opt.device)
         res = {'train_loss': [], 'test_loss': [], 'train_accuracy': [], 'test_accuracy': []}
         for epoch in range(1, opt.num_epochs + 1):
             tl, ta = trainer.train_epoch(train_loader, train_loader.num_samples)

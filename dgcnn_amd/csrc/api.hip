@@ -384,6 +384,17 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                         (hipStream_t)stream);
 }
 
+int dgcnn_collate(int B, int F, int64_t N, int64_t E, int64_t Etot, const int64_t* graph_ids, const int64_t* out_node_ptr,
+                  const int64_t* out_edge_ptr, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
+                  const int64_t* edge_ptr, const int64_t* y_all, float* x, int64_t* edge_index, int64_t* batch,
+                  int64_t* y, dgcnn_stream_t stream) {
+  if (!graph_ids || !out_node_ptr || !out_edge_ptr || !x_all || !node_ptr || !edge_ptr || !y_all || !x || !batch || !y)
+    return DGCNN_EINVAL;
+  if (E > 0 && (!ei_all || !edge_index)) return DGCNN_EINVAL;
+  return dg_launch_collate(B, F, N, E, Etot, graph_ids, out_node_ptr, out_edge_ptr, x_all, ei_all, node_ptr, edge_ptr,
+                           y_all, x, edge_index, batch, y, (hipStream_t)stream);
+}
+
 int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C, float* metrics,
                              dgcnn_stream_t stream) {
   DgWs wl;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 8
+#define DGCNN_ABI_VERSION 9
 
 /* error codes */
 #define DGCNN_OK            0
@@ -280,6 +280,22 @@ int dgcnn_pipeline_create(void** handle);     /* one per training loop: remember
 int dgcnn_pipeline_destroy(void* handle);
 int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
                               dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mini-batch assembly on the device: what the reference's `DataLoader(data_set[idx], batch_size, shuffle)`
+ * (/root/reference/train.py:108-109, PyG collate) produces on the host for every batch -- x rows of the chosen graphs
+ * concatenated, their edge lists shifted by each graph's node offset, the `batch` vector, the labels -- from a dataset
+ * resident in device memory:
+ *   x_all [Ntot,F] f32, ei_all [2,Etot] i64 (GRAPH-LOCAL node ids), node_ptr / edge_ptr [G+1] i64, y_all [G] i64
+ * Per batch: graph_ids [B] i64 (device) and the exclusive prefix sums of the chosen graphs' node / edge counts,
+ * out_node_ptr / out_edge_ptr [B+1] i64 (device; N = out_node_ptr[B], E = out_edge_ptr[B] are passed by value).
+ * Outputs (caller-allocated): x [N,F], edge_index [2,E] i64, batch [N] i64, y [B] i64.  One launch, pure data
+ * movement (bit-exact); concatenating coalesced undirected graphs keeps the union coalesced.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_collate(int B, int F, int64_t N, int64_t E, int64_t Etot, const int64_t* graph_ids, const int64_t* out_node_ptr,
+                  const int64_t* out_edge_ptr, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
+                  const int64_t* edge_ptr, const int64_t* y_all, float* x, int64_t* edge_index, int64_t* batch,
+                  int64_t* y, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Metrics (stand-alone form of the `metrics` argument above): folds the per-graph loss /

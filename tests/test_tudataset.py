@@ -116,3 +116,36 @@ def test_cli_driver_two_folds_on_synthetic(tmp_path):
     rows = (tmp_path / "statistics" / "MUTAG_results_1.csv").read_text().strip().splitlines()
     assert rows[0] == "epoch,train_loss,test_loss,train_accuracy,test_accuracy" and len(rows) == 4
     assert (tmp_path / "statistics" / "MUTAG_results_overall.csv").exists()
+
+
+@pytest.mark.gpu
+def test_device_collate_is_bit_identical_to_host_collate_and_trains():
+    """dgcnn_collate (one launch from a device-resident dataset) == collate(...).to(device), for shuffled ids, a short
+    last batch, a feature width > 1, and through the loader's buffer ring with look-ahead."""
+    from dgcnn_amd.batch import collate
+    from dgcnn_amd.device_data import DeviceDataset, DeviceLoader
+    for name in ("PROTEINS", "COLLAB"):
+        graphs = synth.make_graphs(name, 37, start=5)
+        ds = DeviceDataset(graphs)
+        rng = np.random.default_rng(3)
+        for ids in (rng.permutation(37)[:10], np.array([36]), np.arange(37)):
+            ref = collate([graphs[i] for i in ids])
+            got = ds.assemble(ids)
+            assert got.num_graphs == ref.num_graphs and got.coalesced_undirected == ref.coalesced_undirected
+            assert (got.max_nodes, got.max_edges) == (ref.max_nodes, ref.max_edges)
+            assert torch.equal(got.x.cpu(), ref.x) and torch.equal(got.edge_index.cpu(), ref.edge_index)
+            assert torch.equal(got.batch.cpu(), ref.batch) and torch.equal(got.y.cpu(), ref.y)
+    # loader: same batches as the host loader under the same shuffle; earlier batch still intact after the next one
+    graphs = synth.make_graphs("MUTAG", 23, labels="structure")
+    ds = DeviceDataset(graphs)
+    g1 = torch.Generator().manual_seed(9); g2 = torch.Generator().manual_seed(9)
+    host = list(GraphLoader(graphs, 10, shuffle=True, generator=g1))
+    it = iter(DeviceLoader(ds, 10, shuffle=True, generator=g2))
+    prev = next(it)
+    for k, h in enumerate(host):
+        nxt = next(it, None)
+        torch.cuda.synchronize()
+        assert torch.equal(prev.x.cpu(), h.x) and torch.equal(prev.edge_index.cpu(), h.edge_index), k
+        assert torch.equal(prev.y.cpu(), h.y)
+        prev = nxt
+    assert prev is None
