@@ -250,16 +250,19 @@ class Model(nn.Module):
         return self._total
 
     # ---- forward -----------------------------------------------------------------------
+    # (per-step bookkeeping goes through __dict__: nn.Module.__setattr__ costs ~1.5 us per assignment)
     def _next_seed(self) -> int:
-        if self._seed_base is None:
-            self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        self._fwd_count += 1
-        return (self._seed_base * 0x9E3779B97F4A7C15 + self._fwd_count * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        d = self.__dict__
+        if d["_seed_base"] is None:
+            d["_seed_base"] = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        d["_fwd_count"] += 1
+        return (d["_seed_base"] * 0x9E3779B97F4A7C15 + d["_fwd_count"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     def _next_epoch(self) -> int:
         """non-zero 32-bit tag of a forward call (error words in the workspace are epoch-tagged)."""
-        self._epoch = (self._epoch % 0x7FFFFFFE) + 1
-        return self._epoch
+        d = self.__dict__
+        e = d["_epoch"] = (d["_epoch"] % 0x7FFFFFFE) + 1
+        return e
 
     def _flags_of(self, data) -> int:
         f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0

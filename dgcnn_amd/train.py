@@ -199,7 +199,7 @@ class Trainer:
         prepared = pe is not None and pe[0] is data
         if prepared:
             slot = self._prep_slot               # its workspace was sized when it was handed in as `next`
-            m._epoch = a.epoch
+            m.__dict__["_epoch"] = a.epoch
         else:
             # (a prepared-but-abandoned batch keeps its slot untouched: use the other one)
             slot = self._cur if pe is None else 1 - self._prep_slot
@@ -248,7 +248,8 @@ class Trainer:
         if rc != 0:
             _lib.check(rc, "dgcnn_pipeline_train_step")
         self._ws = ws
-        m._last_ws, m._last_dims = ws, dims
+        md = m.__dict__
+        md["_last_ws"], md["_last_dims"] = ws, dims
         v = self._logp_views.get(B)
         if v is None:
             v = self._logp_views[B] = lp[:B]
