@@ -395,6 +395,48 @@ int dgcnn_collate(int B, int F, int64_t N, int64_t E, int64_t Etot, const int64_
                            y_all, x, edge_index, batch, y, (hipStream_t)stream);
 }
 
+int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_dev, const int64_t* nodes_per_graph_host,
+                      const int64_t* edges_per_graph_host, int64_t num_graphs, int64_t* meta_host, int64_t* meta_dev,
+                      void* ev_uploaded, int64_t Etot, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
+                      const int64_t* edge_ptr, const int64_t* y_all, int64_t cap_nodes, int64_t cap_edges, float* x,
+                      int64_t* edge_index, int64_t* batch, int64_t* y, int64_t* out_sizes, dgcnn_stream_t stream) {
+  if (B <= 0 || F < 1 || !ids_host || !nodes_per_graph_host || !edges_per_graph_host || !meta_host || !meta_dev ||
+      !x_all || !node_ptr || !edge_ptr || !y_all || !y || !out_sizes)
+    return DGCNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t ev = (hipEvent_t)ev_uploaded;
+  // ids already on the device (one upload per epoch) and a small batch: the kernel rebuilds the prefix sums itself,
+  // nothing is uploaded per batch; otherwise the prefix sums go up through the pinned staging buffer
+  const bool scan = ids_dev != nullptr && B <= 256;
+  // the previous asynchronous upload from this staging buffer must have been consumed before it is rewritten
+  if (!scan && ev && hipEventSynchronize(ev) != hipSuccess) return DGCNN_ELAUNCH;
+  int64_t nsum = 0, esum = 0, nmax = 0, emax = 0;
+  meta_host[0] = 0; meta_host[B + 1] = 0;
+  for (int k = 0; k < B; ++k) {
+    const int64_t g = ids_host[k];
+    if (g < 0 || g >= num_graphs) return DGCNN_EINVAL;
+    const int64_t n = nodes_per_graph_host[g], e = edges_per_graph_host[g];
+    nsum += n; esum += e;
+    if (n > nmax) nmax = n;
+    if (e > emax) emax = e;
+    meta_host[k + 1] = nsum;
+    meta_host[B + 2 + k] = esum;
+    meta_host[2 * B + 2 + k] = g;
+  }
+  out_sizes[0] = nsum; out_sizes[1] = esum; out_sizes[2] = nmax; out_sizes[3] = emax;
+  if (nsum > cap_nodes || esum > cap_edges) return DGCNN_EUNSUPPORTED;     // caller grows its buffers and calls again
+  if (nsum <= 0 || !x || !batch) return DGCNN_EINVAL;
+  if (esum > 0 && (!ei_all || !edge_index)) return DGCNN_EINVAL;
+  if (scan)
+    return dg_launch_collate_scan(B, F, nsum, esum, Etot, ids_dev, x_all, ei_all, node_ptr, edge_ptr, y_all, x, edge_index,
+                                  batch, y, s);
+  if (hipMemcpyAsync(meta_dev, meta_host, sizeof(int64_t) * (3 * (size_t)B + 2), hipMemcpyHostToDevice, s) != hipSuccess)
+    return DGCNN_ELAUNCH;
+  if (ev && hipEventRecord(ev, s) != hipSuccess) return DGCNN_ELAUNCH;
+  return dg_launch_collate(B, F, nsum, esum, Etot, meta_dev + 2 * B + 2, meta_dev, meta_dev + B + 1, x_all, ei_all, node_ptr,
+                           edge_ptr, y_all, x, edge_index, batch, y, s);
+}
+
 int dgcnn_accumulate_metrics(int B, const void* ws, int N, int E, int F, int C, float* metrics,
                              dgcnn_stream_t stream) {
   DgWs wl;

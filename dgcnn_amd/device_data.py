@@ -48,49 +48,52 @@ class DeviceDataset:
     def __len__(self) -> int:
         return self.num_graphs
 
-    def assemble(self, ids: np.ndarray, out: Optional[dict] = None) -> Batch:
-        """Batch of graphs ``ids`` (order kept), assembled on the device by ONE launch.  ``out``: reusable buffer dict."""
-        ids = np.asarray(ids, dtype=np.int64)
+    def assemble(self, ids: np.ndarray, out: Optional[dict] = None, ids_dev_ptr: Optional[int] = None) -> Batch:
+        """Batch of graphs ``ids`` (order kept), assembled on the device: ONE C call (``dgcnn_collate_ids``: prefix sums
+        in C, a few-hundred-byte asynchronous upload, one kernel launch).  ``out``: reusable buffer dict (a ring slot)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
         B = int(ids.shape[0])
-        nn_, ne_ = self.nodes_per_graph[ids], self.edges_per_graph[ids]
-        meta = np.empty(3 * B + 2, dtype=np.int64)          # [node prefix (B+1) | edge prefix (B+1) | ids (B)] : one H2D
-        meta[0] = 0; np.cumsum(nn_, out=meta[1:B + 1])
-        meta[B + 1] = 0; np.cumsum(ne_, out=meta[B + 2:2 * B + 2])
-        meta[2 * B + 2:] = ids
-        N, E = int(meta[B]), int(meta[2 * B + 1])
         dev, F = self.device, self.num_features
         if out is None:
             out = {}
-        def buf(name, numel, dtype):
-            t = out.get(name)
-            if t is None or t.numel() < numel:
-                t = out[name] = torch.empty(max(int(numel * 1.25), 16), dtype=dtype, device=dev)
-            return t
-        meta_h = out.get("meta_h")
-        if meta_h is None or meta_h.numel() < meta.shape[0]:
-            meta_h = out["meta_h"] = torch.empty(max(2 * meta.shape[0], 64), dtype=torch.int64).pin_memory()
-        evt = out.get("evt")
-        if evt is not None:
-            evt.synchronize()            # the previous async upload from this pinned buffer has been consumed (normally long ago)
-        else:
-            evt = out["evt"] = torch.cuda.Event()
-        meta_h[:meta.shape[0]].copy_(torch.from_numpy(meta))
-        meta_d = buf("meta_d", meta.shape[0], torch.int64)
-        meta_d[:meta.shape[0]].copy_(meta_h[:meta.shape[0]], non_blocking=True)
-        evt.record()
-        x = buf("x", N * F, torch.float32)[:N * F].view(N, F)
-        ei = buf("ei", 2 * max(E, 1), torch.int64)[:2 * E].view(2, E)
-        bt = buf("batch", N, torch.int64)[:N]
-        y = buf("y", B, torch.int64)[:B]
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        mp = meta_d.data_ptr()
-        _lib.check(_lib.lib().dgcnn_collate(B, F, N, E, self.total_edges, mp + 8 * (2 * B + 2), mp,
-                                            mp + 8 * (B + 1), self.x_all.data_ptr(),
-                                            self.ei_all.data_ptr() if self.total_edges else None, self.node_ptr.data_ptr(),
-                                            self.edge_ptr.data_ptr(), self.y_all.data_ptr(), x.data_ptr(),
-                                            ei.data_ptr() if E else None, bt.data_ptr(), y.data_ptr(), stream),
-                   "dgcnn_collate")
-        return Batch(x, ei, bt, y, B, self.coalesced_undirected, int(nn_.max()), int(ne_.max()))
+        st = out.get("state")
+        if st is None or st["B"] < B:
+            ev = _lib.c_void_p()
+            _lib.check(_lib.lib().dgcnn_event_create(_lib.ctypes.byref(ev)), "dgcnn_event_create")
+            st = out["state"] = {"B": max(B, 64), "ev": ev, "capN": 0, "capE": 0,
+                                 "meta_h": torch.empty(3 * max(B, 64) + 2, dtype=torch.int64).pin_memory(),
+                                 "meta_d": torch.empty(3 * max(B, 64) + 2, dtype=torch.int64, device=dev),
+                                 "y": torch.empty(max(B, 64), dtype=torch.int64, device=dev),
+                                 "sizes": np.zeros(4, dtype=np.int64)}
+        sizes = st["sizes"]
+        L = _lib.lib()
+        stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+        for attempt in (0, 1):
+            rc = L.dgcnn_collate_ids(B, F, ids.ctypes.data, ids_dev_ptr, self.nodes_per_graph.ctypes.data,
+                                     self.edges_per_graph.ctypes.data,
+                                     self.num_graphs, st["meta_h"].data_ptr(), st["meta_d"].data_ptr(), st["ev"],
+                                     self.total_edges, self.x_all.data_ptr(),
+                                     self.ei_all.data_ptr() if self.total_edges else None, self.node_ptr.data_ptr(),
+                                     self.edge_ptr.data_ptr(), self.y_all.data_ptr(), st["capN"], st["capE"],
+                                     st["x"].data_ptr() if st["capN"] else None, st["ei"].data_ptr() if st["capE"] else None,
+                                     st["bt"].data_ptr() if st["capN"] else None, st["y"].data_ptr(), sizes.ctypes.data, stream)
+            if rc == 0:
+                break
+            if rc != -3 or attempt == 1:
+                _lib.check(rc, "dgcnn_collate_ids")
+            # buffers too small for this batch: grow (with slack) and call again
+            N, E = int(sizes[0]), int(sizes[1])
+            if N > st["capN"]:
+                st["capN"] = int(N * 1.25) + 16
+                st["x"] = torch.empty(st["capN"] * F, dtype=torch.float32, device=dev)
+                st["bt"] = torch.empty(st["capN"], dtype=torch.int64, device=dev)
+            if E > st["capE"]:
+                st["capE"] = int(E * 1.25) + 16
+                st["ei"] = torch.empty(2 * st["capE"], dtype=torch.int64, device=dev)
+        N, E = int(sizes[0]), int(sizes[1])
+        x = st["x"][:N * F].view(N, F)
+        ei = st["ei"][:2 * E].view(2, E) if E else torch.zeros(2, 0, dtype=torch.int64, device=dev)
+        return Batch(x, ei, st["bt"][:N], st["y"][:B], B, self.coalesced_undirected, int(sizes[2]), int(sizes[3]))
 
 
 class DeviceLoader:
@@ -118,7 +121,13 @@ class DeviceLoader:
     def __iter__(self) -> Iterator[Batch]:
         n = self.num_samples
         order = self.indices[torch.randperm(n, generator=self.generator).numpy()] if self.shuffle else self.indices
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        # the epoch's permutation goes to the device ONCE; batches then need no upload of their own (B <= 256).
+        # Two generations are kept alive: the previous epoch's last batches may still be in flight.
+        order_dev = torch.from_numpy(order).to(self.ds.device)
+        self._order_keep = (getattr(self, "_order_keep", (None, None))[1], order_dev)
+        base = order_dev.data_ptr()
         for i in range(0, n, self.batch_size):
             out = self._bufs[self._k % len(self._bufs)]
             self._k += 1
-            yield self.ds.assemble(order[i:i + self.batch_size], out)
+            yield self.ds.assemble(order[i:i + self.batch_size], out, base + 8 * i)

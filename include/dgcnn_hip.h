@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 9
+#define DGCNN_ABI_VERSION 11
 
 /* error codes */
 #define DGCNN_OK            0
@@ -296,6 +296,20 @@ int dgcnn_collate(int B, int F, int64_t N, int64_t E, int64_t Etot, const int64_
                   const int64_t* out_edge_ptr, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
                   const int64_t* edge_ptr, const int64_t* y_all, float* x, int64_t* edge_index, int64_t* batch,
                   int64_t* y, dgcnn_stream_t stream);
+
+/* dgcnn_collate with the per-batch bookkeeping done here instead of in the host language: from the graph ids of the
+ * batch (HOST array) and the dataset's per-graph node / edge counts (HOST arrays) it builds the prefix sums in the
+ * caller's pinned staging buffer meta_host [3B+2], uploads them asynchronously to meta_dev [3B+2] and launches the
+ * assembly.  out_sizes (host, 4 values) receives N, E, max nodes per graph, max edges per graph of the batch; if N or E
+ * exceeds the given buffer capacities the call returns DGCNN_EUNSUPPORTED with out_sizes filled and launches nothing.
+ * ev_uploaded (a hipEvent_t from dgcnn_event_create, or NULL) guards the reuse of meta_host across calls.
+ * ids_dev (optional): the same B ids in DEVICE memory (e.g. a slice of the epoch's permutation, uploaded once per
+ * epoch); with it and B <= 256 nothing is uploaded per batch -- the kernel rebuilds the prefix sums in LDS. */
+int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_dev, const int64_t* nodes_per_graph_host,
+                      const int64_t* edges_per_graph_host, int64_t num_graphs, int64_t* meta_host, int64_t* meta_dev,
+                      void* ev_uploaded, int64_t Etot, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
+                      const int64_t* edge_ptr, const int64_t* y_all, int64_t cap_nodes, int64_t cap_edges, float* x,
+                      int64_t* edge_index, int64_t* batch, int64_t* y, int64_t* out_sizes, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Metrics (stand-alone form of the `metrics` argument above): folds the per-graph loss /
