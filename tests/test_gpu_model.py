@@ -74,7 +74,7 @@ def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
     check_backward_parity(m, b, sd)
 
 
-@pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 700), ("PROTEINS", 260)])
+@pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 540), ("PROTEINS", 260)])
 def test_large_batch_two_stage_weight_gradients(name, bs):
     """B > 128 switches the weight-gradient reduction to two stages (chunk partials, then the final sum), and large
     grids use the shallower gather depth: same parity bar as the reference-sized batches."""
