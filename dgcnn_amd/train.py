@@ -136,13 +136,15 @@ class Trainer:
 
     def optimizer_step(self) -> None:
         """Adam + zero_grad over the flat buffer (train.py:41-42)."""
-        L = _lib.lib()
-        flat = self.model.flat_params
+        flat = self.model.flat_params_fast()
         self.step_count += 1
-        stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _lib.check(L.dgcnn_adam_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                     self.exp_avg_sq.data_ptr(), flat.numel(), self.step_count, self.lr,
-                                     self.betas[0], self.betas[1], self.eps, 1, stream), "dgcnn_adam_step")
+        dev = flat.device
+        stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+        rc = _lib.lib().dgcnn_adam_step(flat.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                        self.exp_avg_sq.data_ptr(), flat.numel(), self.step_count, self.lr,
+                                        self.betas[0], self.betas[1], self.eps, 1, stream)
+        if rc != 0:
+            _lib.check(rc, "dgcnn_adam_step")
 
     # ---- pipelined step: ONE C-ABI call per batch, next batch's graph prep on the library's side stream ----
     def _step_args(self, data, y):
