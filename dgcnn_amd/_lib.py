@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 11
+ABI_VERSION = 12
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -40,6 +40,7 @@ class StepArgs(ctypes.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/dgcnn_hip.h declares
 SIGNATURES = {
+    "dgcnn_model_eval_step": (c_int, [ctypes.POINTER(StepArgs), c_void_p]),
     "dgcnn_pipeline_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "dgcnn_pipeline_destroy": (c_int, [c_void_p]),
     "dgcnn_pipeline_train_step": (c_int, [c_void_p, ctypes.POINTER(StepArgs), ctypes.POINTER(StepArgs), c_void_p]),

@@ -377,6 +377,17 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   return DGCNN_OK;
 }
 
+int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream) {
+  if (!a || !a->params || !a->x || !a->batch || !a->ws || !a->logp || a->N <= 0 || a->B <= 0 || a->E < 0 || a->epoch == 0)
+    return DGCNN_EINVAL;
+  DG_TRY(dg_model_forward_impl(a->N, a->E, a->B, a->F, a->C, a->params, a->x, a->edge_index, a->batch, a->ws, a->logp, 0, 0,
+                               a->flags & 0xFFFF & ~DGCNN_FLAG_PREPARED, a->max_nodes, a->max_edges, a->epoch, stream,
+                               nullptr, nullptr));
+  if (a->y && a->metrics)
+    DG_TRY(dg_launch_eval_metrics(a->B, a->C, a->logp, a->y, a->metrics, (hipStream_t)stream));
+  return DGCNN_OK;
+}
+
 int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                     float lr, float beta1, float beta2, float eps, int zero_grads, dgcnn_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq) return DGCNN_EINVAL;

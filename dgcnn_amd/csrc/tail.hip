@@ -740,6 +740,39 @@ __global__ void k_metrics(int B, const float* __restrict__ lossv, float* __restr
   }
 }
 
+// evaluation bookkeeping (the body of /root/reference/train.py:59-64 after `pred = model(data)`):
+//   metrics[0] += mean_b( -logp[b][y_b] )      (nn.NLLLoss() mean, train.py:62,98)
+//   metrics[1] += #{ b : argmax_c logp[b][c] == y_b }   (first maximal index, like torch.argmax; train.py:64)
+// one workgroup, fixed-order reduction
+__global__ void __launch_bounds__(256)
+k_eval_metrics(int B, int C, const float* __restrict__ logp, const int64_t* __restrict__ y, float* __restrict__ metrics) {
+  __shared__ float sl[256], sc[256];
+  float l = 0.f, c = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = logp + (size_t)b * C;
+    const int yb = (int)y[b];
+    int am = 0;
+    float mx = row[0];
+    for (int k = 1; k < C; ++k) { const float v = row[k]; if (v > mx) { mx = v; am = k; } }
+    l -= row[yb];
+    c += (am == yb) ? 1.f : 0.f;
+  }
+  sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) { sl[threadIdx.x] += sl[threadIdx.x + st]; sc[threadIdx.x] += sc[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { metrics[0] += sl[0] / (float)B; metrics[1] += sc[0]; }
+}
+
+int dg_launch_eval_metrics(int B, int C, const float* logp, const int64_t* y, float* metrics, hipStream_t s) {
+  if (B <= 0 || C < 1) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_eval_metrics, dim3(1), dim3(256), 0, s, B, C, logp, y, metrics);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
 int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s) {
   if (B <= 0) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_metrics, dim3(1), dim3(64), 0, s, B, lossv, metrics);

@@ -271,31 +271,44 @@ class Trainer:
 
     @torch.no_grad()
     def eval_step(self, data, y) -> torch.Tensor:
-        """Body of the reference ``test()`` loop (train.py:59-64): forward only + metrics."""
-        L = _lib.lib()
+        """Body of the reference ``test()`` loop (train.py:59-64) as ONE C call (``dgcnn_model_eval_step``): forward in
+        eval mode + loss / #correct folded into the device-side metrics accumulator."""
         m = self.model
-        was = m.training
-        m.eval()
-        try:
-            N, E, B, F, C = self._dims(data)
-            dev = data.x.device
-            ws, logp = self._buffers(N, E, B, F, C, dev)
-            flat = m.flat_params
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
-            _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
-                                             ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
-                                             logp.data_ptr(), 0, 0, m._flags_of(data), m._max_nodes_of(data),
-                                             int(getattr(data, "max_edges", 0) or 0), m._next_epoch(), stream),
-                       "dgcnn_model_forward")
-            m._last_ws, m._last_dims = ws, (N, E, B, F, C)
-            lp = logp[:B]
-            # metrics with plain torch ops (evaluation is not the timed hot path)
-            self.metrics[0] += -lp.gather(1, y.view(-1, 1)).mean()
-            self.metrics[1] += (lp.argmax(dim=1) == y).sum()
-        finally:
-            m.train(was)
-        return lp
+        ent = self._args_cache.get(id(data))
+        if ent is None or ent[0] is not data or ent[1] is not y:
+            ent = self._step_args(data, y)
+        a, need, dims, aref, dev = ent[2], ent[3], ent[5], ent[6], ent[7]
+        flat = m.flat_params_fast()
+        if flat.data_ptr() != self._p_flat:
+            self._p_flat, self._p_grads, self._p_metrics = flat.data_ptr(), self.grads.data_ptr(), self.metrics.data_ptr()
+            self._p_m, self._p_v = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        if self._prep_ent is not None:       # keep a slot that holds a prepared training batch intact
+            self._cur = 1 - self._prep_slot
+        sl = self._slots[self._cur]
+        if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
+            self._slot_ws(self._cur, need, dev)
+        ws = sl["ws"]
+        B, C = dims[2], dims[4]
+        lp = self._logp
+        if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
+            lp = self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
+            self._logp_views = {}
+        a.ws, a.logp, a.params, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_metrics
+        a.training = 0
+        uf = getattr(m, "use_fused", None)
+        a.flags = ent[8] | (0 if uf is None else (_lib.FLAG_FORCE_FUSED if uf else _lib.FLAG_FORCE_TILED))
+        a.epoch = m._next_epoch()
+        rc = _lib.lib().dgcnn_model_eval_step(aref, torch._C._cuda_getCurrentRawStream(
+            dev.index if dev.index is not None else torch.cuda.current_device()))
+        if rc != 0:
+            _lib.check(rc, "dgcnn_model_eval_step")
+        self._ws = ws
+        md = m.__dict__
+        md["_last_ws"], md["_last_dims"] = ws, dims
+        v = self._logp_views.get(B)
+        if v is None:
+            v = self._logp_views[B] = lp[:B]
+        return v
 
     def reset_metrics(self) -> None:
         self.metrics.zero_()

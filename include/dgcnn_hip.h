@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 11
+#define DGCNN_ABI_VERSION 12
 
 /* error codes */
 #define DGCNN_OK            0
@@ -275,6 +275,12 @@ typedef struct dgcnn_step_args {
   float* exp_avg;              /* Adam moments, or NULL */
   float* exp_avg_sq;
 } dgcnn_step_args;
+
+/* Evaluation step, the body of the reference's `test()` loop (/root/reference/train.py:59-64), one call: forward in
+ * eval mode (no dropout) into a->logp and, when a->y and a->metrics are given, metrics[0] += NLLLoss-mean of the batch,
+ * metrics[1] += number of correct argmax predictions.  Uses the same argument block as the training step (optimizer
+ * fields ignored). */
+int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream);
 
 int dgcnn_pipeline_create(void** handle);     /* one per training loop: remembers which workspace holds a prepared batch */
 int dgcnn_pipeline_destroy(void* handle);

@@ -490,3 +490,24 @@ def test_end_to_end_training_learns_a_structural_task_and_generalises():
     vloss, vacc = tr.test_epoch(vl, len(test))
     assert loss < 0.6 * first, (first, loss)
     assert acc > 85.0 and vacc > 85.0, (acc, vacc)
+
+
+def test_eval_step_metrics_match_the_reference_bookkeeping():
+    """dgcnn_model_eval_step: forward in eval mode + metrics[0] += NLLLoss-mean, metrics[1] += #correct (train.py:59-64)."""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["PROTEINS"]
+    batches = [b.to("cuda") for b in synth.make_batches("PROTEINS", 130, 50, start=3)]      # 50, 50, 30 graphs
+    m = make_model(sh.num_features, sh.num_classes)
+    m.train()
+    tr = Trainer(m)
+    tr.reset_metrics()
+    want_loss, want_correct = 0.0, 0
+    for b in batches:
+        lp = tr.eval_step(b, b.y).clone()
+        assert m.training                        # eval_step leaves the module's mode alone
+        lp2 = tr.eval_step(b, b.y).clone()       # eval mode: no dropout, deterministic
+        assert torch.equal(lp, lp2)
+        want_loss += 2 * float(torch.nn.functional.nll_loss(lp, b.y))
+        want_correct += 2 * int((lp.argmax(dim=1) == b.y).sum())
+    loss, correct = tr.read_metrics()
+    assert abs(loss - want_loss) < 1e-4 * max(1.0, abs(want_loss)) and correct == want_correct
