@@ -83,7 +83,9 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 // LDS plan (bytes): region A 32 KiB = sort keys, afterwards reused for the pooled rows (11640),
 // conv5 weights (6208) and conv6 weights (10240); small activations after it.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RD_THREADS)
+// BIG (many graphs): registers capped at 64 so that two workgroups share a CU and hide each other's latency chain
+template <bool BIG>
+__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
 k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
@@ -111,8 +113,13 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  hipLaunchKernelGGL(k_readout_fwd, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1,
-                     x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
+  static const bool nobig = getenv("DG_NO_BIG_READOUT") != nullptr;      // A/B switch (measurement only)
+  if (B >= 512 && !nobig)
+    hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
+                       x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
+  else
+    hipLaunchKernelGGL(k_readout_fwd<false>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
+                       x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
