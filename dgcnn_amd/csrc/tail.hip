@@ -129,7 +129,11 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
 // SortPooling gradient to dense per-node slabs gp1..gp3 [N,32] and produces
 // gas4 = dinv * dL/d(pre-activation of conv4).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RD_THREADS)
+// BIG (many graphs): classifier_1's weights are NOT prefetched into 64 registers at kernel start but read in 4-row
+// chunks at their use (they are L2-resident when thousands of workgroups stream the same 180 KB), and the registers
+// are capped at 64 so that two workgroups share a CU.  Same arithmetic order: bit-identical results.
+template <bool BIG>
+__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
 k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
            const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
            const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
@@ -200,12 +204,12 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   // LDS-only barriers and no further global load, so they land while steps 1-2 run. ----
   // 704 threads = 8 row groups (16 rows each) x 88 column quads: 16 x 16-byte loads per thread (one quarter of the
   // vector-memory instructions a dword-per-lane mapping needs for the same 180 KB)
-  float4 wpre[16];
-  if (tid < 2 * DGCNN_FLAT) {
+  float4 wpre[BIG ? 1 : 16];
+  if (!BIG && tid < 2 * DGCNN_FLAT) {
     const int rg = tid / 88, mq = tid - rg * 88;
     const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
+    for (int j = 0; j < (BIG ? 1 : 16); ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
   }
   st5.store(W5s, tid); st6.store(W6s, tid); stp.store(sps, tid);     // (waits only for the small loads above)
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
@@ -265,11 +269,27 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   if (tid < 2 * DGCNN_FLAT) {
     const int rg = tid / 88, mq = tid - rg * 88;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BIG) {
+      const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
+#pragma unroll 1
+      for (int j0 = 0; j0 < 16; j0 += 4) {
+        float4 wq[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float z = gz1s[rg * 16 + j];
-      g.x = fmaf(z, wpre[j].x, g.x); g.y = fmaf(z, wpre[j].y, g.y);
-      g.z = fmaf(z, wpre[j].z, g.z); g.w = fmaf(z, wpre[j].w, g.w);
+        for (int u = 0; u < 4; ++u) wq[u] = *reinterpret_cast<const float4*>(wc + (size_t)(j0 + u) * DGCNN_FLAT);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float z = gz1s[rg * 16 + j0 + u];
+          g.x = fmaf(z, wq[u].x, g.x); g.y = fmaf(z, wq[u].y, g.y);
+          g.z = fmaf(z, wq[u].z, g.z); g.w = fmaf(z, wq[u].w, g.w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (BIG ? 1 : 16); ++j) {
+        const float z = gz1s[rg * 16 + j];
+        g.x = fmaf(z, wpre[j].x, g.x); g.y = fmaf(z, wpre[j].y, g.y);
+        g.z = fmaf(z, wpre[j].z, g.z); g.w = fmaf(z, wpre[j].w, g.w);
+      }
     }
     *reinterpret_cast<float4*>(&gfh[rg][4 * mq]) = g;
   }
@@ -395,9 +415,15 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  hipLaunchKernelGGL(k_tail_bwd, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr, perm,
-                     dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2, gp3,
-                     gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+  static const bool nobig = getenv("DG_NO_BIG_TAIL") != nullptr;      // A/B switch (measurement only)
+  if (B >= 512 && !nobig)
+    hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+                       perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+  else
+    hipLaunchKernelGGL(k_tail_bwd<false>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+                       perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
