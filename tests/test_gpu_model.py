@@ -511,3 +511,32 @@ def test_eval_step_metrics_match_the_reference_bookkeeping():
         want_correct += 2 * int((lp.argmax(dim=1) == b.y).sum())
     loss, correct = tr.read_metrics()
     assert abs(loss - want_loss) < 1e-4 * max(1.0, abs(want_loss)) and correct == want_correct
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_general_edge_lists_match_the_oracle(seed):
+    """Arbitrary edge lists as a user might hand them over -- directed, unsorted, with duplicates, self loops, isolated
+    nodes, graphs of 1..40 nodes (some below k = 30), several feature widths -- through the general graph-prep path:
+    forward and gradients within the parity bar.  (The oracle implements PyG's semantics: self loops removed, duplicate
+    edges counted twice.)"""
+    from dgcnn_amd.batch import Batch
+    g = torch.Generator().manual_seed(1000 + seed)
+    B = int(torch.randint(1, 9, (1,), generator=g))
+    F = [1, 3, 8, 17, 33, 6][seed]
+    sizes = torch.randint(1, 41, (B,), generator=g).tolist()
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes):
+        m_edges = int(torch.randint(0, 4 * n + 1, (1,), generator=g))
+        src = torch.randint(0, n, (m_edges,), generator=g)
+        dst = torch.randint(0, n, (m_edges,), generator=g)       # self loops and duplicates happen naturally
+        eis.append(torch.stack([src, dst]) + off)
+        xs.append(torch.randn(n, F, generator=g))
+        bs.append(torch.full((n,), gi, dtype=torch.int64))
+        off += n
+    ei = torch.cat(eis, 1)
+    ei = ei[:, torch.randperm(ei.shape[1], generator=g)]          # globally shuffled: nothing is sorted
+    b = Batch(torch.cat(xs), ei, torch.cat(bs), torch.randint(0, 3, (B,), generator=g), B)
+    m = make_model(F, 3)
+    sd = cpu_state_dict(m)
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
