@@ -66,7 +66,18 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
 // depends on the batch only, never on the weights), and its weight gradient dW1 = ga1^T (A_hat X) needs NO
 // gather at all in backward -- it rides on conv2's backward kernel from the saved A_hat X.
 #define DG_AF_MAX_F 32
-#define DG_WG_TWO_STAGE_B 128       // batches above this reduce the per-graph weight-gradient partials in two stages
+#ifndef DG_WG_TWO_STAGE_B
+#define DG_WG_TWO_STAGE_B 1024      // batches above this reduce the per-graph weight-gradient partials in two stages
+                                     // (measured crossover ~1500 graphs: one launch is faster below, two above)
+#endif
+// (environment override DG_WG_TWO_STAGE_B=<n>, read once per process: lets the tests drive the two-stage form with
+// batches small enough for the CPU oracle)
+#include <cstdlib>
+static inline int dg_wg_two_stage_b() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DG_WG_TWO_STAGE_B"); v = (e && atoi(e) > 0) ? atoi(e) : DG_WG_TWO_STAGE_B; }
+  return v;
+}
 #define DG_WG_ROWS_PER_CHUNK 32
 #define DG_WG_FC1_KCHUNK 128
 static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
@@ -138,8 +149,8 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
   R(ax, F <= DG_AF_MAX_F ? 4 * n * F : 0);      // aggregated raw input (aggregate-first conv1), saved for dW1
   // large batches only: stage-1 buffers of the two-stage weight-gradient reduction (tail.hip, dg_launch_wgrad)
-  R(wg_t1, B > DG_WG_TWO_STAGE_B ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * DG_PTAIL(C) : 0);
-  R(wg_t2, B > DG_WG_TWO_STAGE_B ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
+  R(wg_t1, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * DG_PTAIL(C) : 0);
+  R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
 #undef R
   w->total = o;
   return DGCNN_OK;

@@ -677,7 +677,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
   }
   if (which & 1) {
-    const bool small = B <= DG_WG_TWO_STAGE_B;
+    const bool small = B <= dg_wg_two_stage_b();
     const int st = DG_PTAIL(C);
     const float* pt = dg_cptr<float>(ws, wl->ptail);
     int Rt = B;                      // rows the final reduction of the per-graph tail partials runs over

@@ -76,8 +76,8 @@ def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
 
 @pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 540), ("PROTEINS", 260)])
 def test_large_batch_two_stage_weight_gradients(name, bs):
-    """B > 128 switches the weight-gradient reduction to two stages (chunk partials, then the final sum), and large
-    grids use the shallower gather depth: same parity bar as the reference-sized batches."""
+    """large grids use the shallower gather depth / 64-register variants; from 512 graphs the readout pair switches to
+    its two-workgroups-per-CU form: same parity bar as the reference-sized batches."""
     sh = synth.SHAPES[name]
     b = synth.make_batch(name, bs, start=300)
     m = make_model(sh.num_features, sh.num_classes)
@@ -540,3 +540,22 @@ def test_random_general_edge_lists_match_the_oracle(seed):
     sd = cpu_state_dict(m)
     check_forward_parity(m, b, sd)
     check_backward_parity(m, b, sd)
+
+
+def test_two_stage_weight_gradient_reduction_in_a_subprocess():
+    """Batches above DG_WG_TWO_STAGE_B (1024) graphs reduce the per-graph weight-gradient partials in two stages (chunk
+    partials + split-K classifier_1 GEMM, then the final sums).  A batch that large is too slow for the CPU oracle, so a
+    child process lowers the threshold through the environment and runs the usual parity check on 300 graphs."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from dgcnn_amd import synth\n"
+        "from parity_util import check_backward_parity, check_forward_parity, cpu_state_dict, make_model\n"
+        "sh = synth.SHAPES['MUTAG']; b = synth.make_batch('MUTAG', 300, start=41)\n"
+        "m = make_model(sh.num_features, sh.num_classes); sd = cpu_state_dict(m)\n"
+        "check_forward_parity(m, b, sd); check_backward_parity(m, b, sd); print('TWO_STAGE_OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, DG_WG_TWO_STAGE_B="128")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "TWO_STAGE_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
