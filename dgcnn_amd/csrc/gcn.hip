@@ -35,7 +35,9 @@
 #ifndef DG_DEPTH_BWD_BIG
 #define DG_DEPTH_BWD_BIG 2
 #endif
-#define DG_SMALL_GRID_TILES 512
+#ifndef DG_SMALL_GRID_TILES
+#define DG_SMALL_GRID_TILES 256       // = number of CUs: up to one workgroup per CU the deep form wins, beyond it the
+#endif                                // two-workgroups-per-CU forms do (measured at 232 / 300 / 470 tiles)
 #define DG_PERSIST_WGS 512           // persistent large-grid kernels: 2 workgroups per CU
 
 // ---------------------------------------------------------------------------------------------
