@@ -19,6 +19,9 @@
 #include <stdlib.h>
 #include "dg_readout.h"
 #include "dg_prep.h"
+#ifndef DG_TAIL_BIG_MIN_B
+#define DG_TAIL_BIG_MIN_B 257         // more graphs than CUs: the readout pair uses its two-workgroups-per-CU forms
+#endif
 
 __global__ void __launch_bounds__(SP_THREADS)
 k_sortpool_fwd(const int* __restrict__ graph_ptr, const float* __restrict__ x1, const float* __restrict__ x2,
@@ -114,7 +117,7 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static const bool nobig = getenv("DG_NO_BIG_READOUT") != nullptr;      // A/B switch (measurement only)
-  if (B >= 512 && !nobig)
+  if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
                        x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
   else
@@ -416,7 +419,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static const bool nobig = getenv("DG_NO_BIG_TAIL") != nullptr;      // A/B switch (measurement only)
-  if (B >= 512 && !nobig)
+  if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
                        gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
