@@ -76,7 +76,7 @@ def test_raw_feature_widths_aggregate_first_and_linear_first(F, fused):
 
 @pytest.mark.parametrize("name,bs", [("MUTAG", 129), ("MUTAG", 540), ("PROTEINS", 260)])
 def test_large_batch_two_stage_weight_gradients(name, bs):
-    """large grids use the shallower gather depth / 64-register variants; from 512 graphs the readout pair switches to
+    """large grids use the shallower gather depth / 64-register variants; from 257 graphs the readout pair switches to
     its two-workgroups-per-CU form: same parity bar as the reference-sized batches."""
     sh = synth.SHAPES[name]
     b = synth.make_batch(name, bs, start=300)
