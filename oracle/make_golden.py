@@ -11,7 +11,8 @@ from PyG.  If a PyG install ever becomes available, regenerate from the real
 Each fixture holds: inputs (x, edge_index, batch, y), the reference-keyed state_dict
 (init under torch.manual_seed(324), the reference's default seed, train.py:24),
 eval-mode log-probs (fp32 ref_ops and fp64 ref_dense), and one training step with an
-explicit dropout mask: loss and every parameter gradient (fp64 ref_dense, stored f32).
+explicit dropout mask: loss and every parameter gradient (fp64 ref_dense, stored f32); and one EVAL-mode step
+(no dropout): loss, every gradient, and the parameters after one Adam step (the step fixture).
 """
 from __future__ import annotations
 
@@ -71,6 +72,17 @@ def build(name, workload, bs, start, min_margin):
     logp_tr, loss, grads, aux = ref_dense.loss_and_grads_dense(
         sd, b.x, b.edge_index, b.batch, b.y, b.num_graphs, dropout_mask=mask)
     margin = ref_dense.sort_margin(aux["xcat"], aux["ptr"])
+    # step fixture, eval mode so that no dropout mask has to be shared with the kernel: loss,
+    # every gradient, and the parameters after ONE Adam step (torch.optim.Adam defaults, train.py:99) -- all fp64
+    _, loss_ev, grads_ev, _ = ref_dense.loss_and_grads_dense(sd, b.x, b.edge_index, b.batch, b.y, b.num_graphs,
+                                                            dropout_mask=None)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    adam1 = {}
+    for k_, v in sd.items():
+        g64 = grads_ev[k_].double()
+        m1 = (1 - b1) * g64
+        v1 = (1 - b2) * g64 * g64
+        adam1[k_] = v.double() - (lr / (1 - b1)) * (m1 / (v1.sqrt() / (1 - b2) ** 0.5 + eps))
     out = dict(
         x=b.x.numpy(), edge_index=b.edge_index.numpy(), batch=b.batch.numpy(), y=b.y.numpy(),
         num_features=np.int64(shape.num_features), num_classes=np.int64(shape.num_classes),
@@ -83,6 +95,11 @@ def build(name, workload, bs, start, min_margin):
         out["param:" + k_] = v.numpy()
     for k_, v in grads.items():
         out["grad:" + k_] = v.numpy().astype(np.float32)
+    out["loss_eval_f64"] = loss_ev.numpy()
+    for k_, v in grads_ev.items():
+        out["grad_eval:" + k_] = v.numpy().astype(np.float32)
+    for k_, v in adam1.items():
+        out["adam1:" + k_] = v.numpy().astype(np.float32)
     path = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: N={b.num_nodes} E={b.num_edges} B={bs} margin={margin:.3e} "

@@ -7,8 +7,8 @@ import torch
 
 from dgcnn_amd import synth
 from oracle import ref_dense, ref_ops
-from parity_util import (LOGIT_TOL, check_backward_parity, check_forward_parity, cpu_state_dict, load_fixture,
-                         make_model)
+from parity_util import (LOGIT_TOL, check_backward_parity, check_forward_parity, cpu_state_dict, grads_close,
+                         load_fixture, make_model)
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +33,37 @@ def test_golden_fixture_gradients(golden_dir, name):
     m = make_model(int(z["num_features"]), int(z["num_classes"]), sd)
     check_backward_parity(m, b, sd)
     np.testing.assert_array_equal(m.last_workspace_view("perm").cpu().numpy(), z["perm"])
+
+
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5"])
+def test_golden_step_fixture_loss_grads_and_post_adam_parameters(golden_dir, name):
+    """SURVEY 8(c) C5 item 6, the step fixture: one training step of the fused Trainer in eval mode (no dropout mask to
+    share) against the stored fp64 loss, gradients and parameters after ONE Adam step (torch defaults)."""
+    from dgcnn_amd.train import Trainer
+    z, sd, grads, b = load_fixture(golden_dir, name)
+    m = make_model(int(z["num_features"]), int(z["num_classes"]), sd)
+    m.eval()
+    tr = Trainer(m)
+    tr.reset_metrics()
+    before = m.flat_params.clone()
+    tr.train_step(b.to("cuda"), b.y.to("cuda"))
+    loss, _ = tr.read_metrics()
+    assert abs(loss - float(z["loss_eval_f64"])) < 1e-5
+    offs = m._offsets
+    flat, g = m.flat_params.cpu(), tr.grads.cpu()
+    for p, off, key in zip(m._param_list(), offs, ["conv1.lin.weight", "conv1.bias", "conv2.lin.weight", "conv2.bias",
+                                                  "conv3.lin.weight", "conv3.bias", "conv4.lin.weight", "conv4.bias",
+                                                  "conv5.weight", "conv5.bias", "conv6.weight", "conv6.bias",
+                                                  "classifier_1.weight", "classifier_1.bias", "classifier_2.weight",
+                                                  "classifier_2.bias"]):
+        n = p.numel()
+        g_ref = torch.from_numpy(z["grad_eval:" + key]).reshape(-1)
+        a_ref = torch.from_numpy(z["adam1:" + key]).reshape(-1)
+        assert grads_close(g[off:off + n], g_ref), key
+        # the first Adam step moves every element by ~lr * sign(g): compare where the sign is well determined
+        sure = g_ref.abs() > 1e-3 * g_ref.abs().max().clamp_min(1e-30)
+        assert (flat[off:off + n][sure] - a_ref[sure]).abs().max() < 5e-6, key
+        assert torch.equal(flat[off:off + n][g_ref == 0], before.cpu()[off:off + n][g_ref == 0]), key
 
 
 WORKLOADS = [("MUTAG", 50, None), ("PROTEINS", 50, None), ("COLLAB", 50, None), ("COLLAB_REAL", 50, None),

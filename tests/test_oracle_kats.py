@@ -130,3 +130,32 @@ def test_unstable_sort_differs_only_on_ties():
     x = torch.randn(40, 97)
     b = torch.zeros(40, dtype=torch.int64)
     assert torch.equal(ref_ops.sort_pool(x, b, 30, 1, stable=False), ref_ops.sort_pool(x, b, 30, 1, stable=True))
+
+
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5", "collab_b4"])
+def test_step_fixture_is_self_consistent(golden_dir, name):
+    """the eval-mode step stored in the fixtures: fp64 dense loss / gradients are reproduced by the independent fp32
+    edge-list formulation, and the stored post-Adam parameters are torch.optim.Adam's first step."""
+    import numpy as np
+    from dgcnn_amd.batch import Batch
+    from oracle import ref_ops
+    z = np.load(f"{golden_dir}/{name}.npz")
+    b = Batch(torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]), torch.from_numpy(z["batch"]),
+              torch.from_numpy(z["y"]))
+    model = ref_ops.RefModel(int(z["num_features"]), int(z["num_classes"]))
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")})
+    model.eval(); model.stable_sort = True
+    opt = torch.optim.Adam(model.parameters())
+    loss = torch.nn.NLLLoss()(model(b), b.y)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss_eval_f64"])) < 2e-5
+    named = dict(model.named_parameters())
+    if float(z["sort_margin"]) >= 1e-4:          # tie-free fixtures: both formulations select the same nodes
+        for k, p in named.items():
+            g_ref = torch.from_numpy(z["grad_eval:" + k])
+            assert torch.allclose(p.grad, g_ref, rtol=2e-3, atol=2e-5 * float(g_ref.abs().max()) + 1e-9), k
+        opt.step()
+        for k, p in named.items():
+            g_ref = torch.from_numpy(z["grad_eval:" + k])
+            sure = g_ref.abs() > 1e-3 * g_ref.abs().max().clamp_min(1e-30)
+            assert (p.detach()[sure] - torch.from_numpy(z["adam1:" + k])[sure]).abs().max() < 5e-6, k
