@@ -48,6 +48,14 @@ class DeviceDataset:
     def __len__(self) -> int:
         return self.num_graphs
 
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for ev in getattr(self, "_events", []):
+                L.dgcnn_event_destroy(ev)
+        except Exception:
+            pass
+
     def assemble(self, ids: np.ndarray, out: Optional[dict] = None, ids_dev_ptr: Optional[int] = None) -> Batch:
         """Batch of graphs ``ids`` (order kept), assembled on the device: ONE C call (``dgcnn_collate_ids``: prefix sums
         in C, a few-hundred-byte asynchronous upload, one kernel launch).  ``out``: reusable buffer dict (a ring slot)."""
@@ -60,6 +68,7 @@ class DeviceDataset:
         if st is None or st["B"] < B:
             ev = _lib.c_void_p()
             _lib.check(_lib.lib().dgcnn_event_create(_lib.ctypes.byref(ev)), "dgcnn_event_create")
+            self.__dict__.setdefault("_events", []).append(ev)
             st = out["state"] = {"B": max(B, 64), "ev": ev, "capN": 0, "capE": 0,
                                  "meta_h": torch.empty(3 * max(B, 64) + 2, dtype=torch.int64).pin_memory(),
                                  "meta_d": torch.empty(3 * max(B, 64) + 2, dtype=torch.int64, device=dev),

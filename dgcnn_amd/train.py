@@ -29,12 +29,18 @@ from .model import Model, _batch_size_of
 class Trainer:
     """Fused train/eval step for a :class:`dgcnn_amd.Model`.
 
+    Batches are recognised by object identity: a loop that re-uses resident ``Batch`` objects (bench.py's pool, a
+    dataset that fits on the device) pays the argument-block setup once per batch object; up to ``ARGS_CACHE_MAX``
+    batches are remembered (each entry keeps that batch's tensors alive, so the bound is also a memory bound).
+
     lr/betas/eps default to ``torch.optim.Adam`` defaults, which is what the reference uses
     (``Adam(model.parameters())``, /root/reference/train.py:99).
     ``process_group``: when given (data parallel, one process per GPU), gradients are summed over
     ranks with ONE all-reduce of the flat buffer per step and the loss is scaled by the GLOBAL
     batch size, so N ranks x B/N graphs reproduce one rank x B graphs.
     """
+
+    ARGS_CACHE_MAX = 128
 
     def __init__(self, model: Model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None):
@@ -164,7 +170,7 @@ class Trainer:
         a.x, a.edge_index, a.batch, a.y = x.data_ptr(), (ei.data_ptr() if E else None), bt.data_ptr(), yy.data_ptr()
         a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
         need = _lib.workspace_bytes(N, E, B, F, C)
-        if len(self._args_cache) >= 1024:
+        if len(self._args_cache) >= self.ARGS_CACHE_MAX:      # bounded: every entry keeps its batch's tensors alive
             self._args_cache.clear()
         ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C), _lib.ctypes.byref(a), x.device,
                _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0)
