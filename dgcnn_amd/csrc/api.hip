@@ -166,7 +166,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
   const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: prep leaves xs = dinv*x in hsA, no linear at all
   DgLinFirst lf; lf.x = x; lf.W = af ? nullptr : params + pl.off[0]; lf.hs = hsA; lf.F = F;
-  const bool use_lf = !fused || af;    // wide raw features: conv1's linear rides on the second prep launch
+  const bool use_lf = af;              // aggregate-first conv1: graph prep also leaves xs = dinv*x
   int lin_done = 0;
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   if (!(flags & DGCNN_FLAG_PREPARED))

@@ -160,14 +160,16 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     }
   }
   __syncthreads();
-  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (same fma chain as k_lin_first32) ----
+  // ---- conv1 linear: H[i][c] = dinv[i] * sum_k x[i][k] W1[c][k]  (same MFMA sequence as k_lin_first32) ----
   if (!af) {
-    const int c = tid & 31;
-    for (int i = tid >> 5; i < n; i += FG_THREADS / 32) {
-      const float* xr = xin + (size_t)(n0 + i) * F;
-      float acc = 0.f;
-      for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-      H[i * FG_RS + c] = dv[i] * acc;
+    const int tiles = (n + 15) >> 4;
+    for (int job = wave; job < 2 * tiles; job += FG_WAVES) {
+      const int tile = job >> 1, nb = job & 1;
+      dg_mfma_tile16(
+          tile * 16, nb * 16, F, lane,
+          [&](int m, int k) { return (m < n && k < F) ? xin[(size_t)(n0 + m) * F + k] : 0.f; },
+          [&](int k, int nn) { return k < F ? Wt[k * 32 + nn] : 0.f; },
+          [&](int m, int nn, float v) { if (m < n) H[m * FG_RS + nn] = dv[m] * v; });
     }
   }
   dg_lds_barrier();

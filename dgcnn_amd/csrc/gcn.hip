@@ -44,6 +44,9 @@
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
 // FOUT = 32: 8 rows x 32 channels per 256-thread pass.  FOUT = 1: one wave per row.
 // ---------------------------------------------------------------------------------------------
+// FOUT = 32 runs on the fp32 matrix cores: one wave per 16-row tile, two 16x16 output blocks, K = F in steps of 4
+// (v_mfma_f32_16x16x4_f32, operands of 8 k-steps fetched together); W^T staged in LDS.  The fused kernel's conv1
+// linear issues the same MFMA sequence on the same operands, so both paths stay bit-identical.
 __global__ void __launch_bounds__(256)
 k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
               const float* __restrict__ dinv, float* __restrict__ hs) {
@@ -53,12 +56,17 @@ k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict
     Wt[k * 32 + c] = W[t];
   }
   __syncthreads();
-  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-  for (int i = blockIdx.x * 8 + r; i < N; i += gridDim.x * 8) {
-    const float* xr = x + (size_t)i * F;
-    float acc = 0.f;
-    for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-    hs[(size_t)i * 32 + c] = dinv[i] * acc;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tiles = (N + 15) >> 4;
+  for (int tile = blockIdx.x * 4 + w; tile < tiles; tile += gridDim.x * 4) {
+    const int r0 = tile * 16;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+      dg_mfma_tile16(
+          r0, nb * 16, F, lane,
+          [&](int m, int k) { return (m < N && k < F) ? x[(size_t)m * F + k] : 0.f; },
+          [&](int k, int n) { return k < F ? Wt[k * 32 + n] : 0.f; },
+          [&](int m, int n, float v) { if (m < N) hs[(size_t)m * 32 + n] = dinv[m] * v; });
   }
 }
 
@@ -79,7 +87,7 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
                         int Fout, hipStream_t s) {
   if (N <= 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   if (Fout == 32) {
-    int grid = dg_cdiv(N, 8);
+    int grid = dg_cdiv(dg_cdiv(N, 16), 4);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_lin_first32, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, hs);
   } else if (Fout == 1) {

@@ -179,37 +179,15 @@ k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __res
 }
 
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
-// search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.
-// The same launch also carries conv1's linear (hs1[i] = dinv[i] * x[i] W1^T) in a second block range:
-// it only needs the row pointers that kernel A completed (dinv is recomputed locally, bit-identically),
-// so the separate k_lin_first32 launch disappears from the step.
+// search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.  With x given it also
+// writes the pre-scaled raw features xs = dinv*x [N,F] for the aggregate-first conv1 (F <= DG_AF_MAX_F).
 __global__ void __launch_bounds__(256)
 k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
-              float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int nblk_b,
-              int F, const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ hs) {
-  extern __shared__ __attribute__((aligned(16))) float Wt[];   // lin range only: [F][32]
-  if ((int)blockIdx.x >= nblk_b) {      // ---- conv1 linear block range (same arithmetic as k_lin_first32) ----
-    for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
-      const int c = t / F, k = t - c * F;
-      Wt[k * 32 + c] = W1[t];
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const int nlin = (int)gridDim.x - nblk_b;
-    for (int i = ((int)blockIdx.x - nblk_b) * 8 + r; i < N; i += nlin * 8) {
-      const float di = 1.0f / sqrtf((float)(rowptr[i + 1] - rowptr[i] + 1));
-      const float* xr = x + (size_t)i * F;
-      float acc = 0.f;
-      for (int k = 0; k < F; ++k) acc = fmaf(xr[k], Wt[k * 32 + c], acc);
-      hs[(size_t)i * 32 + c] = di * acc;
-    }
-    return;
-  }
-  // W1 == nullptr with x given: "scale mode" for the aggregate-first conv1, hs receives xs = dinv*x [N,F]
-  const bool scale = x != nullptr && W1 == nullptr;
+              float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int F,
+              const float* __restrict__ x, float* __restrict__ xs) {
   dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
-                      err, epoch, scale ? x : nullptr, hs, F);
+                      err, epoch, x, xs, F);
 }
 
 // xs[i][f] = dinv[i] * x[i][f]  (general prep path; the fast path does it inside k_prep_fast_b)
@@ -231,17 +209,11 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
     DG_CHECK_LAUNCH();
-    const int nblk_b = dg_cdiv(work, 256);
-    int nlin = 0;
-    const bool have = lf && lf->x && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
-    if (have && lf->W) {          // conv1 linear block range (raw features wider than DG_AF_MAX_F)
-      nlin = dg_cdiv(N, 8);
-      if (nlin > 4096) nlin = 4096;
-    }
-    hipLaunchKernelGGL(k_prep_fast_b, dim3(nblk_b + nlin), dim3(256), nlin ? sizeof(float) * 32 * lf->F : 0, s,
-                       edge_index, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv, uerr, epoch, nblk_b,
-                       have ? lf->F : 0, have ? lf->x : nullptr, have ? lf->W : nullptr, have ? lf->hs : nullptr);
-    if (have && lin_done) *lin_done = 1;
+    const bool scale = lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr, colidx,
+                       graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
+                       scale ? lf->hs : nullptr);
+    if (scale && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
