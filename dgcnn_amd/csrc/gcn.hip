@@ -583,10 +583,13 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   float wreg[8];
   f32x4 accW = {0.f, 0.f, 0.f, 0.f};
   float pb = 0.f;
-  float acc1[(32 * DGCNN_MAX_F) / DG_TILE_THREADS];   // FIRST: 16 outputs per thread max
+  // FIRST: dW1 [32 x F] as 2 x ceil(F/16) MFMA tiles, dealt round-robin to the 16 waves (<= 4 tiles per wave for
+  // F <= DGCNN_MAX_F = 512); the accumulators persist over this workgroup's tiles
+  f32x4 acc1[(2 * (DGCNN_MAX_F / 16)) / 16];
+  const int ntile1 = FIRST ? 2 * ((F + 15) >> 4) : 0;
   if (FIRST) {
 #pragma unroll
-    for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) acc1[u] = 0.f;
+    for (int u = 0; u < (2 * (DGCNN_MAX_F / 16)) / 16; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   } else if (wave < 2) {   // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + wave * 16 + (lane & 15)];
@@ -635,17 +638,21 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     }
     __syncthreads();
     if (FIRST) {
-      // dW1[c][k] += sum_node ght[node][c] * xs[node][k] ; output o = k*32 + c (c fastest -> conflict-free)
-      const int total = 32 * F;
+      // dW1[c][k] += sum_node ght[node][c] * xs[node][k]  on the matrix cores: A[m][kk] = ght[kk][mb*16+m],
+      // B[kk][n] = xs[kk][nb*16+n], K = the 16 nodes of the tile (4 MFMA steps)
 #pragma unroll
-      for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
-        const int o = u * DG_TILE_THREADS + threadIdx.x;
-        if (o < total) {
-          const int k = o >> 5, c = o & 31;
-          float a = acc1[u];
+      for (int u = 0; u < (2 * (DGCNN_MAX_F / 16)) / 16; ++u) {
+        const int t = u * 16 + wave;
+        if (t < ntile1) {
+          const int mb = t & 1, nb = t >> 1;
+          const int col = nb * 16 + (lane & 15);
 #pragma unroll
-          for (int nd = 0; nd < DG_TILE; ++nd) a = fmaf(ght[nd][c], xs[nd * F + k], a);
-          acc1[u] = a;
+          for (int kk = 0; kk < 4; ++kk) {
+            const int nd = 4 * kk + (lane >> 4);
+            const float a = ght[nd][mb * 16 + (lane & 15)];
+            const float b = col < F ? xs[nd * F + col] : 0.f;
+            acc1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1[u], 0, 0, 0);
+          }
         }
       }
     } else {
@@ -701,14 +708,18 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
     part1[(size_t)blockIdx.x * 32 * Fa + c * Fa + k] = accA;
   }
   if (FIRST) {
-    const int total = 32 * F;
-    float* dst = part + (size_t)blockIdx.x * total;
+    float* dst = part + (size_t)blockIdx.x * 32 * F;
 #pragma unroll
-    for (int u = 0; u < (32 * DGCNN_MAX_F) / DG_TILE_THREADS; ++u) {
-      const int o = u * DG_TILE_THREADS + threadIdx.x;
-      if (o < total) {
-        const int k = o >> 5, c = o & 31;
-        dst[c * F + k] = acc1[u];     // stored in W1's own [32,F] layout
+    for (int u = 0; u < (2 * (DGCNN_MAX_F / 16)) / 16; ++u) {
+      const int t = u * 16 + wave;
+      if (t < ntile1) {
+        const int mb = t & 1, nb = t >> 1;
+        const int k = nb * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = mb * 16 + (lane >> 4) * 4 + r;
+          if (k < F) dst[c * F + k] = acc1[u][r];     // stored in W1's own [32,F] layout
+        }
       }
     }
   } else {
