@@ -421,8 +421,10 @@ int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_
   const bool scan = ids_dev != nullptr && B <= 256;
   // the previous asynchronous upload from this staging buffer must have been consumed before it is rewritten
   if (!scan && ev && hipEventSynchronize(ev) != hipSuccess) return DGCNN_ELAUNCH;
+  // (scan mode never touches meta_host: an earlier batch's asynchronous upload from this ring slot may still be
+  // queued -- the guard above is skipped in scan mode -- and rewriting the staging buffer would corrupt it)
   int64_t nsum = 0, esum = 0, nmax = 0, emax = 0;
-  meta_host[0] = 0; meta_host[B + 1] = 0;
+  if (!scan) { meta_host[0] = 0; meta_host[B + 1] = 0; }
   for (int k = 0; k < B; ++k) {
     const int64_t g = ids_host[k];
     if (g < 0 || g >= num_graphs) return DGCNN_EINVAL;
@@ -430,9 +432,11 @@ int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_
     nsum += n; esum += e;
     if (n > nmax) nmax = n;
     if (e > emax) emax = e;
-    meta_host[k + 1] = nsum;
-    meta_host[B + 2 + k] = esum;
-    meta_host[2 * B + 2 + k] = g;
+    if (!scan) {
+      meta_host[k + 1] = nsum;
+      meta_host[B + 2 + k] = esum;
+      meta_host[2 * B + 2 + k] = g;
+    }
   }
   out_sizes[0] = nsum; out_sizes[1] = esum; out_sizes[2] = nmax; out_sizes[3] = emax;
   if (nsum > cap_nodes || esum > cap_edges) return DGCNN_EUNSUPPORTED;     // caller grows its buffers and calls again

@@ -70,9 +70,15 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
 #define DG_WG_TWO_STAGE_B 1024      // batches above this reduce the per-graph weight-gradient partials in two stages
                                      // (measured crossover ~1500 graphs: one launch is faster below, two above)
 #endif
-// (environment override DG_WG_TWO_STAGE_B=<n>, read once per process: lets the tests drive the two-stage form with
-// batches small enough for the CPU oracle)
+// Measurement A/B switches (environment variables) exist only in -DDG_DEBUG_KNOBS builds (make EXTRA=-DDG_DEBUG_KNOBS);
+// the shipped library reads exactly ONE environment variable, DG_WG_TWO_STAGE_B=<n> (once per process): it lets
+// tests/test_gpu_model.py drive the two-stage weight-gradient form with batches small enough for the CPU oracle.
 #include <cstdlib>
+#ifdef DG_DEBUG_KNOBS
+static inline bool dg_knob(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline constexpr bool dg_knob(const char*) { return false; }
+#endif
 static inline int dg_wg_two_stage_b() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DG_WG_TWO_STAGE_B"); v = (e && atoi(e) > 0) ? atoi(e) : DG_WG_TWO_STAGE_B; }

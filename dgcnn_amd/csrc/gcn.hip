@@ -347,7 +347,7 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
 #define DG_FWD32P_LAUNCH(M, D) hipExtLaunchKernelGGL((k_gcn_fwd32p<M, D>), dim3(DG_PERSIST_WGS), dim3(DG_TILE_THREADS), 0, s, \
                                                      ev_start, ev_stop, 0, N, tiles, rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
   const bool small = tiles <= DG_SMALL_GRID_TILES;
-  static const bool nopersist = getenv("DG_NO_PERSIST") != nullptr;     // A/B switch (measurement only)
+  static const bool nopersist = dg_knob("DG_NO_PERSIST");     // A/B switch (DG_DEBUG_KNOBS builds only)
   const bool persist = tiles >= 4 * DG_PERSIST_WGS && !nopersist;   // pays from ~4 tiles per workgroup (measured)
   if (mode == 0) { if (small) DG_FWD32_LAUNCH(0, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(0, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(0, DG_DEPTH_FWD_BIG); }
   else if (mode == 1) { if (small) DG_FWD32_LAUNCH(1, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(1, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(1, DG_DEPTH_FWD_BIG); }

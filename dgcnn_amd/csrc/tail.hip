@@ -116,7 +116,7 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  static const bool nobig = getenv("DG_NO_BIG_READOUT") != nullptr;      // A/B switch (measurement only)
+  static const bool nobig = dg_knob("DG_NO_BIG_READOUT");      // A/B switch (DG_DEBUG_KNOBS builds only)
   if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
                        x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
@@ -418,7 +418,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  static const bool nobig = getenv("DG_NO_BIG_TAIL") != nullptr;      // A/B switch (measurement only)
+  static const bool nobig = dg_knob("DG_NO_BIG_TAIL");      // A/B switch (DG_DEBUG_KNOBS builds only)
   if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
@@ -721,7 +721,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
   }
   A.nseg = ns;
   if (nb == 0) return DGCNN_OK;
-  static const bool split = getenv("DG_WGRAD_SPLIT") != nullptr;     // diagnostic: one launch per segment
+  static const bool split = dg_knob("DG_WGRAD_SPLIT");     // diagnostic (DG_DEBUG_KNOBS builds only): one launch per segment
   if (split) {
     for (int k = 0; k < ns; ++k) {
       WgArgs One = A;

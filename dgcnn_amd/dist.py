@@ -67,12 +67,14 @@ def graph_range(num_graphs: int, rank: int, world_size: int) -> Tuple[int, int]:
 class GradAllReduce:
     """One flat-bucket gradient all-reduce per step."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force: bool = False):
+        """``force``: issue the collective even in a 1-rank group (lets a 1-GPU box time the N>1 code path)."""
         self.pg = process_group
+        self.force = bool(force)
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
     def __call__(self, flat_grad: torch.Tensor, async_op: bool = False):
-        if self.world_size == 1 and not os.environ.get("BENCH_FORCE_DIST"):
+        if self.world_size == 1 and not self.force:
             return None
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
 

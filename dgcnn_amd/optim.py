@@ -73,6 +73,13 @@ class Adam(Optimizer):
             self.state[p]["step"] = shared
         return m, v, shared
 
+    def load_state_dict(self, state_dict) -> None:
+        """As ``Optimizer.load_state_dict``; the cached flat moment buffers are dropped so that the next ``step()``
+        rebuilds them FROM the loaded ``exp_avg`` / ``exp_avg_sq`` / ``step`` (a resumed run must not continue from
+        the moments it had before the load)."""
+        super().load_state_dict(state_dict)
+        self._flat.clear()
+
     # ---- step -----------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):

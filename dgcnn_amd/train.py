@@ -14,7 +14,8 @@ epoch (the reference syncs twice per batch, train.py:44-45).
 
 PyG / visdom cannot travel to the GPU box, so the reference's ``train.py`` itself cannot run there;
 this is the build's own harness for the same step.  The drop-in route (reference loop + this
-build's ``Model`` + torch's Adam) also works and is what tests/test_gpu_dropin.py exercises.
+build's ``Model`` + torch's Adam) also works and is what tests/test_gpu_model.py
+(``test_fused_train_step_equals_dropin_route_and_oracle_loss``, ``test_dropin_optimizer_*``) exercises.
 """
 from __future__ import annotations
 
@@ -43,13 +44,13 @@ class Trainer:
     ARGS_CACHE_MAX = 128
 
     def __init__(self, model: Model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None):
+                 process_group=None, force_collective: bool = False):
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.pg = process_group
         from .dist import GradAllReduce
-        self._allreduce = GradAllReduce(process_group) if process_group is not None else None
-        if self._allreduce is not None and self._allreduce.world_size == 1 and not __import__('os').environ.get('BENCH_FORCE_DIST'):
+        self._allreduce = GradAllReduce(process_group, force=force_collective) if process_group is not None else None
+        if self._allreduce is not None and self._allreduce.world_size == 1 and not force_collective:
             self._allreduce = None           # a 1-rank group needs no collective
         self.step_count = 0
         flat = model.flat_params

@@ -486,6 +486,31 @@ def test_dropin_optimizer_takes_the_flat_route_and_matches_torch_adam():
     torch.testing.assert_close(res[0], res[1], rtol=1e-4, atol=5e-6)
 
 
+def test_dropin_optimizer_resume_from_loaded_state_continues_the_same_trajectory():
+    """load_state_dict on an optimizer that has already stepped (flat layout cached) must continue from the LOADED
+    moments, not from the ones it had before: 3 steps, checkpoint, 3 more == checkpoint re-loaded into
+    the same optimizer object after 2 stray steps, then the same 3."""
+    import copy
+    from dgcnn_amd.optim import Adam as FlatAdam
+    sh = synth.SHAPES["PROTEINS"]
+    batches = [b.to("cuda") for b in synth.make_batches("PROTEINS", 30, 10, start=7)]
+    m = make_model(sh.num_features, sh.num_classes)
+    m.train(); m._seed_base, m._fwd_count = 11, 0
+    opt = FlatAdam(m.parameters())
+    _dropin_loop(m, opt, batches, 3)
+    torch.cuda.synchronize()
+    ck_model = copy.deepcopy(m.state_dict()); ck_opt = copy.deepcopy(opt.state_dict()); ck_cnt = m._fwd_count
+    _dropin_loop(m, opt, batches, 3)
+    torch.cuda.synchronize()
+    want = m.flat_params.clone()
+    _dropin_loop(m, opt, batches, 2)               # stray steps: moments and counter move on
+    m.load_state_dict(ck_model); opt.load_state_dict(ck_opt); m._fwd_count = ck_cnt
+    _dropin_loop(m, opt, batches, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, want)
+    assert float(opt.state_dict()["state"][0]["step"]) == 6.0
+
+
 def test_dropin_optimizer_falls_back_for_foreign_parameters():
     from dgcnn_amd.optim import Adam as FlatAdam
     lin = torch.nn.Linear(5, 3).cuda()

@@ -149,3 +149,24 @@ def test_device_collate_is_bit_identical_to_host_collate_and_trains():
         assert torch.equal(prev.y.cpu(), h.y)
         prev = nxt
     assert prev is None
+
+
+@pytest.mark.gpu
+def test_device_loader_large_batches_with_short_scan_mode_remainder():
+    """batch_size > 256 takes the staging-buffer upload route, a short last batch (<= 256) the in-kernel scan route;
+    over more than `ring` batches the short batch lands on a ring slot whose earlier upload may still be queued.  The
+    scan route must not touch that slot's pinned staging buffer: every batch equals the host collate."""
+    from dgcnn_amd.batch import collate
+    from dgcnn_amd.device_data import DeviceDataset, DeviceLoader
+    graphs = synth.make_graphs("MUTAG", 4 * 512 + 100, start=0)
+    ds = DeviceDataset(graphs)
+    for rep in range(3):                      # several epochs back to back without a sync between batches
+        got = []
+        for b in DeviceLoader(ds, 512, shuffle=False, ring=4):
+            got.append((b.x.clone(), b.edge_index.clone(), b.batch.clone(), b.y.clone(), b.num_graphs))
+        torch.cuda.synchronize()
+        assert [g[4] for g in got] == [512, 512, 512, 512, 100]
+        for k, g in enumerate(got):
+            ref = collate(graphs[512 * k: 512 * k + g[4]])
+            assert torch.equal(g[0].cpu(), ref.x) and torch.equal(g[1].cpu(), ref.edge_index), (rep, k)
+            assert torch.equal(g[2].cpu(), ref.batch) and torch.equal(g[3].cpu(), ref.y), (rep, k)
