@@ -2,23 +2,38 @@
 """bench.py -- graphs/sec of the DGCNN training step (forward + NLL + backward + Adam) on
 COLLAB-shaped batches of 50 graphs, the metric BASELINE.json names.
 
-    python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: run as given, bench.py re-launches ITSELF as N ranks under ``torch.distributed.run`` (one process
+per GPU, RCCL); launched by the driver under torch.distributed.run it uses the ranks it was given.  On a
+box with fewer than N devices it says so and exits 0 (BENCH_SHARE_GPU=1: all ranks on device 0 with a gloo
+group -- a functional check of the N-rank code path, not a measurement).
 
 A "step" is one pass of the hot path over one batch of synthetic graphs, i.e. the body of the
 reference loop /root/reference/train.py:36-42: forward, mean NLL, backward, Adam step, zero_grad.
 Inputs (x, edge_index, batch, y of every batch) are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line with the contract fields plus:
-  "roofline"     -- the 32-wide aggregation kernel (k_gcn_fwd32): algorithmic bytes per launch
-                    (SURVEY.md §8(d) D4 compulsory-traffic model) / its average launch duration,
-                    measured with HIP events recorded around that launch on its own stream during a
-                    second, instrumented pass over the same steps (event-pair overhead calibrated
-                    and subtracted; both raw and corrected values are reported)
-  "cpu_baseline" -- the oracle's fp32 op-sequence restatement of the reference path (oracle/ref_ops.py,
-                    "port": PyG itself cannot run here) timed on the host cores, rank 0, N=1 only.
 
-Multi-GPU: one process per GPU, each rank trains on its own batches of 50 graphs per step (weak
-scaling, per-GPU work fixed), gradients summed with ONE flat RCCL all-reduce per step and the loss
-scaled by the global batch 50*N.
+Timing protocol: W untimed warm-up steps, then the K-step timed loop -- bracketed by a
+barrier + torch.cuda.synchronize() on both sides, MAX over ranks -- is REPEATED until at least
+``--min-seconds`` (0.25 s) of timed work exists (at least 3 repeats); ``ms_per_step`` / ``value`` are the
+MEDIAN repeat (every repeat's ms/step is listed under "repeats_ms_per_step").
+
+Scaling modes (BASELINE config 5 asks for both):
+  --scaling weak   (default) every GPU trains ``--batch`` graphs per step (per-GPU work fixed)
+  --scaling strong ``--global-batch`` graphs per step in total, sharded cost-balanced over the GPUs
+
+Rank 0 prints ONE JSON line with the contract fields plus:
+  "roofline"     -- the 32-wide aggregation kernel: algorithmic bytes per launch (SURVEY.md §8(d) D4
+                    compulsory-traffic model) / its average launch duration, measured with HIP events attached to
+                    that dispatch (hipExtLaunchKernelGGL) on its own stream over >= 200 launches; "traffic" = HBM
+                    bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes,
+                    FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) that THIS run spawns when
+                    rocprofv3 is present (else the committed profiles/ file, named in "traffic_source")
+  "roofline_large_batch" -- the same kernel family measured at --large-batch graphs per step, where the
+                    aggregation is throughput- rather than dispatch-bound
+  "cpu_baseline" -- the oracle's fp32 op-sequence restatement of the reference path (oracle/ref_ops.py,
+                    "port": PyG itself cannot run here) timed on the host cores, rank 0, N=1 only: median of 30
+                    sustained steps for each of {1,4,8,16,32} threads; "value" is the best sustained one.
 """
 from __future__ import annotations
 
@@ -26,6 +41,8 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -34,28 +51,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+AGG_KERNELS = ("k_gcn_fwd32d", "k_gcn_fwd32p", "k_gcn_fwd32")     # dense-block / persistent / tiled forms
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="COLLAB", help="synthetic shape (dgcnn_amd.synth.SHAPES)")
-    ap.add_argument("--batch", type=int, default=50, help="graphs per step per GPU")
+    ap.add_argument("--batch", type=int, default=50, help="graphs per step per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--global-batch", type=int, default=256,
+                    help="strong scaling: graphs per step over ALL GPUs (BASELINE config 5: 256)")
     ap.add_argument("--pool", type=int, default=40, help="distinct batches resident in HBM per GPU")
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed loop until this much is timed")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: BASELINE config 3's secondary leg (hs stored bf16, X.W on bf16 MFMA); never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
+    ap.add_argument("--large-batch", type=int, default=2048, help="batch size of the roofline_large_batch leg (0 = skip)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="do not software-pipeline graph prep (default: batch i+1's CSR build runs on the library's "
-                         "side stream during step i, one dgcnn_pipeline_train_step call per step)")
+                    help="do not overlap the next batch's graph preparation with the step")
     ap.add_argument("--path", choices=["auto", "fused", "tiled"], default="auto",
                     help="forward kernel family: library heuristic, graph-per-workgroup fused, or tiled")
-    return ap.parse_args()
+    ap.add_argument("--agg", choices=["auto", "sparse", "dense"], default="auto",
+                    help="aggregation form: library heuristic, CSR gather, or dense per-graph blocks on the matrix cores")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
 def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int:
@@ -67,233 +92,392 @@ def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int
 
 
 def algorithmic_bytes_fused_fwd(N: int, E_noself: int, B: int, F: int) -> int:
-    """Compulsory traffic of the fused graph-per-workgroup forward kernel, every array once:
-    reads x [N,F], rowptr, colidx, dinv, graph pointers; writes x1..x3 [N,32], x4 [N] (saved for
-    backward), pooled [B,2910], perm, the saved tail activations and the log-probs."""
+    """Compulsory traffic of the fused graph-per-workgroup forward kernel, every array once."""
     rd = 4 * N * F + 4 * (N + 1) + 4 * E_noself + 4 * N + 8 * (B + 1)
     wr = 3 * 4 * N * 32 + 4 * N + 4 * B * 2910 + 4 * B * 30 + 4 * B * (480 + 352 + 128) + B * 128 + 4 * B * 3
     return rd + wr
 
 
-def cpu_baseline(batches_cpu, F, C, seconds):
-    """Oracle port of the reference step (fwd + NLL + bwd + Adam) on the host cores."""
-    from oracle import ref_ops                      # checker/baseline leg only
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle port; checker/baseline leg only)
+# ------------------------------------------------------------------------------------------------------
+def cpu_baseline(batches_cpu, F, C):
+    """Oracle port of the reference step (fwd + NLL + bwd + Adam) on the host cores: for each candidate thread
+    count, 5 warm-up + 30 timed steps, MEDIAN; the best sustained count is the baseline, the 1-thread
+    figure is reported beside it."""
+    import torch
+    from oracle import ref_ops
     ncpu = os.cpu_count() or 1
     torch.manual_seed(324)
     model = ref_ops.RefModel(F, C)
     model.train()
     opt = torch.optim.Adam(model.parameters())
     n = len(batches_cpu)
-    # The reference runs torch's default intra-op threading; on a many-core host the small ops of
-    # this path get SLOWER with every core (oversubscription), so probe a few thread counts and time
-    # the best one -- the baseline is the port at its fastest, not at its default.
-    probe = {}
-    for th in sorted({1, 4, 8, 16, 32, min(64, ncpu)}):
+    B = batches_cpu[0].num_graphs
+    table = {}
+    t_begin = time.perf_counter()
+    for th in (1, 4, 8, 16, 32):
         if th > ncpu:
             continue
         torch.set_num_threads(th)
-        ref_ops.train_step(model, opt, batches_cpu[0], batches_cpu[0].y)
-        best = float("inf")
-        for i in range(4):                      # min of 4 single steps: robust against scheduler noise
+        k = 0
+        for _ in range(5):
+            ref_ops.train_step(model, opt, batches_cpu[k % n], batches_cpu[k % n].y); k += 1
+        ts = []
+        for _ in range(30):
+            b = batches_cpu[k % n]; k += 1
             t0 = time.perf_counter()
-            ref_ops.train_step(model, opt, batches_cpu[(1 + i) % n], batches_cpu[(1 + i) % n].y)
-            best = min(best, time.perf_counter() - t0)
-        probe[th] = best
-    cores = min(probe, key=probe.get)
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    steps = graphs = 0
-    while True:
-        b = batches_cpu[steps % n]
-        ref_ops.train_step(model, opt, b, b.y)
-        steps += 1
-        graphs += b.num_graphs
-        el = time.perf_counter() - t0
-        if el >= seconds or steps >= 400:
-            break
-    return {"value": graphs / el, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training steps (fwd+NLL+bwd+Adam) of oracle/ref_ops.py (torch-CPU restatement of the "
-                      f"reference op sequence; PyG itself is unavailable) on the same synthetic batches, "
-                      f"{el:.1f} s, torch {torch.__version__}, {cores} threads (best of probe "
-                      f"{ {k: round(v * 1e3, 1) for k, v in probe.items()} } ms/step; host has {ncpu} logical CPUs)",
-            "ms_per_step": 1e3 * el / steps}
+            ref_ops.train_step(model, opt, b, b.y)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > 60.0 and len(ts) >= 10:     # hard bound on a very slow host
+                break
+        table[th] = statistics.median(ts)
+    cores = min(table, key=table.get)
+    el = time.perf_counter() - t_begin
+    return {"value": B / table[cores], "unit": "graphs/s", "cores": cores, "kind": "port",
+            "value_1_thread": B / table[1],
+            "ms_per_step": 1e3 * table[cores],
+            "ms_per_step_by_threads": {str(k): round(v * 1e3, 2) for k, v in table.items()},
+            "sample": f"median of 30 sustained training steps (fwd+NLL+bwd+Adam; 5 warm-up) per thread count "
+                      f"{sorted(table)} of oracle/ref_ops.py -- a torch-CPU restatement of the reference op sequence, "
+                      f"NOT PyG itself (unavailable) -- on the same synthetic batches of {B} graphs; best sustained = "
+                      f"{cores} threads; {el:.1f} s of CPU work in total; torch {torch.__version__}; host has {ncpu} logical CPUs"}
+
+
+# ------------------------------------------------------------------------------------------------------
+# self-launch for N > 1
+# ------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    import socket
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if ndev < args.gpus and not (share and ndev >= 1):
+        msg = (f"bench.py --gpus {args.gpus} needs {args.gpus} devices, this box has {ndev}; nothing measured "
+               f"(BENCH_SHARE_GPU=1 runs all ranks on device 0 over gloo as a functional check)")
+        print(msg, file=sys.stderr)
+        print(json.dumps({"skipped": msg, "n_gpus": args.gpus, "devices_visible": ndev}))
+        return 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+# ------------------------------------------------------------------------------------------------------
+# HBM traffic of the aggregation kernel from rocprofv3 PMC passes spawned by this run
+# ------------------------------------------------------------------------------------------------------
+def live_pmc_traffic(argv_base, timeout_s=240):
+    """Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: TCC slot limits) over a short run of this same
+    bench (child mode: a few steps, no baseline/roofline); returns ({kernel: bytes per dispatch}, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="dgcnn_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--truncate-kernels", "--output-format", "csv", "-d", out, "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__)] + argv_base + ["--pmc-child"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                a = acc.setdefault(row["Kernel_Name"], [0.0, 0])
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+            for k, (v, n) in acc.items():
+                per.setdefault(k, {})[ctr] = v / n
+    except Exception as ex:                                   # noqa: BLE001 -- measurement side channel only
+        return None, f"{type(ex).__name__}: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # KB per dispatch -> bytes; FETCH doubled (gfx950: FETCH_SIZE reports half the bytes of wide streaming reads)
+    return {k: (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0 for k, d in per.items()}, None
+
+
+def committed_pmc_traffic(B):
+    """fallback: the newest committed profiles/rNN_pmc_b<B>.json"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_b{B}.json")), reverse=True):
+        try:
+            pmj = json.load(open(f))
+            for kn in AGG_KERNELS:
+                pm = pmj.get(kn)
+                if pm:
+                    return kn, (2.0 * pm.get("FETCH_SIZE", 0.0) + pm.get("WRITE_SIZE", 0.0)) * 1024.0, \
+                        f"{os.path.relpath(f, ROOT)} (git {pmj.get('_git', 'unknown')})"
+        except Exception:                                     # noqa: BLE001
+            continue
+    return None, None, None
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU: the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("BENCH_SHARE_GPU") == "1" and ndev < world
+    local = local % ndev if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     import torch.distributed as dist
     pg = None
-    # BENCH_FORCE_DIST=1: build the RCCL process group even for one rank (exercises the N>1 code path on a 1-GPU box)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    force = os.environ.get("BENCH_FORCE_DIST") == "1"       # 1-rank RCCL group: times the collective code path on one GPU
+    use_dist = world > 1 or force
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
     from dgcnn_amd import _lib, synth
+    from dgcnn_amd.batch import split_batch
     from dgcnn_amd.model import Model
     from dgcnn_amd.train import Trainer
     L = _lib.lib()
 
     shape = synth.SHAPES[args.workload]
-    F, C, B = shape.num_features, shape.num_classes, args.batch
-    # every rank draws its own graphs: rank r owns graph ids [r*pool*B, (r+1)*pool*B)
-    graphs = synth.make_graphs(args.workload, args.pool * B, start=rank * args.pool * B)
-    batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
+    F, C = shape.num_features, shape.num_classes
+    strong = args.scaling == "strong"
+    if strong:
+        # every rank draws the SAME global batches and keeps its cost-balanced contiguous shard (dist.shard_batch)
+        GB = args.global_batch
+        if GB < world:
+            sys.exit(f"--global-batch {GB} < {world} ranks")
+        graphs = synth.make_graphs(args.workload, args.pool * GB, start=0)
+        globals_cpu = [synth.collate(graphs[i:i + GB]) for i in range(0, len(graphs), GB)]
+        batches_cpu = [split_batch(g, world)[rank] if world > 1 else g for g in globals_cpu]
+        gb = GB
+    else:
+        B = args.batch
+        # every rank draws its own graphs: rank r owns graph ids [r*pool*B, (r+1)*pool*B)
+        graphs = synth.make_graphs(args.workload, args.pool * B, start=rank * args.pool * B)
+        batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
+        gb = B * world
     batches = [b.to(dev) for b in batches_cpu]
     nb = len(batches)
+    Bavg = sum(b.num_graphs for b in batches_cpu) / nb
     avgN = sum(b.num_nodes for b in batches_cpu) / nb
     avgE = sum(b.num_edges for b in batches_cpu) / nb
 
-    torch.manual_seed(324)                    # identical replicas on every rank
-    model = Model(F, C).to(dev)
-    model.train()
-    if args.path != "auto":
-        model.use_fused = args.path == "fused"
-    tr = Trainer(model, process_group=pg)
-    gb = B * world
+    def make_trainer():
+        torch.manual_seed(324)                    # identical replicas on every rank
+        model = Model(F, C).to(dev)
+        model.train()
+        if args.path != "auto":
+            model.use_fused = args.path == "fused"
+        if args.agg != "auto":
+            model.agg_mode = args.agg
+        if args.dtype == "bf16":
+            model.compute_dtype = "bf16"
+        return Trainer(model, process_group=pg, force_collective=force)
 
-    def step(i):
-        b = batches[i % nb]
-        # software-pipelined graph prep (default): the loop tells the step which batch comes next, whose CSR build
-        # then runs on the library's side stream during this step; every batch's prep still runs once per step
-        tr.train_step(b, b.y, global_batch=gb, next_data=batches[(i + 1) % nb] if args.pipeline else None)
+    tr = make_trainer()
+
+    def step(i, bl=batches, t=None):
+        b = bl[i % len(bl)]
+        (t or tr).train_step(b, b.y, global_batch=gb, next_data=bl[(i + 1) % len(bl)] if args.pipeline else None)
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if not share else dist.barrier()
+
+    if args.pmc_child:          # child of live_pmc_traffic: a few steps under rocprofv3 --pmc, nothing printed
+        for i in range(12):
+            step(i)
+        torch.cuda.synchronize(dev)
+        return
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    reps, total, k0 = [], 0.0, args.warmup
+    while len(reps) < 3 or (total < args.min_seconds and len(reps) < 200):
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(k0 + i)
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if not share else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append(el)
+        total += el
+        k0 += args.steps
+    el = statistics.median(reps)
+    nsteps_total = args.warmup + args.steps * len(reps)
     loss_sum, correct = tr.read_metrics()
-    value = args.steps * B * world / el
+    value = args.steps * gb / el
 
     extra = {}
     roofline = None
+    roofline_large = None
     if rank == 0:
         # ---- forward+backward only (no optimizer), reported beside the headline --------------
         torch.cuda.synchronize(dev)
+        n2 = max(args.steps, 100)
         t1 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n2):
             b = batches[i % nb]
             tr.forward_backward(b, b.y, global_batch=gb)
         torch.cuda.synchronize(dev)
-        extra["fwd_bwd_only_graphs_per_s_rank0"] = args.steps * B / (time.perf_counter() - t1)
+        extra["fwd_bwd_only_graphs_per_s_rank0"] = n2 * Bavg / (time.perf_counter() - t1)
 
-    if rank == 0 and not args.no_roofline:
-        # ---- roofline of the dominant kernel: instrumented pass over the same steps ----------
+    def measure_agg(trainer, bl, bl_cpu, nprof):
+        """HIP events attached to the 32-wide aggregation dispatches (conv2 / conv3 round robin; conv1 too when F > 32)"""
         def ev():
             p = ctypes.c_void_p()
             _lib.check(L.dgcnn_event_create(ctypes.byref(p)), "event_create")
             return p
         pairs = []
         ms = ctypes.c_float()
-        b0 = batches_cpu[0]
-        fused = (args.path == "fused" or (args.path == "auto" and B >= (1 << 30))) and \
-            bool(L.dgcnn_fused_fits(max(b.max_nodes for b in batches_cpu), max(b.max_edges for b in batches_cpu), F))
-        nprof = min(args.steps, 300)
+        Bl = bl_cpu[0].num_graphs
+        fused = args.path == "fused" and bool(L.dgcnn_fused_fits(max(b.max_nodes for b in bl_cpu),
+                                                                  max(b.max_edges for b in bl_cpu), F))
         for i in range(nprof):
             a, bb = ev(), ev()
-            # the 32-wide aggregation launches, round robin: conv2 / conv3 (conv1 is the F-wide aggregate-first
-            # kernel k_gcn_fwd_af when F <= 32, a different kernel) or conv1 / conv2 / conv3 when F > 32
             which = 1 + i % 2 if F <= 32 else i % 3
-            # the events are attached to that ONE dispatch (hipExtLaunchKernelGGL): their elapsed time
-            # is the kernel's own start->end, the same timestamps rocprofv3 reports
             _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")
-            b = batches[i % nb]
-            tr.train_step(b, b.y, global_batch=gb) if not use_dist else tr.forward_backward(b, b.y, global_batch=gb)
+            b = bl[i % len(bl)]
+            trainer.train_step(b, b.y, global_batch=gb) if not use_dist else trainer.forward_backward(b, b.y, global_batch=gb)
             pairs.append((a, bb, b.num_nodes, b.num_edges))
         torch.cuda.synchronize(dev)
         tot_us = tot_bytes = 0.0
         for a, bb, n_, e_ in pairs:
             _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
-            tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, B, F) if fused else algorithmic_bytes_agg(n_, e_)
+            tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else algorithmic_bytes_agg(n_, e_)
             L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
         avg_us = max(tot_us / len(pairs), 1e-3)
         bytes_per_launch = tot_bytes / len(pairs)
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        # HBM traffic from the PMC counters: collected in SEPARATE rocprofv3 --pmc passes (tools/pmc.sh) and
-        # committed under profiles/; per launch, FETCH_SIZE doubled as the gfx950 note of
-        # MI355X_MICROARCH.md (HBM section) prescribes for wide streaming reads, KB -> bytes.
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_b{B}.json")
-        kname = "k_fused_fwd" if fused else "k_gcn_fwd32"
-        if args.workload == "COLLAB" and os.path.exists(pmc_file):
-            try:
-                pmj = json.load(open(pmc_file))
-                pm = pmj.get(kname + "p") or pmj.get(kname)     # k_gcn_fwd32p: persistent form used from 2048 node tiles
-                if pm:
-                    traffic = (2.0 * pm.get("FETCH_SIZE", 0.0) + pm.get("WRITE_SIZE", 0.0)) * 1024.0
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup: conv1..conv4 + SortPooling + tail, LDS-resident)" if fused
-                    else "k_gcn_fwd32 (32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA)",
+        return fused, avg_us, bytes_per_launch, achieved, len(pairs)
+
+    kernel_note = ("32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA; the library picks per batch between the "
+                   "CSR-gather forms (k_gcn_fwd32 / k_gcn_fwd32p) and the dense per-graph block form on the matrix cores "
+                   "(k_gcn_fwd32d)")
+    if rank == 0 and not args.no_roofline:
+        fused, avg_us, bpl, achieved, nl = measure_agg(tr, batches, batches_cpu, max(200, min(args.steps, 400)))
+        traffic = traffic_src = kname = None
+        if not args.no_pmc and world == 1:
+            base = ["--workload", args.workload, "--batch", str(args.batch), "--scaling", args.scaling,
+                    "--global-batch", str(args.global_batch), "--pool", "8", "--path", args.path, "--agg", args.agg,
+                    "--dtype", args.dtype] + ([] if args.pipeline else ["--no-pipeline"])
+            per, why = live_pmc_traffic(base)
+            if per:
+                for kn in (("k_fused_fwd",) if fused else AGG_KERNELS):
+                    if kn in per:
+                        kname, traffic = kn, per[kn]
+                        traffic_src = ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) "
+                                       f"spawned by this run over 12 steps of the same workload; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                                       f"per {kn} dispatch; includes the fused next-layer X.W write (4*N*32 B) the algorithmic "
+                                       "model does not count")
+                        break
+            else:
+                extra["pmc_note"] = why
+        if traffic is None:
+            kname, traffic, src = committed_pmc_traffic(int(Bavg))
+            traffic_src = None if traffic is None else f"committed {src}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes"
+        roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup forward, LDS-resident)" if fused else
+                    (f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "traffic_source": (f"profiles/r01_pmc_b{B}.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate "
-                                       "--pmc passes; includes the fused next-layer X.W write (4*N*32 B) that the "
-                                       "algorithmic model does not count") if traffic is not None else None,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "avg_launch_us": avg_us, "launches_measured": len(pairs),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": bpl, "avg_launch_us": avg_us, "launches_measured": nl,
                     "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
-                    "note": ("compulsory traffic of the fused forward (every array once: x, CSR, dinv in; x1..x4, pooled, "
-                             "tail activations out), see DESIGN.md") if fused else
-                            ("compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at B=50 the launch "
-                             "moves ~1.5 MB and is latency-bound, see DESIGN.md for the batch-size sweep")}
+                    "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at 50 graphs the launch "
+                            "moves ~1.6 MB (0.2 us of HBM time) and is dispatch/latency-bound -- see roofline_large_batch and DESIGN.md"}
+        # ---- the same kernel family where it is throughput-bound: a large batch ------------------
+        if args.large_batch and world == 1 and not strong and args.large_batch > args.batch:
+            LB = args.large_batch
+            lg = synth.make_graphs(args.workload, 2 * LB, start=10_000_000)
+            lb_cpu = [synth.collate(lg[i:i + LB]) for i in range(0, len(lg), LB)]
+            lb = [b.to(dev) for b in lb_cpu]
+            tr2 = make_trainer()
+            gb_keep, gb = gb, LB
+            for i in range(6):
+                step(i, lb, tr2)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            nl2 = 40
+            for i in range(nl2):
+                step(i, lb, tr2)
+            torch.cuda.synchronize(dev)
+            ms_large = 1e3 * (time.perf_counter() - t1) / nl2
+            _, avg2, bpl2, ach2, n2_ = measure_agg(tr2, lb, lb_cpu, 60)
+            gb = gb_keep
+            roofline_large = {"bound": "hbm", "batch": LB, "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl2, "avg_launch_us": avg2,
+                              "launches_measured": n2_, "step_ms": ms_large, "graphs_per_s": LB / (ms_large * 1e-3),
+                              "note": f"same code, {LB} {args.workload}-shape graphs per step (secondary figure; the headline "
+                                      f"metric stays batch {args.batch})"}
+            del tr2, lb
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batches_cpu, F, C, args.cpu_seconds)
+        cpu = cpu_baseline(batches_cpu, F, C)
 
     if rank == 0:
+        per_gpu = f"batch_size={args.batch} per GPU" if not strong else f"global batch {gb} sharded over {world} GPU(s)"
+        head = args.workload == "COLLAB" and not strong and args.batch == 50 and args.dtype == "f32"
         out = {
-            "metric": "graphs/sec fwd+bwd (+Adam step), COLLAB-shape batch=50 per GPU" if args.workload == "COLLAB" and B == 50
-                      else f"graphs/sec fwd+bwd (+Adam step), {args.workload}-shape batch={B} per GPU",
+            "metric": "graphs/sec fwd+bwd (+Adam step), COLLAB-shape batch=50 per GPU" if head
+                      else f"graphs/sec fwd+bwd (+Adam step), {args.workload}-shape, {per_gpu}" + ("" if args.dtype == "f32" else f", {args.dtype} leg"),
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-shape synthetic graphs (SURVEY §8(d) D2 cfg: n~N(75,30) clip[32,492], "
-                                   f"mean degree ~37, F={F}, C={C}), batch_size={B} per GPU, {nb} distinct resident batches per GPU"
-                       if args.workload == "COLLAB" else f"{args.workload}-shape synthetic graphs, batch_size={B} per GPU",
-                       "global_batch": gb, "avg_nodes_per_batch": avgN, "avg_directed_edges_per_batch": avgE,
-                       "parallelism": f"dp{world}", "step": "forward + NLL(mean) + backward + fused Adam + zero_grad "
-                       "(+1 flat RCCL all-reduce when dp>1); graph prep (CSR build) of every batch inside the timed region" + (", software-pipelined: prep of batch i+1 runs on a side stream during step i" if args.pipeline else "")},
-            "train_loss_mean": loss_sum / max(args.steps + args.warmup, 1), "correct_frac_rank0": correct / ((args.steps + args.warmup) * B),
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "repeats": len(reps), "repeats_ms_per_step": [round(1e3 * r / args.steps, 5) for r in reps],
+            "timing": f"median of {len(reps)} repeats of the {args.steps}-step timed loop (each bracketed by barrier + "
+                      f"synchronize, max over ranks), {total:.3f} s timed in total",
+            "config": {"workload": (f"{args.workload}-shape synthetic graphs (SURVEY §8(d) D2 cfg: n~N(75,30) clip[32,492], "
+                                    f"mean degree ~37, F={F}, C={C})" if args.workload == "COLLAB" else
+                                    f"{args.workload}-shape synthetic graphs (F={F}, C={C})") +
+                                   f", {per_gpu}, {nb} distinct resident batches per GPU",
+                       "global_batch": gb, "avg_graphs_per_rank_per_step": Bavg, "avg_nodes_per_batch": avgN,
+                       "avg_directed_edges_per_batch": avgE,
+                       "parallelism": f"dp{world}" + (" (all ranks on ONE device over gloo: functional check only)" if share else ""),
+                       "step": "forward + NLL(mean) + backward + fused Adam + zero_grad (+1 flat gradient all-reduce when "
+                               "dp>1); graph prep (CSR build) of every batch inside the timed region" +
+                               (", riding on the step's two graph-per-workgroup launches" if args.pipeline else "")},
+            "train_loss_mean": loss_sum / max(nsteps_total, 1),
+            "correct_frac": correct / max(nsteps_total * gb, 1),
         }
         out.update(extra)
         if roofline is not None:
             out["roofline"] = roofline
+        if roofline_large is not None:
+            out["roofline_large_batch"] = roofline_large
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_port"] = value / cpu["value"]
+            out["speedup_vs_cpu_port_1_thread"] = value / cpu["value_1_thread"]
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

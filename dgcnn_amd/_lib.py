@@ -19,6 +19,9 @@ FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
 FLAG_PREPARED = 8
+FLAG_AGG_SPARSE = 16      # never use the dense per-graph block aggregation
+FLAG_AGG_DENSE = 32       # use it whenever the batch admits it (coalesced_undirected, max_nodes <= 512)
+FLAG_BF16 = 64            # bf16 leg: pre-scaled linear outputs stored bf16, X.W on the bf16 matrix cores
 
 K = 30
 CAT = 97

@@ -228,7 +228,10 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     float g = g_;
     if (!glogp) {
       const float sc = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;
-      const int yb = yb_;
+      // a label outside [0, C) (the reference's NLLLoss raises for it): clamp for memory safety and poison this
+      // graph's loss with NaN, which sticks in the metrics accumulator until Trainer.read_metrics raises
+      const bool ybad = (unsigned)yb_ >= (unsigned)C;
+      const int yb = ybad ? 0 : yb_;
       g = (lane == yb) ? -sc : 0.f;
       // loss and accuracy bookkeeping (train.py:44-45): first max index like torch.argmax
       float mx = lp;
@@ -236,7 +239,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
       const unsigned long long ball = __ballot(lane < C && lp == mx);
       const int am = __ffsll((long long)ball) - 1;
       const float lpy = __shfl(lp, yb);
-      if (lane == 0) { lossv[2 * b] = -lpy * sc; lossv[2 * b + 1] = (am == yb) ? 1.f : 0.f; }
+      if (lane == 0) { lossv[2 * b] = ybad ? __builtin_nanf("") : -lpy * sc; lossv[2 * b + 1] = (am == yb) ? 1.f : 0.f; }
     }
     const float sg = dg_wave_sum(g);
     const float d = lane < C ? g - expf(lp) * sg : 0.f;
@@ -786,11 +789,13 @@ k_eval_metrics(int B, int C, const float* __restrict__ logp, const int64_t* __re
   float l = 0.f, c = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     const float* row = logp + (size_t)b * C;
-    const int yb = (int)y[b];
+    const int yr = (int)y[b];
+    const bool ybad = (unsigned)yr >= (unsigned)C;       // out-of-range label: NaN loss (sticky), no out-of-bounds read
+    const int yb = ybad ? 0 : yr;
     int am = 0;
     float mx = row[0];
     for (int k = 1; k < C; ++k) { const float v = row[k]; if (v > mx) { mx = v; am = k; } }
-    l -= row[yb];
+    l -= ybad ? __builtin_nanf("") : row[yb];
     c += (am == yb) ? 1.f : 0.f;
   }
   sl[threadIdx.x] = l; sc[threadIdx.x] = c;

@@ -264,36 +264,60 @@ class Model(nn.Module):
         e = d["_epoch"] = (d["_epoch"] % 0x7FFFFFFE) + 1
         return e
 
-    def _flags_of(self, data) -> int:
-        f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
-        uf = getattr(self, "use_fused", None)       # None: library heuristic; True/False: force (tests, sweeps)
+    def _mode_flags(self) -> int:
+        """path overrides set as plain attributes (tests, sweeps, bench.py); every one defaults to the library's choice:
+        ``use_fused`` True/False, ``agg_mode`` "dense"/"sparse", ``compute_dtype`` "bf16" (BASELINE config 3's leg)."""
+        d = self.__dict__
+        f = 0
+        uf = d.get("use_fused")
         if uf is True:
             f |= _lib.FLAG_FORCE_FUSED
         elif uf is False:
             f |= _lib.FLAG_FORCE_TILED
+        am = d.get("agg_mode")
+        if am == "dense":
+            f |= _lib.FLAG_AGG_DENSE
+        elif am == "sparse":
+            f |= _lib.FLAG_AGG_SPARSE
+        if d.get("compute_dtype") == "bf16":
+            f |= _lib.FLAG_BF16
         return f
+
+    def _flags_of(self, data) -> int:
+        f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
+        return f | self._mode_flags()
 
     def _max_nodes_of(self, data) -> int:
         """per-graph node bound (host-known hint) for the graph-per-workgroup path"""
         return int(getattr(data, "max_nodes", 0) or 0)
 
-    def check_errors(self) -> None:
-        """Host-side check (one tiny D2H copy = a sync) of the input-error words the most recent
-        forward left in its workspace.  The kernels never mis-compute silently: an out-of-range
-        edge endpoint or a violated ``coalesced_undirected`` promise is flagged here."""
-        if self._last_ws is None:
-            return
-        err = _lib.ws_view(self._last_ws, "err", *self._last_dims).cpu().tolist()
-        e = self._epoch
-        inv = (~e) & 0xFFFFFFFF
-        u = [v & 0xFFFFFFFF for v in err]
-        if u[0] == e and u[2] == inv:
-            raise _lib.DgcnnError("edge_index holds a node id outside [0, N)")
-        if u[1] == e and u[3] == inv:
-            raise _lib.DgcnnError("a host-side promise about the batch does not hold: coalesced_undirected "
-                                  "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
-                                  "present), max_nodes (too small), or block-diagonality (an edge leaves its "
-                                  "graph) -- the forward result of this batch is invalid")
+    def check_errors(self, workspaces=None, since: int = -1) -> None:
+        """Host-side check (one tiny D2H copy per workspace = a sync) of the input-error words the forward calls left
+        behind.  The kernels never mis-compute silently: an out-of-range edge endpoint or a violated
+        ``coalesced_undirected`` promise is flagged here.
+
+        Default: the most recent forward's workspace and tag only.  ``workspaces`` (list of (ws, dims)) with ``since``
+        (an earlier value of the forward counter): any error a forward with tag in (since, now] left in ANY of those
+        workspaces -- the words are epoch-tagged and only ever overwritten by a later error, so one check per epoch of
+        training covers every batch of it (``Trainer.read_metrics``).  Drop-in users of ``Model.forward`` who
+        want the guarantee call ``check_errors()`` after the batches they care about."""
+        if workspaces is None:
+            if self._last_ws is None:
+                return
+            workspaces, since = [(self._last_ws, self._last_dims)], self._epoch - 1
+        now = self._epoch
+        for ws, dims in workspaces:
+            if ws is None:
+                continue
+            u = [v & 0xFFFFFFFF for v in _lib.ws_view(ws, "err", *dims).cpu().tolist()]
+            for k, msg in ((0, "edge_index holds a node id outside [0, N)"),
+                           (1, "a host-side promise about the batch does not hold: coalesced_undirected "
+                               "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
+                               "present), max_nodes (too small), or block-diagonality (an edge leaves its "
+                               "graph) -- the forward result of this batch is invalid")):
+                e = u[k]
+                if e != 0 and u[k + 2] == ((~e) & 0xFFFFFFFF) and (since < e <= now or (now < since and (e > since or e <= now))):
+                    raise _lib.DgcnnError(msg)
 
     @staticmethod
     def _check_inputs(x, edge_index, batch):

@@ -52,6 +52,11 @@ class Trainer:
         self._allreduce = GradAllReduce(process_group, force=force_collective) if process_group is not None else None
         if self._allreduce is not None and self._allreduce.world_size == 1 and not force_collective:
             self._allreduce = None           # a 1-rank group needs no collective
+        self._dp_world = self._allreduce.world_size if self._allreduce is not None else 1
+        if process_group is not None and self._allreduce is None:
+            import torch.distributed as dist
+            self._dp_world = dist.get_world_size(process_group)
+        self._err_checked = model._epoch      # forward tag up to which input errors have been surfaced
         self.step_count = 0
         flat = model.flat_params
         self.exp_avg = torch.zeros_like(flat)
@@ -94,6 +99,7 @@ class Trainer:
         if self._prep_ent is not None:       # an unpipelined call interleaved: keep the prepared slot intact
             self._cur = 1 - self._prep_slot
         self._ws = self._slot_ws(self._cur, need, device)
+        self._slots[self._cur]["dims"] = (N, E, B, F, C)
         if self._logp is None or self._logp.shape[0] < B or self._logp.shape[1] != C or self._logp.device != device:
             self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=device)
         return self._ws, self._logp
@@ -218,6 +224,7 @@ class Trainer:
         if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
             self._slot_ws(slot, need, dev)
         ws = sl["ws"]
+        sl["dims"] = dims
         B, C = dims[2], dims[4]
         lp = self._logp
         if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
@@ -227,9 +234,7 @@ class Trainer:
         a.ws, a.logp, a.params, a.grads, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_grads, self._p_metrics
         a.training = training
         a.seed = m._next_seed() if training else 0
-        uf = getattr(m, "use_fused", None)
-        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | \
-            (0 if uf is None else (_lib.FLAG_FORCE_FUSED if uf else _lib.FLAG_FORCE_TILED))
+        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags()
         a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam:
             self.step_count += 1
@@ -247,7 +252,8 @@ class Trainer:
             nsl = self._slots[1 - slot]
             if nsl["ws"] is None or nent[3] > nsl["bytes"] or nsl["ws"].device != dev:
                 self._slot_ws(1 - slot, nent[3], dev)
-            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8], m._next_epoch()
+            nsl["dims"] = nent[5]
+            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8] | m._mode_flags(), m._next_epoch()
             nref = nent[6]
             self._prep_ent, self._prep_slot = nent, 1 - slot
             self._cur = 1 - slot
@@ -271,6 +277,11 @@ class Trainer:
         if self._allreduce is None:
             # single GPU: optimizer fused into the weight-gradient kernel (no separate Adam launch)
             return self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=True)
+        if global_batch is None and self._dp_world > 1:
+            # the loss is the mean over the GLOBAL batch (nn.NLLLoss() default, train.py:98): without the global size
+            # every rank would scale by 1/B_local and the SUM all-reduce would yield world_size times the gradient.
+            # One tiny all-reduce + host sync; loops with a static split pass `global_batch` and skip it.
+            global_batch = self._allreduce.global_batch(_batch_size_of(data), data.x.device)
         logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
         self._allreduce(self.grads)
         self.optimizer_step()
@@ -295,6 +306,7 @@ class Trainer:
         if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
             self._slot_ws(self._cur, need, dev)
         ws = sl["ws"]
+        sl["dims"] = dims
         B, C = dims[2], dims[4]
         lp = self._logp
         if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
@@ -302,8 +314,7 @@ class Trainer:
             self._logp_views = {}
         a.ws, a.logp, a.params, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_metrics
         a.training = 0
-        uf = getattr(m, "use_fused", None)
-        a.flags = ent[8] | (0 if uf is None else (_lib.FLAG_FORCE_FUSED if uf else _lib.FLAG_FORCE_TILED))
+        a.flags = ent[8] | m._mode_flags()
         a.epoch = m._next_epoch()
         rc = _lib.lib().dgcnn_model_eval_step(aref, torch._C._cuda_getCurrentRawStream(
             dev.index if dev.index is not None else torch.cuda.current_device()))
@@ -321,15 +332,33 @@ class Trainer:
         self.metrics.zero_()
 
     def read_metrics(self) -> Tuple[float, float]:
-        """(sum of per-batch mean losses, number correct) -- ONE host sync; also surfaces any input
-        error the kernels flagged for the most recent batch."""
-        v = self.metrics.tolist()
-        self.model.check_errors()
+        """(sum of per-batch mean losses, number correct) -- ONE host sync.  Under a process group the two numbers are
+        summed over the ranks (every rank scaled its losses by 1/B_global), i.e. the dataset-level values the
+        reference returns (/root/reference/train.py:47,66), identical on every rank.  Also surfaces every input
+        error the kernels flagged since the previous call, in any batch (the error words are epoch-tagged and
+        sticky per workspace slot), and a non-finite loss (a label outside [0, C) poisons the accumulator with
+        NaN -- the reference's NLLLoss raises for it)."""
+        m = self.metrics
+        if self.pg is not None and self._dp_world > 1:
+            import torch.distributed as dist
+            m = m.clone()
+            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.pg)
+        v = m.tolist()
+        dims = self.model._last_dims
+        if dims is not None:
+            self.model.check_errors([(sl["ws"], sl.get("dims")) for sl in self._slots if sl.get("dims")],
+                                    since=self._err_checked)
+            self._err_checked = self.model._epoch
+        if v[0] != v[0]:
+            raise _lib.DgcnnError("non-finite loss: a label outside [0, num_classes) or diverged parameters")
         return float(v[0]), float(v[1])
 
     # ---- epoch loops with the reference's return values ------------------------------------
-    def train_epoch(self, batches: Iterable, num_samples: int) -> Tuple[float, float]:
-        """``train()`` of train.py:27-47: returns (running_loss/num_batches, correct/num_samples*100)."""
+    def train_epoch(self, batches: Iterable, num_samples: int, global_batch=None) -> Tuple[float, float]:
+        """``train()`` of train.py:27-47: returns (running_loss/num_batches, correct/num_samples*100).
+        Data parallel: ``batches`` are this rank's shards, ``num_samples`` the GLOBAL sample count, ``global_batch``
+        the global size of every batch (int, or a sequence with one entry per batch; None = derived per batch with a
+        small all-reduce); the returned numbers are the global ones on every rank."""
         self.model.train()
         self.reset_metrics()
         nb = 0
@@ -337,7 +366,8 @@ class Trainer:
         cur = next(it, None)
         while cur is not None:          # one batch of look-ahead: batch i+1's graph prep overlaps step i
             nxt = next(it, None)
-            self.train_step(cur, cur.y, next_data=nxt)
+            gb = global_batch if global_batch is None or isinstance(global_batch, int) else global_batch[nb]
+            self.train_step(cur, cur.y, global_batch=gb, next_data=nxt)
             nb += 1
             cur = nxt
         loss, correct = self.read_metrics()

@@ -1,6 +1,9 @@
 """Generate tests/golden/*.npz from the oracle (run in the build container):
 
-    python -m oracle.make_golden
+    python -m oracle.make_golden                     # regenerate the fixtures from the oracle
+    python -m oracle.make_golden --from-reference    # ONE-COMMAND PIN: diff the committed fixtures against the REAL
+                                                     # /root/reference/model.py (needs torch_geometric; build
+                                                     # container only -- nothing of the reference travels)
 
 PARITY UNPINNED: the real reference cannot be imported here (``torch_geometric`` is
 missing, /root/reference/model.py:5-6), so these vectors come from the oracle's two
@@ -106,6 +109,65 @@ def build(name, workload, bs, start, min_margin):
           f"max|f32-f64|={float((logp32.double() - logp64).abs().max()):.3e} -> {os.path.normpath(path)}")
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The pin.  When torch_geometric is importable, run the REAL reference model (/root/reference/model.py, imported in
+# place -- never copied) on every committed fixture's inputs with the fixture's state_dict and compare eval-mode
+# log-probs, the eval-mode loss and every parameter gradient with the stored vectors.  Prints one PASS/FAIL line per
+# fixture and "parity PINNED" when all agree; without PyG it prints the reason and "parity unpinned".
+# ---------------------------------------------------------------------------------------------------------
+UNPINNED_MSG = "PyG absent -- parity unpinned"
+REFERENCE_DIR = os.environ.get("DGCNN_REFERENCE_DIR", "/root/reference")
+
+
+def pin_against_reference(golden_dir=None, out=print) -> int:
+    """returns 0 = pinned (all fixtures agree), 1 = a mismatch, 2 = cannot run (PyG or the reference absent)."""
+    try:
+        import torch_geometric                                    # noqa: F401
+        from torch_geometric.data import Data
+    except Exception as ex:                                       # noqa: BLE001
+        out(f"{UNPINNED_MSG} (import torch_geometric: {type(ex).__name__}: {ex})")
+        return 2
+    ref_py = os.path.join(REFERENCE_DIR, "model.py")
+    if not os.path.exists(ref_py):
+        out(f"{ref_py} not found -- parity unpinned (the reference exists only in the build container)")
+        return 2
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dgcnn_reference_model", ref_py)
+    refmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refmod)                               # the reference's own Model class, unmodified
+    golden_dir = golden_dir or os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+    bad = 0
+    for name, *_ in CASES:
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        F_, C_ = int(z["num_features"]), int(z["num_classes"])
+        model = refmod.Model(F_, C_)
+        sd = {k[len("param:"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
+        model.load_state_dict(sd)
+        model.eval()                                              # the step fixture is eval-mode (no dropout mask to share)
+        data = Data(x=torch.from_numpy(z["x"]), edge_index=torch.from_numpy(z["edge_index"]),
+                    batch=torch.from_numpy(z["batch"]))
+        y = torch.from_numpy(z["y"])
+        logp = model(data)
+        loss = torch.nn.NLLLoss()(logp, y)                        # train.py:39,98
+        loss.backward()
+        e_logp = float((logp.detach().double() - torch.from_numpy(z["logp_eval_f64"])).abs().max())
+        e_loss = abs(float(loss) - float(z["loss_eval_f64"]))
+        e_grad = 0.0
+        for k, p in model.named_parameters():
+            want = torch.from_numpy(z["grad_eval:" + k]).double()
+            e_grad = max(e_grad, float((p.grad.double() - want).abs().max() / (want.abs().max() + 1e-12)))
+        tie_free = float(z["sort_margin"]) >= 1e-5               # COLLAB-shape fixture: near ties, sort order undefined
+        ok = e_loss <= 1e-4 and (not tie_free or (e_logp <= 1e-4 and e_grad <= 1e-3))
+        bad += 0 if ok else 1
+        out(f"{'PASS' if ok else 'FAIL'} {name}: max|dlogp| {e_logp:.2e}  |dloss| {e_loss:.2e}  max rel dgrad {e_grad:.2e}"
+            + ("" if tie_free else "  (near-tie fixture: only the loss is order-independent enough to gate)"))
+    out("parity PINNED against /root/reference/model.py + torch_geometric " + torch_geometric.__version__
+        if bad == 0 else f"{bad} fixture(s) DISAGREE with the reference")
+    return 0 if bad == 0 else 1
+
+
 if __name__ == "__main__":
+    if "--from-reference" in sys.argv[1:]:
+        sys.exit(pin_against_reference())
     for c in CASES:
         build(*c)
