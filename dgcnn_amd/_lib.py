@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 12
+ABI_VERSION = 13
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -59,7 +59,7 @@ SIGNATURES = {
     "dgcnn_model_forward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_int, c_uint64, c_int, c_int, c_int,
                                     ctypes.c_uint32, c_void_p]),
     "dgcnn_debug_phase_clocks": (c_int, [c_void_p]),
-    "dgcnn_model_prepare": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_int, ctypes.c_uint32, c_void_p]),
+    "dgcnn_model_prepare": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int, ctypes.c_uint32, c_void_p]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
@@ -167,6 +167,7 @@ def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
         "drop_mask": (torch.uint8, (B, HID1)), "dlogit": (torch.float32, (B, C)),
         "gp1": (torch.float32, (N, 32)), "gp2": (torch.float32, (N, 32)), "gp3": (torch.float32, (N, 32)),
         "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)), "ax": (torch.float32, (N, F)),
+        "adjbits": (torch.int32, (31 * N,)), "dmap": (torch.int32, (N // 64 + B + 1,)),
     }
     dt, shape = shapes[name]
     off = workspace_offset(name, N, E, B, F, C)

@@ -121,19 +121,46 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
 
 #define DG_TRY(expr) do { const int rc__ = (expr); if (rc__ != DGCNN_OK) return rc__; } while (0)
 
+// Aggregation form of a batch: dense per-graph blocks on the matrix cores (gcn_dense.hip) or CSR gather (gcn.hip).
+// A pure function of host-known numbers, so graph preparation (which builds the bitmap only for the dense form) and
+// the forward / backward calls of the same batch always agree.  Dense needs the coalesced + undirected promise (one
+// bitmap serves A and A^T) and a per-graph node bound <= 512.  Cost model (MI355X, measured): the block
+// product costs ~K_g SIMD-cycles per node row (K_g = n_g rounded up to 32), the gather ~28 per edge.
+static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
+  if (flags & DGCNN_FLAG_AGG_SPARSE) return false;
+  if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
+  if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
+  if (flags & DGCNN_FLAG_AGG_DENSE) return true;
+  if (flags & DGCNN_FLAG_BF16) return true;              // the bf16 leg exists in the dense form only
+  // K estimate: twice the mean graph size (size-weighted mean of a spread distribution), capped by the largest graph
+  int64_t kest = 2 * ((int64_t)N / B) + 32;
+  if (kest > max_nodes + 31) kest = max_nodes + 31;
+  kest = (kest / 32) * 32;
+  if (kest < 32) kest = 32;
+  return (int64_t)N * kest <= (int64_t)DG_DENSE_EDGE_COST * ((int64_t)E + N);
+}
+static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
+  DgDense G;
+  G.graph_ptr = dg_cptr<int32_t>(ws, wl.graph_ptr); G.dmap = dg_cptr<int32_t>(ws, wl.dmap);
+  G.bits = dg_cptr<uint32_t>(ws, wl.adjbits); G.N = N; G.B = B; G.NW = dgd_num_items(N, B);
+  return G;
+}
+
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
-                        const int64_t* batch, void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream) {
+                        const int64_t* batch, void* ws, int flags, int max_nodes, uint32_t epoch, dgcnn_stream_t stream) {
   if (!batch || !ws || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   if (F <= DG_AF_MAX_F && !x) return DGCNN_EINVAL;       // the pre-scaled features are part of the preparation
   DgWs wl;
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
   DgLinFirst lf; lf.x = x; lf.W = nullptr; lf.hs = dg_ptr<float>(ws, wl.hsA); lf.F = F;
+  const bool dense = dg_use_dense(N, E, B, flags, max_nodes);
   return dg_launch_prep(edge_index, E, batch, N, B, dg_ptr<int32_t>(ws, wl.rowptr), dg_ptr<int32_t>(ws, wl.colidx),
                         dg_ptr<int32_t>(ws, wl.rowptr_t), dg_ptr<int32_t>(ws, wl.colidx_t), dg_ptr<float>(ws, wl.dinv),
                         dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out), dg_ptr<int32_t>(ws, wl.err),
-                        flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr);
+                        flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr,
+                        dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, dense ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr);
 }
 
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
@@ -164,6 +191,10 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) ||
                           (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
   const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
+  const bool dense = !fused && dg_use_dense(N, E, B, flags, max_nodes);
+  const int bf16 = (flags & DGCNN_FLAG_BF16) ? 1 : 0;
+  if (bf16 && !dense) return DGCNN_EUNSUPPORTED;          // the bf16 leg runs in the dense block form only
+  const DgDense G = dg_dense_view(ws, wl, N, B);
   const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: prep leaves xs = dinv*x in hsA, no linear at all
   DgLinFirst lf; lf.x = x; lf.W = af ? nullptr : params + pl.off[0]; lf.hs = hsA; lf.F = F;
   const bool use_lf = af;              // aggregate-first conv1: graph prep also leaves xs = dinv*x
@@ -173,7 +204,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
-                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done));
+                        dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
+                        dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, dense ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr));
   if (fused) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;
@@ -189,6 +221,23 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
+  if (dense) {
+    // dense per-graph block form (gcn_dense.hip): same four launches, A.H on the matrix cores from the bit-packed adjacency
+    if (af) {
+      DG_TRY(dg_launch_gcn_fwd_af_d(bf16, &G, F, dinv, hsA, params + pl.off[0], params + pl.off[1],
+                                    dg_ptr<float>(ws, wl.ax), x1, params + pl.off[2], hsB, s, DG_PROF_A(0), DG_PROF_B(0)));
+    } else {
+      if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
+      DG_TRY(dg_launch_gcn_fwd32d(0, 0, bf16, &G, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
+                                  DG_PROF_A(0), DG_PROF_B(0)));
+    }
+    DG_TRY(dg_launch_gcn_fwd32d(0, bf16, bf16, &G, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,
+                                DG_PROF_A(1), DG_PROF_B(1)));
+    DG_TRY(dg_launch_gcn_fwd32d(1, bf16, 0, &G, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
+                                DG_PROF_A(2), DG_PROF_B(2)));
+    g_prof_which = -1;
+    DG_TRY(dg_launch_gcn_fwd1d(&G, dinv, h4s, params + pl.off[7], x4, s));
+  } else {
   if (af) {
     DG_TRY(dg_launch_gcn_fwd_af(N, F, rowptr, colidx, dinv, hsA, params + pl.off[0], params + pl.off[1],
                                 dg_ptr<float>(ws, wl.ax), x1, params + pl.off[2], hsB, s, DG_PROF_A(0), DG_PROF_B(0)));
@@ -203,6 +252,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                              DG_PROF_A(2), DG_PROF_B(2)));
   g_prof_which = -1;
   DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
+  }
   // SortPooling + the whole dense tail: one launch, one workgroup per graph
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
@@ -297,7 +347,7 @@ int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, 
 // was measured SLOWER than no overlap at all -- 97 vs 86 us/step: each cross-queue dependency costs ~5 us here.)
 struct DgPipeline {
   const void* prep_ws = nullptr;         // workspace holding a prepared-but-not-yet-consumed graph structure
-  int pN = 0, pE = 0, pB = 0, pflags = 0;
+  int pN = 0, pE = 0, pB = 0, pflags = 0, pmaxn = 0;
   uint32_t pepoch = 0;
 };
 
@@ -325,7 +375,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   if (next && (next->ws == cur->ws || !next->ws || !next->batch || !next->x || next->N <= 0 || next->B <= 0 ||
                next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index)))
     return DGCNN_EINVAL;
-  const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B;
+  // (max_nodes takes part in the choice of the aggregation form, which decides what the preparation built)
+  const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B &&
+                     h->pmaxn == cur->max_nodes;
   const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;     // the host says so explicitly ...
   if (prepared && !match) return DGCNN_EINVAL;                       // ... and it must be the batch we prepared
   int flags = cur->flags;
@@ -349,6 +401,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     const bool naf = next->F <= DG_AF_MAX_F;
     rd.x = naf ? next->x : nullptr; rd.xs = naf ? dg_ptr<float>(next->ws, nl.hsA) : nullptr; rd.F = next->F;
     rd.epoch = next->epoch;
+    if (dg_use_dense(next->N, next->E, next->B, next->flags, next->max_nodes)) {
+      rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = dg_ptr<int>(next->ws, nl.dmap);
+    }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B), 1024);
     rider = &rd;
   }
@@ -370,9 +425,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
     if (!rode)
       DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
-                                 next->ws, next->flags, next->epoch, stream));
+                                 next->ws, next->flags, next->max_nodes, next->epoch, stream));
     h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;
-    h->pepoch = next->epoch;
+    h->pepoch = next->epoch; h->pmaxn = next->max_nodes;
   }
   return DGCNN_OK;
 }

@@ -59,7 +59,7 @@ static inline int dg_param_layout(int F, int C, DgParams* p) {
   X(err) X(cnt_in) X(cnt_out) X(rowptr) X(rowptr_t) X(colidx) X(colidx_t) X(dinv) X(graph_ptr) X(graph_eptr) \
   X(hsA) X(hsB) X(h4s) X(x1) X(x2) X(x3) X(x4) X(perm) X(pooled) X(a5) X(a6) X(a1d) X(drop_mask) \
   X(dlogit) X(gz1) X(gz6) X(gz5) X(gp1) X(gp2) X(gp3) X(gas4) X(gasA) X(gasB) X(lossv) X(gb4p) \
-  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(ax) X(wg_t1) X(wg_t2)
+  X(pa4) X(pb3) X(pb2) X(pb1) X(ptail) X(ax) X(wg_t1) X(wg_t2) X(adjbits) X(dmap)
 
 // conv1 is evaluated aggregate-first, (A_hat X) W1^T instead of A_hat (X W1^T), whenever the raw feature width is
 // <= 32: the gather then moves F floats per edge instead of 32, conv1 needs no stand-alone linear (so graph prep
@@ -84,6 +84,9 @@ static inline int dg_wg_two_stage_b() {
   if (v < 0) { const char* e = getenv("DG_WG_TWO_STAGE_B"); v = (e && atoi(e) > 0) ? atoi(e) : DG_WG_TWO_STAGE_B; }
   return v;
 }
+#ifndef DG_DENSE_EDGE_COST
+#define DG_DENSE_EDGE_COST 12      // dense block form when N * K_estimate <= this * (E + N)   (see dg_use_dense, api.hip)
+#endif
 #define DG_WG_ROWS_PER_CHUNK 32
 #define DG_WG_FC1_KCHUNK 128
 static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
@@ -157,6 +160,9 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   // large batches only: stage-1 buffers of the two-stage weight-gradient reduction (tail.hip, dg_launch_wgrad)
   R(wg_t1, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * DG_PTAIL(C) : 0);
   R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
+  // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
+  R(adjbits, 4 * 31 * n);
+  R(dmap, 4 * (n / 64 + b + 1));
 #undef R
   w->total = o;
   return DGCNN_OK;
@@ -376,13 +382,22 @@ __device__ __forceinline__ float dg_af_transform(float ax, int F, const float* _
 }
 #endif
 
+struct DgDense;
+// dense per-graph block forms of the aggregation kernels (gcn_dense.hip)
+int dg_launch_gcn_fwd32d(int mode, int bf16_in, int bf16_out, const DgDense* G, const float* dinv, const void* hs,
+                         const float* bias, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+int dg_launch_gcn_fwd_af_d(int bf16_out, const DgDense* G, int F, const float* dinv, const float* xs, const float* W1,
+                           const float* bias, float* ax, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+int dg_launch_gcn_fwd1d(const DgDense* G, const float* dinv, const float* h4s, const float* bias, float* x4, hipStream_t s);
 struct DgLinFirst { const float* x; const float* W; float* hs; int F; };   // optional conv1 linear riding on the prep launch
 // kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
-                   int* lin_done = nullptr);
+                   int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
                         int Fout, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step

@@ -173,9 +173,9 @@ __global__ void __launch_bounds__(256)
 k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __restrict__ batch, int B,
               int* __restrict__ rowptr, int* __restrict__ colidx, int* __restrict__ rowptr_t,
               int* __restrict__ colidx_t, int* __restrict__ graph_ptr, unsigned int* __restrict__ err,
-              unsigned int epoch) {
+              unsigned int epoch, unsigned int* __restrict__ bits) {
   dg_prep_fast_a_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, batch, B, rowptr, colidx, rowptr_t, colidx_t,
-                      graph_ptr, err, epoch);
+                      graph_ptr, err, epoch, bits);
 }
 
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
@@ -185,9 +185,10 @@ __global__ void __launch_bounds__(256)
 k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
               float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int F,
-              const float* __restrict__ x, float* __restrict__ xs) {
+              const float* __restrict__ x, float* __restrict__ xs, const int64_t* __restrict__ batch,
+              unsigned int* __restrict__ bits, int* __restrict__ dmap) {
   dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
-                      err, epoch, x, xs, F);
+                      err, epoch, x, xs, F, batch, bits, dmap);
 }
 
 // xs[i][f] = dinv[i] * x[i][f]  (general prep path; the fast path does it inside k_prep_fast_b)
@@ -200,19 +201,21 @@ k_scale_x(int N, int F, const float* __restrict__ x, const float* __restrict__ d
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
-                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done) {
+                   int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done,
+                   uint32_t* bits, int32_t* dmap) {
   if (N <= 0 || E < 0 || B <= 0) return DGCNN_EINVAL;
   if (lin_done) *lin_done = 0;
+  if (!bits || !dmap) { bits = nullptr; dmap = nullptr; }
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
     const int work = dg_prep_fast_work(E, N, B);
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
-                       colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch);
+                       colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch, bits);
     DG_CHECK_LAUNCH();
     const bool scale = lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
     hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr, colidx,
                        graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
-                       scale ? lf->hs : nullptr);
+                       scale ? lf->hs : nullptr, batch, bits, dmap);
     if (scale && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     return DGCNN_OK;

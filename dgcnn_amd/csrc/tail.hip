@@ -96,7 +96,7 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
               uint64_t seed, unsigned long long* dbg, int B, DgPrepRider rd) {
   if ((int)blockIdx.x >= B) {    // rider range: phase A of the NEXT batch's graph preparation (dg_prep.h)
     dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
-                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch);
+                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
     return;
   }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[7] = clock64();
@@ -148,7 +148,8 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   if ((int)blockIdx.x >= B) {    // rider range: phase B of the NEXT batch's graph preparation (phase A rode on the
                                  // readout launch of this step's forward, complete by now)
     dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
-                        rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F);
+                        rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
+                        rd.dmap);
     return;
   }
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 12
+#define DGCNN_ABI_VERSION 13
 
 /* error codes */
 #define DGCNN_OK            0
@@ -63,6 +63,14 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
 #define DGCNN_FLAG_FORCE_TILED 4    /* never use it */
 #define DGCNN_FLAG_PREPARED    8    /* dgcnn_model_forward: the workspace already holds this batch's graph structure
                                        (dgcnn_model_prepare with the SAME sizes, flags and epoch): skip graph prep */
+#define DGCNN_FLAG_AGG_SPARSE  16    /* aggregation: always the CSR gather kernels (gcn.hip) */
+#define DGCNN_FLAG_AGG_DENSE   32    /* aggregation: dense per-graph block products on the matrix cores (gcn_dense.hip)
+                                       whenever the batch admits it (COALESCED_UNDIRECTED promised, max_nodes in 1..512);
+                                       neither flag: the library's cost model picks per batch */
+#define DGCNN_FLAG_BF16        64    /* bf16 leg (BASELINE config 3): the pre-scaled linear outputs hs are STORED in bf16
+                                       (64-B rows) and X.W^T runs on v_mfma_f32_16x16x32_bf16; sums, activations, the
+                                       SortPooling key channel and the whole backward stay fp32.  Dense block form only
+                                       (DGCNN_EUNSUPPORTED otherwise).  Not the reference's arithmetic: a secondary leg. */
 #define DGCNN_FUSED_MIN_GRAPHS (1 << 30) /* the fused path is never chosen automatically: the tiled kernels measured
                                             faster at every batch size (profiles/r01_sweep.txt); FORCE_FUSED selects it */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
@@ -180,9 +188,10 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
  * forward that depends on the batch only, not on the parameters -- CSR by target / by source, dinv, graph ranges and
  * (for F <= 32, where conv1 runs aggregate-first) the pre-scaled raw features dinv*x, which is why `x` is an input
- * (may be NULL only when F > 32).  Follow with dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, same epoch). */
+ * (may be NULL only when F > 32) -- and, when flags / max_nodes select the dense block form of the aggregation, the
+ * bit-packed adjacency.  Follow with dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, same max_nodes, same epoch). */
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
-                        const int64_t* batch, void* ws, int flags, uint32_t epoch, dgcnn_stream_t stream);
+                        const int64_t* batch, void* ws, int flags, int max_nodes, uint32_t epoch, dgcnn_stream_t stream);
 int dgcnn_fused_max_nodes(int F);   /* largest max_nodes the fused path accepts for F input features */
 int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batch fits the fused LDS plan */
 

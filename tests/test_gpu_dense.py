@@ -1,0 +1,116 @@
+"""Dense per-graph block form of the aggregation (gcn_dense.hip): the bit-packed adjacency and work-item map built by
+graph preparation are compared BIT-EXACT with a numpy restatement; the kernels go through the same oracle parity
+protocol as the CSR-gather kernels (tests/parity_util.py), must agree with them within fp32 summation-order noise, be
+run-to-run reproducible and independent of batch composition."""
+import numpy as np
+import pytest
+import torch
+
+from dgcnn_amd import _lib, synth
+from dgcnn_amd.batch import Batch, collate
+from parity_util import check_backward_parity, check_forward_parity, cpu_state_dict, gpu_xcat, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _bitmap_reference(b):
+    """numpy restatement of dg_prep.h's dense structures: (words [31*N] u32, item map [N//64 + B] i32)"""
+    N, B = b.num_nodes, b.num_graphs
+    ptr = np.searchsorted(b.batch.numpy(), np.arange(B + 1))
+    words = np.zeros(31 * N, dtype=np.uint32)
+    dmap = np.full(N // 64 + B, -7, dtype=np.int32)
+    src, dst = b.edge_index[0].numpy(), b.edge_index[1].numpy()
+    gid = b.batch.numpy()
+    def cls(n):
+        k32 = (n + 31) // 32
+        return 0 if k32 <= 1 else 1 if k32 <= 2 else 2 if k32 <= 4 else 3 if k32 <= 8 else 4
+    for g in range(B):
+        n0, n1 = int(ptr[g]), int(ptr[g + 1])
+        s0, s1 = n0 // 64 + g, n1 // 64 + g + 1
+        used = (n1 - n0 + 63) // 64
+        for w in range(s0, s1):
+            dmap[w] = g if w - s0 < used else -1
+    def setbit(i, j):
+        g = gid[i]; n0, n1 = int(ptr[g]), int(ptr[g + 1])
+        S = 1 << cls(n1 - n0)
+        words[N * (S - 1) + i * S + ((j - n0) >> 5)] |= np.uint32(1 << ((j - n0) & 31))
+    for i in range(N):
+        setbit(i, i)
+    for s, d in zip(src, dst):
+        setbit(int(s), int(d))
+    return words, dmap
+
+
+@pytest.mark.parametrize("name,bs", [("MUTAG", 9), ("PROTEINS", 7), ("COLLAB", 6), ("COLLAB_REAL", 5), ("IMDB", 11)])
+def test_dense_structures_bit_exact(name, bs):
+    sh = synth.SHAPES[name]
+    b = synth.make_batch(name, bs, start=40)
+    if b.max_nodes > 512:
+        pytest.skip("graph above the dense bound")
+    m = make_model(sh.num_features, sh.num_classes)
+    m.agg_mode = "dense"
+    m.eval()
+    with torch.no_grad():
+        m(b.to("cuda"))
+    m.check_errors()
+    words, dmap = _bitmap_reference(b)
+    got_w = m.last_workspace_view("adjbits").cpu().numpy().view(np.uint32)[:31 * b.num_nodes]
+    got_m = m.last_workspace_view("dmap").cpu().numpy()[:b.num_nodes // 64 + b.num_graphs]
+    np.testing.assert_array_equal(got_m, dmap)
+    # only the words of each row's OWN stride class are defined content; the other classes are zero
+    np.testing.assert_array_equal(got_w, words)
+
+
+WORKLOADS = [("MUTAG", 50), ("PROTEINS", 24), ("COLLAB", 50), ("COLLAB_REAL", 50), ("IMDB", 50), ("COLLAB", 256)]
+
+
+@pytest.mark.parametrize("name,bs", WORKLOADS, ids=[f"{w[0]}-{w[1]}" for w in WORKLOADS])
+def test_dense_forward_backward_vs_oracle_and_vs_gather(name, bs):
+    sh = synth.SHAPES[name]
+    start = 1000
+    b = synth.make_batch(name, bs, start=start)
+    while b.max_nodes > 512:
+        start += bs
+        b = synth.make_batch(name, bs, start=start)
+    m = make_model(sh.num_features, sh.num_classes)
+    sd = cpu_state_dict(m)
+    m.agg_mode = "dense"
+    check_forward_parity(m, b, sd)
+    xd = gpu_xcat(m)
+    m.agg_mode = "sparse"
+    check_forward_parity(m, b, sd)
+    xs = gpu_xcat(m)
+    assert float((xd - xs).abs().max()) <= 4e-6          # same sums, different order
+    m.agg_mode = "dense"
+    check_backward_parity(m, b, sd)
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 7, 13, 16, 17, 32, 33, 40])
+def test_dense_raw_feature_widths(F):
+    base = synth.make_batch("COLLAB" if F % 2 else "PROTEINS", 12, start=77)
+    g = torch.Generator().manual_seed(F)
+    b = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
+              base.coalesced_undirected, base.max_nodes, base.max_edges)
+    m = make_model(F, 3)
+    m.agg_mode = "dense"
+    sd = cpu_state_dict(m)
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
+
+
+def test_dense_results_do_not_depend_on_batch_composition_and_are_reproducible():
+    sh = synth.SHAPES["COLLAB"]
+    graphs = synth.make_graphs("COLLAB", 96, start=500)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.agg_mode = "dense"
+    m.eval()
+    with torch.no_grad():
+        big = collate(graphs).to("cuda")
+        lp1 = m(big).clone()
+        x1 = gpu_xcat(m)
+        lp2 = m(big).clone()
+        assert torch.equal(lp1, lp2) and torch.equal(x1, gpu_xcat(m))
+        parts = [m(collate(graphs[k:k + 32]).to("cuda")).clone() for k in range(0, 96, 32)]
+        assert torch.equal(torch.cat(parts), lp1)
+        rev = m(collate(graphs[::-1]).to("cuda")).clone()
+        assert torch.equal(rev.flip(0), lp1)
