@@ -62,9 +62,10 @@ SIGNATURES = {
     "dgcnn_model_prepare": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int, ctypes.c_uint32, c_void_p]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
-    "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p]),
     "dgcnn_model_backward_step": (c_int, [c_int] * 5 + [c_void_p] * 5 + [c_float, c_int, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+                                          c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     "dgcnn_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_int64, c_float, c_float, c_float, c_float, c_int,
                                 c_void_p]),
     "dgcnn_collate": (c_int, [c_int, c_int, c_int64, c_int64, c_int64] + [c_void_p] * 13),
@@ -167,7 +168,7 @@ def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
         "drop_mask": (torch.uint8, (B, HID1)), "dlogit": (torch.float32, (B, C)),
         "gp1": (torch.float32, (N, 32)), "gp2": (torch.float32, (N, 32)), "gp3": (torch.float32, (N, 32)),
         "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)), "ax": (torch.float32, (N, F)),
-        "adjbits": (torch.int32, (31 * N,)), "dmap": (torch.int32, (N // 64 + B + 1,)),
+        "adjbits": (torch.int32, (31 * N,)), "dmap": (torch.int32, (1032 + 3 * (N // 64 + B + 1),)),
     }
     dt, shape = shapes[name]
     off = workspace_offset(name, N, E, B, F, C)

@@ -130,6 +130,7 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   if (flags & DGCNN_FLAG_AGG_SPARSE) return false;
   if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
   if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
+  if (dgd_num_items(N, B) > 100000) return false;        // (a workgroup caches at most 128 item records: gcn_dense.hip)
   if (flags & DGCNN_FLAG_AGG_DENSE) return true;
   if (flags & DGCNN_FLAG_BF16) return true;              // the bf16 leg exists in the dense form only
   // K estimate: twice the mean graph size (size-weighted mean of a spread distribution), capped by the largest graph
@@ -138,6 +139,12 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   kest = (kest / 32) * 32;
   if (kest < 32) kest = 32;
   return (int64_t)N * kest <= (int64_t)DG_DENSE_EDGE_COST * ((int64_t)E + N);
+}
+// the backward of a batch takes the form its forward took (same flags and max_nodes; the fused graph-per-workgroup
+// forward never builds the bitmap)
+static bool dg_backward_dense(int N, int E, int B, int flags, int max_nodes) {
+  if (flags & DGCNN_FLAG_FORCE_FUSED) return false;
+  return dg_use_dense(N, E, B, flags, max_nodes);
 }
 static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
   DgDense G;
@@ -273,7 +280,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
                                   float loss_scale, int training, float* grads, float* metrics,
-                                  const DgAdam* adam, hipStream_t s, const DgPrepRider* rider_b = nullptr) {
+                                  const DgAdam* adam, hipStream_t s, bool dense, const DgPrepRider* rider_b = nullptr) {
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -292,6 +299,21 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
                             dg_cptr<float>(ws, wl.pooled), s, rider_b));
+  if (dense) {
+    // dense block form (the forward of this batch took it: the bitmap is in the workspace); F > 32 keeps the gather
+    // kernel for conv1's own backward (its operand is the raw [N,F] input)
+    const DgDense G = dg_dense_view(ws, wl, N, B);
+    DG_TRY(dg_launch_gcn_bwd1d(&G, dinv, gas4, params + pl.off[6], x3, gp3, gasA, dg_ptr<float>(ws, wl.pa4), wl.P1, s));
+    DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasA, params + pl.off[4], x2, gp2, gasB, dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+    if (F <= DG_AF_MAX_F) {
+      DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasB, params + pl.off[2], x1, gp1, gasA, dg_ptr<float>(ws, wl.pb2), wl.P32, s,
+                                  dg_cptr<float>(ws, wl.ax), F, dg_ptr<float>(ws, wl.pb1)));
+    } else {
+      DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasB, params + pl.off[2], x1, gp1, gasA, dg_ptr<float>(ws, wl.pb2), wl.P32, s));
+      DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
+                                 dg_ptr<float>(ws, wl.pb1), wl.P32, s));
+    }
+  } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s));
@@ -311,6 +333,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
     DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                                dg_ptr<float>(ws, wl.pb1), wl.P32, s));
   }
+  }
   // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
@@ -321,24 +344,24 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
 int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
                          const float* glogp, const int64_t* y, float loss_scale, int training,
-                         float* grads, float* metrics, dgcnn_stream_t stream) {
+                         float* grads, float* metrics, int flags, int max_nodes, dgcnn_stream_t stream) {
   if (!params || !x || !ws || !logp || !grads || N <= 0 || B <= 0) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, glogp, y, loss_scale, training ? 1 : 0,
-                                grads, metrics, nullptr, (hipStream_t)stream);
+                                grads, metrics, nullptr, (hipStream_t)stream, dg_backward_dense(N, E, B, flags, max_nodes));
 }
 
 int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, const float* x, void* ws,
                               const float* logp, const int64_t* y, float loss_scale, int training, float* grads,
                               float* metrics, float* exp_avg, float* exp_avg_sq, int64_t step, float lr,
-                              float beta1, float beta2, float eps, dgcnn_stream_t stream) {
+                              float beta1, float beta2, float eps, int flags, int max_nodes, dgcnn_stream_t stream) {
   if (!params || !x || !ws || !logp || !y || !grads || !exp_avg || !exp_avg_sq || N <= 0 || B <= 0 || step < 1)
     return DGCNN_EINVAL;
   DgAdam ad;
   ad.params = params; ad.exp_avg = exp_avg; ad.exp_avg_sq = exp_avg_sq;
   ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step = step;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, nullptr, y, loss_scale, training ? 1 : 0,
-                                grads, metrics, &ad, (hipStream_t)stream);
+                                grads, metrics, &ad, (hipStream_t)stream, dg_backward_dense(N, E, B, flags, max_nodes));
 }
 
 // ---- pipelined training step ------------------------------------------------------------------------
@@ -420,7 +443,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   }
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
-                                rode ? rider : nullptr));
+                                dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr));
   if (next) {
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
     if (!rode)

@@ -162,7 +162,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
   // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
   R(adjbits, 4 * 31 * n);
-  R(dmap, 4 * (n / 64 + b + 1));
+  R(dmap, 4 * (1032 + 3 * (n / 64 + b + 1)));      // item table: shares + records (dg_prep.h: dgd_table_ints)
 #undef R
   w->total = o;
   return DGCNN_OK;
@@ -391,6 +391,11 @@ int dg_launch_gcn_fwd_af_d(int bf16_out, const DgDense* G, int F, const float* d
                            const float* bias, float* ax, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_gcn_fwd1d(const DgDense* G, const float* dinv, const float* h4s, const float* bias, float* x4, hipStream_t s);
+int dg_launch_gcn_bwd32d(const DgDense* G, const float* dinv, const float* gas, const float* Wl, const float* xprev,
+                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
+                         const float* ax = nullptr, int Fa = 0, float* part1 = nullptr);
+int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, const float* W4, const float* x3,
+                        const float* gp3, float* gas3, float* pa4, int P1, hipStream_t s);
 struct DgLinFirst { const float* x; const float* W; float* hs; int F; };   // optional conv1 linear riding on the prep launch
 // kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,

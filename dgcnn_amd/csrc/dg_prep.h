@@ -27,12 +27,21 @@ static inline int dg_prep_fast_work(int E, int N, int B) {
 // rows are stored with a power-of-two word stride S = 2^c >= ceil(n_g/32) (five classes, c = 0..4, i.e. graphs of up
 // to 32/64/128/256/512 nodes); class c lives at word offset N*(2^c - 1), row i at i*2^c inside it -- every offset is
 // a function of (N, i, n_g) only, so building it needs no prefix sum over graphs.  31*N words are reserved.
-// work items: one per (graph, group of DGD_ROWS rows); item ids [n0_g/64 + g, n0_{g+1}/64 + g + 1) are graph g's
-// (>= ceil(n_g/64) of them; the surplus maps to -1), N/64 + B ids in total -- again no prefix sum.
+// work items: one per (graph, group of DGD_ROWS rows), packed in graph order: item table `dmap` =
+//   [0 .. DGD_SPLITS]            split[k] = first item of share k: the items are cut into DGD_SPLITS contiguous shares of
+//                                (nearly) equal COST (cost of an item = 3 * its pipeline stages + 1, i.e. ~ n_g), so that
+//                                persistent workgroups that take equal numbers of shares finish together -- static,
+//                                hence reproducible, and contiguous, hence L2-friendly
+//   [DGD_REC0 + 3w ..]           record of item w: {first node of its graph, node count, first row of the item}
+// built by ONE workgroup of graph preparation's second phase with a block-wide prefix sum over the graphs
+// (dg_prep_dense_plan); at most N/64 + B items.
 #define DGD_MAXN 512
 #define DGD_ROWS 64
 #define DGD_CLASSES 5
-static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }
+#define DGD_SPLITS 1024
+#define DGD_REC0 (DGD_SPLITS + 8)
+static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }       // upper bound
+static inline int64_t dgd_table_ints(int N, int B) { return DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1); }
 struct DgDense { const int* graph_ptr; const int* dmap; const unsigned* bits; int N, B, NW; };
 #ifdef __HIPCC__
 __host__ __device__ __forceinline__ int dgd_class(int ng) {     // smallest c with 32*2^c >= ng  (ng <= 512)
@@ -42,6 +51,54 @@ __host__ __device__ __forceinline__ int dgd_class(int ng) {     // smallest c wi
 #endif
 
 #ifdef __HIPCC__
+// One workgroup of T threads (tid = its thread index): item records + equal-cost shares, see above.  Needs graph_ptr.
+__device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const int* __restrict__ graph_ptr,
+                                                   int* __restrict__ dmap) {
+  __shared__ int sI[1024], sC[1024];
+  __shared__ int carryI, carryC, totalC;
+  for (int pass = 0; pass < 2; ++pass) {          // pass 0: total cost; pass 1: emit
+    if (tid == 0) { carryI = 0; carryC = 0; }
+    __syncthreads();
+    for (int base = 0; base < B; base += T) {
+      const int g = base + tid;
+      int n0 = 0, n = 0;
+      if (g < B) { n0 = graph_ptr[g]; n = graph_ptr[g + 1] - n0; if (n > DGD_MAXN) n = DGD_MAXN; if (n < 0) n = 0; }
+      const int items = (n + DGD_ROWS - 1) / DGD_ROWS;
+      const int ic = 3 * ((n + 63) / 64) + 1;                 // cost of one item (pipeline stages of 64 k-rows + epilogue)
+      sI[tid] = items; sC[tid] = items * ic;
+      __syncthreads();
+      for (int o = 1; o < T; o <<= 1) {                       // inclusive scan (Hillis-Steele)
+        int a = 0, c = 0;
+        if (tid >= o) { a = sI[tid - o]; c = sC[tid - o]; }
+        __syncthreads();
+        sI[tid] += a; sC[tid] += c;
+        __syncthreads();
+      }
+      const int ioff = carryI + sI[tid] - items, coff = carryC + sC[tid] - items * ic;
+      if (pass == 1) {
+        const long long tot = totalC > 0 ? totalC : 1;
+        for (int r = 0; r < items; ++r) {
+          const int w = ioff + r;
+          int* rec = dmap + DGD_REC0 + 3 * w;
+          rec[0] = n0; rec[1] = n; rec[2] = r * DGD_ROWS;
+          const long long c0 = coff + (long long)r * ic, c1 = c0 + ic;
+          const int klo = (int)(c0 * DGD_SPLITS / tot) + 1, khi = (int)(c1 * DGD_SPLITS / tot);
+          for (int k = klo; k <= khi && k <= DGD_SPLITS; ++k) dmap[k] = w + 1;
+        }
+      }
+      __syncthreads();
+      if (tid == T - 1) { carryI += sI[tid]; carryC += sC[tid]; }
+      __syncthreads();
+    }
+    if (pass == 0) {
+      if (tid == 0) { totalC = carryC; dmap[0] = 0; dmap[DGD_SPLITS + 1] = carryI; }
+      if (carryC == 0)                                        // no work at all: every share is empty
+        for (int k = tid; k <= DGD_SPLITS; k += T) dmap[k] = 0;
+      __syncthreads();
+    }
+  }
+}
+
 // Kernel-A body, thread t of max(E, N+1, B+1): range / self-loop / strict (src,dst) order checks, colidx copies,
 // rowptr by ROW-BOUNDARY detection, graph_ptr by binary search on the sorted batch vector.
 __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __restrict__ ei, int E, int N,
@@ -50,14 +107,7 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
                                                     int* __restrict__ colidx_t, int* __restrict__ graph_ptr,
                                                     unsigned int* __restrict__ err, unsigned int epoch,
                                                     unsigned int* __restrict__ bits = nullptr) {
-  if (bits && t < N) {      // adjacency bitmap rows of node t, all five stride classes (phase B ORs the bits in)
-#pragma unroll
-    for (int c = 0; c < DGD_CLASSES; ++c) {
-      unsigned int* row = bits + (size_t)N * ((1 << c) - 1) + (size_t)t * (1 << c);
-#pragma unroll
-      for (int w = 0; w < (1 << c); ++w) row[w] = 0u;
-    }
-  }
+  (void)bits;
   const int64_t* src = ei;
   const int64_t* dst = ei + E;
   if (t < E) {
@@ -104,38 +154,68 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     unsigned int* __restrict__ bits = nullptr,
                                                     int* __restrict__ dmap = nullptr) {
   if (bits) {
-    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j; and the
-    // work-item -> graph map.  Integer atomics only (order-independent result).
-    if (t < N) {                                       // self loop bit
-      const int g = (int)batch[t];
-      if ((unsigned)g < (unsigned)B) {
-        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, j = t - n0;
-        if (j >= 0 && j < ng && ng <= DGD_MAXN) {
-          const int c = dgd_class(ng);
-          atomicOr(bits + (size_t)N * ((1 << c) - 1) + (size_t)t * (1 << c) + (j >> 5), 1u << (j & 31));
-        }
-      }
-    }
+    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j, and the
+    // work-item records.  No atomics and no clearing pass: the edge list is sorted by (src, dst), so the edges that
+    // fall into one 32-bit word of a row are consecutive; the thread of the FIRST edge of such a group ORs the group
+    // (<= 32 edges, from the int32 colidx copy phase A left) and stores the word, plus the empty words between the
+    // previous group and its own (and after it, when it is the row's last group).  Every word is written exactly once.
     if (t < E) {
-      const int64_t s = ei[t], d = ei[(int64_t)E + t];
-      if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
+      const int64_t s64 = ei[t];
+      if ((uint64_t)s64 < (uint64_t)N) {
+        const int s = (int)s64;
         const int g = (int)batch[s];
         if ((unsigned)g < (unsigned)B) {
-          const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, j = (int)d - n0;
-          if (j < 0 || j >= ng) { err[1] = epoch; err[3] = ~epoch; }       // the edge leaves its graph
-          else if (ng <= DGD_MAXN) {
-            const int c = dgd_class(ng);
-            atomicOr(bits + (size_t)N * ((1 << c) - 1) + (size_t)s * (1 << c) + (j >> 5), 1u << (j & 31));
+          const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0;
+          if (ng <= DGD_MAXN && ng > 0) {
+            const int rb = rowptr[s], re = rowptr[s + 1];
+            int j = colidx[t] - n0;
+            if (j < 0 || j >= ng) { err[1] = epoch; err[3] = ~epoch; j = j < 0 ? 0 : ng - 1; }      // the edge leaves its graph
+            const int wi = j >> 5;
+            int pwi = -1;
+            if (t > rb) { int pj = colidx[t - 1] - n0; pj = pj < 0 ? 0 : (pj >= ng ? ng - 1 : pj); pwi = pj >> 5; }
+            if (pwi != wi) {                                  // first edge of this (row, word) group
+              const int S = 1 << dgd_class(ng);
+              unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)s * S;
+              const int sj = s - n0, sw = sj >> 5;
+              const unsigned int sbit = 1u << (sj & 31);
+              for (int gw = pwi + 1; gw < wi; ++gw) row[gw] = gw == sw ? sbit : 0u;
+              unsigned int word = wi == sw ? sbit : 0u;
+              int e = t;
+              bool more = true;
+              while (more && e < re) {                        // 4 edges per round trip
+                int jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) jj[u] = e + u < re ? colidx[e + u] - n0 : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (more && e + u < re) {
+                    const int jc = jj[u] < 0 ? 0 : (jj[u] >= ng ? ng - 1 : jj[u]);
+                    if ((jc >> 5) == wi) word |= 1u << (jc & 31); else more = false;
+                  }
+                }
+                if (more) e += 4;
+              }
+              row[wi] = word;
+              if (more) {                                     // ran to the end of the row: this was its last group
+                for (int gw = wi + 1; gw < S; ++gw) row[gw] = gw == sw ? sbit : 0u;
+              }
+            }
           }
         }
       }
     }
-    if (t < B) {                                       // work items [slot(t), slot(t+1)) belong to graph t
-      const int n0 = graph_ptr[t], n1 = graph_ptr[t + 1], ng = n1 - n0;
-      if (ng > DGD_MAXN) { err[1] = epoch; err[3] = ~epoch; }            // max_nodes promise (<= 512) broken
-      const int s0 = n0 / DGD_ROWS + t, s1 = n1 / DGD_ROWS + t + 1, used = (ng + DGD_ROWS - 1) / DGD_ROWS;
-      for (int w = s0; w < s1; ++w) dmap[w] = (w - s0 < used) ? t : -1;
+    if (t < N && rowptr[t + 1] == rowptr[t]) {          // node without edges: its row is the self bit alone
+      const int g = (int)batch[t];
+      if ((unsigned)g < (unsigned)B) {
+        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, j = t - n0;
+        if (j >= 0 && j < ng && ng <= DGD_MAXN) {
+          const int S = 1 << dgd_class(ng);
+          unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)t * S;
+          for (int gw = 0; gw < S; ++gw) row[gw] = gw == (j >> 5) ? 1u << (j & 31) : 0u;
+        }
+      }
     }
+    if (t < B && graph_ptr[t + 1] - graph_ptr[t] > DGD_MAXN) { err[1] = epoch; err[3] = ~epoch; }      // max_nodes promise (<= 512) broken
   }
   if (t < N) {
     const float di = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));

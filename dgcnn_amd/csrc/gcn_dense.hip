@@ -13,114 +13,164 @@
 // whose edge list is promised (and verified) coalesced + undirected, so the one bitmap serves forward (A) and
 // backward (A^T = A), and whose graphs have at most DGD_MAXN = 512 nodes.
 //
-// Work item = (graph g, group of 64 rows); one workgroup of 4 waves per item, one 16-row MFMA tile per wave:
-//     acc[16 x 32] = sum over k-chunks of 128 rows:  bits[16 x 128] (0/1, expanded in registers) . HS[128 x 32] (LDS)
+// Work item = (graph g, group of 64 rows): 4 waves, one 16-row MFMA tile per wave.  Its block product runs as a
+// sequence of STAGES of 64 k-rows:
+//     acc[16 x 32] += bits[16 x 64] (0/1, two bitmap words per row, expanded in registers) . HS[64 x 32] (LDS)
 // on v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain: the sum runs over the graph's nodes in ascending order,
-// zeros included -- deterministic, independent of batch composition); 32-column words of the bitmap that are zero for
-// all 16 rows are skipped.  Epilogue per tile, wave-private (no workgroup barrier): dst scale, bias, tanh, coalesced
-// row store, next layer's X.W^T on MFMA (fp32 16x16x4, or bf16 16x16x32 for the bf16 leg), stored pre-scaled.
+// zeros included -- deterministic, independent of batch composition); 32-column words that are zero for all 16 rows
+// are skipped.  Workgroups are PERSISTENT: each walks a contiguous range of items, and the stages of all its items
+// form one software pipeline -- stage s+1's rows of hs and bitmap words are in flight (8 + 2 registers per thread)
+// while stage s multiplies out of the other LDS buffer, one barrier per stage.  (The first, one-item-per-workgroup
+// form of this kernel ran at 1.6 TB/s: each workgroup's life was a serial chain of record -> rows -> LDS -> MFMA ->
+// stores with nothing overlapping it.)  Epilogue per tile, wave-private (no workgroup barrier): dst scale, bias, tanh,
+// coalesced row store, next layer's X.W^T on MFMA (fp32 16x16x4, or bf16 16x16x32 for the bf16 leg), stored pre-scaled.
 #include "dg_common.h"
 #include "dg_prep.h"
 #include <hip/hip_ext.h>
 
-#define DGD_KC 128                       // rows of HS staged per chunk
-#define DGD_PLANE (DGD_KC * 16 + 16)     // floats per 16-column plane; +16 puts the two planes on opposite bank halves
+#define DGD_SK 64                        // k rows per pipeline stage
+#define DGD_PLANE (DGD_SK * 16 + 16)     // floats per 16-column plane; +16 puts the two planes on opposite bank halves
+#define DGD_BUF (2 * DGD_PLANE)          // one stage buffer: two planes
 #define DGD_XT 36                        // row stride (floats) of the wave-private 16x32 tiles
 #define DGD_THREADS 256
+#ifndef DGD_MAX_GRID
+#define DGD_MAX_GRID 1024                // persistent forward grid: 4 workgroups per CU
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct DgdItem { int n0, n, r0, K32, S; const unsigned* brow; };
-
-// decode work item w (workgroup-uniform); false = nothing to do
-__device__ __forceinline__ bool dgd_item(const DgDense& G, int w, DgdItem& it) {
-  const int g = __builtin_amdgcn_readfirstlane(G.dmap[w]);
-  if (g < 0) return false;
-  const int n0 = __builtin_amdgcn_readfirstlane(G.graph_ptr[g]);
-  int n = __builtin_amdgcn_readfirstlane(G.graph_ptr[g + 1]) - n0;
-  if (n > DGD_MAXN) n = DGD_MAXN;            // (flagged by graph preparation; keeps the kernel memory-safe)
-  it.n0 = n0; it.n = n;
-  it.r0 = (w - (n0 / DGD_ROWS + g)) * DGD_ROWS;
-  it.K32 = (n + 31) >> 5;
-  it.S = 1 << dgd_class(n);
-  it.brow = G.bits + (size_t)G.N * (it.S - 1);
-  return it.r0 < n;
-}
 
 __device__ __forceinline__ unsigned short dgd_f2bf(float f) {      // round to nearest even (finite inputs)
   unsigned u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ float dgd_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned dgd_pack2(float a, float b) { return (unsigned)dgd_f2bf(a) | ((unsigned)dgd_f2bf(b) << 16); }
 
-// ---- staging of one 128-row chunk of the B operand into LDS planes Hs[nb][k][16] -------------------------------
-// load(): global -> registers (issued early, consumed after the previous chunk's MFMAs); store(): registers -> LDS.
-struct DgdStage32 {          // hs [N,32] fp32: thread = (row rr = t>>3, float4 q = t&7), 4 rows per thread
-  float4 v[4];
-  __device__ __forceinline__ void load(const float* __restrict__ hs, int n0, int n, int kc0, int t) {
+// ---- the stage stream of one workgroup ---------------------------------------------------------------------------
+struct DgdRec { int n0, n, r0; };                        // item record (dg_prep.h): first node, node count, first row
+struct DgdStageDesc { int n0, n, r0, c, nst; };          // stage c of nst of the item (n0, n, r0); all wave-uniform
+
+#define DGD_REC_CACHE 128                 // item records of the workgroup held in LDS (a window, refilled when exhausted)
+struct DgdGen {          // walks this workgroup's items [0, w1) of the global table grec (stride 1), skipping none
+  const int* grec;       // global: record i at grec[3*i]
+  int* lrec;             // LDS window [DGD_REC_CACHE][3] holding items [cbase, cbase + DGD_REC_CACHE)
+  int w, w1, c, cbase;
+  DgdRec cur;
+  __device__ __forceinline__ void fill(int from) {       // all threads of the workgroup; uniform control flow
+    cbase = from;
+    __syncthreads();                                     // nobody still reads the old window
+    const int cnt = min(DGD_REC_CACHE, w1 - from);
+    for (int t = threadIdx.x; t < 3 * cnt; t += DGD_THREADS) lrec[t] = grec[3 * from + t];
+    __syncthreads();
+  }
+  __device__ __forceinline__ DgdRec ld(int i) {
+    DgdRec r = {0, 0, 0};
+    if (i < w1) {
+      if (i >= cbase + DGD_REC_CACHE) fill(i);
+      const int* p = lrec + 3 * (i - cbase);
+      r.n0 = __builtin_amdgcn_readfirstlane(p[0]);
+      r.n = __builtin_amdgcn_readfirstlane(p[1]);
+      r.r0 = __builtin_amdgcn_readfirstlane(p[2]);
+    }
+    return r;
+  }
+  __device__ __forceinline__ void init(const int* __restrict__ grec_, int* lrec_, int count) {
+    grec = grec_; lrec = lrec_; w = 0; w1 = count; c = 0;
+    fill(0);
+    cur = ld(0);
+  }
+  __device__ __forceinline__ bool valid() const { return w < w1; }
+  __device__ __forceinline__ DgdStageDesc get() const {
+    DgdStageDesc d = {cur.n0, cur.n, cur.r0, c, (cur.n + DGD_SK - 1) / DGD_SK};
+    if (w >= w1) d.n = 0;              // past the end: a descriptor whose loads are all predicated off
+    return d;
+  }
+  __device__ __forceinline__ void advance() {
+    if ((c + 1) * DGD_SK < cur.n) { ++c; return; }
+    c = 0; ++w;
+    cur = ld(w);
+  }
+};
+
+// ---- stage loaders: 64 rows of the B operand -> registers -> LDS planes Hs[nb][k][16], plus this lane's two bitmap words
+struct DgdBits {
+  unsigned pend[2], cur[2];
+  __device__ __forceinline__ void load(const DgDense& G, const DgdStageDesc& d, int wave, int lane) {
+    const int m = d.r0 + wave * 16 + (lane & 15);
+    const int K32 = (d.n + 31) >> 5, S = 1 << dgd_class(d.n);
+    const unsigned* bp = G.bits + (size_t)G.N * (S - 1) + (size_t)(d.n0 + m) * S + 2 * d.c;
+    const bool ok = m < d.n;
+    pend[0] = (ok && 2 * d.c < K32) ? bp[0] : 0u;
+    pend[1] = (ok && 2 * d.c + 1 < K32) ? bp[1] : 0u;
+  }
+  __device__ __forceinline__ void commit() { cur[0] = pend[0]; cur[1] = pend[1]; }
+};
+struct DgdStage32 {          // hs [N,32] fp32: thread = (row rr = t>>3, float4 q = t&7), 2 rows per thread
+  float4 v[2];
+  __device__ __forceinline__ void load(const float* __restrict__ hs, const DgdStageDesc& d, int t) {
     const int q = t & 7, rr = t >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = kc0 + rr + 32 * i;
-      v[i] = k < n ? *reinterpret_cast<const float4*>(hs + (size_t)(n0 + k) * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 2; ++i) {
+      const int k = d.c * DGD_SK + rr + 32 * i;
+      v[i] = k < d.n ? *reinterpret_cast<const float4*>(hs + (size_t)(d.n0 + k) * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __device__ __forceinline__ void store(float* Hs, int t) const {
     const int q = t & 7, rr = t >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
       *reinterpret_cast<float4*>(Hs + (q >> 2) * DGD_PLANE + (rr + 32 * i) * 16 + 4 * (q & 3)) = v[i];
   }
 };
-struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows): thread = (row rr = t>>2, 16-B piece q = t&3), 2 rows per thread
-  uint4 v[2];
-  __device__ __forceinline__ void load(const unsigned short* __restrict__ hs, int n0, int n, int kc0, int t) {
-    const int q = t & 3, rr = t >> 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = kc0 + rr + 64 * i;
-      v[i] = k < n ? *reinterpret_cast<const uint4*>(hs + (size_t)(n0 + k) * 32 + 8 * q) : make_uint4(0u, 0u, 0u, 0u);
-    }
+struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows): thread = (row rr = t>>2, 16-B piece q = t&3), 1 row per thread
+  uint4 v;
+  __device__ __forceinline__ void load(const unsigned short* __restrict__ hs, const DgdStageDesc& d, int t) {
+    const int q = t & 3, k = d.c * DGD_SK + (t >> 2);
+    v = k < d.n ? *reinterpret_cast<const uint4*>(hs + (size_t)(d.n0 + k) * 32 + 8 * q) : make_uint4(0u, 0u, 0u, 0u);
   }
   __device__ __forceinline__ void store(float* Hs, int t) const {
     const int q = t & 3, rr = t >> 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float* d = Hs + (q >> 1) * DGD_PLANE + (rr + 64 * i) * 16 + 8 * (q & 1);
-      const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-      *reinterpret_cast<float4*>(d) = make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
-                                                  __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u));
-      *reinterpret_cast<float4*>(d + 4) = make_float4(__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u),
-                                                      __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u));
-    }
+    float* dp = Hs + (q >> 1) * DGD_PLANE + rr * 16 + 8 * (q & 1);
+    *reinterpret_cast<float4*>(dp) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                 __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    *reinterpret_cast<float4*>(dp + 4) = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                                     __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
   }
 };
-struct DgdStageF {           // src [N,F] fp32, F <= 32 (raw features / scalars): element idx = t + 256*i over 128 x F
-  float v[16];
+template <bool ONE>          // src [N,F] fp32, F <= 32 (raw features; ONE: F == 1, a scalar per node)
+struct DgdStageF {
+  float v[ONE ? 1 : 8];
   int F;
-  __device__ __forceinline__ void load(const float* __restrict__ src, int n0, int n, int kc0, int t) {
+  __device__ __forceinline__ void load(const float* __restrict__ src, const DgdStageDesc& d, int t) {
+    if (ONE) {
+      const int k = d.c * DGD_SK + t;
+      v[0] = (t < DGD_SK && k < d.n) ? src[d.n0 + k] : 0.f;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = t + DGD_THREADS * i;
-      const int k = idx / F;
-      v[i] = (idx < DGD_KC * F && kc0 + k < n) ? src[(size_t)(n0 + kc0) * F + idx] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const int idx = t + DGD_THREADS * i;
+        const int k = idx / F;
+        v[i] = (idx < DGD_SK * F && d.c * DGD_SK + k < d.n) ? src[(size_t)(d.n0 + d.c * DGD_SK) * F + idx] : 0.f;
+      }
     }
   }
   __device__ __forceinline__ void store(float* Hs, int t) const {
+    if (ONE) {
+      if (t < DGD_SK) Hs[t * 16] = v[0];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = t + DGD_THREADS * i;
-      if (idx < DGD_KC * F) {
-        const int k = idx / F, f = idx - k * F;
-        Hs[(f >> 4) * DGD_PLANE + k * 16 + (f & 15)] = v[i];
+      for (int i = 0; i < 8; ++i) {
+        const int idx = t + DGD_THREADS * i;
+        if (idx < DGD_SK * F) {
+          const int k = idx / F, f = idx - k * F;
+          Hs[(f >> 4) * DGD_PLANE + k * 16 + (f & 15)] = v[i];
+        }
       }
     }
   }
 };
 
-// ---- the block product of one 16-row tile with the staged chunk: up to 4 bitmap words (32 k each) ------------------
+// ---- the block product of one 16-row tile with 32 staged rows (one bitmap word) -------------------------------------
 // A operand (16x4 per MFMA): lane (m = lane & 15, kq = lane >> 4) holds bit 4u+kq of row m's word, as 0.f / 1.f.
 // B operand: Hs[nb][k][n], lane (n = lane & 15, kq) reads row 4u+kq: conflict-free (rows of equal parity share a bank half).
 template <int NB>
@@ -141,41 +191,77 @@ __device__ __forceinline__ void dgd_mma_word(unsigned w, const float* __restrict
   }
 }
 
-// Aggregation of the item's four tiles (one per wave).  STAGE::load/store move a chunk; all 256 threads take part in
-// the staging and the barriers, only waves with a live tile issue MFMAs.
-template <int NB, typename STAGE, typename SRC>
-__device__ __forceinline__ void dgd_aggregate(const DgdItem& it, STAGE& st, const SRC* __restrict__ src, float* Hs,
-                                              const unsigned (&wb)[16], bool live, int lane, f32x4 (&acc)[NB]) {
+// ---- the pipeline: BODY supplies acc[NB], begin_item(desc) (zero acc, request the item's own operands) and
+// end_item(desc) (the tile epilogue); both are called by every wave (they test their own tile's liveness).
+// smem: two stage buffers of DGD_BUF floats.  Returns after the last stage of the workgroup's item range.
+#ifdef DGD_TIMING       // measurement builds (tools/build_variant.sh): per-workgroup phase clocks of the forward kernel
+#define DGD_T(k) do { if (dbg && lane == 0 && wave == 0) { const unsigned long long now_ = clock64(); dbg[blockIdx.x * 8 + (k)] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define DGD_T(k) do { } while (0)
+#endif
+template <int NB, typename STAGE, typename SRC, typename BODY>
+__device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __restrict__ src, float* Hs, STAGE& st, BODY& body,
+                                             int lane, int wave, unsigned long long* dbg = nullptr) {
   const int t = threadIdx.x;
-  st.load(src, it.n0, it.n, 0, t);
-#pragma unroll
-  for (int c = 0; c < DGD_MAXN / DGD_KC; ++c) {
-    if (c * DGD_KC >= it.n) break;
-    st.store(Hs, t);
-    __syncthreads();
-    const bool more = (c + 1) * DGD_KC < it.n;
-    if (more) st.load(src, it.n0, it.n, (c + 1) * DGD_KC, t);      // next chunk's loads fly during this chunk's MFMAs
-    if (live) {
-#pragma unroll
-      for (int j = 0; j < DGD_KC / 32; ++j) {
-        const int kw = 4 * c + j;
-        if (kw < it.K32) {
-          const unsigned w = wb[kw];
-          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB>(w, Hs, 32 * j, lane, acc);
-        }
-      }
-    }
-    if (more) __syncthreads();
+#ifdef DGD_TIMING
+  unsigned long long tprev_ = clock64();
+  if (dbg && lane == 0 && wave == 0) { for (int k = 0; k < 8; ++k) dbg[blockIdx.x * 8 + k] = 0; dbg[blockIdx.x * 8 + 7] = tprev_; }
+#endif
+  __shared__ int lrec[3 * DGD_REC_CACHE];
+  DgdGen gen;
+  {   // this workgroup's contiguous range of equal-cost shares of the item table (dg_prep.h), laid out XCD-contiguously
+      // (workgroup b runs on XCD b % 8): a graph's rows stay in one L2, and workgroups finish together
+    const int Gd = (int)gridDim.x;
+    const int wg = dg_xcd_tile((int)blockIdx.x, Gd);
+    const int s0 = (int)(((long long)wg * DGD_SPLITS) / Gd), s1 = (int)(((long long)(wg + 1) * DGD_SPLITS) / Gd);
+    const int w0 = __builtin_amdgcn_readfirstlane(G.dmap[s0]), w1 = __builtin_amdgcn_readfirstlane(G.dmap[s1]);
+    gen.init(G.dmap + DGD_REC0 + 3 * w0, lrec, max(0, w1 - w0));
   }
-}
-
-// bitmap words of this lane's row (row m = m0 + (lane & 15)); rows beyond the graph read as empty
-__device__ __forceinline__ void dgd_load_bits(const DgdItem& it, int m0, int lane, unsigned (&wb)[16]) {
-  const int m = m0 + (lane & 15);
-  const unsigned* bp = it.brow + (size_t)(it.n0 + m) * it.S;
-  const bool ok = m < it.n;
+  if (!gen.valid()) return;
+  DgdBits bits;
+  DgdStageDesc cur = gen.get();
+  st.load(src, cur, t); bits.load(G, cur, wave, lane);
+  gen.advance();
+  DgdStageDesc nxt = gen.get();
+  bool nv = gen.valid();
+  st.store(Hs, t); bits.commit();
+  // (the loads of a stage past the end are all predicated off by its n = 0: issuing them UNCONDITIONALLY lets the
+  // compiler load straight into the loop-carried registers -- behind an `if` it loaded into temporaries and had to
+  // wait for the data at the loop latch just to move it, i.e. right after issuing it)
+  st.load(src, nxt, t); bits.load(G, nxt, wave, lane);
+  int p = 0;
+  DGD_T(0);                                // 0: prologue (records, first stage)
+  while (true) {
+    dg_lds_barrier();                      // buffer p is complete, buffer p^1 is free (LDS-only barrier: the epilogue's
+                                           // global stores are NOT drained here)
+    DGD_T(1);                              // 1: barrier
+    if (cur.c == 0) body.begin_item(cur);
+    if (cur.r0 + wave * 16 < cur.n) {
+      const float* hb = Hs + p * DGD_BUF;
+      const int K32 = (cur.n + 31) >> 5;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) wb[u] = (ok && u < it.K32) ? bp[u] : 0u;
+      for (int j = 0; j < 2; ++j)
+        if (2 * cur.c + j < K32) {
+          const unsigned w = bits.cur[j];
+          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB>(w, hb, 32 * j, lane, body.acc);
+        }
+    }
+    DGD_T(2);                              // 2: block product
+    st.store(Hs + (p ^ 1) * DGD_BUF, t); bits.commit();             // (waits for the rows requested one stage ago)
+    DGD_T(3);                              // 3: wait for the prefetched rows + LDS store
+    if (nv) gen.advance();
+    const DgdStageDesc nn = gen.get();
+    const bool nnv = gen.valid();
+    st.load(src, nn, t); bits.load(G, nn, wave, lane);
+    DGD_T(4);                              // 4: issue of the next loads
+    if (cur.c == cur.nst - 1) body.end_item(cur);                   // epilogue under the loads just requested
+    DGD_T(5);                              // 5: epilogue
+#ifdef DGD_TIMING
+    if (dbg && lane == 0 && wave == 0) dbg[blockIdx.x * 8 + 6] += 1;   // 6: stages
+#endif
+    if (!nv) break;
+    cur = nxt; nxt = nn; nv = nnv; p ^= 1;
+  }
 }
 
 __device__ __forceinline__ void dgd_wave_sync() {      // orders this wave's LDS traffic (wave-private tiles: no s_barrier)
@@ -284,186 +370,492 @@ __device__ __forceinline__ void dgd_load_wnext(const float* __restrict__ Wn, int
 // =================================================================================================================
 // forward, 32-wide layer (conv2, conv3; conv1 when F > 32 after its stand-alone linear)
 // =================================================================================================================
+template <int MODE, bool BF16>
+struct DgdFwd32Body {
+  f32x4 acc[2];
+  float dpre[4];
+  float wreg[2][8]; bf16x8 wbf[2]; float w4[8];
+  float bc0, bc1;
+  const float* dinv; float* xout; void* hs_next; float* xt;
+  int lane, wave;
+  __device__ __forceinline__ void begin_item(const DgdStageDesc& d) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = d.r0 + wave * 16 + (lane >> 4) * 4 + r;
+      dpre[r] = m < d.n ? dinv[d.n0 + m] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    const int m0 = d.r0 + wave * 16;
+    if (m0 >= d.n) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (lane >> 4) * 4 + r;
+      xt[row * DGD_XT + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[0][r], bc0));
+      xt[row * DGD_XT + 16 + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[1][r], bc1));
+    }
+    dgd_tile_epilogue<MODE, BF16>(xt, d.n0 + m0, min(16, d.n - m0), lane, dpre, dinv, xout, wreg, wbf, w4, hs_next);
+  }
+};
+
 template <int MODE, bool BFIN, bool BF16>     // BFIN: hs is bf16; BF16: hs_next is bf16 and X.W runs on the bf16 matrix cores
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd32d(DgDense G, const float* __restrict__ dinv, const void* __restrict__ hs, const float* __restrict__ bias,
-             float* __restrict__ xout, const float* __restrict__ Wn, void* __restrict__ hs_next) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_PLANE];
+             float* __restrict__ xout, const float* __restrict__ Wn, void* __restrict__ hs_next, unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
   __shared__ __attribute__((aligned(16))) float xts[4][16 * DGD_XT];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float wreg[2][8]; bf16x8 wbf[2]; float w4[8];
-  dgd_load_wnext<MODE, BF16>(Wn, lane, wreg, wbf, w4);
-  const float bc0 = bias[lane & 15], bc1 = bias[16 + (lane & 15)];
-
-  for (int wi = blockIdx.x; wi < G.NW; wi += gridDim.x) {
-    const int w = (gridDim.x == (unsigned)G.NW) ? dg_xcd_tile(wi, G.NW) : wi;
-    DgdItem it;
-    if (!dgd_item(G, w, it)) continue;
-    const int m0 = it.r0 + wave * 16;
-    const bool live = m0 < it.n;
-    unsigned wb[16];
-    dgd_load_bits(it, m0, lane, wb);
-    float dpre[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + (lane >> 4) * 4 + r;
-      dpre[r] = m < it.n ? dinv[it.n0 + m] : 0.f;
-    }
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (BFIN) {
-      DgdStage32bf st;
-      dgd_aggregate<2>(it, st, reinterpret_cast<const unsigned short*>(hs), Hs, wb, live, lane, acc);
-    } else {
-      DgdStage32 st;
-      dgd_aggregate<2>(it, st, reinterpret_cast<const float*>(hs), Hs, wb, live, lane, acc);
-    }
-    if (live) {
-      float* xt = xts[wave];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) * 4 + r;
-        xt[row * DGD_XT + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[0][r], bc0));
-        xt[row * DGD_XT + 16 + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[1][r], bc1));
-      }
-      dgd_tile_epilogue<MODE, BF16>(xt, it.n0 + m0, min(16, it.n - m0), lane, dpre, dinv, xout, wreg, wbf, w4, hs_next);
-    }
-    __syncthreads();          // Hs is rewritten by the next item
+  DgdFwd32Body<MODE, BF16> body;
+  dgd_load_wnext<MODE, BF16>(Wn, lane, body.wreg, body.wbf, body.w4);
+  body.bc0 = bias[lane & 15]; body.bc1 = bias[16 + (lane & 15)];
+  body.dinv = dinv; body.xout = xout; body.hs_next = hs_next; body.xt = xts[wave]; body.lane = lane; body.wave = wave;
+  if (BFIN) {
+    DgdStage32bf st;
+    dgd_pipeline<2>(G, reinterpret_cast<const unsigned short*>(hs), Hs, st, body, lane, wave, dbg);
+  } else {
+    DgdStage32 st;
+    dgd_pipeline<2>(G, reinterpret_cast<const float*>(hs), Hs, st, body, lane, wave, dbg);
   }
 }
 
 // =================================================================================================================
 // forward of conv1, aggregate-first (raw feature width F <= 32):  ax = A_hat x (saved), x1 = tanh(ax W1^T + b1),
-// hs2 = dinv * (x1 W2^T).  xs = dinv * x [N,F] comes from graph preparation.
+// hs2 = dinv * (x1 W2^T).  xs = dinv * x [N,F] comes from graph preparation.  NB = number of 16-column planes (F > 16: 2).
 // =================================================================================================================
-template <bool BF16>
+template <int NB, bool BF16>
+struct DgdAfBody {
+  f32x4 acc[NB];
+  float dpre[4];
+  float wreg[2][8]; bf16x8 wbf[2]; float w4[8];
+  float w1r[2][NB * 4];                  // B operand of ax . W1^T : B[k][n] = W1[n][k], K = F padded to a multiple of 4
+  float bc0, bc1;
+  const float* dinv; float* xout; float* axout; void* hs_next; float* xt;
+  int lane, wave, F, F4;
+  __device__ __forceinline__ void begin_item(const DgdStageDesc& d) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = d.r0 + wave * 16 + (lane >> 4) * 4 + r;
+      dpre[r] = m < d.n ? dinv[d.n0 + m] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    const int m0 = d.r0 + wave * 16;
+    if (m0 >= d.n) return;
+    // ax tile (columns >= F are exact zeros: their B columns are zero) -> LDS + the saved slab
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r, col = nb * 16 + (lane & 15);
+        const float ax = dpre[r] * acc[nb][r];
+        xt[row * DGD_XT + col] = ax;
+        if (col < F && m0 + row < d.n) axout[(size_t)(d.n0 + m0 + row) * F + col] = ax;
+      }
+    dgd_wave_sync();
+    float a[NB * 4];
+#pragma unroll
+    for (int kk = 0; kk < NB * 4; ++kk) a[kk] = kk < F4 ? xt[(lane & 15) * DGD_XT + 4 * kk + (lane >> 4)] : 0.f;
+    f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < NB * 4; ++kk)
+      if (kk < F4) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], w1r[nb][kk], d1[nb], 0, 0, 0);
+      }
+    dgd_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (lane >> 4) * 4 + r;
+      xt[row * DGD_XT + (lane & 15)] = dg_tanh(d1[0][r] + bc0);
+      xt[row * DGD_XT + 16 + (lane & 15)] = dg_tanh(d1[1][r] + bc1);
+    }
+    dgd_tile_epilogue<0, BF16>(xt, d.n0 + m0, min(16, d.n - m0), lane, dpre, dinv, xout, wreg, wbf, w4, hs_next);
+  }
+};
+
+template <int NB, bool ONE, bool BF16>
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd_af_d(DgDense G, int F, const float* __restrict__ dinv, const float* __restrict__ xs, const float* __restrict__ W1,
                const float* __restrict__ bias, float* __restrict__ axout, float* __restrict__ xout,
                const float* __restrict__ Wn, void* __restrict__ hs_next) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_PLANE];
+  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
   __shared__ __attribute__((aligned(16))) float xts[4][16 * DGD_XT];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float wreg[2][8]; bf16x8 wbf[2]; float w4[8];
-  dgd_load_wnext<0, BF16>(Wn, lane, wreg, wbf, w4);
-  const float bc0 = bias[lane & 15], bc1 = bias[16 + (lane & 15)];
-  // B operand of ax . W1^T : B[k][n] = W1[n][k], K = F padded to a multiple of 4
-  float w1r[2][8];
+  DgdAfBody<NB, BF16> body;
+  dgd_load_wnext<0, BF16>(Wn, lane, body.wreg, body.wbf, body.w4);
+  body.bc0 = bias[lane & 15]; body.bc1 = bias[16 + (lane & 15)];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < NB * 4; ++kk) {
       const int k = 4 * kk + (lane >> 4);
-      w1r[nb][kk] = k < F ? W1[(nb * 16 + (lane & 15)) * F + k] : 0.f;
+      body.w1r[nb][kk] = k < F ? W1[(nb * 16 + (lane & 15)) * F + k] : 0.f;
     }
+  body.dinv = dinv; body.xout = xout; body.axout = axout; body.hs_next = hs_next; body.xt = xts[wave];
+  body.lane = lane; body.wave = wave; body.F = F; body.F4 = (F + 3) >> 2;
   // columns >= F of the planes are never staged: clear them once (0 * garbage could be NaN)
-  for (int t = threadIdx.x; t < 2 * DGD_PLANE; t += DGD_THREADS) Hs[t] = 0.f;
+  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
   __syncthreads();
-  const int F4 = (F + 3) >> 2;
-
-  for (int wi = blockIdx.x; wi < G.NW; wi += gridDim.x) {
-    const int w = (gridDim.x == (unsigned)G.NW) ? dg_xcd_tile(wi, G.NW) : wi;
-    DgdItem it;
-    if (!dgd_item(G, w, it)) continue;
-    const int m0 = it.r0 + wave * 16;
-    const bool live = m0 < it.n;
-    unsigned wb[16];
-    dgd_load_bits(it, m0, lane, wb);
-    float dpre[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + (lane >> 4) * 4 + r;
-      dpre[r] = m < it.n ? dinv[it.n0 + m] : 0.f;
-    }
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    DgdStageF st; st.F = F;
-    if (F > 16) dgd_aggregate<2>(it, st, xs, Hs, wb, live, lane, acc);
-    else {
-      f32x4 a1[1] = {{0.f, 0.f, 0.f, 0.f}};
-      dgd_aggregate<1>(it, st, xs, Hs, wb, live, lane, a1);
-      acc[0] = a1[0];
-    }
-    if (live) {
-      float* xt = xts[wave];
-      // ax tile (columns >= F are exact zeros: their B columns are zero) -> LDS + the saved slab
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (lane >> 4) * 4 + r, col = nb * 16 + (lane & 15);
-          const float ax = dpre[r] * acc[nb][r];
-          xt[row * DGD_XT + col] = ax;
-          if (col < F && m0 + row < it.n) axout[(size_t)(it.n0 + m0 + row) * F + col] = ax;
-        }
-      dgd_wave_sync();
-      float a[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) a[kk] = kk < F4 ? xt[(lane & 15) * DGD_XT + 4 * kk + (lane >> 4)] : 0.f;
-      f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
-        if (kk < F4) {
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], w1r[nb][kk], d1[nb], 0, 0, 0);
-        }
-      dgd_wave_sync();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) * 4 + r;
-        xt[row * DGD_XT + (lane & 15)] = dg_tanh(d1[0][r] + bc0);
-        xt[row * DGD_XT + 16 + (lane & 15)] = dg_tanh(d1[1][r] + bc1);
-      }
-      dgd_tile_epilogue<0, BF16>(xt, it.n0 + m0, min(16, it.n - m0), lane, dpre, dinv, xout, wreg, wbf, w4, hs_next);
-    }
-    __syncthreads();
-  }
+  DgdStageF<ONE> st; st.F = F;
+  dgd_pipeline<NB>(G, xs, Hs, st, body, lane, wave);
 }
 
 // =================================================================================================================
 // forward of conv4 (32 -> 1): x4[i] = tanh( dinv[i] * sum_{j in N(i)+{i}} h4s[j] + b )
 // =================================================================================================================
+struct DgdFwd1Body {
+  f32x4 acc[1];
+  float dpre[4];
+  float b;
+  const float* dinv; float* x4;
+  int lane, wave;
+  __device__ __forceinline__ void begin_item(const DgdStageDesc& d) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = d.r0 + wave * 16 + (lane >> 4) * 4 + r;
+      dpre[r] = m < d.n ? dinv[d.n0 + m] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    if ((lane & 15) != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = d.r0 + wave * 16 + (lane >> 4) * 4 + r;
+      if (m < d.n) x4[d.n0 + m] = dg_tanh(fmaf(dpre[r], acc[0][r], b));
+    }
+  }
+};
+
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
             float* __restrict__ x4) {
-  __shared__ __attribute__((aligned(16))) float Hs[DGD_PLANE];
+  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const float b = bias[0];
-  for (int t = threadIdx.x; t < DGD_PLANE; t += DGD_THREADS) Hs[t] = 0.f;
+  DgdFwd1Body body;
+  body.b = bias[0]; body.dinv = dinv; body.x4 = x4; body.lane = lane; body.wave = wave;
+  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
   __syncthreads();
-  for (int wi = blockIdx.x; wi < G.NW; wi += gridDim.x) {
-    const int w = (gridDim.x == (unsigned)G.NW) ? dg_xcd_tile(wi, G.NW) : wi;
-    DgdItem it;
-    if (!dgd_item(G, w, it)) continue;
-    const int m0 = it.r0 + wave * 16;
-    const bool live = m0 < it.n;
-    unsigned wb[16];
-    dgd_load_bits(it, m0, lane, wb);
-    float dpre[4];
+  DgdStageF<true> st; st.F = 1;
+  dgd_pipeline<1>(G, h4s, Hs, st, body, lane, wave);
+}
+
+// =================================================================================================================
+// backward of a 32-wide layer l (l = 3, 2), dense block form of k_gcn_bwd32 (gcn.hip): with gas_l = dinv * dL/d(pre-act_l)
+//   gh[j]      = dinv[j] * sum_{i in N(j)+{j}} gas_l[i]          (block product, A^T = A)
+//   dW_l      += gh^T . x_{l-1}                                   (MFMA, K = the tile's 16 nodes; per-wave accumulators)
+//   gx_{l-1}   = gh . W_l + gp_{l-1}                              (MFMA)
+//   ga_{l-1}   = gx_{l-1} * (1 - x_{l-1}^2) ; gas_{l-1} = dinv * ga_{l-1} ; db_{l-1} += ga_{l-1}
+//   AF (layer 2 when conv1 ran aggregate-first): dW_1 += ga_1^T . ax  from the saved A_hat X slab, no gas_1 output
+// Grid = the P32 partial slots of the workspace; every workgroup writes one partial row {dW_l [32x32], db_{l-1} [32]}
+// (+ dW_1 [32 x Fa]), reduced later in a fixed order.
+// =================================================================================================================
+#define DGD_BW_TILES 3
+#define DGD_BW_SMEM (2 * DGD_BUF + 4 * DGD_BW_TILES * 16 * DGD_XT)      // stage buffers + per wave {ght, xt, aux} tiles
+
+template <bool AF>
+struct DgdBwd32Body {
+  f32x4 acc[2];
+  float dpre[4], gpp[2][4];
+  float4 xr[2];
+  float axv[AF ? 8 : 1];
+  float wreg[2][8];                        // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
+  f32x4 accW[2][2], accA[2][2];
+  float pb[2];
+  const float *dinv, *xprev, *gpprev, *axin;
+  float* gas_prev;
+  float *ght, *xt, *aux;
+  int lane, wave, Fa, nbA;
+  __device__ __forceinline__ void begin_item(const DgdStageDesc& d) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m0 = d.r0 + wave * 16, kq = lane >> 4, nl = lane & 15;
+    // everything of the epilogue that does not depend on the block product is requested now
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + kq * 4 + r;
+      const bool ok = m < d.n;
+      dpre[r] = ok ? dinv[d.n0 + m] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) gpp[nb][r] = ok ? gpprev[(size_t)(d.n0 + m) * 32 + nb * 16 + nl] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = m0 + p * 8 + (lane >> 3);
+      xr[p] = m < d.n ? *reinterpret_cast<const float4*>(xprev + (size_t)(d.n0 + m) * 32 + 4 * (lane & 7))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (AF) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {          // ax tile [16][Fa]: element idx = lane + 64u -> (row idx / 32, col idx % 32)
+        const int idx = lane + 64 * u, row = idx >> 5, col = idx & 31;
+        axv[u] = (col < Fa && m0 + row < d.n) ? axin[(size_t)(d.n0 + m0 + row) * Fa + col] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    const int m0 = d.r0 + wave * 16, kq = lane >> 4, nl = lane & 15;
+    if (m0 >= d.n) return;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ght[(kq * 4 + r) * DGD_XT + nb * 16 + nl] = dpre[r] * acc[nb][r];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(xt + (p * 8 + (lane >> 3)) * DGD_XT + 4 * (lane & 7)) = xr[p];
+    if (AF) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = lane + 64 * u; aux[(idx >> 5) * DGD_XT + (idx & 31)] = axv[u]; }
+    }
+    dgd_wave_sync();
+    // gx = gh . W_l
+    f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    {
+      float a[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) a[kk] = ght[nl * DGD_XT + 4 * kk + kq];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) gx[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wreg[nb][kk], gx[nb], 0, 0, 0);
+    }
+    // dW_l += gh^T . x_prev : A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n], K = 16 nodes
+    {
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          a[h][kk] = ght[(4 * kk + kq) * DGD_XT + h * 16 + nl];
+          b[h][kk] = xt[(4 * kk + kq) * DGD_XT + h * 16 + nl];
+        }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            accW[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][kk], b[nb][kk], accW[mb][nb], 0, 0, 0);
+    }
+    // tanh' of the previous layer, its bias gradient, and the propagated gradient
+    float ga[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xv = xt[(kq * 4 + r) * DGD_XT + nb * 16 + nl];
+        ga[nb][r] = (gx[nb][r] + gpp[nb][r]) * (1.f - xv * xv);
+        pb[nb] += ga[nb][r];
+      }
+    dgd_wave_sync();                      // all reads of ght done: it now carries ga (AF) or dinv*ga (the output rows)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ght[(kq * 4 + r) * DGD_XT + nb * 16 + nl] = AF ? ga[nb][r] : dpre[r] * ga[nb][r];
+    dgd_wave_sync();
+    if (AF) {
+      // dW_1 += ga_1^T . ax : A[m][k] = gat[k][mb*16+m], B[k][n] = ax[k][nq*16+n]
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          a[h][kk] = ght[(4 * kk + kq) * DGD_XT + h * 16 + nl];
+          b[h][kk] = aux[(4 * kk + kq) * DGD_XT + h * 16 + nl];
+        }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nq = 0; nq < 2; ++nq)
+            if (nq < nbA) accA[mb][nq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][kk], b[nq][kk], accA[mb][nq], 0, 0, 0);
+    } else {
+      const int rows_live = min(16, d.n - m0);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = p * 8 + (lane >> 3), q = lane & 7;
+        const float4 v = *reinterpret_cast<const float4*>(ght + row * DGD_XT + 4 * q);
+        if (row < rows_live) *reinterpret_cast<float4*>(gas_prev + (size_t)(d.n0 + m0 + row) * 32 + 4 * q) = v;
+      }
+    }
+    dgd_wave_sync();                      // the tiles are rewritten by this wave's next item
+  }
+};
+
+template <bool AF>
+__global__ void __launch_bounds__(DGD_THREADS)
+k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
+             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
+             float* __restrict__ part, const float* __restrict__ axin, int Fa, float* __restrict__ part1) {
+  __shared__ __attribute__((aligned(16))) float smem[DGD_BW_SMEM];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kq = lane >> 4, nl = lane & 15;
+  DgdBwd32Body<AF> body;
+  body.ght = smem + 2 * DGD_BUF + wave * DGD_BW_TILES * 16 * DGD_XT;
+  body.xt = body.ght + 16 * DGD_XT;
+  body.aux = body.xt + 16 * DGD_XT;           // AF: ax tile [16][<=32], zero padded
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) body.wreg[nb][kk] = Wl[(4 * kk + kq) * 32 + nb * 16 + nl];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) { body.accW[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; body.accA[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  body.pb[0] = 0.f; body.pb[1] = 0.f;
+  body.dinv = dinv; body.xprev = xprev; body.gpprev = gpprev; body.axin = axin; body.gas_prev = gas_prev;
+  body.lane = lane; body.wave = wave; body.Fa = Fa; body.nbA = AF ? ((Fa + 15) >> 4) : 0;
+  DgdStage32 st;
+  dgd_pipeline<2>(G, gas, smem, st, body, lane, wave);
+
+  // ---- this workgroup's partial row: the four waves' accumulators combined in a fixed order -----------------------
+  __syncthreads();
+  float* red = smem;                         // [4][1056] (the stage buffers and tiles are dead now)
+  {
+    float* my = red + wave * 1056;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my[(mb * 16 + kq * 4 + r) * 32 + nb * 16 + nl] = body.accW[mb][nb][r];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float p = body.pb[nb];
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lane < 16) my[1024 + nb * 16 + lane] = p;
+    }
+  }
+  __syncthreads();
+  float* dst = part + (size_t)blockIdx.x * 1056;
+  for (int t = threadIdx.x; t < 1056; t += DGD_THREADS)
+    dst[t] = (red[t] + red[1056 + t]) + (red[2 * 1056 + t] + red[3 * 1056 + t]);
+  if (AF) {
+    __syncthreads();
+    float* my = red + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my[(mb * 16 + kq * 4 + r) * 32 + nq * 16 + nl] = body.accA[mb][nq][r];
+    __syncthreads();
+    float* d1 = part1 + (size_t)blockIdx.x * 32 * Fa;
+    for (int t = threadIdx.x; t < 32 * Fa; t += DGD_THREADS) {
+      const int c = t / Fa, k = t - c * Fa;
+      const int o = c * 32 + k;
+      d1[t] = (red[o] + red[1024 + o]) + (red[2 * 1024 + o] + red[3 * 1024 + o]);      // W1's own [32,Fa] layout
+    }
+  }
+}
+
+// =================================================================================================================
+// backward of conv4 (F_out = 1) fused with the start of conv3's backward, dense block form of k_gcn_bwd1 (gcn.hip):
+//   gh4[j] = dinv[j] * sum_{i in N(j)+{j}} gas4[i] ;  gx3 = gh4 * W4 + gp3 ;  ga3 = gx3 * (1 - x3^2) ; gas3 = dinv * ga3
+//   partials: dW4 += gh4 * x3 (32), db3 += ga3 (32)    ->  pa4[P1][64]
+// =================================================================================================================
+struct DgdBwd1Body {
+  f32x4 acc[1];
+  float dpre[4];
+  float4 xr[2], gr[2], w4q, pW, pB;
+  float dj[2];
+  const float *dinv, *x3, *gp3;
+  float* gas3; float* gh4s;
+  int lane, wave;
+  __device__ __forceinline__ void begin_item(const DgdStageDesc& d) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m0 = d.r0 + wave * 16, q = lane & 7;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + (lane >> 4) * 4 + r;
-      dpre[r] = m < it.n ? dinv[it.n0 + m] : 0.f;
+      dpre[r] = m < d.n ? dinv[d.n0 + m] : 0.f;
     }
-    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    DgdStageF st; st.F = 1;
-    dgd_aggregate<1>(it, st, h4s, Hs, wb, live, lane, acc);
-    if (live && (lane & 15) == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (lane >> 4) * 4 + r;
-        if (m < it.n) x4[it.n0 + m] = dg_tanh(fmaf(dpre[r], acc[0][r], b));
+    for (int p = 0; p < 2; ++p) {
+      const int m = m0 + p * 8 + (lane >> 3);
+      const bool ok = m < d.n;
+      xr[p] = ok ? *reinterpret_cast<const float4*>(x3 + (size_t)(d.n0 + m) * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gr[p] = ok ? *reinterpret_cast<const float4*>(gp3 + (size_t)(d.n0 + m) * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dj[p] = ok ? dinv[d.n0 + m] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    const int m0 = d.r0 + wave * 16, q = lane & 7;
+    if (m0 >= d.n) return;
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gh4s[(lane >> 4) * 4 + r] = dpre[r] * acc[0][r];
+    }
+    dgd_wave_sync();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = p * 8 + (lane >> 3), m = m0 + row;
+      if (m < d.n) {
+        const float gh = gh4s[row];
+        float4 ga;
+        ga.x = fmaf(gh, w4q.x, gr[p].x) * (1.f - xr[p].x * xr[p].x);
+        ga.y = fmaf(gh, w4q.y, gr[p].y) * (1.f - xr[p].y * xr[p].y);
+        ga.z = fmaf(gh, w4q.z, gr[p].z) * (1.f - xr[p].z * xr[p].z);
+        ga.w = fmaf(gh, w4q.w, gr[p].w) * (1.f - xr[p].w * xr[p].w);
+        *reinterpret_cast<float4*>(gas3 + (size_t)(d.n0 + m) * 32 + 4 * q) =
+            make_float4(dj[p] * ga.x, dj[p] * ga.y, dj[p] * ga.z, dj[p] * ga.w);
+        pW.x = fmaf(gh, xr[p].x, pW.x); pW.y = fmaf(gh, xr[p].y, pW.y);
+        pW.z = fmaf(gh, xr[p].z, pW.z); pW.w = fmaf(gh, xr[p].w, pW.w);
+        pB.x += ga.x; pB.y += ga.y; pB.z += ga.z; pB.w += ga.w;
       }
     }
-    __syncthreads();
+    dgd_wave_sync();
   }
+};
+
+__global__ void __launch_bounds__(DGD_THREADS)
+k_gcn_bwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
+            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
+            float* __restrict__ pa4) {
+  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
+  __shared__ float gh4s[4][16];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  DgdBwd1Body body;
+  body.w4q = *reinterpret_cast<const float4*>(W4 + 4 * (lane & 7));
+  body.pW = make_float4(0.f, 0.f, 0.f, 0.f); body.pB = make_float4(0.f, 0.f, 0.f, 0.f);
+  body.dinv = dinv; body.x3 = x3; body.gp3 = gp3; body.gas3 = gas3; body.gh4s = gh4s[wave];
+  body.lane = lane; body.wave = wave;
+  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
+  __syncthreads();
+  DgdStageF<true> st; st.F = 1;
+  dgd_pipeline<1>(G, gas4, Hs, st, body, lane, wave);
+  // lanes with equal q (8 row groups) -> wave totals -> fixed-order sum over the 4 waves
+  float4 pW = body.pW, pB = body.pB;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    pW = dg_add4(pW, dg_shfl_xor4(pW, o));
+    pB = dg_add4(pB, dg_shfl_xor4(pB, o));
+  }
+  if (lane < 8) {
+    *reinterpret_cast<float4*>(&red[wave][4 * lane]) = pW;
+    *reinterpret_cast<float4*>(&red[wave][32 + 4 * lane]) = pB;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // =================================================================================================================
 // host launchers
 // =================================================================================================================
-static inline int dgd_grid(const DgDense* G) { return G->NW; }
+static inline int dgd_grid(const DgDense* G) {      // persistent: every workgroup takes DGD_SPLITS / grid equal-cost shares
+  return G->NW < DGD_MAX_GRID ? G->NW : DGD_MAX_GRID;       // (NW = upper bound of the item count; <= 100000, api.hip)
+}
 
 int dg_launch_gcn_fwd32d(int mode, int bf16_in, int bf16_out, const DgDense* G, const float* dinv, const void* hs,
                          const float* bias, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
@@ -471,7 +863,7 @@ int dg_launch_gcn_fwd32d(int mode, int bf16_in, int bf16_out, const DgDense* G, 
   if (!G || G->NW <= 0) return DGCNN_EINVAL;
   if (mode != 0) bf16_out = 0;            // only the 32x32 linear step has a bf16 form (the 32->1 output is a fp32 scalar)
 #define DGD_L(M, BI, BO) hipExtLaunchKernelGGL((k_gcn_fwd32d<M, BI, BO>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, \
-                                               ev_stop, 0, *G, dinv, hs, bias, xout, Wnext, hs_next)
+                                               ev_stop, 0, *G, dinv, hs, bias, xout, Wnext, hs_next, dg_debug_buffer())
   if (mode == 0) {
     if (bf16_in && bf16_out) DGD_L(0, true, true); else if (bf16_in) DGD_L(0, true, false);
     else if (bf16_out) DGD_L(0, false, true); else DGD_L(0, false, false);
@@ -486,12 +878,12 @@ int dg_launch_gcn_fwd_af_d(int bf16_out, const DgDense* G, int F, const float* d
                            const float* bias, float* ax, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!G || G->NW <= 0 || F < 1 || F > DG_AF_MAX_F) return DGCNN_EINVAL;
-  if (bf16_out)
-    hipExtLaunchKernelGGL((k_gcn_fwd_af_d<true>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, ev_stop, 0, *G, F, dinv,
-                          xs, W1, bias, ax, xout, Wnext, hs_next);
-  else
-    hipExtLaunchKernelGGL((k_gcn_fwd_af_d<false>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, ev_stop, 0, *G, F, dinv,
-                          xs, W1, bias, ax, xout, Wnext, hs_next);
+#define DGD_L(NB, ONE, BF) hipExtLaunchKernelGGL((k_gcn_fwd_af_d<NB, ONE, BF>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, \
+                                                 ev_stop, 0, *G, F, dinv, xs, W1, bias, ax, xout, Wnext, hs_next)
+  if (F == 1) { if (bf16_out) DGD_L(1, true, true); else DGD_L(1, true, false); }
+  else if (F <= 16) { if (bf16_out) DGD_L(1, false, true); else DGD_L(1, false, false); }
+  else { if (bf16_out) DGD_L(2, false, true); else DGD_L(2, false, false); }
+#undef DGD_L
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -499,6 +891,30 @@ int dg_launch_gcn_fwd_af_d(int bf16_out, const DgDense* G, int F, const float* d
 int dg_launch_gcn_fwd1d(const DgDense* G, const float* dinv, const float* h4s, const float* bias, float* x4, hipStream_t s) {
   if (!G || G->NW <= 0) return DGCNN_EINVAL;
   hipLaunchKernelGGL(k_gcn_fwd1d, dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, *G, dinv, h4s, bias, x4);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+int dg_launch_gcn_bwd32d(const DgDense* G, const float* dinv, const float* gas, const float* Wl, const float* xprev,
+                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s, const float* ax, int Fa,
+                         float* part1) {
+  if (!G || G->NW <= 0 || P32 <= 0) return DGCNN_EINVAL;
+  if (ax) {
+    if (Fa < 1 || Fa > DG_AF_MAX_F || !part1) return DGCNN_EINVAL;
+    hipLaunchKernelGGL((k_gcn_bwd32d<true>), dim3(P32), dim3(DGD_THREADS), 0, s, *G, dinv, gas, Wl, xprev, gpprev, gas_prev,
+                       part, ax, Fa, part1);
+  } else {
+    hipLaunchKernelGGL((k_gcn_bwd32d<false>), dim3(P32), dim3(DGD_THREADS), 0, s, *G, dinv, gas, Wl, xprev, gpprev, gas_prev,
+                       part, nullptr, 0, nullptr);
+  }
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, const float* W4, const float* x3,
+                        const float* gp3, float* gas3, float* pa4, int P1, hipStream_t s) {
+  if (!G || G->NW <= 0 || P1 <= 0) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_gcn_bwd1d, dim3(P1), dim3(DGD_THREADS), 0, s, *G, dinv, gas4, W4, x3, gp3, gas3, pa4);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

@@ -189,6 +189,7 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
               unsigned int* __restrict__ bits, int* __restrict__ dmap) {
   dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
                       err, epoch, x, xs, F, batch, bits, dmap);
+  if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 256, B, graph_ptr, dmap);
 }
 
 // xs[i][f] = dinv[i] * x[i][f]  (general prep path; the fast path does it inside k_prep_fast_b)

@@ -150,6 +150,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
                         rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
                         rd.dmap);
+    if (rd.dmap && (int)blockIdx.x == B) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
     return;
   }
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)

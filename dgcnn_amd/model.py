@@ -95,7 +95,7 @@ class _DGCNNFunction(torch.autograd.Function):
                                          max_nodes, max_edges, model._next_epoch(), stream),
                    "dgcnn_model_forward")
         ctx.model = model
-        ctx.dims = (N, E, B, F, C, int(training))
+        ctx.dims = (N, E, B, F, C, int(training), int(flags), int(max_nodes))
         ctx.save_for_backward(x, ws, logp)
         model._last_ws = ws
         model._last_dims = (N, E, B, F, C)
@@ -105,7 +105,7 @@ class _DGCNNFunction(torch.autograd.Function):
     def backward(ctx, glogp):
         L = _lib.lib()
         model = ctx.model
-        N, E, B, F, C, training = ctx.dims
+        N, E, B, F, C, training, flags, max_nodes = ctx.dims
         x, ws, logp = ctx.saved_tensors
         glogp = glogp.contiguous()
         flat = model.flat_params_fast()
@@ -113,7 +113,7 @@ class _DGCNNFunction(torch.autograd.Function):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), glogp.data_ptr(), None, 0.0, training,
-                                          grads.data_ptr(), None, stream), "dgcnn_model_backward")
+                                          grads.data_ptr(), None, flags, max_nodes, stream), "dgcnn_model_backward")
         model._last_flat_grad = grads
         # the 16 gradients handed to autograd are views of ONE flat buffer in the parameter layout: autograd keeps them
         # as they are (no copies), so an optimizer that recognises the layout (dgcnn_amd.optim.Adam) updates the

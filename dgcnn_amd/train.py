@@ -125,10 +125,11 @@ class Trainer:
         seed = m._next_seed() if training else 0
         x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
         flags = m._flags_of(data)
+        maxn = m._max_nodes_of(data)
         epoch = m._next_epoch()
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
                                          ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
-                                         logp.data_ptr(), training, seed, flags, m._max_nodes_of(data),
+                                         logp.data_ptr(), training, seed, flags, maxn,
                                          int(getattr(data, "max_edges", 0) or 0), epoch, stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam:
@@ -138,11 +139,11 @@ class Trainer:
                                                    self.grads.data_ptr(), self.metrics.data_ptr(),
                                                    self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                                    self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                                                   stream), "dgcnn_model_backward_step")
+                                                   flags, maxn, stream), "dgcnn_model_backward_step")
         else:
             _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                               logp.data_ptr(), None, y.data_ptr(), scale, training,
-                                              self.grads.data_ptr(), self.metrics.data_ptr(), stream),
+                                              self.grads.data_ptr(), self.metrics.data_ptr(), flags, maxn, stream),
                        "dgcnn_model_backward")
         m._last_ws, m._last_dims = ws, (N, E, B, F, C)
         return logp[:B]

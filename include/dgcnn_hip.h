@@ -208,11 +208,13 @@ int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batc
  *           so hand in a buffer whose gaps are zero (e.g. allocated zeroed once)
  *   metrics: optional (label mode only) 2-float device accumulator: metrics[0] += sum_b loss_b,
  *           metrics[1] += #correct -- replaces the two `.item()` syncs per batch of train.py:44-45
+ *   flags, max_nodes: the values the matching dgcnn_model_forward was given (they select the aggregation form,
+ *           whose structures the forward left in the workspace)
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
                          const float* glogp, const int64_t* y, float loss_scale, int training,
-                         float* grads, float* metrics, dgcnn_stream_t stream);
+                         float* grads, float* metrics, int flags, int max_nodes, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward + optimizer in one call (single-GPU training step): as dgcnn_model_backward in label
@@ -225,7 +227,7 @@ int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, 
                               const float* logp, const int64_t* y, float loss_scale, int training,
                               float* grads, float* metrics, float* exp_avg, float* exp_avg_sq,
                               int64_t step, float lr, float beta1, float beta2, float eps,
-                              dgcnn_stream_t stream);
+                              int flags, int max_nodes, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam step over the flat buffer: replaces `optimizer.step(); optimizer.zero_grad()`

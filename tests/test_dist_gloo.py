@@ -126,12 +126,11 @@ def _gpu_worker(rank, world, port, ret):
         tr.train_step(cur, cur.y, global_batch=14, next_data=nxt)
     torch.cuda.synchronize()
     m.check_errors()
-    loss, correct = tr.read_metrics()
-    t = torch.tensor([loss, correct], dtype=torch.float64)
-    dist.all_reduce(t)
+    loss, correct = tr.read_metrics()          # reduced over the ranks inside: the dataset-level numbers, on every rank
+    ret[f"metrics{rank}"] = (loss, correct)
     if rank == 0:
         ret["params"] = m.flat_params.detach().cpu()
-        ret["loss"], ret["correct"] = float(t[0]), float(t[1])
+        ret["loss"], ret["correct"] = loss, correct
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,6 +158,7 @@ def test_two_rank_data_parallel_trainer_on_gpu_equals_single_rank():
         tr.train_step(fulls[k % 3], fulls[k % 3].y, next_data=fulls[(k + 1) % 3])
     torch.cuda.synchronize()
     loss, correct = tr.read_metrics()
+    assert ret["metrics0"] == ret["metrics1"]            # Trainer.read_metrics all-reduces under a process group
     assert abs(ret["loss"] - loss) < 1e-4 * max(1.0, abs(loss)) and ret["correct"] == correct
     # same gradients up to summation order; six Adam steps of size 1e-3 amplify that to at most a few 1e-6
     torch.testing.assert_close(ret["params"], m.flat_params.detach().cpu(), rtol=1e-4, atol=1e-5)

@@ -14,22 +14,29 @@ pytestmark = pytest.mark.gpu
 
 
 def _bitmap_reference(b):
-    """numpy restatement of dg_prep.h's dense structures: (words [31*N] u32, item map [N//64 + B] i32)"""
+    """numpy restatement of dg_prep.h's dense structures: (words [31*N] u32, item records [(n0, n, r0)...], shares [1025])"""
     N, B = b.num_nodes, b.num_graphs
     ptr = np.searchsorted(b.batch.numpy(), np.arange(B + 1))
     words = np.zeros(31 * N, dtype=np.uint32)
-    dmap = np.full(N // 64 + B, -7, dtype=np.int32)
     src, dst = b.edge_index[0].numpy(), b.edge_index[1].numpy()
     gid = b.batch.numpy()
     def cls(n):
         k32 = (n + 31) // 32
         return 0 if k32 <= 1 else 1 if k32 <= 2 else 2 if k32 <= 4 else 3 if k32 <= 8 else 4
+    recs, costs = [], []
     for g in range(B):
         n0, n1 = int(ptr[g]), int(ptr[g + 1])
-        s0, s1 = n0 // 64 + g, n1 // 64 + g + 1
-        used = (n1 - n0 + 63) // 64
-        for w in range(s0, s1):
-            dmap[w] = g if w - s0 < used else -1
+        n = n1 - n0
+        for r in range((n + 63) // 64):
+            recs.append((n0, n, 64 * r)); costs.append(3 * ((n + 63) // 64) + 1)
+    tot = max(sum(costs), 1)
+    split = np.zeros(1025, dtype=np.int64)
+    c0 = 0
+    for w, ic in enumerate(costs):
+        c1 = c0 + ic
+        for k in range(c0 * 1024 // tot + 1, min(c1 * 1024 // tot, 1024) + 1):
+            split[k] = w + 1
+        c0 = c1
     def setbit(i, j):
         g = gid[i]; n0, n1 = int(ptr[g]), int(ptr[g + 1])
         S = 1 << cls(n1 - n0)
@@ -38,7 +45,7 @@ def _bitmap_reference(b):
         setbit(i, i)
     for s, d in zip(src, dst):
         setbit(int(s), int(d))
-    return words, dmap
+    return words, np.array(recs, dtype=np.int32).reshape(-1, 3), split
 
 
 @pytest.mark.parametrize("name,bs", [("MUTAG", 9), ("PROTEINS", 7), ("COLLAB", 6), ("COLLAB_REAL", 5), ("IMDB", 11)])
@@ -53,12 +60,21 @@ def test_dense_structures_bit_exact(name, bs):
     with torch.no_grad():
         m(b.to("cuda"))
     m.check_errors()
-    words, dmap = _bitmap_reference(b)
+    words, recs, split = _bitmap_reference(b)
     got_w = m.last_workspace_view("adjbits").cpu().numpy().view(np.uint32)[:31 * b.num_nodes]
-    got_m = m.last_workspace_view("dmap").cpu().numpy()[:b.num_nodes // 64 + b.num_graphs]
-    np.testing.assert_array_equal(got_m, dmap)
-    # only the words of each row's OWN stride class are defined content; the other classes are zero
-    np.testing.assert_array_equal(got_w, words)
+    tab = m.last_workspace_view("dmap").cpu().numpy()
+    np.testing.assert_array_equal(tab[:1025], split)                       # equal-cost shares
+    assert tab[1025] == len(recs)
+    np.testing.assert_array_equal(tab[1032:1032 + 3 * len(recs)].reshape(-1, 3), recs)
+    # only the words of each row's OWN stride class are defined content (the other classes are never written)
+    ptr = np.searchsorted(b.batch.numpy(), np.arange(b.num_graphs + 1))
+    N = b.num_nodes
+    for g in range(b.num_graphs):
+        n0, n1 = int(ptr[g]), int(ptr[g + 1])
+        k32 = (n1 - n0 + 31) // 32
+        S = 1 if k32 <= 1 else 2 if k32 <= 2 else 4 if k32 <= 4 else 8 if k32 <= 8 else 16
+        lo, hi = N * (S - 1) + n0 * S, N * (S - 1) + n1 * S
+        np.testing.assert_array_equal(got_w[lo:hi], words[lo:hi], err_msg=f"graph {g}")
 
 
 WORKLOADS = [("MUTAG", 50), ("PROTEINS", 24), ("COLLAB", 50), ("COLLAB_REAL", 50), ("IMDB", 50), ("COLLAB", 256)]
