@@ -133,11 +133,16 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   if (dgd_num_items(N, B) > 100000) return false;        // (a workgroup caches at most 128 item records: gcn_dense.hip)
   if (flags & DGCNN_FLAG_AGG_DENSE) return true;
   if (flags & DGCNN_FLAG_BF16) return true;              // the bf16 leg exists in the dense form only
-  // K estimate: twice the mean graph size (size-weighted mean of a spread distribution), capped by the largest graph
-  int64_t kest = 2 * ((int64_t)N / B) + 32;
-  if (kest > max_nodes + 31) kest = max_nodes + 31;
-  kest = (kest / 32) * 32;
-  if (kest < 32) kest = 32;
+  // Automatic choice.  (1) The dense kernels are persistent pipelines with a fixed prologue (~2.5 us: item records,
+  // first stage) and their bitmap costs extra graph-preparation work; below a few hundred work items per launch the
+  // one-tile-per-workgroup gather kernels are as fast or faster (measured, COLLAB shape: 50 graphs 5.3 vs 8.2 us per
+  // aggregation, 256 graphs 13.5 vs 12.9 us but 138 vs 171 us per step, 2048 graphs 69 vs 25 us and 706 vs 570 us).
+  // (2) Cost model: K_g SIMD-cycles per node row (K_g = n_g rounded up to 64) against ~28 per edge of the gather.
+  if (N < DG_DENSE_MIN_NODES) return false;
+  int64_t kest = 2 * ((int64_t)N / B) + 64;       // ~ size-weighted mean graph size of a spread distribution
+  if (kest > max_nodes + 63) kest = max_nodes + 63;
+  kest = (kest / 64) * 64;
+  if (kest < 64) kest = 64;
   return (int64_t)N * kest <= (int64_t)DG_DENSE_EDGE_COST * ((int64_t)E + N);
 }
 // the backward of a batch takes the form its forward took (same flags and max_nodes; the fused graph-per-workgroup

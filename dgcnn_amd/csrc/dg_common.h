@@ -87,6 +87,9 @@ static inline int dg_wg_two_stage_b() {
 #ifndef DG_DENSE_EDGE_COST
 #define DG_DENSE_EDGE_COST 12      // dense block form when N * K_estimate <= this * (E + N)   (see dg_use_dense, api.hip)
 #endif
+#ifndef DG_DENSE_MIN_NODES
+#define DG_DENSE_MIN_NODES 49152   // ... and the batch has at least this many nodes (~650 COLLAB-shaped graphs)
+#endif
 #define DG_WG_ROWS_PER_CHUNK 32
 #define DG_WG_FC1_KCHUNK 128
 static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
@@ -162,7 +165,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
   // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
   R(adjbits, 4 * 31 * n);
-  R(dmap, 4 * (1032 + 3 * (n / 64 + b + 1)));      // item table: shares + records (dg_prep.h: dgd_table_ints)
+  R(dmap, 4 * (1032 + 3 * (n / 128 + b + 1)));      // item table: shares + records (dg_prep.h: dgd_table_ints)
 #undef R
   w->total = o;
   return DGCNN_OK;

@@ -27,7 +27,7 @@ static inline int dg_prep_fast_work(int E, int N, int B) {
 // rows are stored with a power-of-two word stride S = 2^c >= ceil(n_g/32) (five classes, c = 0..4, i.e. graphs of up
 // to 32/64/128/256/512 nodes); class c lives at word offset N*(2^c - 1), row i at i*2^c inside it -- every offset is
 // a function of (N, i, n_g) only, so building it needs no prefix sum over graphs.  31*N words are reserved.
-// work items: one per (graph, group of DGD_ROWS rows), packed in graph order: item table `dmap` =
+// work items: one per (graph, group of DGD_ROWS = 128 rows: 8 waves x one 16-row tile), packed in graph order: item table `dmap` =
 //   [0 .. DGD_SPLITS]            split[k] = first item of share k: the items are cut into DGD_SPLITS contiguous shares of
 //                                (nearly) equal COST (cost of an item = 3 * its pipeline stages + 1, i.e. ~ n_g), so that
 //                                persistent workgroups that take equal numbers of shares finish together -- static,
@@ -36,7 +36,7 @@ static inline int dg_prep_fast_work(int E, int N, int B) {
 // built by ONE workgroup of graph preparation's second phase with a block-wide prefix sum over the graphs
 // (dg_prep_dense_plan); at most N/64 + B items.
 #define DGD_MAXN 512
-#define DGD_ROWS 64
+#define DGD_ROWS 128
 #define DGD_CLASSES 5
 #define DGD_SPLITS 1024
 #define DGD_REC0 (DGD_SPLITS + 8)

@@ -29,12 +29,15 @@
 #include <hip/hip_ext.h>
 
 #define DGD_SK 64                        // k rows per pipeline stage
-#define DGD_PLANE (DGD_SK * 16 + 16)     // floats per 16-column plane; +16 puts the two planes on opposite bank halves
-#define DGD_BUF (2 * DGD_PLANE)          // one stage buffer: two planes
+#define DGD_HT_ROW 72                    // bf16 per column of a staged part: 64 k + 8 pad (144 B: 16-B aligned, and the 16
+                                         // columns a b128 read group touches fall on distinct banks)
+#define DGD_HT_PART (32 * DGD_HT_ROW)    // one part: 32 columns
+#define DGD_BUF (3 * DGD_HT_PART)        // one stage buffer, in bf16 units: three parts (13.5 KiB)
 #define DGD_XT 36                        // row stride (floats) of the wave-private 16x32 tiles
-#define DGD_THREADS 256
+#define DGD_WAVES 8                      // one 16-row tile per wave: an item is 128 rows (DGD_ROWS, dg_prep.h)
+#define DGD_THREADS (64 * DGD_WAVES)
 #ifndef DGD_MAX_GRID
-#define DGD_MAX_GRID 1024                // persistent forward grid: 4 workgroups per CU
+#define DGD_MAX_GRID 512                 // persistent forward grid: 2 workgroups of 8 waves per CU
 #endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -105,104 +108,115 @@ struct DgdBits {
   }
   __device__ __forceinline__ void commit() { cur[0] = pend[0]; cur[1] = pend[1]; }
 };
-struct DgdStage32 {          // hs [N,32] fp32: thread = (row rr = t>>3, float4 q = t&7), 2 rows per thread
-  float4 v[2];
+// The block product runs on the BF16 matrix cores and is nevertheless exact in fp32: the adjacency operand is 0/1
+// (exact in bf16) and every fp32 value h is split, at staging time, into THREE bf16 parts h = h0 + h1 + h2 -- the top
+// 8, middle 8 and low 8 bits of its 24-bit significand (two masks and two exact subtractions) -- so
+//     A.H = A.H0 + A.H1 + A.H2     with exact products and fp32 accumulation inside v_mfma_f32_16x16x32_bf16,
+// 3 MFMAs of K = 32 (~17 cycles each per SIMD) instead of 8 fp32 MFMAs of K = 4 (32 cycles each): 5x less
+// matrix-pipe time for the same bits.  (bf16 leg: hs is stored in bf16, one part.)
+// Staged layout Ht[part][column][k] (k contiguous): thread (column c = t & 31, k block kb = t >> 5) loads 8 consecutive
+// rows of its column (a wave-instruction reads two 128-B row segments) and writes 16 B per part; the B operand of the
+// MFMA (lane (n, kg): 8 consecutive k of column n) is then one ds_read_b128.
+__device__ __forceinline__ void dgd_split3(float h, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned u0 = __float_as_uint(h) & 0xffff0000u;
+  const float r1 = h - __uint_as_float(u0);                  // exact: <= 16 significant bits
+  const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(u1);                 // exact: <= 8 significant bits, i.e. a bf16 value
+  p0 = u0 >> 16; p1 = u1 >> 16; p2 = __float_as_uint(r2) >> 16;
+}
+// Loads are issued UNCONDITIONALLY from base + constant row offsets (one address computation per stage) and rows at or
+// beyond the graph's end are zeroed by a select: the over-read stays inside the caller's workspace arena (<= 3 rows
+// past the last node of a slab that is never the arena's last region) and costs nothing, while predicated loads cost an
+// exec-mask branch and a 64-bit address computation each.
+template <int PARTS>
+__device__ __forceinline__ void dgd_store_col4(unsigned short* Ht, int c, int kb, const float (&v)[4]) {
+  unsigned q[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (PARTS == 3) dgd_split3(v[i], q[0][i], q[1][i], q[2][i]);
+    else q[0][i] = __float_as_uint(v[i]) >> 16;               // (bf16 leg: the value IS a bf16)
+  }
+#pragma unroll
+  for (int p = 0; p < PARTS; ++p)
+    *reinterpret_cast<uint2*>(Ht + p * DGD_HT_PART + c * DGD_HT_ROW + 4 * kb) =
+        make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
+}
+struct DgdStage32 {          // hs [N,32] fp32: thread (column c = t & 31, k block kb = t >> 5 of 4 rows)
+  static constexpr int PARTS = 3;
+  float v[4];
   __device__ __forceinline__ void load(const float* __restrict__ hs, const DgdStageDesc& d, int t) {
-    const int q = t & 7, rr = t >> 3;
+    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
+    const float* bp = hs + (size_t)(d.n0 + k0) * 32 + c;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = d.c * DGD_SK + rr + 32 * i;
-      v[i] = k < d.n ? *reinterpret_cast<const float4*>(hs + (size_t)(d.n0 + k) * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 4; ++i) { const float x = bp[i * 32]; v[i] = k0 + i < d.n ? x : 0.f; }
   }
-  __device__ __forceinline__ void store(float* Hs, int t) const {
-    const int q = t & 7, rr = t >> 3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(Hs + (q >> 2) * DGD_PLANE + (rr + 32 * i) * 16 + 4 * (q & 3)) = v[i];
-  }
+  __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<3>(Ht, t & 31, t >> 5, v); }
 };
-struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows): thread = (row rr = t>>2, 16-B piece q = t&3), 1 row per thread
-  uint4 v;
+struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows)
+  static constexpr int PARTS = 1;
+  float v[4];
   __device__ __forceinline__ void load(const unsigned short* __restrict__ hs, const DgdStageDesc& d, int t) {
-    const int q = t & 3, k = d.c * DGD_SK + (t >> 2);
-    v = k < d.n ? *reinterpret_cast<const uint4*>(hs + (size_t)(d.n0 + k) * 32 + 8 * q) : make_uint4(0u, 0u, 0u, 0u);
+    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
+    const unsigned short* bp = hs + (size_t)(d.n0 + k0) * 32 + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const unsigned x = bp[i * 32]; v[i] = k0 + i < d.n ? __uint_as_float(x << 16) : 0.f; }
   }
-  __device__ __forceinline__ void store(float* Hs, int t) const {
-    const int q = t & 3, rr = t >> 2;
-    float* dp = Hs + (q >> 1) * DGD_PLANE + rr * 16 + 8 * (q & 1);
-    *reinterpret_cast<float4*>(dp) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                                                 __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-    *reinterpret_cast<float4*>(dp + 4) = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
-                                                     __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
-  }
+  __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<1>(Ht, t & 31, t >> 5, v); }
 };
-template <bool ONE>          // src [N,F] fp32, F <= 32 (raw features; ONE: F == 1, a scalar per node)
-struct DgdStageF {
-  float v[ONE ? 1 : 8];
+struct DgdStageF {           // src [N,F] fp32, F <= 32 (raw features; F == 1: a scalar per node); columns >= F stay zero
+  static constexpr int PARTS = 3;
+  float v[4];
   int F;
   __device__ __forceinline__ void load(const float* __restrict__ src, const DgdStageDesc& d, int t) {
-    if (ONE) {
-      const int k = d.c * DGD_SK + t;
-      v[0] = (t < DGD_SK && k < d.n) ? src[d.n0 + k] : 0.f;
-    } else {
+    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = t + DGD_THREADS * i;
-        const int k = idx / F;
-        v[i] = (idx < DGD_SK * F && d.c * DGD_SK + k < d.n) ? src[(size_t)(d.n0 + d.c * DGD_SK) * F + idx] : 0.f;
-      }
-    }
+    for (int i = 0; i < 4; ++i) v[i] = (c < F && k0 + i < d.n) ? src[(size_t)(d.n0 + k0 + i) * F + c] : 0.f;
   }
-  __device__ __forceinline__ void store(float* Hs, int t) const {
-    if (ONE) {
-      if (t < DGD_SK) Hs[t * 16] = v[0];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int idx = t + DGD_THREADS * i;
-        if (idx < DGD_SK * F) {
-          const int k = idx / F, f = idx - k * F;
-          Hs[(f >> 4) * DGD_PLANE + k * 16 + (f & 15)] = v[i];
-        }
-      }
-    }
+  __device__ __forceinline__ void store(unsigned short* Ht, int t) const {
+    if ((t & 31) < F) dgd_store_col4<3>(Ht, t & 31, t >> 5, v);
   }
 };
 
 // ---- the block product of one 16-row tile with 32 staged rows (one bitmap word) -------------------------------------
-// A operand (16x4 per MFMA): lane (m = lane & 15, kq = lane >> 4) holds bit 4u+kq of row m's word, as 0.f / 1.f.
-// B operand: Hs[nb][k][n], lane (n = lane & 15, kq) reads row 4u+kq: conflict-free (rows of equal parity share a bank half).
-template <int NB>
-__device__ __forceinline__ void dgd_mma_word(unsigned w, const float* __restrict__ Hs, int krow0, int lane, f32x4 (&acc)[NB]) {
-  const int kq = lane >> 4;
-  const unsigned wk = w >> kq;
-  const float* hp = Hs + (krow0 + kq) * 16 + (lane & 15);
-  float b[NB][8];
+// A operand (16 x 32 bf16): lane (m = lane & 15, kg = lane >> 4) holds bits 8kg .. 8kg+7 of row m's word as bf16 0 / 1,
+// expanded through a 16-entry nibble table in LDS (tab[nib] = four bf16).  B operand: 16 B of Ht per (part, plane).
+template <int NB, int PARTS>
+__device__ __forceinline__ void dgd_mma_word(unsigned w, const unsigned short* __restrict__ Ht, int krow0, int lane,
+                                             const uint2* __restrict__ tab, f32x4 (&acc)[NB]) {
+  const int kg = lane >> 4;
+  const unsigned byte = (w >> (8 * kg)) & 0xffu;
+  const uint2 lo = tab[byte & 15u], hi = tab[byte >> 4];
+  bf16x8 a;
+  unsigned* au = reinterpret_cast<unsigned*>(&a);
+  au[0] = lo.x; au[1] = lo.y; au[2] = hi.x; au[3] = hi.y;
+  const unsigned short* hp = Ht + (lane & 15) * DGD_HT_ROW + krow0 + 8 * kg;
+  bf16x8 b[PARTS][NB];
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
+  for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[nb][u] = hp[nb * DGD_PLANE + u * 64];
+    for (int nb = 0; nb < NB; ++nb)
+      b[p][nb] = *reinterpret_cast<const bf16x8*>(hp + p * DGD_HT_PART + nb * 16 * DGD_HT_ROW);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const float a = (float)((wk >> (4 * u)) & 1u);
+  for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nb][u], acc[nb], 0, 0, 0);
-  }
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[p][nb], acc[nb], 0, 0, 0);
 }
 
 // ---- the pipeline: BODY supplies acc[NB], begin_item(desc) (zero acc, request the item's own operands) and
 // end_item(desc) (the tile epilogue); both are called by every wave (they test their own tile's liveness).
-// smem: two stage buffers of DGD_BUF floats.  Returns after the last stage of the workgroup's item range.
+// Hs: two stage buffers of DGD_BUF bf16.  Returns after the last stage of the workgroup's item range.
 #ifdef DGD_TIMING       // measurement builds (tools/build_variant.sh): per-workgroup phase clocks of the forward kernel
 #define DGD_T(k) do { if (dbg && lane == 0 && wave == 0) { const unsigned long long now_ = clock64(); dbg[blockIdx.x * 8 + (k)] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else
 #define DGD_T(k) do { } while (0)
 #endif
 template <int NB, typename STAGE, typename SRC, typename BODY>
-__device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __restrict__ src, float* Hs, STAGE& st, BODY& body,
-                                             int lane, int wave, unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __restrict__ src, unsigned short* Hs, STAGE& st,
+                                             BODY& body, int lane, int wave, unsigned long long* dbg = nullptr) {
   const int t = threadIdx.x;
+  __shared__ uint2 tab[16];                // nibble -> four bf16 (0 / 1.0): the A operand of the block product
+  if (t < 16) tab[t] = make_uint2(((t & 1) ? 0x3f80u : 0u) | ((t & 2) ? 0x3f800000u : 0u),
+                                  ((t & 4) ? 0x3f80u : 0u) | ((t & 8) ? 0x3f800000u : 0u));
 #ifdef DGD_TIMING
   unsigned long long tprev_ = clock64();
   if (dbg && lane == 0 && wave == 0) { for (int k = 0; k < 8; ++k) dbg[blockIdx.x * 8 + k] = 0; dbg[blockIdx.x * 8 + 7] = tprev_; }
@@ -237,13 +251,13 @@ __device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __rest
     DGD_T(1);                              // 1: barrier
     if (cur.c == 0) body.begin_item(cur);
     if (cur.r0 + wave * 16 < cur.n) {
-      const float* hb = Hs + p * DGD_BUF;
+      const unsigned short* hb = Hs + p * DGD_BUF;
       const int K32 = (cur.n + 31) >> 5;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (2 * cur.c + j < K32) {
           const unsigned w = bits.cur[j];
-          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB>(w, hb, 32 * j, lane, body.acc);
+          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB, STAGE::PARTS>(w, hb, 32 * j, lane, tab, body.acc);
         }
     }
     DGD_T(2);                              // 2: block product
@@ -403,8 +417,8 @@ template <int MODE, bool BFIN, bool BF16>     // BFIN: hs is bf16; BF16: hs_next
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd32d(DgDense G, const float* __restrict__ dinv, const void* __restrict__ hs, const float* __restrict__ bias,
              float* __restrict__ xout, const float* __restrict__ Wn, void* __restrict__ hs_next, unsigned long long* dbg) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
-  __shared__ __attribute__((aligned(16))) float xts[4][16 * DGD_XT];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2 * DGD_BUF];
+  __shared__ __attribute__((aligned(16))) float xts[DGD_WAVES][16 * DGD_XT];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   DgdFwd32Body<MODE, BF16> body;
@@ -477,13 +491,13 @@ struct DgdAfBody {
   }
 };
 
-template <int NB, bool ONE, bool BF16>
+template <int NB, bool BF16>
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd_af_d(DgDense G, int F, const float* __restrict__ dinv, const float* __restrict__ xs, const float* __restrict__ W1,
                const float* __restrict__ bias, float* __restrict__ axout, float* __restrict__ xout,
                const float* __restrict__ Wn, void* __restrict__ hs_next) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
-  __shared__ __attribute__((aligned(16))) float xts[4][16 * DGD_XT];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2 * DGD_BUF];
+  __shared__ __attribute__((aligned(16))) float xts[DGD_WAVES][16 * DGD_XT];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   DgdAfBody<NB, BF16> body;
@@ -498,10 +512,10 @@ k_gcn_fwd_af_d(DgDense G, int F, const float* __restrict__ dinv, const float* __
     }
   body.dinv = dinv; body.xout = xout; body.axout = axout; body.hs_next = hs_next; body.xt = xts[wave];
   body.lane = lane; body.wave = wave; body.F = F; body.F4 = (F + 3) >> 2;
-  // columns >= F of the planes are never staged: clear them once (0 * garbage could be NaN)
-  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
+  // columns >= F of the staged parts are never written: clear them once (0 * garbage could be NaN)
+  for (int t = threadIdx.x; t < DGD_BUF; t += DGD_THREADS) reinterpret_cast<unsigned*>(Hs)[t] = 0u;
   __syncthreads();
-  DgdStageF<ONE> st; st.F = F;
+  DgdStageF st; st.F = F;
   dgd_pipeline<NB>(G, xs, Hs, st, body, lane, wave);
 }
 
@@ -535,14 +549,14 @@ struct DgdFwd1Body {
 __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_fwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ h4s, const float* __restrict__ bias,
             float* __restrict__ x4) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2 * DGD_BUF];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   DgdFwd1Body body;
   body.b = bias[0]; body.dinv = dinv; body.x4 = x4; body.lane = lane; body.wave = wave;
-  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
+  for (int t = threadIdx.x; t < DGD_BUF; t += DGD_THREADS) reinterpret_cast<unsigned*>(Hs)[t] = 0u;
   __syncthreads();
-  DgdStageF<true> st; st.F = 1;
+  DgdStageF st; st.F = 1;
   dgd_pipeline<1>(G, h4s, Hs, st, body, lane, wave);
 }
 
@@ -556,8 +570,8 @@ k_gcn_fwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__
 // Grid = the P32 partial slots of the workspace; every workgroup writes one partial row {dW_l [32x32], db_{l-1} [32]}
 // (+ dW_1 [32 x Fa]), reduced later in a fixed order.
 // =================================================================================================================
-#define DGD_BW_TILES 3
-#define DGD_BW_SMEM (2 * DGD_BUF + 4 * DGD_BW_TILES * 16 * DGD_XT)      // stage buffers + per wave {ght, xt, aux} tiles
+#define DGD_BW_HF DGD_BUF                 // the two stage buffers (2 * DGD_BUF bf16) measured in floats
+#define DGD_BW_SMEM (DGD_BW_HF + DGD_WAVES * 2 * 16 * DGD_XT)      // stage buffers + per wave {ght, xt} tiles
 
 template <bool AF>
 struct DgdBwd32Body {
@@ -607,10 +621,6 @@ struct DgdBwd32Body {
       for (int r = 0; r < 4; ++r) ght[(kq * 4 + r) * DGD_XT + nb * 16 + nl] = dpre[r] * acc[nb][r];
 #pragma unroll
     for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(xt + (p * 8 + (lane >> 3)) * DGD_XT + 4 * (lane & 7)) = xr[p];
-    if (AF) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int idx = lane + 64 * u; aux[(idx >> 5) * DGD_XT + (idx & 31)] = axv[u]; }
-    }
     dgd_wave_sync();
     // gx = gh . W_l
     f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -656,6 +666,10 @@ struct DgdBwd32Body {
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ght[(kq * 4 + r) * DGD_XT + nb * 16 + nl] = AF ? ga[nb][r] : dpre[r] * ga[nb][r];
+    if (AF) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = lane + 64 * u; aux[(idx >> 5) * DGD_XT + (idx & 31)] = axv[u]; }
+    }
     dgd_wave_sync();
     if (AF) {
       // dW_1 += ga_1^T . ax : A[m][k] = gat[k][mb*16+m], B[k][n] = ax[k][nq*16+n]
@@ -697,9 +711,9 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kq = lane >> 4, nl = lane & 15;
   DgdBwd32Body<AF> body;
-  body.ght = smem + 2 * DGD_BUF + wave * DGD_BW_TILES * 16 * DGD_XT;
+  body.ght = smem + DGD_BW_HF + wave * 2 * 16 * DGD_XT;
   body.xt = body.ght + 16 * DGD_XT;
-  body.aux = body.xt + 16 * DGD_XT;           // AF: ax tile [16][<=32], zero padded
+  body.aux = body.xt;                         // AF: the ax tile [16][<=32] replaces x_prev once tanh' has read it
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -712,11 +726,11 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
   body.dinv = dinv; body.xprev = xprev; body.gpprev = gpprev; body.axin = axin; body.gas_prev = gas_prev;
   body.lane = lane; body.wave = wave; body.Fa = Fa; body.nbA = AF ? ((Fa + 15) >> 4) : 0;
   DgdStage32 st;
-  dgd_pipeline<2>(G, gas, smem, st, body, lane, wave);
+  dgd_pipeline<2>(G, gas, reinterpret_cast<unsigned short*>(smem), st, body, lane, wave);
 
   // ---- this workgroup's partial row: the four waves' accumulators combined in a fixed order -----------------------
   __syncthreads();
-  float* red = smem;                         // [4][1056] (the stage buffers and tiles are dead now)
+  float* red = smem;                         // [DGD_WAVES][1056] (the stage buffers and tiles are dead now)
   {
     float* my = red + wave * 1056;
 #pragma unroll
@@ -735,8 +749,12 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
   }
   __syncthreads();
   float* dst = part + (size_t)blockIdx.x * 1056;
-  for (int t = threadIdx.x; t < 1056; t += DGD_THREADS)
-    dst[t] = (red[t] + red[1056 + t]) + (red[2 * 1056 + t] + red[3 * 1056 + t]);
+  for (int t = threadIdx.x; t < 1056; t += DGD_THREADS) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < DGD_WAVES; ++w) a += red[w * 1056 + t];        // fixed order
+    dst[t] = a;
+  }
   if (AF) {
     __syncthreads();
     float* my = red + wave * 1024;
@@ -751,7 +769,10 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
     for (int t = threadIdx.x; t < 32 * Fa; t += DGD_THREADS) {
       const int c = t / Fa, k = t - c * Fa;
       const int o = c * 32 + k;
-      d1[t] = (red[o] + red[1024 + o]) + (red[2 * 1024 + o] + red[3 * 1024 + o]);      // W1's own [32,Fa] layout
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < DGD_WAVES; ++w) a += red[w * 1024 + o];
+      d1[t] = a;                                                                     // W1's own [32,Fa] layout
     }
   }
 }
@@ -819,9 +840,9 @@ __global__ void __launch_bounds__(DGD_THREADS)
 k_gcn_bwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
             const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
             float* __restrict__ pa4) {
-  __shared__ __attribute__((aligned(16))) float Hs[2 * DGD_BUF];
-  __shared__ float gh4s[4][16];
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2 * DGD_BUF];
+  __shared__ float gh4s[DGD_WAVES][16];
+  __shared__ float red[DGD_WAVES][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   DgdBwd1Body body;
@@ -829,9 +850,9 @@ k_gcn_bwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__
   body.pW = make_float4(0.f, 0.f, 0.f, 0.f); body.pB = make_float4(0.f, 0.f, 0.f, 0.f);
   body.dinv = dinv; body.x3 = x3; body.gp3 = gp3; body.gas3 = gas3; body.gh4s = gh4s[wave];
   body.lane = lane; body.wave = wave;
-  for (int t = threadIdx.x; t < 2 * DGD_BUF; t += DGD_THREADS) Hs[t] = 0.f;
+  for (int t = threadIdx.x; t < DGD_BUF; t += DGD_THREADS) reinterpret_cast<unsigned*>(Hs)[t] = 0u;
   __syncthreads();
-  DgdStageF<true> st; st.F = 1;
+  DgdStageF st; st.F = 1;
   dgd_pipeline<1>(G, gas4, Hs, st, body, lane, wave);
   // lanes with equal q (8 row groups) -> wave totals -> fixed-order sum over the 4 waves
   float4 pW = body.pW, pB = body.pB;
@@ -845,9 +866,12 @@ k_gcn_bwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__
     *reinterpret_cast<float4*>(&red[wave][32 + 4 * lane]) = pB;
   }
   __syncthreads();
-  if (threadIdx.x < 64)
-    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < DGD_WAVES; ++w) a += red[w][threadIdx.x];        // fixed order
+    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = a;
+  }
 }
 
 // =================================================================================================================
@@ -878,11 +902,10 @@ int dg_launch_gcn_fwd_af_d(int bf16_out, const DgDense* G, int F, const float* d
                            const float* bias, float* ax, float* xout, const float* Wnext, void* hs_next, hipStream_t s,
                            hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!G || G->NW <= 0 || F < 1 || F > DG_AF_MAX_F) return DGCNN_EINVAL;
-#define DGD_L(NB, ONE, BF) hipExtLaunchKernelGGL((k_gcn_fwd_af_d<NB, ONE, BF>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, \
-                                                 ev_stop, 0, *G, F, dinv, xs, W1, bias, ax, xout, Wnext, hs_next)
-  if (F == 1) { if (bf16_out) DGD_L(1, true, true); else DGD_L(1, true, false); }
-  else if (F <= 16) { if (bf16_out) DGD_L(1, false, true); else DGD_L(1, false, false); }
-  else { if (bf16_out) DGD_L(2, false, true); else DGD_L(2, false, false); }
+#define DGD_L(NB, BF) hipExtLaunchKernelGGL((k_gcn_fwd_af_d<NB, BF>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, \
+                                            ev_stop, 0, *G, F, dinv, xs, W1, bias, ax, xout, Wnext, hs_next)
+  if (F <= 16) { if (bf16_out) DGD_L(1, true); else DGD_L(1, false); }
+  else { if (bf16_out) DGD_L(2, true); else DGD_L(2, false); }
 #undef DGD_L
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

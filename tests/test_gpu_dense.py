@@ -27,8 +27,8 @@ def _bitmap_reference(b):
     for g in range(B):
         n0, n1 = int(ptr[g]), int(ptr[g + 1])
         n = n1 - n0
-        for r in range((n + 63) // 64):
-            recs.append((n0, n, 64 * r)); costs.append(3 * ((n + 63) // 64) + 1)
+        for r in range((n + 127) // 128):            # items of 128 rows; cost = 3 * (pipeline stages of 64 k-rows) + 1
+            recs.append((n0, n, 128 * r)); costs.append(3 * ((n + 63) // 64) + 1)
     tot = max(sum(costs), 1)
     split = np.zeros(1025, dtype=np.int64)
     c0 = 0
