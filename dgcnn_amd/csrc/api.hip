@@ -467,7 +467,7 @@ int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream) {
                                a->flags & 0xFFFF & ~DGCNN_FLAG_PREPARED, a->max_nodes, a->max_edges, a->epoch, stream,
                                nullptr, nullptr));
   if (a->y && a->metrics)
-    DG_TRY(dg_launch_eval_metrics(a->B, a->C, a->logp, a->y, a->metrics, (hipStream_t)stream));
+    DG_TRY(dg_launch_eval_metrics(a->B, a->C, a->logp, a->y, a->metrics, a->loss_scale, (hipStream_t)stream));
   return DGCNN_OK;
 }
 

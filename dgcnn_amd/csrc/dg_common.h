@@ -461,7 +461,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);
 int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s);
-int dg_launch_eval_metrics(int B, int C, const float* logp, const int64_t* y, float* metrics, hipStream_t s);
+int dg_launch_eval_metrics(int B, int C, const float* logp, const int64_t* y, float* metrics, float loss_scale, hipStream_t s);
 int dg_launch_collate_scan(int B, int F, int64_t N, int64_t E, int64_t Etot, const int64_t* ids_dev, const float* x_all,
                            const int64_t* ei_all, const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* y_all,
                            float* x, int64_t* ei, int64_t* batch, int64_t* y, hipStream_t s);

@@ -786,7 +786,8 @@ __global__ void k_metrics(int B, const float* __restrict__ lossv, float* __restr
 //   metrics[1] += #{ b : argmax_c logp[b][c] == y_b }   (first maximal index, like torch.argmax; train.py:64)
 // one workgroup, fixed-order reduction
 __global__ void __launch_bounds__(256)
-k_eval_metrics(int B, int C, const float* __restrict__ logp, const int64_t* __restrict__ y, float* __restrict__ metrics) {
+k_eval_metrics(int B, int C, const float* __restrict__ logp, const int64_t* __restrict__ y, float* __restrict__ metrics,
+               float scale) {
   __shared__ float sl[256], sc[256];
   float l = 0.f, c = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
@@ -806,12 +807,13 @@ k_eval_metrics(int B, int C, const float* __restrict__ logp, const int64_t* __re
     if ((int)threadIdx.x < st) { sl[threadIdx.x] += sl[threadIdx.x + st]; sc[threadIdx.x] += sc[threadIdx.x + st]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { metrics[0] += sl[0] / (float)B; metrics[1] += sc[0]; }
+  if (threadIdx.x == 0) { metrics[0] += sl[0] * scale; metrics[1] += sc[0]; }
 }
 
-int dg_launch_eval_metrics(int B, int C, const float* logp, const int64_t* y, float* metrics, hipStream_t s) {
+int dg_launch_eval_metrics(int B, int C, const float* logp, const int64_t* y, float* metrics, float loss_scale, hipStream_t s) {
   if (B <= 0 || C < 1) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_eval_metrics, dim3(1), dim3(256), 0, s, B, C, logp, y, metrics);
+  hipLaunchKernelGGL(k_eval_metrics, dim3(1), dim3(256), 0, s, B, C, logp, y, metrics,
+                     loss_scale != 0.f ? loss_scale : 1.0f / (float)B);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

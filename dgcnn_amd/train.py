@@ -289,10 +289,14 @@ class Trainer:
         return logp
 
     @torch.no_grad()
-    def eval_step(self, data, y) -> torch.Tensor:
+    def eval_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
         """Body of the reference ``test()`` loop (train.py:59-64) as ONE C call (``dgcnn_model_eval_step``): forward in
-        eval mode + loss / #correct folded into the device-side metrics accumulator."""
+        eval mode + loss / #correct folded into the device-side metrics accumulator.  Data parallel: the batch loss is
+        scaled by 1/``global_batch`` (derived with one small all-reduce when not given) so that the ranks' contributions
+        add up to the global batch mean."""
         m = self.model
+        if global_batch is None and self._dp_world > 1 and self._allreduce is not None:
+            global_batch = self._allreduce.global_batch(_batch_size_of(data), data.x.device)
         ent = self._args_cache.get(id(data))
         if ent is None or ent[0] is not data or ent[1] is not y:
             ent = self._step_args(data, y)
@@ -315,6 +319,7 @@ class Trainer:
             self._logp_views = {}
         a.ws, a.logp, a.params, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_metrics
         a.training = 0
+        a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         a.flags = ent[8] | m._mode_flags()
         a.epoch = m._next_epoch()
         rc = _lib.lib().dgcnn_model_eval_step(aref, torch._C._cuda_getCurrentRawStream(

@@ -288,9 +288,10 @@ typedef struct dgcnn_step_args {
 } dgcnn_step_args;
 
 /* Evaluation step, the body of the reference's `test()` loop (/root/reference/train.py:59-64), one call: forward in
- * eval mode (no dropout) into a->logp and, when a->y and a->metrics are given, metrics[0] += NLLLoss-mean of the batch,
- * metrics[1] += number of correct argmax predictions.  Uses the same argument block as the training step (optimizer
- * fields ignored). */
+ * eval mode (no dropout) into a->logp and, when a->y and a->metrics are given, metrics[0] += NLLLoss-mean of the batch
+ * (sum of the per-graph losses times a->loss_scale; 0 = 1/B, data parallel: 1/B_global so that the ranks' sums add up to
+ * the global mean), metrics[1] += number of correct argmax predictions.  Uses the same argument block as the training
+ * step (optimizer fields ignored). */
 int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream);
 
 int dgcnn_pipeline_create(void** handle);     /* one per training loop: remembers which workspace holds a prepared batch */

@@ -18,14 +18,15 @@ def test_golden_fixture_forward(golden_dir, name):
     z, sd, grads, b = load_fixture(golden_dir, name)
     m = make_model(int(z["num_features"]), int(z["num_classes"]), sd)
     logp, perm, err, err_x = check_forward_parity(m, b, sd)
-    if float(z["sort_margin"]) >= 1e-4:
-        # tie-free fixture: must match the stored vectors directly, permutation included
+    if float(z["sort_margin"]) >= 1e-5:
+        # tie-free fixture (smallest deciding key gap >= 10x the fp32 key noise; the COLLAB one was searched for it):
+        # must match the stored vectors directly, permutation included
         np.testing.assert_array_equal(perm.numpy(), z["perm"])
         np.testing.assert_allclose(logp.numpy(), z["logp_eval_f64"], rtol=0, atol=LOGIT_TOL)
         np.testing.assert_allclose(logp.numpy(), z["logp_eval_f32"], rtol=0, atol=LOGIT_TOL)
 
 
-@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5"])
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5", "collab_b4"])
 def test_golden_fixture_gradients(golden_dir, name):
     """with the fixture's dropout mask unavailable to the kernel (it draws its own), compare through
     the oracle run on the kernel's mask; additionally the tie-free fixtures' stored perm must match."""
@@ -35,7 +36,7 @@ def test_golden_fixture_gradients(golden_dir, name):
     np.testing.assert_array_equal(m.last_workspace_view("perm").cpu().numpy(), z["perm"])
 
 
-@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5"])
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5", "collab_b4"])
 def test_golden_step_fixture_loss_grads_and_post_adam_parameters(golden_dir, name):
     """SURVEY 8(c) C5 item 6, the step fixture: one training step of the fused Trainer in eval mode (no dropout mask to
     share) against the stored fp64 loss, gradients and parameters after ONE Adam step (torch defaults)."""
