@@ -29,6 +29,12 @@ HID1 = 128
 FLAT = 352
 NUM_SEG = 16
 
+class DenseView(ctypes.Structure):
+    """``dgcnn_dense_view`` of include/dgcnn_hip.h"""
+    _fields_ = [("B", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("graph_ptr", c_void_p), ("item_table", c_void_p),
+                ("adj_bits", c_void_p)]
+
+
 class StepArgs(ctypes.Structure):
     """``dgcnn_step_args`` of include/dgcnn_hip.h (field order and types must match)."""
     _fields_ = [("N", ctypes.c_int32), ("E", ctypes.c_int32), ("B", ctypes.c_int32), ("F", ctypes.c_int32),
@@ -51,9 +57,16 @@ SIGNATURES = {
     "dgcnn_param_layout": (c_int64, [c_int, c_int, ctypes.POINTER(c_int64)]),
     "dgcnn_workspace_bytes": (c_int64, [c_int] * 5),
     "dgcnn_workspace_offset": (c_int64, [c_char_p] + [c_int] * 5),
-    "dgcnn_graph_prep": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
+    "dgcnn_graph_prep": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_void_p,
+                                 c_void_p]),
+    "dgcnn_dense_table_ints": (c_int64, [c_int, c_int]),
+    "dgcnn_dense_bitmap_words": (c_int64, [c_int]),
     "dgcnn_gcn_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                              c_void_p, c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "dgcnn_gcn_bwd_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dgcnn_gcn_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                              c_int64, c_void_p]),
     "dgcnn_sortpool_fwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
     "dgcnn_sortpool_bwd": (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
     "dgcnn_model_forward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_int, c_uint64, c_int, c_int, c_int,

@@ -10,6 +10,8 @@ static thread_local hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
 #define DG_PROF_A(idx) (g_prof_which == (idx) ? g_prof_a : nullptr)
 #define DG_PROF_B(idx) (g_prof_which == (idx) ? g_prof_b : nullptr)
 
+#define DG_TRY(expr) do { const int rc__ = (expr); if (rc__ != DGCNN_OK) return rc__; } while (0)
+
 extern "C" {
 
 int dgcnn_profile_next_forward(int which, void* ev_start, void* ev_stop) {
@@ -84,26 +86,101 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                      int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                      float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag, int flags,
-                     dgcnn_stream_t stream) {
+                     uint32_t* adj_bits, int32_t* item_table, dgcnn_stream_t stream) {
   if (!batch || !rowptr || !rowptr_t || !dinv || !graph_ptr || !scratch || !err_flag) return DGCNN_EINVAL;
   if (E > 0 && (!edge_index || !colidx || !colidx_t)) return DGCNN_EINVAL;
+  if ((adj_bits == nullptr) != (item_table == nullptr)) return DGCNN_EINVAL;
+  if (adj_bits && (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0)) return DGCNN_EUNSUPPORTED;   // one bitmap for A and A^T
   // stand-alone entry: plain semantics "err_flag[0..1] != 0 on error" -> clear, then tag with epoch 1
   if (hipMemsetAsync(err_flag, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return DGCNN_ELAUNCH;
   // graph_eptr (first edge position per graph) is an internal by-product: park it in the scratch tail
   return dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, rowptr_t, colidx_t, dinv, graph_ptr,
-                        scratch + 2 * (N + 1), scratch, scratch + (N + 1), err_flag, flags, 1u, (hipStream_t)stream);
+                        scratch + 2 * (N + 1), scratch, scratch + (N + 1), err_flag, flags, 1u, (hipStream_t)stream,
+                        nullptr, nullptr, adj_bits, item_table);
+}
+
+int64_t dgcnn_dense_table_ints(int N, int B) { return (N < 0 || B < 0) ? DGCNN_EINVAL : dgd_table_ints(N, B); }
+int64_t dgcnn_dense_bitmap_words(int N) { return N < 0 ? DGCNN_EINVAL : 31 * (int64_t)N; }
+
+static bool dg_view_ok(const dgcnn_dense_view* v) { return v && v->graph_ptr && v->item_table && v->adj_bits && v->B > 0; }
+static DgDense dg_dense_of(const dgcnn_dense_view* v, int N) {
+  DgDense G;
+  G.graph_ptr = v->graph_ptr; G.dmap = v->item_table; G.bits = v->adj_bits; G.N = N; G.B = v->B; G.NW = dgd_num_items(N, v->B);
+  return G;
 }
 
 int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                   const float* x, int Fin, const float* W, const float* bias, int Fout,
-                  float* out, float* hs_scratch, dgcnn_stream_t stream) {
+                  float* out, void* hs_scratch, int flags, const dgcnn_dense_view* dense, dgcnn_stream_t stream) {
   if (!rowptr || !dinv || !x || !W || !bias || !out || !hs_scratch) return DGCNN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  int rc = dg_launch_lin_first(N, Fin, x, W, dinv, hs_scratch, Fout, s);
+  const int bf16 = (flags & DGCNN_FLAG_BF16) ? 1 : 0;
+  const bool use_dense = (flags & DGCNN_FLAG_AGG_DENSE) != 0 || bf16;
+  if (use_dense && !dg_view_ok(dense)) return DGCNN_EINVAL;
+  if (bf16 && Fout != 32) return DGCNN_EUNSUPPORTED;           // the 32 -> 1 layer's scalar stays fp32
+  int rc = dg_launch_lin_first(N, Fin, x, W, dinv, reinterpret_cast<float*>(hs_scratch), Fout, s, bf16);
   if (rc != DGCNN_OK) return rc;
-  if (Fout == 32) return dg_launch_gcn_fwd32(2, N, rowptr, colidx, dinv, hs_scratch, bias, out, nullptr, nullptr, s);
-  if (Fout == 1) return dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, hs_scratch, bias, out, s);
+  if (use_dense) {
+    const DgDense G = dg_dense_of(dense, N);
+    if (Fout == 32) return dg_launch_gcn_fwd32d(2, bf16, 0, &G, dinv, hs_scratch, bias, out, nullptr, nullptr, s);
+    if (Fout == 1) return dg_launch_gcn_fwd1d(&G, dinv, reinterpret_cast<const float*>(hs_scratch), bias, out, s);
+    return DGCNN_EUNSUPPORTED;
+  }
+  const float* hs = reinterpret_cast<const float*>(hs_scratch);
+  if (Fout == 32) return dg_launch_gcn_fwd32(2, N, rowptr, colidx, dinv, hs, bias, out, nullptr, nullptr, s);
+  if (Fout == 1) return dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, hs, bias, out, s);
   return DGCNN_EUNSUPPORTED;
+}
+
+// partial-row scratch of dgcnn_gcn_bwd, in floats: [P x 1056] | [P x 32*Fin or 32*Fa] (P = the production grid size)
+int64_t dgcnn_gcn_bwd_scratch_bytes(int N, int Fin, int Fout) {
+  if (N <= 0 || Fin < 1 || Fin > DGCNN_MAX_F || (Fout != 32 && Fout != 1)) return DGCNN_EINVAL;
+  const int64_t P = dg_grid32(N);
+  return 4 * (P * 1056 + P * 32 * (int64_t)(Fin > 32 ? Fin : 32));
+}
+
+int dgcnn_gcn_bwd(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv, const float* gas, int Fout,
+                  const float* W, const float* x_prev, int Fin, int first, const float* gp_prev, float* gas_prev,
+                  float* gW, float* gb_prev, const float* ax, int Fa, float* gW_af, const dgcnn_dense_view* dense,
+                  void* scratch, int64_t scratch_bytes, dgcnn_stream_t stream) {
+  if (!rowptr_t || !dinv || !gas || !x_prev || !gW || !scratch || N <= 0) return DGCNN_EINVAL;
+  const int64_t need = dgcnn_gcn_bwd_scratch_bytes(N, Fin, Fout);
+  if (need < 0 || scratch_bytes < need) return DGCNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = dg_grid32(N);                      // = dg_grid1(N): both production grids
+  float* part = reinterpret_cast<float*>(scratch);
+  float* part1 = part + (size_t)P * 1056;
+  const bool use_dense = dense != nullptr;
+  if (use_dense && !dg_view_ok(dense)) return DGCNN_EINVAL;
+  DgDense G{};
+  if (use_dense) G = dg_dense_of(dense, N);
+  if (Fout == 1) {                                 // conv4 form: k_gcn_bwd1 / k_gcn_bwd1d
+    if (!W || !gp_prev || !gas_prev || !gb_prev || Fin != 32 || first) return DGCNN_EINVAL;
+    if (use_dense) DG_TRY(dg_launch_gcn_bwd1d(&G, dinv, gas, W, x_prev, gp_prev, gas_prev, part, P, s));
+    else DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas, W, x_prev, gp_prev, gas_prev, part, P, s));
+    const DgRedSeg segs[2] = {{32, P, 64, part, gW}, {32, P, 64, part + 32, gb_prev}};
+    return dg_launch_reduce_cols(2, segs, s);
+  }
+  if (Fout != 32) return DGCNN_EUNSUPPORTED;
+  if (first) {                                     // conv1, linear-first: only dW_1 [32,Fin] (the gather kernel in both forms)
+    if (Fin < 1 || Fin > DGCNN_MAX_F) return DGCNN_EINVAL;
+    DG_TRY(dg_launch_gcn_bwd32(1, N, Fin, rowptr_t, colidx_t, dinv, gas, nullptr, x_prev, nullptr, nullptr, part1, P, s));
+    const DgRedSeg seg = {32 * Fin, P, 32 * Fin, part1, gW};
+    return dg_launch_reduce_cols(1, &seg, s);
+  }
+  if (!W || !gp_prev || !gb_prev || Fin != 32) return DGCNN_EINVAL;
+  if (ax) {                                        // conv2 form carrying conv1's weight gradient (aggregate-first conv1)
+    if (Fa < 1 || Fa > DG_AF_MAX_F || !gW_af) return DGCNN_EINVAL;
+    if (use_dense) DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gas, W, x_prev, gp_prev, nullptr, part, P, s, ax, Fa, part1));
+    else DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gas, W, x_prev, gp_prev, nullptr, part, P, s, ax, Fa, part1));
+    const DgRedSeg segs[3] = {{1024, P, 1056, part, gW}, {32, P, 1056, part + 1024, gb_prev}, {32 * Fa, P, 32 * Fa, part1, gW_af}};
+    return dg_launch_reduce_cols(3, segs, s);
+  }
+  if (!gas_prev) return DGCNN_EINVAL;
+  if (use_dense) DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gas, W, x_prev, gp_prev, gas_prev, part, P, s));
+  else DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gas, W, x_prev, gp_prev, gas_prev, part, P, s));
+  const DgRedSeg segs[2] = {{1024, P, 1056, part, gW}, {32, P, 1056, part + 1024, gb_prev}};
+  return dg_launch_reduce_cols(2, segs, s);
 }
 
 int dgcnn_sortpool_fwd(int N, int B, const int32_t* graph_ptr, const float* x1, const float* x2,
@@ -118,8 +195,6 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
   if (!graph_ptr || !perm || !gpooled || !g1 || !g2 || !g3 || !g4) return DGCNN_EINVAL;
   return dg_launch_sortpool_bwd(N, B, graph_ptr, perm, gpooled, g1, g2, g3, g4, (hipStream_t)stream);
 }
-
-#define DG_TRY(expr) do { const int rc__ = (expr); if (rc__ != DGCNN_OK) return rc__; } while (0)
 
 // Aggregation form of a batch: dense per-graph blocks on the matrix cores (gcn_dense.hip) or CSR gather (gcn.hip).
 // A pure function of host-known numbers, so graph preparation (which builds the bitmap only for the dense form) and

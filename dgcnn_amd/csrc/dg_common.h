@@ -407,7 +407,9 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
                    int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
-                        int Fout, hipStream_t s);
+                        int Fout, hipStream_t s, int bf16_out = 0);
+struct DgRedSeg { int count, R, stride; const float* src; float* out; };     // out[c] = sum_{r<R} src[r*stride + c]
+int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,

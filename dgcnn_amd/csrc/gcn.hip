@@ -47,9 +47,12 @@
 // FOUT = 32 runs on the fp32 matrix cores: one wave per 16-row tile, two 16x16 output blocks, K = F in steps of 4
 // (v_mfma_f32_16x16x4_f32, operands of 8 k-steps fetched together); W^T staged in LDS.  The fused kernel's conv1
 // linear issues the same MFMA sequence on the same operands, so both paths stay bit-identical.
+template <bool BF>       // BF: the pre-scaled output is stored in bf16 (round to nearest even): the bf16 leg's storage format
 __global__ void __launch_bounds__(256)
 k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
-              const float* __restrict__ dinv, float* __restrict__ hs) {
+              const float* __restrict__ dinv, void* __restrict__ hsv) {
+  float* hs = reinterpret_cast<float*>(hsv);
+  unsigned short* hb = reinterpret_cast<unsigned short*>(hsv);
   extern __shared__ __attribute__((aligned(16))) float Wt[];   // [F][32] (transposed: conflict-free)
   for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
     const int c = t / F, k = t - c * F;
@@ -66,7 +69,13 @@ k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict
           r0, nb * 16, F, lane,
           [&](int m, int k) { return (m < N && k < F) ? x[(size_t)m * F + k] : 0.f; },
           [&](int k, int n) { return k < F ? Wt[k * 32 + n] : 0.f; },
-          [&](int m, int n, float v) { if (m < N) hs[(size_t)m * 32 + n] = dinv[m] * v; });
+          [&](int m, int n, float v) {
+            if (m < N) {
+              const float o = dinv[m] * v;
+              if (BF) { unsigned u = __float_as_uint(o); u += 0x7fffu + ((u >> 16) & 1u); hb[(size_t)m * 32 + n] = (unsigned short)(u >> 16); }
+              else hs[(size_t)m * 32 + n] = o;
+            }
+          });
   }
 }
 
@@ -84,12 +93,13 @@ k_lin_first1(int N, int F, const float* __restrict__ x, const float* __restrict_
 }
 
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,
-                        int Fout, hipStream_t s) {
+                        int Fout, hipStream_t s, int bf16_out) {
   if (N <= 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   if (Fout == 32) {
     int grid = dg_cdiv(dg_cdiv(N, 16), 4);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_lin_first32, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, hs);
+    if (bf16_out) hipLaunchKernelGGL(k_lin_first32<true>, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, (void*)hs);
+    else hipLaunchKernelGGL(k_lin_first32<false>, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, (void*)hs);
   } else if (Fout == 1) {
     int grid = dg_cdiv(N, 4);
     if (grid > 4096) grid = 4096;

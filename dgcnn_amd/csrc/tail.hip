@@ -744,6 +744,27 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
   return DGCNN_OK;
 }
 
+// fixed-order column sums of partial rows through the production reduction (k_wgrad, WG_REDUCE_COL segments):
+// used by the stand-alone dgcnn_gcn_bwd
+int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s) {
+  if (nseg < 1 || nseg > WG_MAX_SEG || !segs) return DGCNN_EINVAL;
+  WgArgs A;
+  memset(&A, 0, sizeof(A));
+  int nb = 0;
+  for (int k = 0; k < nseg; ++k) {
+    WgSeg& g = A.seg[k];
+    g.type = WG_REDUCE_COL; g.count = segs[k].count; g.lpo = 1; g.R = segs[k].R; g.block0 = nb; g.stride = segs[k].stride;
+    g.aux = 0; g.src = segs[k].src; g.out = segs[k].out;
+    nb += dg_cdiv(segs[k].count, 64);
+  }
+  A.nseg = nseg;
+  A.grads_base = segs[0].out;
+  if (nb == 0) return DGCNN_OK;
+  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam defaults semantics) + fused zero_grad; metrics accumulation
 // ---------------------------------------------------------------------------------------------

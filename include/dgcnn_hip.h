@@ -126,18 +126,59 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                      int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                      float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag, int flags,
-                     dgcnn_stream_t stream);
+                     uint32_t* adj_bits, int32_t* item_table, dgcnn_stream_t stream);
+
+/* Dense per-graph block form of the aggregation (gcn_dense.hip).  For batches of SMALL graphs (every graph
+ * <= 512 nodes) whose edge list is coalesced + undirected, graph preparation can additionally emit
+ *   adj_bits   [dgcnn_dense_bitmap_words(N)] u32 : a bit-packed adjacency row per node (self bit included)
+ *   item_table [dgcnn_dense_table_ints(N,B)] i32 : work items (graph, 128-row group) + 1024 equal-cost shares of them
+ * (pass both or neither; needs DGCNN_FLAG_COALESCED_UNDIRECTED).  The aggregation kernels then evaluate
+ * (A+I)_g . H_g per graph on the matrix cores instead of gathering one 128-B row per edge. */
+typedef struct dgcnn_dense_view {
+  int32_t B;                      /* graphs in the batch */
+  int32_t reserved_;
+  const int32_t* graph_ptr;       /* [B+1] */
+  const int32_t* item_table;
+  const uint32_t* adj_bits;
+} dgcnn_dense_view;
+int64_t dgcnn_dense_table_ints(int N, int B);
+int64_t dgcnn_dense_bitmap_words(int N);
 
 /* ------------------------------------------------------------------------------------
  * One graph-convolution layer, forward: out = tanh( D~^-1/2 (A+I) D~^-1/2 (x W^T) + b ).
  * Replaces `torch.tanh(self.convN(x, edge_index))` (model.py:30-33; PyG GCNConv:
  * linear without bias first, then gather/scale/scatter-add over edges, then + bias).
  *   x [N,Fin] f32, W [Fout,Fin], bias [Fout], Fout in {32, 1}, out [N,Fout] (row stride Fout)
- *   hs_scratch [N,Fout] f32 (the pre-scaled linear output dinv[j] * (x W^T)[j])
+ *   hs_scratch [N,Fout] : the pre-scaled linear output dinv[j] * (x W^T)[j]; f32, or bf16 with DGCNN_FLAG_BF16
+ *   flags : 0 | DGCNN_FLAG_AGG_DENSE (needs `dense`) | DGCNN_FLAG_BF16 (dtype flag of the bf16 leg: hs stored in bf16 --
+ *           the linear step itself runs in fp32 here and rounds on store; Fout = 32 and `dense` required)
+ *   dense : structures from dgcnn_graph_prep, or NULL (CSR gather kernels)
  * ---------------------------------------------------------------------------------- */
 int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                   const float* x, int Fin, const float* W, const float* bias, int Fout,
-                  float* out, float* hs_scratch, dgcnn_stream_t stream);
+                  float* out, void* hs_scratch, int flags, const dgcnn_dense_view* dense, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * One link of the graph-convolution BACKWARD chain: the production kernels of dgcnn_model_backward, stand-alone, so
+ * that a per-layer gradient can be checked on its own (what `loss.backward()`, /root/reference/train.py:40, runs for
+ * one `torch.tanh(self.convN(...))` of model.py:30-33).  Layer l computed x_l = tanh(A_hat (x_{l-1} W_l^T) + b_l).
+ * Input  gas [N,Fout] = dinv[i] * dL/d(pre-activation of layer l)[i]   (= dinv * dL/dx_l * (1 - x_l^2))
+ *   Fout = 32, first = 0 (conv2 / conv3 form):  x_prev [N,32] = x_{l-1} (a tanh output), gp_prev [N,32] = gradient that
+ *       reaches x_{l-1} from elsewhere (SortPooling's; zeros if none):
+ *         gW [32,32] = dL/dW_l ;  gb_prev [32] = dL/db_{l-1} ;
+ *         gas_prev [N,32] = dinv * (dL/dx_{l-1} + gp_prev) * (1 - x_prev^2)      (the next link's input)
+ *       with ax [N,Fa] (Fa <= 32, the saved A_hat X of an aggregate-first conv1) and gW_af: additionally
+ *         gW_af [32,Fa] = dL/dW_1, and no gas_prev (may be NULL)
+ *   Fout = 32, first = 1 (conv1, linear-first): x_prev [N,Fin] = raw input; only gW [32,Fin]
+ *   Fout = 1  (conv4 form): W [1,32]; gW [32], gb_prev [32], gas_prev [N,32] as above
+ *   dense : NULL = CSR gather kernels on rowptr_t / colidx_t (CSR by source); else the dense block kernels
+ *   scratch : dgcnn_gcn_bwd_scratch_bytes(N, Fin, Fout) bytes (per-workgroup partial rows; reduced in a fixed order)
+ * ---------------------------------------------------------------------------------- */
+int64_t dgcnn_gcn_bwd_scratch_bytes(int N, int Fin, int Fout);
+int dgcnn_gcn_bwd(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv, const float* gas, int Fout,
+                  const float* W, const float* x_prev, int Fin, int first, const float* gp_prev, float* gas_prev,
+                  float* gW, float* gb_prev, const float* ax, int Fa, float* gW_af, const dgcnn_dense_view* dense,
+                  void* scratch, int64_t scratch_bytes, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * SortPooling forward: replaces `self.sort_pool(x, batch)` = PyG SortAggregation(k=30)

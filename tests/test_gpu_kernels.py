@@ -31,7 +31,7 @@ def run_prep(ei, batch, N, B, flags=0):
     err = torch.ones(4, dtype=torch.int32, device=DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, b_d.data_ptr(), N, B, rowptr.data_ptr(),
                                   colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
-                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), flags, _stream()), "prep")
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), flags, None, None, _stream()), "prep")
     torch.cuda.synchronize()
     e = err.cpu().tolist()
     return rowptr.cpu(), colidx.cpu(), rowptr_t.cpu(), colidx_t.cpu(), dinv.cpu(), gptr.cpu(), (e[0], e[1])
@@ -168,12 +168,13 @@ def run_gcn(x, ei, W, b, Fout):
     bd = batch.to(DEV)
     _lib.check(L.dgcnn_graph_prep(ei_d.data_ptr() if E else None, E, bd.data_ptr(), N, 1, rowptr.data_ptr(),
                                   colidx.data_ptr(), rowptr_t.data_ptr(), colidx_t.data_ptr(), dinv.data_ptr(),
-                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), 0, _stream()), "prep")
+                                  gptr.data_ptr(), scratch.data_ptr(), err.data_ptr(), 0, None, None, _stream()), "prep")
     xd, Wd, bd2 = x.to(DEV).contiguous(), W.to(DEV).contiguous(), b.to(DEV).contiguous()
     out = torch.full((N, Fout), float("nan"), device=DEV)
     hs = torch.empty(N, Fout, device=DEV)
     _lib.check(L.dgcnn_gcn_fwd(N, rowptr.data_ptr(), colidx.data_ptr(), dinv.data_ptr(), xd.data_ptr(), Fin,
-                               Wd.data_ptr(), bd2.data_ptr(), Fout, out.data_ptr(), hs.data_ptr(), _stream()), "gcn_fwd")
+                               Wd.data_ptr(), bd2.data_ptr(), Fout, out.data_ptr(), hs.data_ptr(), 0, None, _stream()),
+               "gcn_fwd")
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -312,3 +313,140 @@ def test_adam_matches_torch_adam():
         torch.cuda.synchronize()
         assert float(gd.abs().max()) == 0.0          # fused zero_grad
         np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=2e-6, atol=2e-7)
+
+
+# ---- dgcnn_gcn_bwd: one link of the backward chain, production kernels, vs torch autograd of the oracle's gcn_conv ----
+def _prep_device(ei, batch, N, B, flags=0, dense=False):
+    L = _lib.lib()
+    E = ei.shape[1]
+    d = {"ei": ei.to(DEV).contiguous(), "batch": batch.to(DEV).contiguous()}
+    d["rowptr"] = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    d["rowptr_t"] = torch.empty(N + 1, dtype=torch.int32, device=DEV)
+    d["colidx"] = torch.zeros(max(E, 1), dtype=torch.int32, device=DEV)
+    d["colidx_t"] = torch.zeros(max(E, 1), dtype=torch.int32, device=DEV)
+    d["dinv"] = torch.empty(N, dtype=torch.float32, device=DEV)
+    d["gptr"] = torch.empty(B + 1, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(2 * N + B + 4 + 64, dtype=torch.int32, device=DEV)
+    err = torch.zeros(4, dtype=torch.int32, device=DEV)
+    bits = tab = None
+    if dense:
+        bits = torch.empty(int(L.dgcnn_dense_bitmap_words(N)) + 4, dtype=torch.int32, device=DEV)
+        tab = torch.empty(int(L.dgcnn_dense_table_ints(N, B)), dtype=torch.int32, device=DEV)
+    _lib.check(L.dgcnn_graph_prep(d["ei"].data_ptr() if E else None, E, d["batch"].data_ptr(), N, B, d["rowptr"].data_ptr(),
+                                  d["colidx"].data_ptr(), d["rowptr_t"].data_ptr(), d["colidx_t"].data_ptr(),
+                                  d["dinv"].data_ptr(), d["gptr"].data_ptr(), scratch.data_ptr(), err.data_ptr(), flags,
+                                  bits.data_ptr() if dense else None, tab.data_ptr() if dense else None, _stream()), "prep")
+    torch.cuda.synchronize()
+    assert err.cpu().tolist()[:2] == [0, 0]
+    d["view"] = None
+    if dense:
+        v = _lib.DenseView()
+        v.B, v.graph_ptr, v.item_table, v.adj_bits = B, d["gptr"].data_ptr(), tab.data_ptr(), bits.data_ptr()
+        d["view"], d["_keep"] = v, (bits, tab)
+    return d
+
+
+def _run_gcn_bwd(d, N, gas, Fout, W, x_prev, first, gp_prev=None, ax=None):
+    L = _lib.lib()
+    Fin = x_prev.shape[1]
+    t = lambda a: None if a is None else a.to(DEV).float().contiguous()
+    gas_d, W_d, xp_d, gp_d, ax_d = t(gas), t(W), t(x_prev), t(gp_prev), t(ax)
+    nb = int(L.dgcnn_gcn_bwd_scratch_bytes(N, Fin, Fout))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    gas_prev = torch.full((N, 32), float("nan"), device=DEV)
+    gW = torch.full((32, Fin) if Fout == 32 else (32,), float("nan"), device=DEV)
+    gb = torch.full((32,), float("nan"), device=DEV)
+    Fa = 0 if ax is None else ax.shape[1]
+    gWaf = torch.full((32, max(Fa, 1)), float("nan"), device=DEV)
+    p = lambda a: None if a is None else a.data_ptr()
+    view = ctypes.byref(d["view"]) if d["view"] is not None else None
+    _lib.check(L.dgcnn_gcn_bwd(N, d["rowptr_t"].data_ptr(), d["colidx_t"].data_ptr(), d["dinv"].data_ptr(), p(gas_d), Fout,
+                               p(W_d), p(xp_d), Fin, int(first), p(gp_d), gas_prev.data_ptr(), gW.data_ptr(), gb.data_ptr(),
+                               p(ax_d), Fa, gWaf.data_ptr() if ax is not None else None, view, scratch.data_ptr(), nb,
+                               _stream()), "gcn_bwd")
+    torch.cuda.synchronize()
+    return gas_prev.cpu(), gW.cpu(), gb.cpu(), gWaf.cpu()
+
+
+def _close(a, b, rtol=2e-4):
+    scale = float(b.abs().max())
+    err = float((a.double() - b.double()).abs().max())
+    assert err <= rtol * max(scale, 1e-12) + 1e-7, (err, scale)
+
+
+@pytest.mark.parametrize("form", ["conv32", "conv32_af", "first", "conv4"])
+@pytest.mark.parametrize("dense", [False, True], ids=["gather", "dense"])
+@pytest.mark.parametrize("workload,bs", [("PROTEINS", 9), ("COLLAB", 7)])
+def test_gcn_bwd_link_vs_autograd(form, dense, workload, bs):
+    """x_l = tanh(gcn_conv(x_prev, W, b)) with x_prev = tanh(z): for an upstream gradient G on x_l and an extra gradient gp
+    on x_prev, autograd of the oracle gives dL/dW_l, dL/dz (-> gas_prev = dinv * dL/dz, gb_prev = sum dL/dz)."""
+    start = 300
+    b = synth.make_batch(workload, bs, start=start)
+    while b.max_nodes > 512:
+        start += bs
+        b = synth.make_batch(workload, bs, start=start)
+    N = b.num_nodes
+    d = _prep_device(b.edge_index, b.batch, N, b.num_graphs, _lib.FLAG_COALESCED_UNDIRECTED, dense=dense)
+    dinv = d["dinv"].cpu().double()
+    g = torch.Generator().manual_seed(N)
+    Fout = 1 if form == "conv4" else 32
+    Fin = 19 if form == "first" else 32
+    W = (torch.randn(Fout, Fin, generator=g) / np.sqrt(Fin)).double().requires_grad_(True)
+    bias = (0.1 * torch.randn(Fout, generator=g)).double()
+    G = torch.randn(N, Fout, generator=g).double()
+    ei = ref_ops.remove_self_loops(b.edge_index)
+    if form == "first":
+        x_prev = torch.randn(N, Fin, generator=g).double()
+        out = torch.tanh(ref_ops.gcn_conv(x_prev, ei, W, bias))
+        (out * G).sum().backward()
+        gas = dinv.view(-1, 1) * G * (1 - out.detach() ** 2)
+        _, gW, _, _ = _run_gcn_bwd(d, N, gas, 32, None, x_prev, True)
+        _close(gW, W.grad)
+        return
+    gp = torch.randn(N, 32, generator=g).double()
+    ax = W1 = None
+    if form == "conv32_af":       # x_prev = tanh(ax W1^T + b1) with ax = A_hat x the saved slab of an aggregate-first conv1
+        Fa = 5
+        ax = torch.randn(N, Fa, generator=g).double()
+        W1 = (torch.randn(32, Fa, generator=g) / np.sqrt(Fa)).double().requires_grad_(True)
+        z = ax @ W1.t()
+        z.retain_grad()
+    else:
+        z = torch.randn(N, 32, generator=g).double().requires_grad_(True)
+    x_prev = torch.tanh(z)
+    out = torch.tanh(ref_ops.gcn_conv(x_prev, ei, W, bias))
+    ((out * G).sum() + (x_prev * gp).sum()).backward()
+    gas = dinv.view(-1, 1) * G * (1 - out.detach() ** 2)
+    gas_prev, gW, gb, gWaf = _run_gcn_bwd(d, N, gas, Fout, W.detach(), x_prev.detach(), False, gp, ax)
+    _close(gW.reshape(-1), W.grad.reshape(-1))
+    _close(gb, z.grad.sum(0))
+    if form == "conv32_af":
+        _close(gWaf, W1.grad)
+    else:
+        _close(gas_prev, dinv.view(-1, 1) * z.grad)
+
+
+def test_gcn_fwd_dense_and_bf16_storage_flag():
+    """dgcnn_gcn_fwd with the dense view equals the gather form within fp32 order noise; with DGCNN_FLAG_BF16 the
+    pre-scaled linear output is stored in bf16 (stated tolerance 1e-2 on |out| <= 1)"""
+    L = _lib.lib()
+    b = synth.make_batch("COLLAB", 6, start=11)
+    N = b.num_nodes
+    d = _prep_device(b.edge_index, b.batch, N, b.num_graphs, _lib.FLAG_COALESCED_UNDIRECTED, dense=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 32, generator=g); W = torch.randn(32, 32, generator=g) / np.sqrt(32); bias = 0.1 * torch.randn(32, generator=g)
+    xd, Wd, bd = x.to(DEV), W.to(DEV), bias.to(DEV)
+    outs = {}
+    for name, flags, view in (("gather", 0, None), ("dense", _lib.FLAG_AGG_DENSE, d["view"]), ("bf16", _lib.FLAG_BF16, d["view"])):
+        out = torch.full((N, 32), float("nan"), device=DEV)
+        hs = torch.empty(N, 32, device=DEV)
+        _lib.check(L.dgcnn_gcn_fwd(N, d["rowptr"].data_ptr(), d["colidx"].data_ptr(), d["dinv"].data_ptr(), xd.data_ptr(), 32,
+                                   Wd.data_ptr(), bd.data_ptr(), 32, out.data_ptr(), hs.data_ptr(), flags,
+                                   ctypes.byref(view) if view is not None else None, _stream()), "gcn_fwd")
+        torch.cuda.synchronize()
+        outs[name] = out.cpu()
+    ref = torch.tanh(ref_ops.gcn_conv(x.double(), ref_ops.remove_self_loops(b.edge_index), W.double(), bias.double()))
+    assert float((outs["gather"].double() - ref).abs().max()) <= 3e-6
+    assert float((outs["dense"].double() - ref).abs().max()) <= 3e-6
+    e = float((outs["bf16"].double() - ref).abs().max())
+    assert 1e-5 < e <= 1e-2, e
