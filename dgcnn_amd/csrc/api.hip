@@ -277,8 +277,15 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   // and are faster; from a few hundred graphs per batch the LDS-resident kernel wins (no L2 gathers).
   const bool want_fused = (flags & DGCNN_FLAG_FORCE_FUSED) ||
                           (!(flags & DGCNN_FLAG_FORCE_TILED) && B >= DGCNN_FUSED_MIN_GRAPHS);
-  const bool fused = want_fused && max_nodes > 0 && max_edges > 0 && dg_fused_fits(max_nodes, max_edges, F);
-  const bool dense = !fused && dg_use_dense(N, E, B, flags, max_nodes);
+  const bool fused = want_fused && !(flags & DGCNN_FLAG_AGG_DENSE) && max_nodes > 0 && max_edges > 0 &&
+                     dg_fused_fits(max_nodes, max_edges, F);
+  // graph-per-workgroup forward in the dense block form: small batches of small graphs (the reference's batch of 50),
+  // where four per-layer launches + the readout launch cost ~5 us of dispatch and cold-read latency EACH
+  const bool fd_ok = !fused && !(flags & (DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_BF16)) && F <= DG_AF_MAX_F && max_nodes > 0 &&
+                     max_nodes <= dg_fused_d_max_nodes();
+  const bool fused_d = fd_ok && (((flags & DGCNN_FLAG_FORCE_FUSED) && (flags & DGCNN_FLAG_AGG_DENSE)) ||
+                                 (!(flags & (DGCNN_FLAG_AGG_SPARSE | DGCNN_FLAG_AGG_DENSE)) && B <= DG_FUSED_D_MAX_B));
+  const bool dense = !fused && !fused_d && dg_use_dense(N, E, B, flags, max_nodes);
   const int bf16 = (flags & DGCNN_FLAG_BF16) ? 1 : 0;
   if (bf16 && !dense) return DGCNN_EUNSUPPORTED;          // the bf16 leg runs in the dense block form only
   const DgDense G = dg_dense_view(ws, wl, N, B);
@@ -293,6 +300,17 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
                         dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, dense ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr));
+  if (fused_d) {
+    DG_TRY(dg_launch_fused_fwd_d(N, B, F, C, params, &pl, x, rowptr, colidx, dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
+                                 dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
+                                 dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
+                                 dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,
+                                 dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a,
+                                 g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
+    g_prof_which = -1;
+    if (rider_a && rode) *rode = 1;
+    return DGCNN_OK;
+  }
   if (fused) {
     // graph-per-workgroup path: conv1..conv4 + SortPooling + tail in ONE launch, activations in LDS
     const int nmax = ((max_nodes + 15) / 16) * 16;

@@ -399,6 +399,21 @@ int dg_launch_gcn_bwd32d(const DgDense* G, const float* dinv, const float* gas, 
                          const float* ax = nullptr, int Fa = 0, float* part1 = nullptr);
 int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, const float* W4, const float* x3,
                         const float* gp3, float* gas3, float* pa4, int P1, hipStream_t s);
+// graph-per-workgroup fused forward in the dense block form (gcn_dense.hip): conv1..conv4 + readout, one launch
+struct DgParams;
+int dg_fused_d_max_nodes();
+int dg_launch_fused_fwd_d(int N, int B, int F, int C, const float* params, const DgParams* pl, const float* x,
+                          const int32_t* rowptr, const int32_t* colidx, const float* dinv, const int32_t* graph_ptr, float* ax,
+                          float* x1, float* x2, float* x3, float* x4, float* pooled, int32_t* perm, float* a5, float* a6,
+                          float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed, int32_t* err, uint32_t epoch,
+                          hipStream_t s, const struct DgPrepRider* rider = nullptr, hipEvent_t ev_start = nullptr,
+                          hipEvent_t ev_stop = nullptr);
+#ifndef DG_FUSED_D_MAX_B
+#define DG_FUSED_D_MAX_B 0          // fused dense forward (one workgroup per graph) chosen automatically up to this many graphs.
+                                    // 0 = never: measured at the reference's batch of 50 COLLAB-shaped graphs it takes 26.6 us
+                                    // against 29.5 us for the five launches it replaces (step 56.9 vs 57.6 us) -- the longest
+                                    // graph's serial chain (n = 126: 50 k cycles) sets its duration; FORCE_FUSED + AGG_DENSE selects it
+#endif
 struct DgLinFirst { const float* x; const float* W; float* hs; int F; };   // optional conv1 linear riding on the prep launch
 // kernel launchers implemented in the .hip files (host side, internal linkage across TUs)
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,

@@ -26,6 +26,7 @@
 // coalesced row store, next layer's X.W^T on MFMA (fp32 16x16x4, or bf16 16x16x32 for the bf16 leg), stored pre-scaled.
 #include "dg_common.h"
 #include "dg_prep.h"
+#include "dg_readout.h"
 #include <hip/hip_ext.h>
 
 #define DGD_SK 64                        // k rows per pipeline stage
@@ -180,22 +181,23 @@ struct DgdStageF {           // src [N,F] fp32, F <= 32 (raw features; F == 1: a
 // ---- the block product of one 16-row tile with 32 staged rows (one bitmap word) -------------------------------------
 // A operand (16 x 32 bf16): lane (m = lane & 15, kg = lane >> 4) holds bits 8kg .. 8kg+7 of row m's word as bf16 0 / 1,
 // expanded through a 16-entry nibble table in LDS (tab[nib] = four bf16).  B operand: 16 B of Ht per (part, plane).
-template <int NB, int PARTS>
+template <int NB, int PARTS, int ROW = DGD_HT_ROW>
 __device__ __forceinline__ void dgd_mma_word(unsigned w, const unsigned short* __restrict__ Ht, int krow0, int lane,
                                              const uint2* __restrict__ tab, f32x4 (&acc)[NB]) {
+  constexpr int PART = 32 * ROW;
   const int kg = lane >> 4;
   const unsigned byte = (w >> (8 * kg)) & 0xffu;
   const uint2 lo = tab[byte & 15u], hi = tab[byte >> 4];
   bf16x8 a;
   unsigned* au = reinterpret_cast<unsigned*>(&a);
   au[0] = lo.x; au[1] = lo.y; au[2] = hi.x; au[3] = hi.y;
-  const unsigned short* hp = Ht + (lane & 15) * DGD_HT_ROW + krow0 + 8 * kg;
+  const unsigned short* hp = Ht + (lane & 15) * ROW + krow0 + 8 * kg;
   bf16x8 b[PARTS][NB];
 #pragma unroll
   for (int p = 0; p < PARTS; ++p)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      b[p][nb] = *reinterpret_cast<const bf16x8*>(hp + p * DGD_HT_PART + nb * 16 * DGD_HT_ROW);
+      b[p][nb] = *reinterpret_cast<const bf16x8*>(hp + p * PART + nb * 16 * ROW);
 #pragma unroll
   for (int p = 0; p < PARTS; ++p)
 #pragma unroll
@@ -872,6 +874,325 @@ k_gcn_bwd1d(DgDense G, const float* __restrict__ dinv, const float* __restrict__
     for (int w = 0; w < DGD_WAVES; ++w) a += red[w][threadIdx.x];        // fixed order
     pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = a;
   }
+}
+
+
+// =================================================================================================================
+// FUSED forward, dense block form: ONE workgroup per graph runs conv1..conv4 and the SortPooling readout + dense tail
+// (/root/reference/model.py:26-45) in a single launch -- for small batches of small graphs (the reference's batch of 50),
+// where the per-layer launches are bound by ~5 us of dispatch + cold-read latency each, not by work.
+//   * the graph's adjacency bitmap is built in LDS from its CSR slice (LDS integer atomics; no graph-preparation change)
+//   * hs of the current layer lives in LDS as three bf16 parts, k-contiguous (Ht[part][col][k]); every layer is
+//     acc = bits . Ht on v_mfma_f32_16x16x32_bf16 (exact, see dgd_split3), one 16-row tile per wave, then the tile epilogue
+//     (dst scale, bias, tanh, x_l row store for backward / SortPooling) and the next layer's X.W^T on the fp32 matrix
+//     cores, whose output is split and written STRAIGHT into the other Ht buffer (each lane owns 4 consecutive k of its
+//     column: one 8-byte LDS store per part) -- between layers there is one barrier and no global traffic
+//   * conv4 (32 -> 1) is the same product with a single column; its output feeds the LDS sort of dg_readout.h directly
+// Limits: n_g <= FD_NMAX (192: 12 tiles), F <= 32 (aggregate-first conv1).  Same sums as the per-layer dense kernels.
+// =================================================================================================================
+#define FD_NMAX 192
+#define FD_THREADS 1024
+#define FD_ROW (FD_NMAX + 8)             // bf16 per staged column: 400 B (16-B aligned; 100 dwords = 36 mod 64: the 16
+                                         // columns of a b128 read group fall on distinct banks)
+#define FD_PART (32 * FD_ROW)
+#define FD_HT (3 * FD_PART)              // one hs buffer (bf16 units): 37.5 KiB
+#define FD_KW (FD_NMAX / 32)             // bitmap words per row
+#define FD_WS 33                         // row stride of the transposed weight tiles in LDS
+
+__device__ __forceinline__ void fd_store_hs4(unsigned short* Ht, int col, int row0, const float (&v)[4]) {
+  unsigned q[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dgd_split3(v[i], q[0][i], q[1][i], q[2][i]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    *reinterpret_cast<uint2*>(Ht + p * FD_PART + col * FD_ROW + row0) = make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
+}
+
+struct FdW { const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4; };
+
+__global__ void __launch_bounds__(FD_THREADS)
+k_fused_fwd_d(int F, int C, FdW gw, TailW tw, const float* __restrict__ xin, const int* __restrict__ rowptr,
+              const int* __restrict__ colidx, const float* __restrict__ dinv, const int* __restrict__ graph_ptr,
+              float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3,
+              float* __restrict__ x4, float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g,
+              float* __restrict__ a6g, float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp,
+              int training, uint64_t seed, unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg,
+              int B, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {    // rider range: phase A of the NEXT batch's graph preparation (dg_prep.h), as on k_readout_fwd
+    dg_prep_fast_a_body(((int)blockIdx.x - B) * FD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
+                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
+    return;
+  }
+#define FD_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+#ifdef DGD_TIMING
+  const unsigned long long tstart_ = clock64();
+#endif
+  FD_MARK(0);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS plan: [Ht0 | Ht1] (2 x 37.5 KiB; the readout's 32-KiB region aliases it afterwards) | xt tiles 12 x 2304 B |
+  //           bits 192 x 6 x 4 | dv, x4s (192 floats each) | tab | readout small
+  unsigned short* Ht0 = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Ht1 = Ht0 + FD_HT;
+  float* xts = reinterpret_cast<float*>(Ht1 + FD_HT);
+  unsigned* bits = reinterpret_cast<unsigned*>(xts + (FD_NMAX / 16) * 16 * DGD_XT);
+  float* dv = reinterpret_cast<float*>(bits + FD_NMAX * FD_KW);
+  float* x4s = dv + FD_NMAX;
+  uint2* tab = reinterpret_cast<uint2*>(x4s + FD_NMAX);
+  float* W1t = reinterpret_cast<float*>(tab + 16);         // [k][33]: W^T of conv1 (rows k >= F zero), conv2, conv3 --
+  float* W2t = W1t + 32 * FD_WS;                           // loaded ONCE per workgroup with coalesced reads; a per-lane
+  float* W3t = W2t + 32 * FD_WS;                           // register copy costs 48 scattered loads x 16 waves (13 us!)
+  char* small = reinterpret_cast<char*>(W3t + 32 * FD_WS);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, nl = lane & 15;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  if (n > FD_NMAX) {                     // host hint (max_nodes) violated: flag, produce nothing
+    if (tid == 0) { err[1] = epoch; err[3] = ~epoch; }
+    return;
+  }
+  FD_MARK(14);
+  const int K32 = (n + 31) >> 5;
+  const int m0 = wave * 16;              // this wave's tile (live iff m0 < n)
+  const bool live = m0 < n;
+  // ---- prologue: everything in flight at once -------------------------------------------------------------------
+  if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
+                                      ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+  for (int t = tid; t < FD_NMAX * FD_KW; t += FD_THREADS) bits[t] = 0u;
+  // both hs buffers: k < 32*K32 of every (part, column) -- the block products read exactly that range; rows >= n and
+  // columns >= F must be 0.  16-B stores: (2 buffers x 96 columns) x 4*K32 pieces
+  for (int t = tid; t < 2 * 96 * 4 * K32; t += FD_THREADS) {
+    const int pc = t / (4 * K32), piece = t - pc * (4 * K32);
+    *reinterpret_cast<uint4*>(Ht0 + pc * FD_ROW + 8 * piece) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  FD_MARK(15);
+  {   // transposed weights -> LDS (thread t: element (row cc = t >> 5, column k = t & 31) of the [32,32] matrices)
+    const int cc = tid >> 5, k = tid & 31;
+    W2t[k * FD_WS + cc] = gw.W2[tid];
+    W3t[k * FD_WS + cc] = gw.W3[tid];
+    W1t[k * FD_WS + cc] = 0.f;
+  }
+  float w4v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w4v[k] = gw.W4[8 * (lane & 3) + k];
+  const float b1c0 = gw.b1[nl], b1c1 = gw.b1[16 + nl], b2c0 = gw.b2[nl], b2c1 = gw.b2[16 + nl];
+  const float b3c0 = gw.b3[nl], b3c1 = gw.b3[16 + nl], b4s = gw.b4[0];
+  float dpre[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int m = m0 + kq * 4 + r; dpre[r] = m < n ? dinv[n0 + m] : 0.f; }
+  for (int t = tid; t < n; t += FD_THREADS) dv[t] = dinv[n0 + t];
+  __syncthreads();                       // zeroed LDS visible
+  for (int t = tid; t < 32 * F; t += FD_THREADS) { const int cc = t / F, k = t - cc * F; W1t[k * FD_WS + cc] = gw.W1[t]; }
+  FD_MARK(1);
+  // adjacency bitmap: wave per row, lanes over the row's neighbours; self bit by lane 0
+  {
+    bool bad = false;
+    for (int i = wave; i < n; i += FD_THREADS / 64) {
+      const int s = rowptr[n0 + i], e = rowptr[n0 + i + 1];
+      if (lane == 0) atomicOr(&bits[i * FD_KW + (i >> 5)], 1u << (i & 31));
+      for (int q = s + lane; q < e; q += 64) {
+        const int j = colidx[q] - n0;
+        if ((unsigned)j < (unsigned)n) atomicOr(&bits[i * FD_KW + (j >> 5)], 1u << (j & 31)); else bad = true;
+      }
+    }
+    if (bad) { err[1] = epoch; err[3] = ~epoch; }           // an edge left its graph: the batch is not block-diagonal
+  }
+  // conv1 operand: xs = dinv * x -> Ht0 (columns < F), thread (column c, 4 consecutive rows)
+  for (int t = tid; t < 32 * (FD_NMAX / 4); t += FD_THREADS) {
+    const int c = t & 31, r0 = 4 * (t >> 5);
+    if (c < F && r0 < n) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float xv = 0.f;
+        if (r0 + i < n) { xv = dinv[n0 + r0 + i] * xin[(size_t)(n0 + r0 + i) * F + c]; asm volatile("" : "+v"(xv)); }
+        v[i] = xv;
+      }
+      fd_store_hs4(Ht0, c, r0, v);
+    }
+  }
+  __syncthreads();
+  FD_MARK(2);
+  unsigned wb[FD_KW];
+#pragma unroll
+  for (int u = 0; u < FD_KW; ++u) wb[u] = (live && u < K32) ? bits[(m0 + nl) * FD_KW + u] : 0u;   // rows >= n are empty
+  float* xt = xts + wave * 16 * DGD_XT;
+  const int rows_live = min(16, n - m0);
+
+  // ---- conv1 (aggregate-first): ax = dv * (bits . xs), x1 = tanh(ax W1^T + b1), hs2 = dv * (x1 W2^T) -> Ht1 --------
+  if (live) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int u = 0; u < FD_KW; ++u)
+      if (u < K32 && __builtin_amdgcn_ballot_w64(wb[u] != 0u) != 0ull) {
+        if (F > 16) dgd_mma_word<2, 3, FD_ROW>(wb[u], Ht0, 32 * u, lane, tab, acc);
+        else { f32x4 a1[1] = {acc[0]}; dgd_mma_word<1, 3, FD_ROW>(wb[u], Ht0, 32 * u, lane, tab, a1); acc[0] = a1[0]; }
+      }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r, col = nb * 16 + nl;
+        const float ax = dpre[r] * acc[nb][r];
+        xt[row * DGD_XT + col] = ax;
+        if (col < F && row < rows_live) axg[(size_t)(n0 + m0 + row) * F + col] = ax;
+      }
+    dgd_wave_sync();
+    const int F4 = (F + 3) >> 2;
+    float a[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) a[kk] = kk < F4 ? xt[nl * DGD_XT + 4 * kk + kq] : 0.f;
+    f32x4 d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      if (kk < F4) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          d1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], W1t[(4 * kk + kq) * FD_WS + nb * 16 + nl], d1[nb], 0, 0, 0);
+      }
+    dgd_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xt[(kq * 4 + r) * DGD_XT + nl] = dg_tanh(d1[0][r] + b1c0);
+      xt[(kq * 4 + r) * DGD_XT + 16 + nl] = dg_tanh(d1[1][r] + b1c1);
+    }
+  }
+  // shared tail of a 32-wide layer: xt holds the activated tile; store its rows, next X.W^T, split into `Hn`
+  auto finish32 = [&](float* __restrict__ xout, const float* __restrict__ Wt, unsigned short* Hn) {
+    dgd_wave_sync();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = p * 8 + (lane >> 3), q = lane & 7;
+      const float4 v = *reinterpret_cast<const float4*>(xt + row * DGD_XT + 4 * q);
+      if (row < rows_live) *reinterpret_cast<float4*>(xout + (size_t)(n0 + m0 + row) * 32 + 4 * q) = v;
+    }
+    float a[8], wv[2][8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      a[kk] = xt[nl * DGD_XT + 4 * kk + kq];
+      wv[0][kk] = Wt[(4 * kk + kq) * FD_WS + nl]; wv[1][kk] = Wt[(4 * kk + kq) * FD_WS + 16 + nl];      // B[k][n] = W[n][k]
+    }
+    f32x4 d2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) d2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wv[nb][kk], d2[nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = dpre[r] * d2[nb][r];        // rows >= n: dpre = 0 -> zeros
+      fd_store_hs4(Hn, nb * 16 + nl, m0 + kq * 4, v);
+    }
+  };
+  if (live) finish32(x1, W2t, Ht1);
+  dg_lds_barrier();
+  FD_MARK(3);
+
+  // ---- conv2: from Ht1, hs3 -> Ht0 ----------------------------------------------------------------------------------
+  auto aggregate32 = [&](const unsigned short* Hc, float bc0, float bc1) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int u = 0; u < FD_KW; ++u)
+      if (u < K32 && __builtin_amdgcn_ballot_w64(wb[u] != 0u) != 0ull) dgd_mma_word<2, 3, FD_ROW>(wb[u], Hc, 32 * u, lane, tab, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xt[(kq * 4 + r) * DGD_XT + nl] = dg_tanh(fmaf(dpre[r], acc[0][r], bc0));
+      xt[(kq * 4 + r) * DGD_XT + 16 + nl] = dg_tanh(fmaf(dpre[r], acc[1][r], bc1));
+    }
+  };
+  if (live) { aggregate32(Ht1, b2c0, b2c1); finish32(x2, W3t, Ht0); }
+  dg_lds_barrier();
+  FD_MARK(4);
+
+  // ---- conv3: from Ht0; next linear is 32 -> 1: h4s = dv * (x3 . w4) -> column 0 of Ht1 -------------------------------
+  for (int t = tid; t < 96 * 4 * K32; t += FD_THREADS) {        // (only column 0 is rewritten below)
+    const int pc = t / (4 * K32), piece = t - pc * (4 * K32);
+    *reinterpret_cast<uint4*>(Ht1 + pc * FD_ROW + 8 * piece) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (live) {
+    aggregate32(Ht0, b3c0, b3c1);
+    dgd_wave_sync();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = p * 8 + (lane >> 3), q = lane & 7;
+      const float4 v = *reinterpret_cast<const float4*>(xt + row * DGD_XT + 4 * q);
+      if (row < rows_live) *reinterpret_cast<float4*>(x3 + (size_t)(n0 + m0 + row) * 32 + 4 * q) = v;
+    }
+    const int row = lane >> 2, seg = lane & 3;
+    const float4 va = *reinterpret_cast<const float4*>(xt + row * DGD_XT + 8 * seg);
+    const float4 vb = *reinterpret_cast<const float4*>(xt + row * DGD_XT + 8 * seg + 4);
+    float p = va.x * w4v[0];
+    p = fmaf(va.y, w4v[1], p); p = fmaf(va.z, w4v[2], p); p = fmaf(va.w, w4v[3], p);
+    p = fmaf(vb.x, w4v[4], p); p = fmaf(vb.y, w4v[5], p); p = fmaf(vb.z, w4v[6], p); p = fmaf(vb.w, w4v[7], p);
+    p += __shfl_xor(p, 1);
+    p += __shfl_xor(p, 2);
+    dgd_wave_sync();
+    if (seg == 0) xt[row] = row < rows_live ? dv[m0 + row] * p : 0.f;      // h4s of the tile's 16 rows
+  }
+  dg_lds_barrier();                      // Ht1 cleared by everyone, h4s tiles written
+  if (live && lane < 4) {                // lane l: rows 4l .. 4l+3 of the tile -> column 0, three parts
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = xt[4 * lane + i];
+    fd_store_hs4(Ht1, 0, m0 + 4 * lane, v);
+  }
+  dg_lds_barrier();
+  FD_MARK(5);
+
+  // ---- conv4 (32 -> 1): x4 = tanh(dv * (bits . h4s) + b4): sort keys in LDS + the saved slab --------------------------
+  if (live) {
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int u = 0; u < FD_KW; ++u)
+      if (u < K32 && __builtin_amdgcn_ballot_w64(wb[u] != 0u) != 0ull) dgd_mma_word<1, 3, FD_ROW>(wb[u], Ht1, 32 * u, lane, tab, acc);
+    if (nl == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + kq * 4 + r;
+        if (m < n) { const float v4 = dg_tanh(fmaf(dpre[r], acc[0][r], b4s)); x4s[m] = v4; x4[n0 + m] = v4; }
+      }
+    }
+  }
+  __syncthreads();      // full barrier: x1..x4 of this graph are complete and visible to this workgroup
+  FD_MARK(6);
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[7] = dbg[6];
+
+  // ---- SortPooling + dense tail (keys from LDS, rows from the slabs just written); region0 aliases the hs buffers ----
+  const RdSmem M = dg_rd_carve(smem, small);
+  dg_readout_fwd_body(M, b, n0, n, C, tw, x4s, 0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp, training, seed, dbg);
+#ifdef DGD_TIMING
+  if (dbg && tid == 0) { dbg[16 + 2 * b] = clock64() - tstart_; dbg[17 + 2 * b] = n; }
+#endif
+}
+
+#define FD_LDS_BYTES (2 * FD_HT * 2 + (FD_NMAX / 16) * 16 * DGD_XT * 4 + FD_NMAX * FD_KW * 4 + 2 * FD_NMAX * 4 + 16 * 8 + 3 * 32 * FD_WS * 4 + RD_SMALL_BYTES + 64)
+
+int dg_fused_d_max_nodes() { return FD_NMAX; }
+
+int dg_launch_fused_fwd_d(int N, int B, int F, int C, const float* params, const DgParams* pl, const float* x,
+                          const int32_t* rowptr, const int32_t* colidx, const float* dinv, const int32_t* graph_ptr, float* ax,
+                          float* x1, float* x2, float* x3, float* x4, float* pooled, int32_t* perm, float* a5, float* a6,
+                          float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed, int32_t* err, uint32_t epoch,
+                          hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (N <= 0 || B <= 0 || F < 1 || F > DG_AF_MAX_F) return DGCNN_EINVAL;
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  static_assert(2 * FD_HT * 2 >= RD_REGION0_BYTES, "the readout's region aliases the hs buffers");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_fwd_d), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            FD_LDS_BYTES) != hipSuccess)
+      return DGCNN_ELAUNCH;
+    attr_set = true;
+  }
+  FdW gw;
+  gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
+  gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
+  hipExtLaunchKernelGGL(k_fused_fwd_d, dim3(B + rd.nblk), dim3(FD_THREADS), FD_LDS_BYTES, s, ev_start, ev_stop, 0, F, C, gw,
+                        dg_tail_w(params, pl), x, rowptr, colidx, dinv, graph_ptr, ax, x1, x2, x3, x4, pooled, perm, a5, a6, a1d,
+                        drop_mask, logp, training, seed, reinterpret_cast<unsigned int*>(err), epoch, dg_debug_buffer(), B, rd);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
 }
 
 // =================================================================================================================

@@ -130,3 +130,74 @@ def test_dense_results_do_not_depend_on_batch_composition_and_are_reproducible()
         assert torch.equal(torch.cat(parts), lp1)
         rev = m(collate(graphs[::-1]).to("cuda")).clone()
         assert torch.equal(rev.flip(0), lp1)
+
+
+# ---- fused dense forward: one workgroup per graph, conv1..conv4 + readout in one launch (small batches) ----------
+FUSED_WORKLOADS = [("MUTAG", 50), ("PROTEINS", 20), ("COLLAB", 50), ("COLLAB_REAL", 30), ("IMDB", 50), ("COLLAB", 1), ("COLLAB", 128)]
+
+
+@pytest.mark.parametrize("name,bs", FUSED_WORKLOADS, ids=[f"{w[0]}-{w[1]}" for w in FUSED_WORKLOADS])
+def test_fused_dense_forward_vs_oracle_and_backward_through_it(name, bs):
+    sh = synth.SHAPES[name]
+    start = 1000
+    b = synth.make_batch(name, bs, start=start)
+    while b.max_nodes > 192:
+        start += bs
+        b = synth.make_batch(name, bs, start=start)
+    m = make_model(sh.num_features, sh.num_classes)
+    sd = cpu_state_dict(m)
+    m.use_fused, m.agg_mode = True, "dense"
+    check_forward_parity(m, b, sd)
+    xf = gpu_xcat(m)
+    m.use_fused, m.agg_mode = False, "sparse"
+    check_forward_parity(m, b, sd)
+    assert float((xf - gpu_xcat(m)).abs().max()) <= 4e-6
+    m.use_fused, m.agg_mode = True, "dense"
+    check_backward_parity(m, b, sd)          # backward (tiled kernels) from the activations the fused forward saved
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 7, 13, 16, 17, 32])
+def test_fused_dense_raw_feature_widths(F):
+    base = synth.make_batch("COLLAB" if F % 2 else "PROTEINS", 12, start=77)
+    g = torch.Generator().manual_seed(F)
+    b = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
+              base.coalesced_undirected, base.max_nodes, base.max_edges)
+    m = make_model(F, 3)
+    m.use_fused, m.agg_mode = True, "dense"
+    sd = cpu_state_dict(m)
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
+
+
+def test_fused_dense_reproducible_composition_independent_and_pipelined():
+    """the one-launch forward (opt-in: FORCE_FUSED + AGG_DENSE): results are bit-identical run to run, for any batch
+    composition and graph order, and the trainer's pipelined step (graph prep of the next batch riding on the fused
+    launch) reproduces the unpipelined one bit for bit"""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    graphs = synth.make_graphs("COLLAB", 96, start=700)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.eval()
+    with torch.no_grad():
+        full = collate(graphs).to("cuda")
+        m.use_fused, m.agg_mode = True, "dense"
+        lp = m(full).clone()
+        xa = gpu_xcat(m)
+        assert torch.equal(m(full), lp) and torch.equal(gpu_xcat(m), xa)
+        parts = [m(collate(graphs[k:k + 24]).to("cuda")).clone() for k in range(0, 96, 24)]
+        assert torch.equal(torch.cat(parts), lp)
+        assert torch.equal(m(collate(graphs[::-1]).to("cuda")).flip(0), lp)
+    m.check_errors()
+    batches = [collate(graphs[k:k + 32]).to("cuda") for k in range(0, 96, 32)]
+    res = []
+    for look in (False, True):
+        mm = make_model(sh.num_features, sh.num_classes)
+        mm.train(); mm._seed_base, mm._fwd_count = 5, 0
+        mm.use_fused, mm.agg_mode = True, "dense"
+        tr = Trainer(mm)
+        for k in range(6):
+            tr.train_step(batches[k % 3], batches[k % 3].y, next_data=batches[(k + 1) % 3] if look else None)
+        torch.cuda.synchronize()
+        tr.read_metrics()
+        res.append(mm.flat_params.clone())
+    assert torch.equal(res[0], res[1])
