@@ -251,12 +251,14 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
 }
 
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
-// *rode = 1 when it was attached)
+// *rode = 1 when it was attached).  tt != null (training step with labels): the readout forward and the readout
+// backward run as ONE launch when the batch allows it; *tail_done = 1 then tells the backward to skip its first launch.
+struct DgTrainTail { const int64_t* y; float loss_scale; };
 static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float* params,
                                  const float* x, const int64_t* edge_index, const int64_t* batch,
                                  void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                                  int max_edges, uint32_t epoch, dgcnn_stream_t stream, const DgPrepRider* rider_a,
-                                 int* rode) {
+                                 int* rode, const DgTrainTail* tt = nullptr, int* tail_done = nullptr) {
   if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (E > 0 && !edge_index) return DGCNN_EINVAL;
   DgParams pl; DgWs wl;
@@ -358,6 +360,20 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   g_prof_which = -1;
   DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
   }
+  if (tt && tail_done && !dense && B <= dg_readout_tail_max_b()) {
+    // training step: readout forward + backward in one launch (operands of the backward stay on the CU that made them)
+    DG_TRY(dg_launch_readout_tail(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
+                                  dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
+                                  dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp,
+                                  training, seed, dinv, tt->y, tt->loss_scale, dg_ptr<float>(ws, wl.dlogit),
+                                  dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.gz5),
+                                  dg_ptr<float>(ws, wl.gp1), dg_ptr<float>(ws, wl.gp2), dg_ptr<float>(ws, wl.gp3),
+                                  dg_ptr<float>(ws, wl.gas4), dg_ptr<float>(ws, wl.gb4p), dg_ptr<float>(ws, wl.lossv),
+                                  dg_ptr<float>(ws, wl.ptail), s, rider_a));
+    *tail_done = 1;
+    if (rider_a && rode) *rode = 1;
+    return DGCNN_OK;
+  }
   // SortPooling + the whole dense tail: one launch, one workgroup per graph
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
@@ -378,7 +394,8 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
                                   float loss_scale, int training, float* grads, float* metrics,
-                                  const DgAdam* adam, hipStream_t s, bool dense, const DgPrepRider* rider_b = nullptr) {
+                                  const DgAdam* adam, hipStream_t s, bool dense, const DgPrepRider* rider_b = nullptr,
+                                  bool tail_done = false) {
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -390,6 +407,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   const float *x1 = dg_cptr<float>(ws, wl.x1), *x2 = dg_cptr<float>(ws, wl.x2), *x3 = dg_cptr<float>(ws, wl.x3),
               *x4 = dg_cptr<float>(ws, wl.x4);
 
+  if (!tail_done)
   DG_TRY(dg_launch_tail_bwd(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm),
                             dinv, x4, dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6),
                             dg_cptr<float>(ws, wl.a1d), logp, glogp, y, loss_scale, training,
@@ -414,7 +432,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, tail_done ? rider_b : nullptr));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
                              dg_ptr<float>(ws, wl.pb3), wl.P32, s));
@@ -528,10 +546,12 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B), 1024);
     rider = &rd;
   }
-  int rode = 0;
+  int rode = 0, tail_done = 0;
+  DgTrainTail tt;
+  tt.y = cur->y; tt.loss_scale = cur->loss_scale;
   DG_TRY(dg_model_forward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->edge_index, cur->batch,
                                cur->ws, cur->logp, cur->training, cur->seed, flags, cur->max_nodes, cur->max_edges,
-                               epoch, stream, rider, &rode));
+                               epoch, stream, rider, &rode, &tt, &tail_done));
   DgAdam ad;
   const DgAdam* adam = nullptr;
   if (cur->exp_avg) {
@@ -541,7 +561,8 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   }
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
-                                dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr));
+                                dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr,
+                                tail_done != 0));
   if (next) {
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
     if (!rode)

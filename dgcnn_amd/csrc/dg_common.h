@@ -433,7 +433,15 @@ int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, cons
                        const float* h4s, const float* bias, float* x4, hipStream_t s);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s);
+                       float* gas3, float* pa4, int P1, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+// readout forward + readout backward of a training step (labels) as ONE launch (tail.hip)
+int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled, int32_t* perm,
+                           float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed,
+                           const float* dinv, const int64_t* y, float loss_scale, float* dlogit, float* gz1, float* gz6,
+                           float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
+                           float* ptail, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+int dg_readout_tail_max_b();
 // which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,

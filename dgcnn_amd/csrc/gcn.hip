@@ -22,6 +22,7 @@
 //     dL/dx_prev = gh . W       (MFMA)            dL/dW += gh^T . x_prev   (MFMA, K = nodes)
 // with per-workgroup partial weight gradients reduced later in a fixed order (no fp atomics).
 #include "dg_common.h"
+#include "dg_prep.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 // Gather depth = row loads in flight per wavefront.  Few tiles (the reference's batch of 50: one workgroup per CU,
@@ -512,13 +513,20 @@ __global__ void __launch_bounds__(1024)
 k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
-           float* __restrict__ pa4) {
+           float* __restrict__ pa4, int P1, DgPrepRider rd) {
+  if ((int)blockIdx.x >= P1) {   // rider range: phase B of the NEXT batch's graph preparation, when the step's readout
+                                 // forward + backward ran as one launch (k_readout_tail carried phase A)
+    dg_prep_fast_b_body(((int)blockIdx.x - P1) * 1024 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
+                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap);
+    if (rd.dmap && (int)blockIdx.x == P1) dg_prep_dense_plan((int)threadIdx.x, 1024, rd.B, rd.graph_ptr, rd.dmap);
+    return;
+  }
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & 31;
   const float w4c = W4[c];
   float pW = 0.f, pb = 0.f;
-  for (int j = blockIdx.x * 16 + w; j < N; j += gridDim.x * 16) {
+  for (int j = blockIdx.x * 16 + w; j < N; j += P1 * 16) {
     const int start = rowptr_t[j], end = rowptr_t[j + 1];
     // issue everything that does not depend on the gather before it
     float xv = 0.f, gpv = 0.f;
@@ -550,10 +558,12 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
 
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s) {
+                       float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
-  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
-                     pa4);
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rd.nblk), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
+                     pa4, P1, rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

@@ -135,24 +135,18 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
 // BIG (many graphs): classifier_1's weights are NOT prefetched into 64 registers at kernel start but read in 4-row
 // chunks at their use (they are L2-resident when thousands of workgroups stream the same 180 KB), and the registers
 // are capped at 64 so that two workgroups share a CU.  Same arithmetic order: bit-identical results.
+// body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
+// training kernel k_readout_tail (forward readout + this, one launch)
 template <bool BIG>
-__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
-k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
-           const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
-           const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
-           const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
-           float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
-           float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
-           float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
-  if ((int)blockIdx.x >= B) {    // rider range: phase B of the NEXT batch's graph preparation (phase A rode on the
-                                 // readout launch of this step's forward, complete by now)
-    dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
-                        rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
-                        rd.dmap);
-    if (rd.dmap && (int)blockIdx.x == B) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
-    return;
-  }
+__device__ __forceinline__ void dg_tail_bwd_body(
+    int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+    const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
+    const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
+    const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
+    float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
+    float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
+    float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
+    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg) {
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
   __shared__ float W5s[NW5];
@@ -412,6 +406,80 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
     gb4p[b] = sum;
   }
 }
+
+template <bool BIG>
+__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
+k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+           const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
+           const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
+           const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
+           float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
+           float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
+           float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
+           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {    // rider range: phase B of the NEXT batch's graph preparation (phase A rode on the
+                                 // readout launch of this step's forward, complete by now)
+    dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
+                        rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
+                        rd.dmap);
+    if (rd.dmap && (int)blockIdx.x == B) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
+    return;
+  }
+  dg_tail_bwd_body<BIG>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, glogp, y, loss_scale, training, dlogit, gz1g,
+                        gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training steps with labels: readout forward and readout backward of a graph need nothing of any other graph (the
+// NLL-mean scale 1/B is a constant), so ONE launch runs both per graph -- one dispatch and one cold-read chain fewer
+// per step (the backward's operands were written by this very workgroup, on this CU).  Rider range: phase A of the next
+// batch's graph preparation, as on k_readout_fwd; phase B then rides on the conv4-backward launch.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
+               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
+               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
+               float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training, uint64_t seed,
+               const float* __restrict__ dinv, const int64_t* __restrict__ y, float loss_scale,
+               float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g, float* __restrict__ gz5g,
+               float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3, float* __restrict__ gas4,
+               float* __restrict__ gb4p, float* __restrict__ lossv, float* __restrict__ ptail, unsigned long long* dbg,
+               int B, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {
+    dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
+                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
+    return;
+  }
+  {
+    __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
+    __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
+    const RdSmem M = dg_rd_carve(region0, small);
+    const int b = blockIdx.x;
+    const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+    dg_readout_fwd_body(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp, training, seed,
+                        nullptr);
+  }
+  __syncthreads();        // (full barrier, vmcnt(0): this graph's logp / activations / pooled rows / perm are written)
+  dg_tail_bwd_body<false>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training, dlogit,
+                          gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+}
+
+int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled, int32_t* perm,
+                           float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed,
+                           const float* dinv, const int64_t* y, float loss_scale, float* dlogit, float* gz1, float* gz6,
+                           float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
+                           float* ptail, hipStream_t s, const DgPrepRider* rider) {
+  if (B <= 0 || B >= DG_TAIL_BIG_MIN_B || N <= 0 || C < 1 || C > DGCNN_MAX_C || !y) return DGCNN_EINVAL;
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  hipLaunchKernelGGL(k_readout_tail, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2, x3,
+                     x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dinv, y, loss_scale, dlogit, gz1, gz6, gz5,
+                     gp1, gp2, gp3, gas4, gb4p, lossv, ptail, dg_debug_buffer(), B, rd);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+int dg_readout_tail_max_b() { return DG_TAIL_BIG_MIN_B - 1; }
 
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
