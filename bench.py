@@ -433,7 +433,11 @@ def main():
             ms_large = 1e3 * (time.perf_counter() - t1) / nl2
             _, avg2, bpl2, ach2, n2_ = measure_agg(tr2, lb, lb_cpu, 60)
             gb = gb_keep
-            roofline_large = {"bound": "hbm", "batch": LB, "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kn2, tr2_, src2 = committed_pmc_traffic(LB)
+            roofline_large = {"bound": "hbm", "batch": LB, "kernel": "k_gcn_fwd32d (dense per-graph block form: bit-packed adjacency x bf16x3-split rows on "
+                              "v_mfma_f32_16x16x32_bf16, exact in fp32) when the library's cost model picks it, else k_gcn_fwd32p",
+                              "traffic": tr2_, "traffic_source": None if tr2_ is None else f"committed {src2}, kernel {kn2}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch",
+                              "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl2, "avg_launch_us": avg2,
                               "launches_measured": n2_, "step_ms": ms_large, "graphs_per_s": LB / (ms_large * 1e-3),
                               "note": f"same code, {LB} {args.workload}-shape graphs per step (secondary figure; the headline "

@@ -6,7 +6,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   rocprofv3 --pmc $C --kernel-trace --truncate-kernels --output-format csv -d $OUT/pmc_${TAG}_$C -o p -- \
-      python $R/bench.py "$@" --no-cpu-baseline --no-roofline > $OUT/pmc_${TAG}_$C.log 2>&1
+      python $R/bench.py "$@" --no-cpu-baseline --no-roofline --no-pmc --large-batch 0 --steps 60 --warmup 10 --pool 8 > $OUT/pmc_${TAG}_$C.log 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, json, collections
@@ -24,8 +24,9 @@ for c in os.environ.get("PMC_COUNTERS", "FETCH_SIZE WRITE_SIZE").split():
     for k, (v, n) in acc.items():
         res.setdefault(k, {})[c] = v / n
         res[k]["dispatches"] = n
+res["_git"] = os.environ.get("GIT_HASH", "unknown")
 json.dump(res, open(f"{out}/pmc_{tag}.json", "w"), indent=1)
-for k, d in sorted(res.items()):
+for k, d in sorted((k, d) for k, d in res.items() if isinstance(d, dict)):
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         fs, wsz = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
         print(f"{k:22s} n={d['dispatches']:5d} FETCH_SIZE={fs:10.1f} KB  WRITE_SIZE={wsz:10.1f} KB  -> (2*F+W)*1024 = {(2*fs+wsz)*1024/1e6:8.2f} MB")
