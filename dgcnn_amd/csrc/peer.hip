@@ -1,0 +1,123 @@
+// peer.hip -- one-shot gradient all-reduce + Adam over peer-mapped buffers (data parallel).
+//
+// The reference is single-device (/root/reference/train.py:75-79).  Data parallel, the step needs ONE exchange: the sum of
+// the ranks' flat gradients (208 KB), followed by the identical Adam update on every replica (train.py:41).  Adam must
+// precede the next forward, so the exchange cannot hide behind compute; what can go is the collective library's call
+// overhead and the separate optimizer launch (+12 us at one rank).  Here every rank's gradient buffer
+// lives in fine-grained device memory that all ranks of the node map (hipIpc handles; xGMI peer access between GPUs, the
+// same mapping between two processes of one GPU), and ONE kernel per rank
+//     publishes "my gradient of step s is complete"      (system-scope release store of the step tag; the gradient was
+//                                                          written by the previous kernel of this stream)
+//     waits for the same tag of every peer                (bounded poll, acquire)
+//     sums the R gradients in RANK ORDER                  (every rank forms the identical fp32 sum: replicas stay bit-equal)
+//     applies Adam to its replica                         (same arithmetic as k_adam, tail.hip)
+// Gradient buffers are double-buffered by step parity: a rank that runs ahead writes step s+1's gradient into the other
+// buffer, and cannot reach step s+2 before every peer has published s+1, i.e. finished reading step s.
+// No hardware here has more than one GPU: the 2-process-on-one-GPU test (tests/test_dist_gloo.py) checks the kernel
+// bit for bit against the all_reduce + dgcnn_adam_step route; no multi-GPU timing exists (DESIGN.md §5 says so).
+#include "dg_common.h"
+
+#define DG_PEER_MAX 16
+struct DgPeers {
+  const float* grad[DG_PEER_MAX];
+  unsigned int* flag[DG_PEER_MAX];
+};
+
+__global__ void __launch_bounds__(256)
+k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __restrict__ params, float* __restrict__ m,
+                 float* __restrict__ v, float* __restrict__ gsum_out, int64_t n, float lr, float b1, float b2, float eps,
+                 float bc1, float bc2_sqrt, unsigned int* __restrict__ err) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0)
+      __hip_atomic_store(P.flag[rank], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    int good = 1;
+    for (int r = 0; r < world; ++r) {
+      if (r == rank) continue;
+      int spins = 0;
+      // tags only grow: wait until the peer's tag has reached ours (a peer may already be one step ahead)
+      while ((int)(__hip_atomic_load(P.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1 << 24)) { good = 0; break; }         // bounded: a lost peer must not hang the GPU
+      }
+    }
+    if (!good) err[0] = tag;
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = 0.f;
+  for (int r = 0; r < world; ++r)                              // fixed rank order on every rank
+    g += __builtin_nontemporal_load(P.grad[r] + i);
+  if (gsum_out) gsum_out[i] = g;
+  const float mi = b1 * m[i] + (1.f - b1) * g;
+  const float vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  params[i] = params[i] - (lr / bc1) * (mi / denom);
+}
+
+extern "C" {
+
+int dgcnn_peer_alloc(int64_t bytes, void** dev_ptr, void* ipc_handle64) {
+  if (bytes <= 0 || !dev_ptr || !ipc_handle64) return DGCNN_EINVAL;
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle fits the 64-byte slot");
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc(&p, (size_t)bytes) != hipSuccess) return DGCNN_ELAUNCH;
+  }
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess) { (void)hipFree(p); return DGCNN_ELAUNCH; }
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) { (void)hipFree(p); return DGCNN_ELAUNCH; }
+  memset(ipc_handle64, 0, 64);
+  memcpy(ipc_handle64, &h, sizeof(h));
+  *dev_ptr = p;
+  return DGCNN_OK;
+}
+
+int dgcnn_peer_open(const void* ipc_handle64, void** dev_ptr) {
+  if (!ipc_handle64 || !dev_ptr) return DGCNN_EINVAL;
+  hipIpcMemHandle_t h;
+  memcpy(&h, ipc_handle64, sizeof(h));
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return DGCNN_ELAUNCH; }
+  *dev_ptr = p;
+  return DGCNN_OK;
+}
+
+int dgcnn_peer_close(void* dev_ptr) {
+  if (!dev_ptr) return DGCNN_EINVAL;
+  return hipIpcCloseMemHandle(dev_ptr) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
+}
+
+int dgcnn_peer_free(void* dev_ptr) {
+  if (!dev_ptr) return DGCNN_EINVAL;
+  return hipFree(dev_ptr) == hipSuccess ? DGCNN_OK : DGCNN_ELAUNCH;
+}
+
+int dgcnn_allreduce_adam_step(int world, int rank, const float* const* peer_grads, unsigned int* const* peer_flags,
+                              uint32_t tag, float* params, float* exp_avg, float* exp_avg_sq, float* grad_sum_out, int64_t n,
+                              int64_t step, float lr, float beta1, float beta2, float eps, uint32_t* err,
+                              dgcnn_stream_t stream) {
+  if (world < 1 || world > DG_PEER_MAX || rank < 0 || rank >= world || !peer_grads || !peer_flags || !params || !exp_avg ||
+      !exp_avg_sq || !err || n <= 0 || step < 1 || tag == 0)
+    return DGCNN_EINVAL;
+  DgPeers P;
+  memset(&P, 0, sizeof(P));
+  for (int r = 0; r < world; ++r) {
+    if (!peer_grads[r] || !peer_flags[r]) return DGCNN_EINVAL;
+    P.grad[r] = peer_grads[r]; P.flag[r] = peer_flags[r];
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_allreduce_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, world, rank,
+                     tag, params, exp_avg, exp_avg_sq, grad_sum_out, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
+                     err);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+}  // extern "C"

@@ -109,3 +109,96 @@ def flatten_grads(params: Sequence[torch.nn.Parameter]) -> Tuple[torch.Tensor, L
 def unflatten_grads(flat: torch.Tensor, metas, params: Sequence[torch.nn.Parameter]) -> None:
     for p, (off, n, shape) in zip(params, metas):
         p.grad = flat[off:off + n].view(shape).clone()
+
+
+class _RawCudaBuffer:
+    """``__cuda_array_interface__`` over foreign device memory, so that torch can view it (no ownership)"""
+
+    def __init__(self, ptr: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class PeerExchange:
+    """One-shot gradient all-reduce + Adam over peer-mapped memory (``dgcnn_allreduce_adam_step``, csrc/peer.hip).
+
+    Every rank allocates [flag block 64 B | gradient buffer 0 | gradient buffer 1] in fine-grained device memory, the
+    ranks swap the IPC handles through the process group (any backend: the handles are 64 opaque bytes) and map each
+    other's blocks -- peers on other GPUs of the node over xGMI, or, as in the tests of this repository (one GPU), another
+    process on the same device.  The weight-gradient kernel writes straight into the current buffer; ONE launch per rank
+    then replaces ``all_reduce`` + the optimizer launch.  No multi-GPU hardware was available to time it:
+    it is opt-in (``Trainer(..., one_shot=True)``), RCCL stays the default.
+    """
+
+    HDR = 64
+
+    def __init__(self, numel: int, process_group=None, device=None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        L = _lib.lib()
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.numel = int(numel)
+        self.stride = ((self.numel * 4 + 255) // 256) * 256
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        nbytes = self.HDR + 2 * self.stride
+        own = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(L.dgcnn_peer_alloc(nbytes, ctypes.byref(own), handle), "dgcnn_peer_alloc")
+        self._own = own.value
+        handles = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(handles, bytes(handle.raw), group=process_group)
+        else:
+            handles[0] = bytes(handle.raw)
+        self._bases, self._opened = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                self._bases.append(self._own)
+                continue
+            p = ctypes.c_void_p()
+            hb = ctypes.create_string_buffer(handles[r], 64)
+            _lib.check(L.dgcnn_peer_open(hb, ctypes.byref(p)), f"dgcnn_peer_open(rank {r})")
+            self._bases.append(p.value)
+            self._opened.append(p.value)
+        arr = ctypes.c_void_p * self.world
+        self._flags = arr(*[b for b in self._bases])
+        self._grads = [arr(*[b + self.HDR + par * self.stride for b in self._bases]) for par in (0, 1)]
+        self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._views = [torch.as_tensor(_RawCudaBuffer(self._own + self.HDR + par * self.stride, self.numel),
+                                       device=self.device) for par in (0, 1)]
+        if self.world > 1:
+            dist.barrier(group=process_group)          # everybody has mapped everybody before the first step
+
+    def grad_ptr(self, parity: int) -> int:
+        return self._own + self.HDR + (parity & 1) * self.stride
+
+    def grad_tensor(self, parity: int) -> torch.Tensor:
+        return self._views[parity & 1]
+
+    def step(self, tag: int, params: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, adam_step: int,
+             lr: float, betas, eps: float, stream: int, grad_sum_out: Optional[torch.Tensor] = None) -> None:
+        """sum of every rank's buffer ``tag & 1`` in rank order + Adam on this replica; ``tag`` = 1, 2, 3, ..."""
+        rc = self._lib.lib().dgcnn_allreduce_adam_step(
+            self.world, self.rank, self._grads[tag & 1], self._flags, tag, params.data_ptr(), exp_avg.data_ptr(),
+            exp_avg_sq.data_ptr(), None if grad_sum_out is None else grad_sum_out.data_ptr(), self.numel, adam_step,
+            lr, betas[0], betas[1], eps, self.err.data_ptr(), stream)
+        self._lib.check(rc, "dgcnn_allreduce_adam_step")
+
+    def check(self) -> None:
+        """host-side check (a sync): did a peer fail to arrive within the kernel's bounded wait?"""
+        if int(self.err[0].item()) != 0:
+            raise self._lib.DgcnnError("one-shot all-reduce: a peer never published its gradient (lost rank?)")
+
+    def close(self) -> None:
+        L = self._lib.lib()
+        if getattr(self, "_own", None) is None:
+            return
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.pg)                # nobody still reads a buffer that is about to go away
+        for p in self._opened:
+            L.dgcnn_peer_close(p)
+        L.dgcnn_peer_free(self._own)
+        self._own, self._opened = None, []

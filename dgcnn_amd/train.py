@@ -44,7 +44,7 @@ class Trainer:
     ARGS_CACHE_MAX = 128
 
     def __init__(self, model: Model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, force_collective: bool = False):
+                 process_group=None, force_collective: bool = False, one_shot: bool = False):
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.pg = process_group
@@ -57,6 +57,10 @@ class Trainer:
             import torch.distributed as dist
             self._dp_world = dist.get_world_size(process_group)
         self._err_checked = model._epoch      # forward tag up to which input errors have been surfaced
+        # one-shot exchange (dgcnn_amd.dist.PeerExchange): gradients land in peer-mapped memory, ONE kernel per rank sums
+        # them in rank order and applies Adam -- instead of all_reduce + dgcnn_adam_step.  Opt-in (no multi-GPU timing yet).
+        self._one_shot = bool(one_shot) and self._allreduce is not None
+        self._peer = None
         self.step_count = 0
         flat = model.flat_params
         self.exp_avg = torch.zeros_like(flat)
@@ -76,6 +80,12 @@ class Trainer:
         self._args_cache = {}    # id(batch) -> (batch, y, StepArgs, ws bytes, keep-alive tensors, dims)
         self._prep_ent = None    # cache entry of the batch whose graph structure the last pipelined call prepared
         self._prep_slot = 0
+
+    def close(self) -> None:
+        """release the peer-mapped exchange block (collective: every rank calls it)"""
+        if self._peer is not None:
+            self._peer.close()
+            self._peer = None
 
     def __del__(self):
         try:
@@ -233,6 +243,8 @@ class Trainer:
             self._logp_views = {}
         training = 1 if m.training else 0
         a.ws, a.logp, a.params, a.grads, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_grads, self._p_metrics
+        if self._peer is not None and not fuse_adam:          # one-shot route: this step's buffer of the exchange block
+            a.grads = self._peer.grad_ptr(self.step_count + 1)
         a.training = training
         a.seed = m._next_seed() if training else 0
         a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags()
@@ -283,6 +295,17 @@ class Trainer:
             # every rank would scale by 1/B_local and the SUM all-reduce would yield world_size times the gradient.
             # One tiny all-reduce + host sync; loops with a static split pass `global_batch` and skip it.
             global_batch = self._allreduce.global_batch(_batch_size_of(data), data.x.device)
+        if self._one_shot:
+            if self._peer is None:
+                from .dist import PeerExchange
+                self._peer = PeerExchange(self.model.flat_params.numel(), self.pg, data.x.device)
+            logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
+            self.step_count += 1
+            flat = self.model.flat_params_fast()
+            dev = flat.device
+            self._peer.step(self.step_count, flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas,
+                            self.eps, torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+            return logp
         logp = self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False)
         self._allreduce(self.grads)
         self.optimizer_step()
@@ -355,6 +378,8 @@ class Trainer:
             self.model.check_errors([(sl["ws"], sl.get("dims")) for sl in self._slots if sl.get("dims")],
                                     since=self._err_checked)
             self._err_checked = self.model._epoch
+        if self._peer is not None:
+            self._peer.check()
         if v[0] != v[0]:
             raise _lib.DgcnnError("non-finite loss: a label outside [0, num_classes) or diverged parameters")
         return float(v[0]), float(v[1])

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 13
+#define DGCNN_ABI_VERSION 14
 
 /* error codes */
 #define DGCNN_OK            0
@@ -369,6 +369,28 @@ int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_
                       void* ev_uploaded, int64_t Etot, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
                       const int64_t* edge_ptr, const int64_t* y_all, int64_t cap_nodes, int64_t cap_edges, float* x,
                       int64_t* edge_index, int64_t* batch, int64_t* y, int64_t* out_sizes, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Data parallel, one-shot exchange (the reference has no multi-GPU code, train.py:75-79): the ranks'
+ * flat gradients live in peer-mapped fine-grained device memory and ONE kernel per rank sums them in rank order and
+ * applies Adam to its replica -- it replaces `all_reduce(grads)` + dgcnn_adam_step (= `optimizer.step()`, train.py:41).
+ *   dgcnn_peer_alloc : allocate `bytes` of exchange memory (zeroed) and return its 64-byte IPC handle; the owner lays out
+ *                      [flag u32 x16 | gradient buffer 0 | gradient buffer 1] (buffers alternate by step parity)
+ *   dgcnn_peer_open  : map a peer's handle (another process: another GPU of the node, or the same GPU)
+ *   dgcnn_allreduce_adam_step: peer_grads[r] / peer_flags[r] (HOST arrays of device pointers, r < world; entry `rank` is
+ *                      the caller's own) -- publishes `tag` (non-zero, strictly increasing per step) in the own flag,
+ *                      waits (bounded) for every peer's tag, g = sum_r peer_grads[r] in rank order, Adam as
+ *                      dgcnn_adam_step.  grad_sum_out (optional) receives g.  err[0] = tag if a peer never arrived.
+ * The own gradient must have been written by earlier work on `stream`.
+ * ---------------------------------------------------------------------------------- */
+int dgcnn_peer_alloc(int64_t bytes, void** dev_ptr, void* ipc_handle64);
+int dgcnn_peer_open(const void* ipc_handle64, void** dev_ptr);
+int dgcnn_peer_close(void* dev_ptr);
+int dgcnn_peer_free(void* dev_ptr);
+int dgcnn_allreduce_adam_step(int world, int rank, const float* const* peer_grads, unsigned int* const* peer_flags,
+                              uint32_t tag, float* params, float* exp_avg, float* exp_avg_sq, float* grad_sum_out, int64_t n,
+                              int64_t step, float lr, float beta1, float beta2, float eps, uint32_t* err,
+                              dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Metrics (stand-alone form of the `metrics` argument above): folds the per-graph loss /

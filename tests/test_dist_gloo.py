@@ -162,3 +162,49 @@ def test_two_rank_data_parallel_trainer_on_gpu_equals_single_rank():
     assert abs(ret["loss"] - loss) < 1e-4 * max(1.0, abs(loss)) and ret["correct"] == correct
     # same gradients up to summation order; six Adam steps of size 1e-3 amplify that to at most a few 1e-6
     torch.testing.assert_close(ret["params"], m.flat_params.detach().cpu(), rtol=1e-4, atol=1e-5)
+
+
+def _oneshot_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from dgcnn_amd import dist as ddist, synth
+    from dgcnn_amd.train import Trainer
+    from parity_util import make_model
+    ddist.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    sh = synth.SHAPES["PROTEINS"]
+    fulls = [synth.make_batch("PROTEINS", 14, start=500 + 14 * k) for k in range(3)]
+    shards = [ddist.shard_batch(f, rank, world).to("cuda") for f in fulls]
+    out = {}
+    for route in ("collective", "one_shot"):
+        m = make_model(sh.num_features, sh.num_classes, seed=324)
+        m.eval()
+        tr = Trainer(m, process_group=dist.group.WORLD, one_shot=(route == "one_shot"))
+        for k in range(7):
+            tr.train_step(shards[k % 3], shards[k % 3].y, global_batch=14, next_data=shards[(k + 1) % 3])
+        torch.cuda.synchronize()
+        tr.read_metrics()
+        out[route] = m.flat_params.detach().cpu().clone()
+        if route == "one_shot":
+            out["gsum"] = tr._peer.grad_tensor(7).detach().cpu().clone()      # own gradient of the last step (buffer 7 & 1)
+        tr.close()
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_one_shot_peer_allreduce_adam_equals_the_collective_route_bit_for_bit():
+    """dgcnn_allreduce_adam_step (gradients in hipIpc-mapped fine-grained memory, rank-ordered sum + Adam in one launch per
+    rank) against all_reduce + dgcnn_adam_step: two processes sharing the one GPU, 7 pipelined data-parallel steps --
+    identical parameters on both ranks and between the two routes, bit for bit (2 ranks: a + b is order-free)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_oneshot_worker, args=(2, port, ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert torch.equal(a["collective"], b["collective"]) and torch.equal(a["one_shot"], b["one_shot"])
+    assert torch.equal(a["one_shot"], a["collective"])
+    assert float(a["gsum"].abs().max()) > 0 and not torch.equal(a["gsum"], b["gsum"])       # ranks hold different shards
