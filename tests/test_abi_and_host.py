@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -192,3 +193,29 @@ def test_split_batch_partitions_graphs():
         assert int(p.edge_index.min()) >= 0 and int(p.edge_index.max()) < p.num_nodes
     with pytest.raises(ValueError):
         split_batch(b, 12)
+
+
+def test_host_side_of_the_library_under_address_sanitizer():
+    """SURVEY §5 / VERDICT r1 hygiene: one -fsanitize=address pass over the host side of the C ABI (layout queries, argument
+    validation, step-args plumbing, the host prefix sums of dgcnn_collate_ids), no GPU needed.  Builds the sanitizer
+    variant of the library once (tools/build_variant.sh) and runs tools/asan_host_check.py under the ASan runtime."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang) or shutil.which("make") is None:
+        pytest.skip("ROCm clang not present")
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("ASan runtime not present")
+    lib = os.path.join(root, "dgcnn_amd", "variants", "lib_asan.so")
+    srcs = [os.path.join(root, "dgcnn_amd", "csrc", f) for f in os.listdir(os.path.join(root, "dgcnn_amd", "csrc"))
+            if f.endswith((".hip", ".h"))] + [os.path.join(root, "include", "dgcnn_hip.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        r = subprocess.run(["bash", os.path.join(root, "tools", "build_variant.sh"), "asan", "-fsanitize=address -shared-libasan -g"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and os.path.exists(lib), r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_host_check.py"), lib], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert "ASAN_HOST_OK" in r.stdout and "AddressSanitizer" not in r.stderr, r.stdout[-1000:] + r.stderr[-3000:]
