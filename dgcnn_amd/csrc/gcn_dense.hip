@@ -254,13 +254,14 @@ __device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __rest
     if (cur.c == 0) body.begin_item(cur);
     if (cur.r0 + wave * 16 < cur.n) {
       const unsigned short* hb = Hs + p * DGD_BUF;
-      const int K32 = (cur.n + 31) >> 5;
+      // (words beyond the graph's last one were loaded as 0 for every row: the emptiness test covers them.  Fetching both
+      // words' operands before the first MFMA -- 48 more registers -- was measured: block-product phase 9.8 k -> 9.0 k
+      // cycles per workgroup, kernel time unchanged, one workgroup per CU less for the backward kernel; not kept)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (2 * cur.c + j < K32) {
-          const unsigned w = bits.cur[j];
-          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB, STAGE::PARTS>(w, hb, 32 * j, lane, tab, body.acc);
-        }
+      for (int j = 0; j < 2; ++j) {
+        const unsigned w = bits.cur[j];
+        if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB, STAGE::PARTS>(w, hb, 32 * j, lane, tab, body.acc);
+      }
     }
     DGD_T(2);                              // 2: block product
     st.store(Hs + (p ^ 1) * DGD_BUF, t); bits.commit();             // (waits for the rows requested one stage ago)
@@ -580,8 +581,7 @@ struct DgdBwd32Body {
   f32x4 acc[2];
   float dpre[4], gpp[2][4];
   float4 xr[2];
-  float axv[AF ? 8 : 1];
-  float wreg[2][8];                        // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
+  const float* Wlds;                       // W_l [32][33] in LDS: B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
   f32x4 accW[2][2], accA[2][2];
   float pb[2];
   const float *dinv, *xprev, *gpprev, *axin;
@@ -606,17 +606,18 @@ struct DgdBwd32Body {
       xr[p] = m < d.n ? *reinterpret_cast<const float4*>(xprev + (size_t)(d.n0 + m) * 32 + 4 * (lane & 7))
                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (AF) {
+  }
+  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
+    const int m0 = d.r0 + wave * 16, kq = lane >> 4, nl = lane & 15;
+    if (m0 >= d.n) return;
+    float axv[AF ? 8 : 1];
+    if (AF) {      // (requested here, not at the item's start: 8 registers less over the block product -> 2 workgroups per CU)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {          // ax tile [16][Fa]: element idx = lane + 64u -> (row idx / 32, col idx % 32)
         const int idx = lane + 64 * u, row = idx >> 5, col = idx & 31;
         axv[u] = (col < Fa && m0 + row < d.n) ? axin[(size_t)(d.n0 + m0 + row) * Fa + col] : 0.f;
       }
     }
-  }
-  __device__ __forceinline__ void end_item(const DgdStageDesc& d) {
-    const int m0 = d.r0 + wave * 16, kq = lane >> 4, nl = lane & 15;
-    if (m0 >= d.n) return;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -627,13 +628,16 @@ struct DgdBwd32Body {
     // gx = gh . W_l
     f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     {
-      float a[8];
+      float a[8], wv[2][8];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) a[kk] = ght[nl * DGD_XT + 4 * kk + kq];
+      for (int kk = 0; kk < 8; ++kk) {
+        a[kk] = ght[nl * DGD_XT + 4 * kk + kq];
+        wv[0][kk] = Wlds[(4 * kk + kq) * 33 + nl]; wv[1][kk] = Wlds[(4 * kk + kq) * 33 + 16 + nl];
+      }
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) gx[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wreg[nb][kk], gx[nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) gx[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wv[nb][kk], gx[nb], 0, 0, 0);
     }
     // dW_l += gh^T . x_prev : A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n], K = 16 nodes
     {
@@ -704,7 +708,7 @@ struct DgdBwd32Body {
 };
 
 template <bool AF>
-__global__ void __launch_bounds__(DGD_THREADS)
+__global__ void __launch_bounds__(DGD_THREADS) __attribute__((amdgpu_waves_per_eu(AF ? 2 : 4)))      // plain form: <= 128 registers, 2 workgroups per CU (forcing the AF form into 128 spills 35 registers: 51 -> ~95 us)
 k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
              const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
              float* __restrict__ part, const float* __restrict__ axin, int Fa, float* __restrict__ part1) {
@@ -716,10 +720,10 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
   body.ght = smem + DGD_BW_HF + wave * 2 * 16 * DGD_XT;
   body.xt = body.ght + 16 * DGD_XT;
   body.aux = body.xt;                         // AF: the ax tile [16][<=32] replaces x_prev once tanh' has read it
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) body.wreg[nb][kk] = Wl[(4 * kk + kq) * 32 + nb * 16 + nl];
+  __shared__ float Wlds[32 * 33];         // (registers: 16 fewer per lane -> two workgroups per CU)
+  for (int t = threadIdx.x; t < 1024; t += DGD_THREADS) Wlds[(t >> 5) * 33 + (t & 31)] = Wl[t];
+  body.Wlds = Wlds;
+  __syncthreads();
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
