@@ -38,7 +38,7 @@ static inline int dg_prep_fast_work(int E, int N, int B) {
 #define DGD_MAXN 512
 #define DGD_ROWS 128
 #define DGD_CLASSES 5
-#define DGD_SPLITS 1024
+#define DGD_SPLITS 3072
 #define DGD_REC0 (DGD_SPLITS + 8)
 static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }       // upper bound
 static inline int64_t dgd_table_ints(int N, int B) { return DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1); }

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _bitmap_reference(b):
-    """numpy restatement of dg_prep.h's dense structures: (words [31*N] u32, item records [(n0, n, r0)...], shares [1025])"""
+    """numpy restatement of dg_prep.h's dense structures: (words [31*N] u32, item records [(n0, n, r0)...], shares [3073])"""
     N, B = b.num_nodes, b.num_graphs
     ptr = np.searchsorted(b.batch.numpy(), np.arange(B + 1))
     words = np.zeros(31 * N, dtype=np.uint32)
@@ -30,11 +30,11 @@ def _bitmap_reference(b):
         for r in range((n + 127) // 128):            # items of 128 rows; cost = 3 * (pipeline stages of 64 k-rows) + 1
             recs.append((n0, n, 128 * r)); costs.append(3 * ((n + 63) // 64) + 1)
     tot = max(sum(costs), 1)
-    split = np.zeros(1025, dtype=np.int64)
+    split = np.zeros(3073, dtype=np.int64)
     c0 = 0
     for w, ic in enumerate(costs):
         c1 = c0 + ic
-        for k in range(c0 * 1024 // tot + 1, min(c1 * 1024 // tot, 1024) + 1):
+        for k in range(c0 * 3072 // tot + 1, min(c1 * 3072 // tot, 3072) + 1):
             split[k] = w + 1
         c0 = c1
     def setbit(i, j):
@@ -63,9 +63,9 @@ def test_dense_structures_bit_exact(name, bs):
     words, recs, split = _bitmap_reference(b)
     got_w = m.last_workspace_view("adjbits").cpu().numpy().view(np.uint32)[:31 * b.num_nodes]
     tab = m.last_workspace_view("dmap").cpu().numpy()
-    np.testing.assert_array_equal(tab[:1025], split)                       # equal-cost shares
-    assert tab[1025] == len(recs)
-    np.testing.assert_array_equal(tab[1032:1032 + 3 * len(recs)].reshape(-1, 3), recs)
+    np.testing.assert_array_equal(tab[:3073], split)                       # equal-cost shares
+    assert tab[3073] == len(recs)
+    np.testing.assert_array_equal(tab[3080:3080 + 3 * len(recs)].reshape(-1, 3), recs)
     # only the words of each row's OWN stride class are defined content (the other classes are never written)
     ptr = np.searchsorted(b.batch.numpy(), np.arange(b.num_graphs + 1))
     N = b.num_nodes
