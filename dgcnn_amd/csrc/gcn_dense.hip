@@ -126,10 +126,9 @@ __device__ __forceinline__ void dgd_split3(float h, unsigned& p0, unsigned& p1, 
   const float r2 = r1 - __uint_as_float(u1);                 // exact: <= 8 significant bits, i.e. a bf16 value
   p0 = u0 >> 16; p1 = u1 >> 16; p2 = __float_as_uint(r2) >> 16;
 }
-// Loads are issued UNCONDITIONALLY from base + constant row offsets (one address computation per stage) and rows at or
-// beyond the graph's end are zeroed by a select: the over-read stays inside the caller's workspace arena (<= 3 rows
-// past the last node of a slab that is never the arena's last region) and costs nothing, while predicated loads cost an
-// exec-mask branch and a 64-bit address computation each.
+// Loads are issued UNCONDITIONALLY (no exec-mask branch per row) from one base address per stage; rows at or beyond the
+// graph's end are zeroed by a select, and the row offset is clamped to the slab's last row (N - 1) so that the over-read
+// of up to 3 rows past the LAST graph of the batch never leaves the caller's buffer.
 template <int PARTS>
 __device__ __forceinline__ void dgd_store_col4(unsigned short* Ht, int c, int kb, const float (&v)[4]) {
   unsigned q[3][4];
@@ -146,22 +145,26 @@ __device__ __forceinline__ void dgd_store_col4(unsigned short* Ht, int c, int kb
 struct DgdStage32 {          // hs [N,32] fp32: thread (column c = t & 31, k block kb = t >> 5 of 4 rows)
   static constexpr int PARTS = 3;
   float v[4];
+  int N;
   __device__ __forceinline__ void load(const float* __restrict__ hs, const DgdStageDesc& d, int t) {
     const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
-    const float* bp = hs + (size_t)(d.n0 + k0) * 32 + c;
+    const int r0 = min(d.n0 + k0, N - 1), lim = N - 1 - r0;
+    const float* bp = hs + (size_t)r0 * 32 + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float x = bp[i * 32]; v[i] = k0 + i < d.n ? x : 0.f; }
+    for (int i = 0; i < 4; ++i) { const float x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? x : 0.f; }
   }
   __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<3>(Ht, t & 31, t >> 5, v); }
 };
 struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows)
   static constexpr int PARTS = 1;
   float v[4];
+  int N;
   __device__ __forceinline__ void load(const unsigned short* __restrict__ hs, const DgdStageDesc& d, int t) {
     const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
-    const unsigned short* bp = hs + (size_t)(d.n0 + k0) * 32 + c;
+    const int r0 = min(d.n0 + k0, N - 1), lim = N - 1 - r0;
+    const unsigned short* bp = hs + (size_t)r0 * 32 + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const unsigned x = bp[i * 32]; v[i] = k0 + i < d.n ? __uint_as_float(x << 16) : 0.f; }
+    for (int i = 0; i < 4; ++i) { const unsigned x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? __uint_as_float(x << 16) : 0.f; }
   }
   __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<1>(Ht, t & 31, t >> 5, v); }
 };
@@ -430,10 +433,10 @@ k_gcn_fwd32d(DgDense G, const float* __restrict__ dinv, const void* __restrict__
   body.bc0 = bias[lane & 15]; body.bc1 = bias[16 + (lane & 15)];
   body.dinv = dinv; body.xout = xout; body.hs_next = hs_next; body.xt = xts[wave]; body.lane = lane; body.wave = wave;
   if (BFIN) {
-    DgdStage32bf st;
+    DgdStage32bf st; st.N = G.N;
     dgd_pipeline<2>(G, reinterpret_cast<const unsigned short*>(hs), Hs, st, body, lane, wave, dbg);
   } else {
-    DgdStage32 st;
+    DgdStage32 st; st.N = G.N;
     dgd_pipeline<2>(G, reinterpret_cast<const float*>(hs), Hs, st, body, lane, wave, dbg);
   }
 }
@@ -732,7 +735,7 @@ k_gcn_bwd32d(DgDense G, const float* __restrict__ dinv, const float* __restrict_
   body.pb[0] = 0.f; body.pb[1] = 0.f;
   body.dinv = dinv; body.xprev = xprev; body.gpprev = gpprev; body.axin = axin; body.gas_prev = gas_prev;
   body.lane = lane; body.wave = wave; body.Fa = Fa; body.nbA = AF ? ((Fa + 15) >> 4) : 0;
-  DgdStage32 st;
+  DgdStage32 st; st.N = G.N;
   dgd_pipeline<2>(G, gas, reinterpret_cast<unsigned short*>(smem), st, body, lane, wave);
 
   // ---- this workgroup's partial row: the four waves' accumulators combined in a fixed order -----------------------
