@@ -563,6 +563,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
                                 dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr,
                                 tail_done != 0));
+  if (next && rode && rd.bits)      // dense next batch: its reverse-edge check on the bitmap the riders just built
+    DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
+                              reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));
   if (next) {
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
     if (!rode)

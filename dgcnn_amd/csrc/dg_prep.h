@@ -154,64 +154,46 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     unsigned int* __restrict__ bits = nullptr,
                                                     int* __restrict__ dmap = nullptr) {
   if (bits) {
-    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j, and the
-    // work-item records.  No atomics and no clearing pass: the edge list is sorted by (src, dst), so the edges that
-    // fall into one 32-bit word of a row are consecutive; the thread of the FIRST edge of such a group ORs the group
-    // (<= 32 edges, from the int32 colidx copy phase A left) and stores the word, plus the empty words between the
-    // previous group and its own (and after it, when it is the row's last group).  Every word is written exactly once.
-    if (t < E) {
-      const int64_t s64 = ei[t];
-      if ((uint64_t)s64 < (uint64_t)N) {
-        const int s = (int)s64;
-        const int g = (int)batch[s];
-        if ((unsigned)g < (unsigned)B) {
-          const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0;
-          if (ng <= DGD_MAXN && ng > 0) {
-            const int rb = rowptr[s], re = rowptr[s + 1];
-            int j = colidx[t] - n0;
-            if (j < 0 || j >= ng) { err[1] = epoch; err[3] = ~epoch; j = j < 0 ? 0 : ng - 1; }      // the edge leaves its graph
-            const int wi = j >> 5;
-            int pwi = -1;
-            if (t > rb) { int pj = colidx[t - 1] - n0; pj = pj < 0 ? 0 : (pj >= ng ? ng - 1 : pj); pwi = pj >> 5; }
-            if (pwi != wi) {                                  // first edge of this (row, word) group
-              const int S = 1 << dgd_class(ng);
-              unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)s * S;
-              const int sj = s - n0, sw = sj >> 5;
-              const unsigned int sbit = 1u << (sj & 31);
-              for (int gw = pwi + 1; gw < wi; ++gw) row[gw] = gw == sw ? sbit : 0u;
-              unsigned int word = wi == sw ? sbit : 0u;
-              int e = t;
-              bool more = true;
-              while (more && e < re) {                        // 4 edges per round trip
-                int jj[4];
+    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  One thread per
+    // ROW walks the row's (ascending) neighbour list from the int32 colidx copy phase A left, 8 entries per round trip,
+    // and stores each 32-bit word once -- no atomics, no clearing pass, one load per edge.  (An edge-parallel form --
+    // the first edge of every (row, word) group ORs its group -- needed 8 loads per edge for the group test alone:
+    // 92 us at 2048 COLLAB-shaped graphs; an atomicOr per edge: 365 us.)
+    if (t < N) {
+      const int g = (int)batch[t];
+      if ((unsigned)g < (unsigned)B) {
+        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, sj = t - n0;
+        if (sj >= 0 && sj < ng && ng <= DGD_MAXN) {
+          const int S = 1 << dgd_class(ng);
+          unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)t * S;
+          const int sw = sj >> 5;
+          const unsigned int sbit = 1u << (sj & 31);
+          int cw = 0;                                   // word being assembled
+          unsigned int word = sw == 0 ? sbit : 0u;
+          bool bad = false;
+          const int re = rowptr[t + 1];
+          for (int e = rowptr[t]; e < re; e += 8) {
+            int jj[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) jj[u] = e + u < re ? colidx[e + u] - n0 : -1;
+            for (int u = 0; u < 8; ++u) jj[u] = e + u < re ? colidx[e + u] - n0 : -1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  if (more && e + u < re) {
-                    const int jc = jj[u] < 0 ? 0 : (jj[u] >= ng ? ng - 1 : jj[u]);
-                    if ((jc >> 5) == wi) word |= 1u << (jc & 31); else more = false;
-                  }
+            for (int u = 0; u < 8; ++u) {
+              if (e + u < re) {
+                int j = jj[u];
+                if (j < 0 || j >= ng) { bad = true; j = j < 0 ? 0 : ng - 1; }        // the edge leaves its graph
+                const int wi = j >> 5;
+                if (wi > cw) {                          // (ascending lists: words complete in order)
+                  row[cw] = word;
+                  for (int gw = cw + 1; gw < wi; ++gw) row[gw] = gw == sw ? sbit : 0u;
+                  cw = wi; word = wi == sw ? sbit : 0u;
                 }
-                if (more) e += 4;
-              }
-              row[wi] = word;
-              if (more) {                                     // ran to the end of the row: this was its last group
-                for (int gw = wi + 1; gw < S; ++gw) row[gw] = gw == sw ? sbit : 0u;
+                word |= 1u << (j & 31);
               }
             }
           }
-        }
-      }
-    }
-    if (t < N && rowptr[t + 1] == rowptr[t]) {          // node without edges: its row is the self bit alone
-      const int g = (int)batch[t];
-      if ((unsigned)g < (unsigned)B) {
-        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, j = t - n0;
-        if (j >= 0 && j < ng && ng <= DGD_MAXN) {
-          const int S = 1 << dgd_class(ng);
-          unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)t * S;
-          for (int gw = 0; gw < S; ++gw) row[gw] = gw == (j >> 5) ? 1u << (j & 31) : 0u;
+          row[cw] = word;
+          for (int gw = cw + 1; gw < S; ++gw) row[gw] = gw == sw ? sbit : 0u;
+          if (bad) { err[1] = epoch; err[3] = ~epoch; }
         }
       }
     }
@@ -225,7 +207,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
     }
   }
   if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
-  if (t < E) {
+  if (t < E && !bits) {      // (dense batches verify the reverse edges on the bitmap afterwards: dg_prep_sym_body)
     const int64_t s = ei[t], d = ei[(int64_t)E + t];
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
       const int end = rowptr[d + 1];
@@ -237,5 +219,24 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       if (!(a < end && colidx[a] == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
     }
   }
+}
+// Phase C, dense batches only, after phase B: the reverse (d,s) of every edge (s,d) must exist -- ONE bitmap word of row d
+// per edge instead of phase B's binary search through row d's neighbour list (log2(deg) dependent loads per edge: 95 of
+// phase B's 150 us at 2048 COLLAB-shaped graphs).
+__device__ __forceinline__ void dg_prep_sym_body(int t, const int64_t* __restrict__ ei, int E, int N, int B,
+                                                 const int64_t* __restrict__ batch, const int* __restrict__ graph_ptr,
+                                                 const unsigned int* __restrict__ bits, unsigned int* __restrict__ err,
+                                                 unsigned int epoch) {
+  if (t >= E) return;
+  const int64_t s = ei[t], d = ei[(int64_t)E + t];
+  if ((uint64_t)s >= (uint64_t)N || (uint64_t)d >= (uint64_t)N) return;        // (range errors: flagged by phase A)
+  const int g = (int)batch[s];
+  if ((unsigned)g >= (unsigned)B) return;
+  const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0;
+  const int js = (int)s - n0, jd = (int)d - n0;
+  if (ng > DGD_MAXN || jd < 0 || jd >= ng) return;                               // (flagged by phase B)
+  const int S = 1 << dgd_class(ng);
+  const unsigned int w = bits[(size_t)N * (S - 1) + (size_t)d * S + (js >> 5)];
+  if (!((w >> (js & 31)) & 1u)) { err[1] = epoch; err[3] = ~epoch; }
 }
 #endif

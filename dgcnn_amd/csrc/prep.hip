@@ -192,6 +192,21 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
   if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 256, B, graph_ptr, dmap);
 }
 
+__global__ void __launch_bounds__(256)
+k_prep_sym(const int64_t* __restrict__ ei, int E, int N, int B, const int64_t* __restrict__ batch,
+           const int* __restrict__ graph_ptr, const unsigned int* __restrict__ bits, unsigned int* __restrict__ err,
+           unsigned int epoch) {
+  dg_prep_sym_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, batch, graph_ptr, bits, err, epoch);
+}
+int dg_launch_prep_sym(const int64_t* edge_index, int E, int N, int B, const int64_t* batch, const int32_t* graph_ptr,
+                       const uint32_t* bits, int32_t* err, uint32_t epoch, hipStream_t s) {
+  if (E <= 0 || !bits) return DGCNN_OK;
+  hipLaunchKernelGGL(k_prep_sym, dim3(dg_cdiv(E, 256)), dim3(256), 0, s, edge_index, E, N, B, batch, graph_ptr, bits,
+                     reinterpret_cast<unsigned int*>(err), epoch);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
 // xs[i][f] = dinv[i] * x[i][f]  (general prep path; the fast path does it inside k_prep_fast_b)
 __global__ void __launch_bounds__(256)
 k_scale_x(int N, int F, const float* __restrict__ x, const float* __restrict__ dinv, float* __restrict__ xs) {
@@ -219,7 +234,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                        scale ? lf->hs : nullptr, batch, bits, dmap);
     if (scale && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
-    return DGCNN_OK;
+    return dg_launch_prep_sym(edge_index, E, N, B, batch, graph_ptr, bits, err, epoch, s);
   }
   hipLaunchKernelGGL(k_prep_zero, dim3(dg_cdiv(N + 1, 256)), dim3(256), 0, s, N, cnt_in, cnt_out);
   DG_CHECK_LAUNCH();

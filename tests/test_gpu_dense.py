@@ -201,3 +201,34 @@ def test_fused_dense_reproducible_composition_independent_and_pipelined():
         tr.read_metrics()
         res.append(mm.flat_params.clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("route", ["forward", "pipelined"])
+def test_dense_form_detects_a_missing_reverse_edge(route):
+    """the dense form relies on A == A^T (one bitmap for both directions): a coalesced_undirected promise that does not
+    hold must be flagged -- checked on the bitmap itself (one word per edge) after it has been built"""
+    from dgcnn_amd import _lib
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    good = synth.make_batch("COLLAB", 12, start=900)
+    ei = good.edge_index
+    keep = torch.ones(ei.shape[1], dtype=torch.bool)
+    keep[ei.shape[1] // 2] = False                         # drop ONE directed edge: still sorted, no longer symmetric
+    bad = Batch(good.x, ei[:, keep].contiguous(), good.batch, good.y, good.num_graphs, True, good.max_nodes, good.max_edges)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.agg_mode = "dense"
+    if route == "forward":
+        m.eval()
+        with torch.no_grad():
+            m(good.to("cuda")); m.check_errors()
+            m(bad.to("cuda"))
+        with pytest.raises(_lib.DgcnnError):
+            m.check_errors()
+    else:
+        m.train()
+        tr = Trainer(m)
+        g, b = good.to("cuda"), bad.to("cuda")
+        tr.train_step(g, g.y, next_data=b)                 # bad's structures (and the check) are built during this step
+        tr.train_step(b, b.y, next_data=g)
+        with pytest.raises(_lib.DgcnnError):
+            tr.read_metrics()
