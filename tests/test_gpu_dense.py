@@ -232,3 +232,64 @@ def test_dense_form_detects_a_missing_reverse_edge(route):
         tr.train_step(b, b.y, next_data=g)
         with pytest.raises(_lib.DgcnnError):
             tr.read_metrics()
+
+
+# ---- edge cases of the dense forms: word / tile / stage / class boundaries, isolated nodes, single-node graphs ----------
+def _sized_batch(sizes, F=3, seed=0, isolated=()):
+    """graphs of exactly the given node counts (G(n,p), both directions, sorted by (src,dst)); graph indices in
+    `isolated` get NO edges at all for their first node (and single-node graphs have none by construction)"""
+    from dgcnn_amd.batch import Graph
+    rng = np.random.default_rng(seed)
+    gs = []
+    for gi, n in enumerate(sizes):
+        if n == 1:
+            ei = torch.zeros(2, 0, dtype=torch.int64)
+        else:
+            p = min(1.0, 6.0 / max(n - 1, 1)) if n > 40 else 0.5
+            m = np.triu(rng.random((n, n)) < p, 1)
+            if gi in isolated:
+                m[0, :] = False
+            if not m.any():
+                m[n - 2, n - 1] = True
+            a, b = np.nonzero(m)
+            src, dst = np.concatenate([a, b]), np.concatenate([b, a])
+            o = np.lexsort((dst, src))
+            ei = torch.from_numpy(np.stack([src[o], dst[o]]).astype(np.int64))
+        x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+        gs.append(Graph(x=x, edge_index=ei, y=int(rng.integers(0, 2)), coalesced_undirected=True))
+    return collate(gs)
+
+
+@pytest.mark.parametrize("sizes,isolated", [
+    ([31, 32, 33, 63, 64, 65], ()), ([127, 128, 129, 16, 15, 17], ()), ([191, 192, 193, 1, 2, 3], (0, 2)),
+    ([255, 256, 257], ()), ([511, 512, 5], (1,)), ([1, 1, 1, 40], ()), ([2], ())],
+    ids=["words", "stage", "fused_limit", "class8", "max512", "single_nodes", "one_tiny_graph"])
+def test_dense_boundary_sizes_isolated_nodes_and_single_node_graphs(sizes, isolated):
+    b = _sized_batch(sizes, seed=sum(sizes), isolated=isolated)
+    m = make_model(3, 2)
+    sd = cpu_state_dict(m)
+    m.agg_mode = "dense"
+    check_forward_parity(m, b, sd)
+    xd = gpu_xcat(m)
+    check_backward_parity(m, b, sd)
+    m.agg_mode = "sparse"
+    check_forward_parity(m, b, sd)
+    assert float((xd - gpu_xcat(m)).abs().max()) <= 4e-6
+    if max(sizes) <= 192:
+        m.agg_mode, m.use_fused = "dense", True
+        check_forward_parity(m, b, sd)
+        assert float((xd - gpu_xcat(m)).abs().max()) <= 4e-6
+
+
+def test_dense_is_not_taken_above_512_nodes_and_the_bf16_leg_says_so():
+    from dgcnn_amd import _lib
+    b = _sized_batch([513, 20], seed=7)
+    m = make_model(3, 2)
+    sd = cpu_state_dict(m)
+    m.agg_mode = "dense"                    # asked for, not admissible: the gather form runs, results stay right
+    check_forward_parity(m, b, sd)
+    m.compute_dtype = "bf16"
+    m.eval()
+    with pytest.raises(_lib.DgcnnError):
+        with torch.no_grad():
+            m(b.to("cuda"))
