@@ -296,7 +296,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float e = lane < C ? expf(v - mx) : 0.f;
     e = dg_wave_sum(e);
-    if (lane < C) logp[(size_t)b * C + lane] = (v - mx) - logf(e);
+    if (lane < C) { const float lpv = (v - mx) - logf(e); logp[(size_t)b * C + lane] = lpv; lg[lane] = lpv; }
+    // (lg now holds the log-probabilities: the merged training kernel's backward half reads them from LDS)
   }
   RD_MARK(13);
 #undef RD_MARK

@@ -137,7 +137,8 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
 // are capped at 64 so that two workgroups share a CU.  Same arithmetic order: bit-identical results.
 // body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
 // training kernel k_readout_tail (forward readout + this, one launch)
-template <bool BIG>
+struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb; };      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+template <bool BIG, bool MERGED = false>
 __device__ __forceinline__ void dg_tail_bwd_body(
     int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
     const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
@@ -146,14 +147,19 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
     float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
     float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg) {
+    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{}) {
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
-  __shared__ float W5s[NW5];
+  // MERGED (k_readout_tail): conv5 / conv6 weights, the pooled rows and the log-probabilities are still in the forward
+  // body's LDS -- no reload, and the first barrier no longer waits for a global round trip
+  __shared__ float W5s_own[MERGED ? 1 : NW5];
   __shared__ float a1ds[DGCNN_HID1];
   __shared__ float p5s[DGCNN_C5 * DGCNN_T5];
-  __shared__ float sps[KCAT];            // this graph's pooled rows (conv5's weight-gradient operand)
-  __shared__ float W6s[NW6];
+  __shared__ float sps_own[MERGED ? 1 : KCAT];            // this graph's pooled rows (conv5's weight-gradient operand)
+  __shared__ float W6s_own[MERGED ? 1 : NW6];
+  const float* W5s = MERGED ? ext.W5s : W5s_own;
+  const float* W6s = MERGED ? ext.W6s : W6s_own;
+  const float* sps = MERGED ? ext.sp : sps_own;
   __shared__ float dl[DGCNN_MAX_C];
   __shared__ float gz1s[DGCNN_HID1];
   __shared__ __attribute__((aligned(16))) float gfh[8][DGCNN_FLAT];
@@ -172,29 +178,34 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   DgStage<NW5, RD_THREADS> st5;
   DgStage<NW6, RD_THREADS> st6;
   DgStage<KCAT, RD_THREADS> stp;
-  st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)blockIdx.x * KCAT, tid);
+  if (!MERGED) { st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)blockIdx.x * KCAT, tid); }
   float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
   int yb_ = 0;
   if (wv == 0) {
-    lp_ = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
+    if (MERGED) lp_ = lane < C ? ext.lg[lane] : -INFINITY;
+    else lp_ = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
     if (glogp) g_ = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
-    else yb_ = (int)y[b];
+    else yb_ = MERGED ? ext.yb : (int)y[b];
   }
   // operands of the later steps that live in global memory: loaded NOW (their round trips overlap steps 1-2)
   float a6_ = 0.f, a5a_ = 0.f, a5b_ = 0.f;
-  if (tid < DGCNN_FLAT) a6_ = a6g[(size_t)b * DGCNN_FLAT + tid];                       // step 3: ReLU mask of conv6
+  if (tid < DGCNN_FLAT) a6_ = MERGED ? ext.flat[tid] : a6g[(size_t)b * DGCNN_FLAT + tid];          // step 3: ReLU mask of conv6
   if (tid < DGCNN_C5 * DGCNN_T5) {                                                     // step 5: MaxPool argmax
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
-    a5a_ = a5g[base]; a5b_ = a5g[base + 1];
+    if (MERGED) { a5a_ = ext.a5s[c * DGCNN_K + 2 * u]; a5b_ = ext.a5s[c * DGCNN_K + 2 * u + 1]; }
+    else { a5a_ = a5g[base]; a5b_ = a5g[base + 1]; }
   }
   int node_ = -1;                                                                      // step 6: scatter targets
-  if (tid >= 64 && tid < 64 + DGCNN_K) node_ = perm[b * DGCNN_K + (tid - 64)];
+  if (tid >= 64 && tid < 64 + DGCNN_K) {
+    if (MERGED) { const int ls = ext.sel[tid - 64]; node_ = ls >= 0 ? n0 + ls : -1; }
+    else node_ = perm[b * DGCNN_K + (tid - 64)];
+  }
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
 #pragma unroll
   for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
   if (tid < DGCNN_HID1) {
-    a1_ = a1dg[(size_t)b * DGCNN_HID1 + tid];
+    a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
 #pragma unroll
     for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
   }
@@ -210,7 +221,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
 #pragma unroll
     for (int j = 0; j < (BIG ? 1 : 16); ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
   }
-  st5.store(W5s, tid); st6.store(W6s, tid); stp.store(sps, tid);     // (waits only for the small loads above)
+  if (!MERGED) { st5.store(W5s_own, tid); st6.store(W6s_own, tid); stp.store(sps_own, tid); }     // (waits only for the small loads above)
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
   for (int t = tid; t < n * 32; t += RD_THREADS) {
     gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
@@ -450,18 +461,26 @@ k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* _
                         rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
     return;
   }
+  TbExt ext;
   {
     __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
     __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
     const RdSmem M = dg_rd_carve(region0, small);
+    {   // (layout of region0 after the sort: dg_readout_fwd_body)
+      const float* sp = reinterpret_cast<const float*>(M.region0);
+      ext.sp = sp; ext.W5s = sp + 2912; ext.W6s = sp + 2912 + NW5; ext.lg = M.lg;
+      ext.flat = M.flat; ext.a5s = M.a5s; ext.a1s = M.a1s; ext.sel = M.sel;
+    }
+    ext.yb = (threadIdx.x < 64) ? (int)y[blockIdx.x] : 0;      // (wave 0 needs it after the forward half: no cold load there)
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
     dg_readout_fwd_body(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp, training, seed,
-                        nullptr);
+                        dbg);
   }
-  __syncthreads();        // (full barrier, vmcnt(0): this graph's logp / activations / pooled rows / perm are written)
-  dg_tail_bwd_body<false>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training, dlogit,
-                          gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+  __syncthreads();        // (full barrier, vmcnt(0): this graph's activations / perm are written)
+  dg_tail_bwd_body<false, true>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training,
+                                dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg, ext);
 }
 
 int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
