@@ -38,7 +38,7 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
       // tags only grow: wait until the peer's tag has reached ours (a peer may already be one step ahead)
       while ((int)(__hip_atomic_load(P.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1 << 24)) { good = 0; break; }         // bounded: a lost peer must not hang the GPU
+        if (++spins > (1 << 21)) { good = 0; break; }         // bounded (~2 s): a lost peer must not hang the GPU
       }
     }
     if (!good) err[0] = tag;
