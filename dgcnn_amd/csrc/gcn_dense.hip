@@ -29,9 +29,13 @@
 #include "dg_readout.h"
 #include <hip/hip_ext.h>
 
-#define DGD_SK 64                        // k rows per pipeline stage
-#define DGD_HT_ROW 72                    // bf16 per column of a staged part: 64 k + 8 pad (144 B: 16-B aligned, and the 16
-                                         // columns a b128 read group touches fall on distinct banks)
+#ifndef DGD_SK
+#define DGD_SK 64                        // k rows per pipeline stage (64 or 128)
+#endif
+#define DGD_SW (DGD_SK / 32)             // bitmap words per stage
+#define DGD_KPT (DGD_SK / 16)            // consecutive k rows per thread in the staging (32 columns x 16 k-blocks = 512 threads)
+#define DGD_HT_ROW (DGD_SK + 8)          // bf16 per column of a staged part: SK k + 8 pad (144 / 272 B: 16-B aligned, and the
+                                         // 16 columns a b128 read group touches fall on distinct banks)
 #define DGD_HT_PART (32 * DGD_HT_ROW)    // one part: 32 columns
 #define DGD_BUF (3 * DGD_HT_PART)        // one stage buffer, in bf16 units: three parts (13.5 KiB)
 #define DGD_XT 36                        // row stride (floats) of the wave-private 16x32 tiles
@@ -99,16 +103,19 @@ struct DgdGen {          // walks this workgroup's items [0, w1) of the global t
 
 // ---- stage loaders: 64 rows of the B operand -> registers -> LDS planes Hs[nb][k][16], plus this lane's two bitmap words
 struct DgdBits {
-  unsigned pend[2], cur[2];
+  unsigned pend[DGD_SW], cur[DGD_SW];
   __device__ __forceinline__ void load(const DgDense& G, const DgdStageDesc& d, int wave, int lane) {
     const int m = d.r0 + wave * 16 + (lane & 15);
     const int K32 = (d.n + 31) >> 5, S = 1 << dgd_class(d.n);
-    const unsigned* bp = G.bits + (size_t)G.N * (S - 1) + (size_t)(d.n0 + m) * S + 2 * d.c;
+    const unsigned* bp = G.bits + (size_t)G.N * (S - 1) + (size_t)(d.n0 + m) * S + DGD_SW * d.c;
     const bool ok = m < d.n;
-    pend[0] = (ok && 2 * d.c < K32) ? bp[0] : 0u;
-    pend[1] = (ok && 2 * d.c + 1 < K32) ? bp[1] : 0u;
+#pragma unroll
+    for (int j = 0; j < DGD_SW; ++j) pend[j] = (ok && DGD_SW * d.c + j < K32) ? bp[j] : 0u;
   }
-  __device__ __forceinline__ void commit() { cur[0] = pend[0]; cur[1] = pend[1]; }
+  __device__ __forceinline__ void commit() {
+#pragma unroll
+    for (int j = 0; j < DGD_SW; ++j) cur[j] = pend[j];
+  }
 };
 // The block product runs on the BF16 matrix cores and is nevertheless exact in fp32: the adjacency operand is 0/1
 // (exact in bf16) and every fp32 value h is split, at staging time, into THREE bf16 parts h = h0 + h1 + h2 -- the top
@@ -130,52 +137,57 @@ __device__ __forceinline__ void dgd_split3(float h, unsigned& p0, unsigned& p1, 
 // graph's end are zeroed by a select, and the row offset is clamped to the slab's last row (N - 1) so that the over-read
 // of up to 3 rows past the LAST graph of the batch never leaves the caller's buffer.
 template <int PARTS>
-__device__ __forceinline__ void dgd_store_col4(unsigned short* Ht, int c, int kb, const float (&v)[4]) {
-  unsigned q[3][4];
+__device__ __forceinline__ void dgd_store_col4(unsigned short* Ht, int c, int kb, const float (&v)[DGD_KPT]) {
+  unsigned q[3][DGD_KPT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < DGD_KPT; ++i) {
     if (PARTS == 3) dgd_split3(v[i], q[0][i], q[1][i], q[2][i]);
     else q[0][i] = __float_as_uint(v[i]) >> 16;               // (bf16 leg: the value IS a bf16)
   }
 #pragma unroll
-  for (int p = 0; p < PARTS; ++p)
-    *reinterpret_cast<uint2*>(Ht + p * DGD_HT_PART + c * DGD_HT_ROW + 4 * kb) =
-        make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
+  for (int p = 0; p < PARTS; ++p) {
+    unsigned short* dp = Ht + p * DGD_HT_PART + c * DGD_HT_ROW + DGD_KPT * kb;
+    if (DGD_KPT == 8)
+      *reinterpret_cast<uint4*>(dp) = make_uint4(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16),
+                                                 q[p][DGD_KPT - 4] | (q[p][DGD_KPT - 3] << 16), q[p][DGD_KPT - 2] | (q[p][DGD_KPT - 1] << 16));
+    else
+      *reinterpret_cast<uint2*>(dp) = make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
+  }
 }
 struct DgdStage32 {          // hs [N,32] fp32: thread (column c = t & 31, k block kb = t >> 5 of 4 rows)
   static constexpr int PARTS = 3;
-  float v[4];
+  float v[DGD_KPT];
   int N;
   __device__ __forceinline__ void load(const float* __restrict__ hs, const DgdStageDesc& d, int t) {
-    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
+    const int c = t & 31, k0 = d.c * DGD_SK + DGD_KPT * (t >> 5);
     const int r0 = min(d.n0 + k0, N - 1), lim = N - 1 - r0;
     const float* bp = hs + (size_t)r0 * 32 + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? x : 0.f; }
+    for (int i = 0; i < DGD_KPT; ++i) { const float x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? x : 0.f; }
   }
   __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<3>(Ht, t & 31, t >> 5, v); }
 };
 struct DgdStage32bf {        // hs [N,32] bf16 (64-B rows)
   static constexpr int PARTS = 1;
-  float v[4];
+  float v[DGD_KPT];
   int N;
   __device__ __forceinline__ void load(const unsigned short* __restrict__ hs, const DgdStageDesc& d, int t) {
-    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
+    const int c = t & 31, k0 = d.c * DGD_SK + DGD_KPT * (t >> 5);
     const int r0 = min(d.n0 + k0, N - 1), lim = N - 1 - r0;
     const unsigned short* bp = hs + (size_t)r0 * 32 + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const unsigned x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? __uint_as_float(x << 16) : 0.f; }
+    for (int i = 0; i < DGD_KPT; ++i) { const unsigned x = bp[min(i, lim) * 32]; v[i] = k0 + i < d.n ? __uint_as_float(x << 16) : 0.f; }
   }
   __device__ __forceinline__ void store(unsigned short* Ht, int t) const { dgd_store_col4<1>(Ht, t & 31, t >> 5, v); }
 };
 struct DgdStageF {           // src [N,F] fp32, F <= 32 (raw features; F == 1: a scalar per node); columns >= F stay zero
   static constexpr int PARTS = 3;
-  float v[4];
+  float v[DGD_KPT];
   int F;
   __device__ __forceinline__ void load(const float* __restrict__ src, const DgdStageDesc& d, int t) {
-    const int c = t & 31, k0 = d.c * DGD_SK + 4 * (t >> 5);
+    const int c = t & 31, k0 = d.c * DGD_SK + DGD_KPT * (t >> 5);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (c < F && k0 + i < d.n) ? src[(size_t)(d.n0 + k0 + i) * F + c] : 0.f;
+    for (int i = 0; i < DGD_KPT; ++i) v[i] = (c < F && k0 + i < d.n) ? src[(size_t)(d.n0 + k0 + i) * F + c] : 0.f;
   }
   __device__ __forceinline__ void store(unsigned short* Ht, int t) const {
     if ((t & 31) < F) dgd_store_col4<3>(Ht, t & 31, t >> 5, v);
@@ -262,7 +274,7 @@ __device__ __forceinline__ void dgd_pipeline(const DgDense& G, const SRC* __rest
       // words' operands before the first MFMA -- 48 more registers -- was measured: block-product phase 9.8 k -> 9.0 k
       // cycles per workgroup, kernel time unchanged, one workgroup per CU less for the backward kernel; not kept)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < DGD_SW; ++j) {
         const unsigned w = bits.cur[j];
         if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) dgd_mma_word<NB, STAGE::PARTS>(w, hb, 32 * j, lane, tab, body.acc);
       }
@@ -440,6 +452,156 @@ k_gcn_fwd32d(DgDense G, const float* __restrict__ dinv, const void* __restrict__
     dgd_pipeline<2>(G, reinterpret_cast<const float*>(hs), Hs, st, body, lane, wave, dbg);
   }
 }
+
+#ifdef DGD_WAVE_FWD32     // measurement builds only (tools/build_variant.sh wave "-DDGD_WAVE_FWD32"): a NEGATIVE result, kept
+                          // for the record -- 34.4 us against the staged pipeline's 25.7 us at 2048 COLLAB-shape graphs.
+                          // Wave-life clocks (tools/wave_timing.py): 16.9 k cycles per 16-row tile -- 1.7 k record fetch,
+                          // 4.7 k to ISSUE the first 56 loads (84 cycles each: 16 waves per CU queue at the address unit),
+                          // 2.7 k latency, 5.5 k block product (the per-tile split is ~450 VALU instructions), 2.4 k
+                          // epilogue; 103 VGPRs = 4 waves per SIMD and 8-wave workgroups leave 46 % of the wave slots idle.
+// ---- the same layer with INDEPENDENT WAVES (no staging, no workgroup barrier) --------------------------------------
+// One workgroup per item, launched for every item (the hardware dispatcher balances them); wave w owns the 16-row tile
+// r0 + 16w and leaves at once when the graph has no such rows.  Each wave fetches the B operand of its block product
+// straight from global memory in the matrix-core layout -- lane (n = lane & 15, kg = lane >> 4) reads rows 8kg..8kg+7 of
+// columns n and 16 + n of the 32-row k block: a wave instruction covers four 64-B row segments -- splits it into the
+// three bf16 parts in registers and multiplies.  The rows of a graph are read once per tile (n/16 times, from L1/L2:
+// ~100 MB of L1 traffic per launch at 2048 COLLAB-shape graphs against the 750 MB of the CSR gather), the split work
+// is repeated per tile (VALU is idle anyway), and in exchange nothing ever waits for another wave: the staged
+// pipeline above spends ~60 % of a workgroup's life in barriers, prologue and exposed load latency with only two
+// 8-wave workgroups resident per CU and ~4 items per workgroup.
+template <int PARTS>
+__device__ __forceinline__ void dgw_consume(const float (&raw)[2][8], unsigned w, int lane, const uint2* __restrict__ tab,
+                                            f32x4 (&acc)[2]) {
+  if (__builtin_amdgcn_ballot_w64(w != 0u) == 0ull) return;
+  const unsigned byte = (w >> (8 * (lane >> 4))) & 0xffu;
+  const uint2 lo = tab[byte & 15u], hi = tab[byte >> 4];
+  bf16x8 a;
+  unsigned* au = reinterpret_cast<unsigned*>(&a);
+  au[0] = lo.x; au[1] = lo.y; au[2] = hi.x; au[3] = hi.y;
+  bf16x8 b[PARTS][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    unsigned q[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (PARTS == 3) dgd_split3(raw[nb][i], q[0][i], q[1][i], q[2][i]);
+      else q[0][i] = __float_as_uint(raw[nb][i]) >> 16;
+    }
+#pragma unroll
+    for (int p = 0; p < PARTS; ++p) {
+      unsigned* bu = reinterpret_cast<unsigned*>(&b[p][nb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bu[j] = q[p][2 * j] | (q[p][2 * j + 1] << 16);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[p][nb], acc[nb], 0, 0, 0);
+}
+
+template <bool BFIN>
+__device__ __forceinline__ void dgw_load(const void* __restrict__ hs, const unsigned* __restrict__ brow, int n0, int n, int kb,
+                                         int K32, bool rowok, int lane, float (&raw)[2][8], unsigned& w) {
+  // (every load is issued unconditionally on a clamped address: see dgd_pipeline)
+  const int k0 = 32 * kb + 8 * (lane >> 4), c = lane & 15;
+  const int r0 = min(k0, n - 1), lim = n - 1 - r0;
+  w = brow[min(kb, K32 - 1)];
+  w = (rowok && kb < K32) ? w : 0u;
+  if (BFIN) {
+    const unsigned short* bp = reinterpret_cast<const unsigned short*>(hs) + (size_t)(n0 + r0) * 32 + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int o = min(i, lim) * 32;
+      const unsigned x0 = bp[o], x1 = bp[o + 16];
+      raw[0][i] = k0 + i < n ? __uint_as_float(x0 << 16) : 0.f;
+      raw[1][i] = k0 + i < n ? __uint_as_float(x1 << 16) : 0.f;
+    }
+  } else {
+    const float* bp = reinterpret_cast<const float*>(hs) + (size_t)(n0 + r0) * 32 + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int o = min(i, lim) * 32;
+      const float x0 = bp[o], x1 = bp[o + 16];
+      raw[0][i] = k0 + i < n ? x0 : 0.f;
+      raw[1][i] = k0 + i < n ? x1 : 0.f;
+    }
+  }
+}
+
+template <int MODE, bool BFIN, bool BF16>
+__global__ void __launch_bounds__(DGD_THREADS)
+k_gcn_fwd32w(DgDense G, const float* __restrict__ dinv, const void* __restrict__ hs, const float* __restrict__ bias,
+             float* __restrict__ xout, const float* __restrict__ Wn, void* __restrict__ hs_next, unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) float xts[DGD_WAVES][16 * DGD_XT];
+  __shared__ uint2 tabs[DGD_WAVES][16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef DGD_TIMING      // measurement builds: wave-life phase totals (tools/wave_timing.py)
+  unsigned long long tw_ = clock64();
+  const unsigned long long tw0_ = tw_;
+#define DGW_T(k) do { if (dbg && lane == 0) { const unsigned long long now_ = clock64(); dbg[65536 + 8 * (blockIdx.x * 8 + wave) + (k)] += now_ - tw_; tw_ = now_; } } while (0)
+#else
+#define DGW_T(k) do { } while (0)
+#endif
+  if ((int)blockIdx.x >= G.dmap[DGD_SPLITS + 1]) { DGW_T(6); return; }
+  const int* rec = G.dmap + DGD_REC0 + 3 * blockIdx.x;
+  const int n0 = rec[0], n = rec[1], m0 = rec[2] + wave * 16;
+  if (m0 >= n) { DGW_T(5); return; }
+  DGW_T(0);                              // 0: record
+  uint2* tab = tabs[wave];
+  if (lane < 16) tab[lane] = make_uint2(((lane & 1) ? 0x3f80u : 0u) | ((lane & 2) ? 0x3f800000u : 0u),
+                                        ((lane & 4) ? 0x3f80u : 0u) | ((lane & 8) ? 0x3f800000u : 0u));
+  const int K32 = (n + 31) >> 5, S = 1 << dgd_class(n);
+  const int mrow = m0 + (lane & 15);
+  const bool rowok = mrow < n;
+  const unsigned* brow = G.bits + (size_t)G.N * (S - 1) + (size_t)(n0 + min(mrow, n - 1)) * S;
+  float ra[2][8], rb[2][8];
+  unsigned wa, wb;
+  dgw_load<BFIN>(hs, brow, n0, n, 0, K32, rowok, lane, ra, wa);
+  dgw_load<BFIN>(hs, brow, n0, n, 1, K32, rowok, lane, rb, wb);
+  // operands of the epilogue, requested behind the first rows
+  float wreg[2][8]; bf16x8 wbf[2]; float w4[8];
+  dgd_load_wnext<MODE, BF16>(Wn, lane, wreg, wbf, w4);
+  const float bc0 = bias[lane & 15], bc1 = bias[16 + (lane & 15)];
+  float dpre[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + (lane >> 4) * 4 + r;
+    dpre[r] = m < n ? dinv[n0 + m] : 0.f;
+  }
+  dgd_wave_sync();                       // the table
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  constexpr int PARTS = BFIN ? 1 : 3;
+  DGW_T(1);                              // 1: issue of the first loads
+#ifdef DGD_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  DGW_T(2);                              // 2: their latency
+#endif
+  for (int kb = 0; ; kb += 2) {
+    dgw_consume<PARTS>(ra, wa, lane, tab, acc);
+    if (kb + 1 >= K32) break;
+    dgw_load<BFIN>(hs, brow, n0, n, kb + 2, K32, rowok, lane, ra, wa);
+    dgw_consume<PARTS>(rb, wb, lane, tab, acc);
+    if (kb + 2 >= K32) break;
+    dgw_load<BFIN>(hs, brow, n0, n, kb + 3, K32, rowok, lane, rb, wb);
+  }
+  DGW_T(3);                              // 3: block product (+ the later loads)
+  float* xt = xts[wave];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) * 4 + r;
+    xt[row * DGD_XT + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[0][r], bc0));
+    xt[row * DGD_XT + 16 + (lane & 15)] = dg_tanh(fmaf(dpre[r], acc[1][r], bc1));
+  }
+  dgd_tile_epilogue<MODE, BF16>(xt, n0 + m0, min(16, n - m0), lane, dpre, dinv, xout, wreg, wbf, w4, hs_next);
+  DGW_T(4);                              // 4: epilogue
+#ifdef DGD_TIMING
+  if (dbg && lane == 0) dbg[65536 + 8 * (blockIdx.x * 8 + wave) + 7] += 1;
+#endif
+}
+
+#endif   // DGD_WAVE_FWD32
 
 // =================================================================================================================
 // forward of conv1, aggregate-first (raw feature width F <= 32):  ax = A_hat x (saved), x1 = tanh(ax W1^T + b1),
@@ -1215,8 +1377,13 @@ int dg_launch_gcn_fwd32d(int mode, int bf16_in, int bf16_out, const DgDense* G, 
                          hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (!G || G->NW <= 0) return DGCNN_EINVAL;
   if (mode != 0) bf16_out = 0;            // only the 32x32 linear step has a bf16 form (the 32->1 output is a fp32 scalar)
+#ifdef DGD_WAVE_FWD32
+#define DGD_L(M, BI, BO) hipExtLaunchKernelGGL((k_gcn_fwd32w<M, BI, BO>), dim3(G->NW), dim3(DGD_THREADS), 0, s, ev_start, \
+                                               ev_stop, 0, *G, dinv, hs, bias, xout, Wnext, hs_next, dg_debug_buffer())
+#else
 #define DGD_L(M, BI, BO) hipExtLaunchKernelGGL((k_gcn_fwd32d<M, BI, BO>), dim3(dgd_grid(G)), dim3(DGD_THREADS), 0, s, ev_start, \
                                                ev_stop, 0, *G, dinv, hs, bias, xout, Wnext, hs_next, dg_debug_buffer())
+#endif
   if (mode == 0) {
     if (bf16_in && bf16_out) DGD_L(0, true, true); else if (bf16_in) DGD_L(0, true, false);
     else if (bf16_out) DGD_L(0, false, true); else DGD_L(0, false, false);
