@@ -83,6 +83,7 @@ def parse(argv=None):
                     help="gradient exchange when --gpus > 1: RCCL all_reduce + Adam launch, or the one-shot peer-memory kernel "
                          "(dgcnn_allreduce_adam_step); auto = one-shot if it sets up and the replicas verify identical, else RCCL")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-exchange", action="store_true", help=argparse.SUPPRESS)     # child job: try the one-shot exchange, exit 0 / 3
     return ap.parse_args(argv)
 
 
@@ -312,6 +313,40 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return bool(torch.equal(lo, hi))
 
+    if exchange["mode"] == "oneshot" and args.exchange == "auto" and world > 1 and not args.probe_exchange and \
+            (not share or os.environ.get("BENCH_PROBE_SHARED") == "1"):        # (shared-GPU functional runs: only on request)
+        # The one-shot exchange has only ever run between two processes of ONE GPU.  On a node it has never seen, a peer
+        # mapping that is not really there would be a GPU memory fault, which no `except` catches: so it is first tried
+        # in a THROW-AWAY job of its own (same ranks, same devices, 8 steps); only if that job exits cleanly does this
+        # one use it.  Rank 0 runs the probe, the others wait at the broadcast.
+        verdict = torch.zeros(1, dtype=torch.int32, device="cpu" if share else dev)
+        if rank == 0:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                pport = so.getsockname()[1]
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                                "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                                "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "ROLE_NAME",
+                                "TORCHELASTIC_ERROR_FILE")}
+            pcmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                    "--master-addr", "127.0.0.1", "--master-port", str(pport), os.path.abspath(__file__),
+                    "--gpus", str(world), "--workload", args.workload, "--batch", str(args.batch), "--scaling", args.scaling,
+                    "--global-batch", str(args.global_batch), "--pool", "2", "--exchange", "oneshot", "--probe-exchange"]
+            try:
+                pr = subprocess.run(pcmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+                verdict[0] = 0 if pr.returncode == 0 else 1
+                if pr.returncode != 0:
+                    exchange["note"] = f"one-shot probe job failed (rc {pr.returncode}): {pr.stderr.decode(errors='replace')[-160:]!r}"
+            except Exception as ex:                           # noqa: BLE001 (timeout included)
+                verdict[0] = 1
+                exchange["note"] = f"one-shot probe job: {type(ex).__name__}"
+        dist.broadcast(verdict, src=0)
+        if int(verdict.item()) != 0:
+            exchange["mode"] = "rccl"
+            exchange["note"] = exchange["note"] or "one-shot probe job failed; RCCL route timed"
+
     tr = make_trainer()
     if exchange["mode"] == "oneshot":
         # the one-shot exchange has only ever run between two processes of ONE GPU: verify it on this node before timing
@@ -337,6 +372,8 @@ def main():
                 tr.close()
             except Exception:                                 # noqa: BLE001
                 pass
+        if args.probe_exchange:
+            sys.exit(0 if int(flag.item()) == 0 else 3)
         tr = make_trainer()
 
     def step(i, bl=batches, t=None):
