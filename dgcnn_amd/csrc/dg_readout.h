@@ -120,6 +120,11 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
 // SortPooling + dense tail for graph b, executed by one workgroup of RD_THREADS threads.
 //   keys/key_n0: where the sort keys (channel 96) of this graph's nodes are read from (global x4 with
 //   key_n0 = n0, or an LDS copy with key_n0 = 0).  Rows are gathered from the global slabs x1..x4.
+// BIG (thousands of graphs per launch, registers capped at 64 for two workgroups per CU): nothing is held in registers
+// over the sort or over conv5/conv6 -- the conv weights are loaded after the sort and classifier_1's rows at their
+// use (every weight is L2-resident when thousands of workgroups read the same 209 KB; the early prefetch only bought
+// 7 spilled registers = 58 MB of scratch traffic per launch at 2048 graphs).  Same arithmetic order: bit-identical.
+template <bool BIG = false>
 __device__ __forceinline__ void dg_readout_fwd_body(
     const RdSmem& M, int b, int n0, int n, int C, const TailW& w, const float* keys, int key_n0,
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ x3,
@@ -145,10 +150,11 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // stored to LDS afterwards -- no memory round trip of theirs is left on the critical path
   DgStage<NW5, RD_THREADS> st5;
   DgStage<NW6, RD_THREADS> st6;
-  st5.load(w.W5, tid); st6.load(w.W6, tid);
+  if (!BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   float wf2a = 0.f, wf2b = 0.f;                   // classifier_2 row of class `wv` (used at the very end: no cold load there)
-  if (wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }
+  if (!BIG && wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
+  if (BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
   {   // SortPooling gather: all row loads in flight, then the LDS / global stores
@@ -186,8 +192,10 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // spread over conv5's MFMA, conv5's combine and pool/conv6 instead of standing in front of the first barrier.
   float4 wf[11];
   const float* wr = w.Wf1 + (size_t)(((wv + b) & 15) * 8 + (lane >> 3)) * DGCNN_FLAT + 4 * (lane & 7);
+  if (!BIG) {
 #pragma unroll
-  for (int jq = 0; jq < 4; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+    for (int jq = 0; jq < 4; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+  }
   // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16]:
   // two 16x16 tiles, K split over 4 waves each (28 + 24 + 24 + 24 columns), partial tiles combined in a fixed
   // order; ReLU + bias at the combine.  output index o*30+s ([B,16,30])
@@ -203,8 +211,10 @@ __device__ __forceinline__ void dg_readout_fwd_body(
           [&](int s, int o, float v) { part[(kc * 32 + s) * 16 + o] = v; });
     }
     dg_lds_barrier();
+    if (!BIG) {
 #pragma unroll
-    for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+      for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+    }
     if (tid < DGCNN_C5 * DGCNN_K) {
       const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
       const float v = (part[(0 * 32 + s) * 16 + o] + part[(1 * 32 + s) * 16 + o]) +
@@ -216,8 +226,10 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   dg_lds_barrier();
   RD_MARK(10);
+  if (!BIG) {
 #pragma unroll
-  for (int jq = 8; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+    for (int jq = 8; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+  }
   // MaxPool1d(2,2): [16,30] -> [16,15]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
@@ -254,6 +266,10 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   {
     const int p8 = lane & 7;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (BIG) {
+#pragma unroll
+      for (int jq = 0; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+    }
 #pragma unroll
     for (int jq = 0; jq < 11; ++jq) {
       const float4 f = *reinterpret_cast<const float4*>(flat + 32 * jq + 4 * p8);
@@ -282,7 +298,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // classifier_2: 128 -> C, wave per class
   for (int c = wv; c < C; c += RD_THREADS / 64) {
     const float* wr = w.Wf2 + c * DGCNN_HID1;
-    const bool pre = c == wv;                     // first class of this wave: row prefetched with the conv weights
+    const bool pre = !BIG && c == wv;             // first class of this wave: row prefetched with the conv weights
     float acc = (pre ? wf2a : wr[lane]) * a1s[lane];
     acc = fmaf(pre ? wf2b : wr[lane + 64], a1s[lane + 64], acc);
     acc = dg_wave_sum(acc);

@@ -105,8 +105,8 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
   const RdSmem M = dg_rd_carve(region0, small);
   const int b = blockIdx.x;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
-  dg_readout_fwd_body(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
-                      training, seed, dbg);
+  dg_readout_fwd_body<BIG>(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
+                           training, seed, dbg);
 }
 
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,

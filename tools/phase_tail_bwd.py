@@ -6,7 +6,8 @@ from dgcnn_amd.model import Model
 from dgcnn_amd.train import Trainer
 L = _lib.lib()
 sh = synth.SHAPES["COLLAB"]
-b = synth.make_batch("COLLAB", 50, start=0).to("cuda")
+BS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+b = synth.make_batch("COLLAB", BS, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
 tr = Trainer(m)
