@@ -193,15 +193,15 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
 }
 
 __global__ void __launch_bounds__(256)
-k_prep_sym(const int64_t* __restrict__ ei, int E, int N, int B, const int64_t* __restrict__ batch,
-           const int* __restrict__ graph_ptr, const unsigned int* __restrict__ bits, unsigned int* __restrict__ err,
-           unsigned int epoch) {
-  dg_prep_sym_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, batch, graph_ptr, bits, err, epoch);
+k_prep_sym(int N, int B, const int64_t* __restrict__ batch, const int* __restrict__ graph_ptr,
+           const unsigned int* __restrict__ bits, unsigned int* __restrict__ err, unsigned int epoch) {
+  dg_prep_sym_body(blockIdx.x * blockDim.x + threadIdx.x, N, B, batch, graph_ptr, bits, err, epoch);
 }
 int dg_launch_prep_sym(const int64_t* edge_index, int E, int N, int B, const int64_t* batch, const int32_t* graph_ptr,
                        const uint32_t* bits, int32_t* err, uint32_t epoch, hipStream_t s) {
+  (void)edge_index;
   if (E <= 0 || !bits) return DGCNN_OK;
-  hipLaunchKernelGGL(k_prep_sym, dim3(dg_cdiv(E, 256)), dim3(256), 0, s, edge_index, E, N, B, batch, graph_ptr, bits,
+  hipLaunchKernelGGL(k_prep_sym, dim3(dg_cdiv(4 * N, 256)), dim3(256), 0, s, N, B, batch, graph_ptr, bits,
                      reinterpret_cast<unsigned int*>(err), epoch);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
