@@ -543,7 +543,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     if (dg_use_dense(next->N, next->E, next->B, next->flags, next->max_nodes)) {
       rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = dg_ptr<int>(next->ws, nl.dmap);
     }
-    rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B), 1024);
+    rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
     rider = &rd;
   }
   int rode = 0, tail_done = 0;

@@ -17,8 +17,9 @@ struct DgPrepRider {
   int nblk;        // rider workgroups appended to the host kernel's grid (0 = none)
   unsigned int* bits; int* dmap;   // dense per-graph block structures (dg_dense.h); bits == nullptr: not built
 };
-static inline int dg_prep_fast_work(int E, int N, int B) {
+static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {      // threads of phase A / phase B
   int work = E > N + 1 ? E : N + 1;
+  if (dense && 8LL * N < 0x7fffffffLL && 8 * N > work) work = 8 * N;                  // bitmap: 8 lanes per row
   return B + 1 > work ? B + 1 : work;
 }
 
@@ -154,45 +155,39 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     unsigned int* __restrict__ bits = nullptr,
                                                     int* __restrict__ dmap = nullptr) {
   if (bits) {
-    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  One thread per
-    // ROW walks the row's (ascending) neighbour list from the int32 colidx copy phase A left, 8 entries per round trip,
-    // and stores each 32-bit word once -- no atomics, no clearing pass, one load per edge.  (An edge-parallel form --
-    // the first edge of every (row, word) group ORs its group -- needed 8 loads per edge for the group test alone:
-    // 92 us at 2048 COLLAB-shaped graphs; an atomicOr per edge: 365 us.)
-    if (t < N) {
-      const int g = (int)batch[t];
+    // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
+    // per row; lane l owns words l, l + 8 of the row and scans the row's whole neighbour list (int32 colidx copy of
+    // phase A; the 8 lanes read the same addresses: one line per wave-instruction and row) with 8 independent loads per
+    // round, keeping the bits that fall into its word -- no atomics, no clearing pass, every word stored once, and a
+    // row is ONE round trip per 8 neighbours instead of a serial walk by one thread (phase B 58 -> 34 us at 2048 COLLAB-shaped
+    // graphs: the one-thread-per-row form had 155 k threads for the whole chip).  (An edge-parallel form -- the first
+    // edge of every (row, word) group ORs its group -- needed 8 loads per edge for the group test alone: 92 us; an
+    // atomicOr per edge: 365 us.)
+    const int row = t >> 3, l8 = t & 7;
+    if (row < N && (8LL * N < 0x7fffffffLL)) {
+      const int g = (int)batch[row];
       if ((unsigned)g < (unsigned)B) {
-        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, sj = t - n0;
+        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, sj = row - n0;
         if (sj >= 0 && sj < ng && ng <= DGD_MAXN) {
           const int S = 1 << dgd_class(ng);
-          unsigned int* row = bits + (size_t)N * (S - 1) + (size_t)t * S;
-          const int sw = sj >> 5;
-          const unsigned int sbit = 1u << (sj & 31);
-          int cw = 0;                                   // word being assembled
-          unsigned int word = sw == 0 ? sbit : 0u;
+          unsigned int* rw = bits + (size_t)N * (S - 1) + (size_t)row * S;
+          const int rs = rowptr[row], re = rowptr[row + 1];
           bool bad = false;
-          const int re = rowptr[t + 1];
-          for (int e = rowptr[t]; e < re; e += 8) {
-            int jj[8];
+          for (int k = l8; k < S; k += 8) {
+            unsigned int word = k == (sj >> 5) ? 1u << (sj & 31) : 0u;
+            for (int e = rs; e < re; e += 8) {
+              int jj[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) jj[u] = e + u < re ? colidx[e + u] - n0 : -1;
+              for (int u = 0; u < 8; ++u) jj[u] = colidx[min(e + u, re - 1)] - n0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              if (e + u < re) {
+              for (int u = 0; u < 8; ++u) {
                 int j = jj[u];
                 if (j < 0 || j >= ng) { bad = true; j = j < 0 ? 0 : ng - 1; }        // the edge leaves its graph
-                const int wi = j >> 5;
-                if (wi > cw) {                          // (ascending lists: words complete in order)
-                  row[cw] = word;
-                  for (int gw = cw + 1; gw < wi; ++gw) row[gw] = gw == sw ? sbit : 0u;
-                  cw = wi; word = wi == sw ? sbit : 0u;
-                }
-                word |= 1u << (j & 31);
+                if (e + u < re && (j >> 5) == k) word |= 1u << (j & 31);
               }
             }
+            rw[k] = word;
           }
-          row[cw] = word;
-          for (int gw = cw + 1; gw < S; ++gw) row[gw] = gw == sw ? sbit : 0u;
           if (bad) { err[1] = epoch; err[3] = ~epoch; }
         }
       }

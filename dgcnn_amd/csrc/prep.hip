@@ -224,7 +224,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
   if (!bits || !dmap) { bits = nullptr; dmap = nullptr; }
   unsigned int* uerr = reinterpret_cast<unsigned int*>(err);
   if ((flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0) {
-    const int work = dg_prep_fast_work(E, N, B);
+    const int work = dg_prep_fast_work(E, N, B, bits != nullptr);
     hipLaunchKernelGGL(k_prep_fast_a, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, batch, B, rowptr,
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch, bits);
     DG_CHECK_LAUNCH();
