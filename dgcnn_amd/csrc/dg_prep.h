@@ -44,6 +44,7 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }       // upper bound
 static inline int64_t dgd_table_ints(int N, int B) { return DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1); }
 struct DgDense { const int* graph_ptr; const int* dmap; const unsigned* bits; int N, B, NW; };
+#include <type_traits>
 #ifdef __HIPCC__
 __host__ __device__ __forceinline__ int dgd_class(int ng) {     // smallest c with 32*2^c >= ng  (ng <= 512)
   const int k32 = (ng + 31) >> 5;
@@ -55,48 +56,60 @@ __host__ __device__ __forceinline__ int dgd_class(int ng) {     // smallest c wi
 // One workgroup of T threads (tid = its thread index): item records + equal-cost shares, see above.  Needs graph_ptr.
 __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const int* __restrict__ graph_ptr,
                                                    int* __restrict__ dmap) {
-  __shared__ int sI[1024], sC[1024];
+  // (wave-level scans + one combine through LDS: three barriers per chunk of T graphs; the Hillis-Steele form over the
+  //  whole workgroup took ~20 barriers per chunk and pass -- a quarter of phase B's time at 2048 graphs)
+  __shared__ int wI[16], wC[16];
   __shared__ int carryI, carryC, totalC;
-  for (int pass = 0; pass < 2; ++pass) {          // pass 0: total cost; pass 1: emit
-    if (tid == 0) { carryI = 0; carryC = 0; }
+  const int lane = tid & 63, wave = tid >> 6, nw = (T + 63) >> 6;
+  auto graph_items = [&](int g, int& n0, int& n, int& items, int& ic) {
+    n0 = 0; n = 0;
+    if (g < B) { n0 = graph_ptr[g]; n = graph_ptr[g + 1] - n0; if (n > DGD_MAXN) n = DGD_MAXN; if (n < 0) n = 0; }
+    items = (n + DGD_ROWS - 1) / DGD_ROWS;
+    ic = 3 * ((n + 63) / 64) + 1;                   // cost of one item (pipeline stages of 64 k-rows + epilogue)
+  };
+  // pass 0: totals
+  {
+    int sI = 0, sC = 0;
+    for (int g = tid; g < B; g += T) { int n0, n, items, ic; graph_items(g, n0, n, items, ic); sI += items; sC += items * ic; }
+    for (int o = 32; o > 0; o >>= 1) { sI += __shfl_xor(sI, o); sC += __shfl_xor(sC, o); }
+    if (lane == 0) { wI[wave] = sI; wC[wave] = sC; }
     __syncthreads();
-    for (int base = 0; base < B; base += T) {
-      const int g = base + tid;
-      int n0 = 0, n = 0;
-      if (g < B) { n0 = graph_ptr[g]; n = graph_ptr[g + 1] - n0; if (n > DGD_MAXN) n = DGD_MAXN; if (n < 0) n = 0; }
-      const int items = (n + DGD_ROWS - 1) / DGD_ROWS;
-      const int ic = 3 * ((n + 63) / 64) + 1;                 // cost of one item (pipeline stages of 64 k-rows + epilogue)
-      sI[tid] = items; sC[tid] = items * ic;
-      __syncthreads();
-      for (int o = 1; o < T; o <<= 1) {                       // inclusive scan (Hillis-Steele)
-        int a = 0, c = 0;
-        if (tid >= o) { a = sI[tid - o]; c = sC[tid - o]; }
-        __syncthreads();
-        sI[tid] += a; sC[tid] += c;
-        __syncthreads();
-      }
-      const int ioff = carryI + sI[tid] - items, coff = carryC + sC[tid] - items * ic;
-      if (pass == 1) {
-        const long long tot = totalC > 0 ? totalC : 1;
-        for (int r = 0; r < items; ++r) {
-          const int w = ioff + r;
-          int* rec = dmap + DGD_REC0 + 3 * w;
-          rec[0] = n0; rec[1] = n; rec[2] = r * DGD_ROWS;
-          const long long c0 = coff + (long long)r * ic, c1 = c0 + ic;
-          const int klo = (int)(c0 * DGD_SPLITS / tot) + 1, khi = (int)(c1 * DGD_SPLITS / tot);
-          for (int k = klo; k <= khi && k <= DGD_SPLITS; ++k) dmap[k] = w + 1;
-        }
-      }
-      __syncthreads();
-      if (tid == T - 1) { carryI += sI[tid]; carryC += sC[tid]; }
-      __syncthreads();
+    if (tid == 0) {
+      int tI = 0, tC = 0;
+      for (int w = 0; w < nw; ++w) { tI += wI[w]; tC += wC[w]; }
+      totalC = tC; carryI = 0; carryC = 0;
+      dmap[0] = 0; dmap[DGD_SPLITS + 1] = tI;
     }
-    if (pass == 0) {
-      if (tid == 0) { totalC = carryC; dmap[0] = 0; dmap[DGD_SPLITS + 1] = carryI; }
-      if (carryC == 0)                                        // no work at all: every share is empty
-        for (int k = tid; k <= DGD_SPLITS; k += T) dmap[k] = 0;
-      __syncthreads();
+    __syncthreads();
+    if (totalC == 0)                                          // no work at all: every share is empty
+      for (int k = tid; k <= DGD_SPLITS; k += T) dmap[k] = 0;
+  }
+  // pass 1: emit records and share boundaries, chunk by chunk
+  const long long tot = totalC > 0 ? totalC : 1;
+  for (int base = 0; base < B; base += T) {
+    int n0, n, items, ic;
+    graph_items(base + tid, n0, n, items, ic);
+    int inI = items, inC = items * ic;                        // inclusive scans inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int a = __shfl_up(inI, o), c = __shfl_up(inC, o);
+      if (lane >= o) { inI += a; inC += c; }
     }
+    if (lane == 63) { wI[wave] = inI; wC[wave] = inC; }
+    __syncthreads();
+    int preI = carryI, preC = carryC;
+    for (int w = 0; w < wave; ++w) { preI += wI[w]; preC += wC[w]; }
+    const int ioff = preI + inI - items, coff = preC + inC - items * ic;
+    for (int r = 0; r < items; ++r) {
+      const int w = ioff + r;
+      int* rec = dmap + DGD_REC0 + 3 * w;
+      rec[0] = n0; rec[1] = n; rec[2] = r * DGD_ROWS;
+      const long long c0 = coff + (long long)r * ic, c1 = c0 + ic;
+      const int klo = (int)(c0 * DGD_SPLITS / tot) + 1, khi = (int)(c1 * DGD_SPLITS / tot);
+      for (int k = klo; k <= khi && k <= DGD_SPLITS; ++k) dmap[k] = w + 1;
+    }
+    __syncthreads();                                          // everybody has read the carries and the wave totals
+    if (tid == T - 1) { carryI = preI + inI; carryC = preC + inC; }
+    __syncthreads();
   }
 }
 
@@ -156,41 +169,58 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     int* __restrict__ dmap = nullptr) {
   if (bits) {
     // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
-    // per row; lane l owns words l, l + 8 of the row and scans the row's whole neighbour list (int32 colidx copy of
-    // phase A; the 8 lanes read the same addresses: one line per wave-instruction and row) with 8 independent loads per
-    // round, keeping the bits that fall into its word -- no atomics, no clearing pass, every word stored once, and a
-    // row is ONE round trip per 8 neighbours instead of a serial walk by one thread (phase B 58 -> 34 us at 2048 COLLAB-shaped
-    // graphs: the one-thread-per-row form had 155 k threads for the whole chip).  (An edge-parallel form -- the first
-    // edge of every (row, word) group ORs its group -- needed 8 loads per edge for the group test alone: 92 us; an
-    // atomicOr per edge: 365 us.)
+    // per row: lane l takes neighbours l, l + 8, ... of the row (int32 colidx copy of phase A; the 8 lanes read 8
+    // consecutive ids), ALL of its loads in flight together (one round trip per 64 neighbours), ORs them into its own
+    // copy of the row's words, and three xor-shuffles combine the 8 copies; lane k then stores word k -- no atomics, no
+    // clearing pass, every word stored once, one load per edge.  (History at 2048 COLLAB-shaped graphs: an atomicOr per
+    // edge 365 us; the first edge of every (row, word) group ORs its group 92 us; one thread walking the row 58 us;
+    // 8 lanes each scanning the whole row for its own word 34 us.)
     const int row = t >> 3, l8 = t & 7;
-    if (row < N && (8LL * N < 0x7fffffffLL)) {
-      const int g = (int)batch[row];
-      if ((unsigned)g < (unsigned)B) {
-        const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, sj = row - n0;
-        if (sj >= 0 && sj < ng && ng <= DGD_MAXN) {
-          const int S = 1 << dgd_class(ng);
-          unsigned int* rw = bits + (size_t)N * (S - 1) + (size_t)row * S;
-          const int rs = rowptr[row], re = rowptr[row + 1];
-          bool bad = false;
-          for (int k = l8; k < S; k += 8) {
-            unsigned int word = k == (sj >> 5) ? 1u << (sj & 31) : 0u;
-            for (int e = rs; e < re; e += 8) {
-              int jj[8];
+    if (8LL * N < 0x7fffffffLL) {
+      // (all 8 lanes of a row take the same branches: the shuffles below are executed by whole groups)
+      const bool live = row < N;
+      const int g = live ? (int)batch[row] : -1;
+      int n0 = 0, ng = 0;
+      if ((unsigned)g < (unsigned)B) { n0 = graph_ptr[g]; ng = graph_ptr[g + 1] - n0; }
+      const int sj = row - n0;
+      const bool ok = live && (unsigned)g < (unsigned)B && sj >= 0 && sj < ng && ng <= DGD_MAXN;
+      const int S = ok ? 1 << dgd_class(ng) : 0;
+      const int rs = ok ? rowptr[row] : 0, re = ok ? rowptr[row + 1] : 0;
+      bool bad = false;
+      auto build = [&](auto tag) {
+        constexpr int W = decltype(tag)::value;           // words kept per lane (>= S)
+        unsigned int acc[W];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) jj[u] = colidx[min(e + u, re - 1)] - n0;
+        for (int k = 0; k < W; ++k) acc[k] = 0u;
+        for (int e = rs + l8; e < re; e += 64) {
+          int jj[8];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                int j = jj[u];
-                if (j < 0 || j >= ng) { bad = true; j = j < 0 ? 0 : ng - 1; }        // the edge leaves its graph
-                if (e + u < re && (j >> 5) == k) word |= 1u << (j & 31);
-              }
-            }
-            rw[k] = word;
+          for (int u = 0; u < 8; ++u) jj[u] = colidx[min(e + 8 * u, re - 1)] - n0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int j = jj[u];
+            if (j < 0 || j >= ng) { bad = true; j = j < 0 ? 0 : ng - 1; }          // the edge leaves its graph
+            const unsigned int bit = e + 8 * u < re ? 1u << (j & 31) : 0u;
+            const int wi = j >> 5;
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc[k] |= wi == k ? bit : 0u;
           }
-          if (bad) { err[1] = epoch; err[3] = ~epoch; }
         }
-      }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          acc[k] |= __shfl_xor(acc[k], 1); acc[k] |= __shfl_xor(acc[k], 2); acc[k] |= __shfl_xor(acc[k], 4);
+        }
+        if (ok) {
+          unsigned int* rw = bits + (size_t)N * (S - 1) + (size_t)row * S;
+#pragma unroll
+          for (int k = 0; k < W; ++k)
+            if (k < S && (k & 7) == l8) rw[k] = acc[k] | (k == (sj >> 5) ? 1u << (sj & 31) : 0u);
+        }
+      };
+      // (rows of one wave may belong to graphs of different classes: every group of 8 aligned lanes runs the variant its
+      //  own graph needs, and the shuffles stay inside the group)
+      if (S <= 4) build(std::integral_constant<int, 4>{}); else build(std::integral_constant<int, 16>{});
+      if (bad) { err[1] = epoch; err[3] = ~epoch; }
     }
     if (t < B && graph_ptr[t + 1] - graph_ptr[t] > DGD_MAXN) { err[1] = epoch; err[3] = ~epoch; }      // max_nodes promise (<= 512) broken
   }
