@@ -407,6 +407,9 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   const float *x1 = dg_cptr<float>(ws, wl.x1), *x2 = dg_cptr<float>(ws, wl.x2), *x3 = dg_cptr<float>(ws, wl.x3),
               *x4 = dg_cptr<float>(ws, wl.x4);
 
+  // readout forward + backward ran as one launch (which carried phase A of the next batch's preparation): phase B rides
+  // on the LAST launch of the step, the weight-gradient kernel, when that is the single-launch form
+  const bool wg_rider = tail_done && rider_b && !dense && dg_wgrad_takes_rider(B);
   if (!tail_done)
   DG_TRY(dg_launch_tail_bwd(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm),
                             dinv, x4, dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6),
@@ -432,7 +435,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, tail_done ? rider_b : nullptr));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
                              dg_ptr<float>(ws, wl.pb3), wl.P32, s));
@@ -453,7 +456,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
-  DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s));
+  DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s,
+                         wg_rider ? rider_b : nullptr));
   return DGCNN_OK;
 }
 

@@ -484,7 +484,8 @@ struct DgAdam {          // optional optimizer step fused into the weight-gradie
   int64_t step;
 };
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s);
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+int dg_wgrad_takes_rider(int B);
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);
 int dg_launch_metrics(int B, const float* lossv, float* metrics, hipStream_t s);

@@ -631,7 +631,15 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
 }
 
 __global__ void __launch_bounds__(256)
-k_wgrad(WgArgs A) {
+k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
+  if ((int)blockIdx.x >= nb_host) {   // rider range: phase B of the NEXT batch's graph preparation.  This launch is the
+                                      // step's last and longest short kernel (7.4 us at batch 50): phase B (5 us alone)
+                                      // disappears under it, whereas it stretched k_gcn_bwd1 from 4.8 to 6.1 us
+    dg_prep_fast_b_body(((int)blockIdx.x - nb_host) * 256 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
+                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap);
+    if (rd.dmap && (int)blockIdx.x == nb_host) dg_prep_dense_plan((int)threadIdx.x, 256, rd.B, rd.graph_ptr, rd.dmap);
+    return;
+  }
   int si = 0;
   for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
   const WgSeg sg = A.seg[si];
@@ -726,8 +734,9 @@ k_wgrad(WgArgs A) {
 
 // which: bit 0 = tail parameters (depend on k_tail_bwd only), bit 1 = GCN parameters (depend on the GCN
 // backward kernels).  The two halves can run on different streams.
+int dg_wgrad_takes_rider(int B) { return B <= dg_wg_two_stage_b() ? 1 : 0; }      // single-launch form only
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s) {
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const DgPrepRider* rider) {
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
@@ -794,7 +803,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       g1.stride = st; g1.aux = B; g1.src = pt; g1.out = t1;
       nb1 += dg_cdiv(g1.count, 256);
       S.nseg = 2;
-      hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S);
+      hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
       DG_CHECK_LAUNCH();
       pt = t1; Rt = nch;
       add_col(DGCNN_HID1 * DGCNN_FLAT, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
@@ -820,12 +829,16 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
       const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4)
                      : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 64) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
-      hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One);
+      hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
     }
+    if (rider && rider->nblk > 0)       // (diagnostic mode: the rider as a launch of its own)
+      hipLaunchKernelGGL(k_wgrad, dim3(4 * rider->nblk), dim3(256), 0, s, A, *rider, 0);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
-  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  hipLaunchKernelGGL(k_wgrad, dim3(nb + 4 * rd.nblk), dim3(256), 0, s, A, rd, nb);      // (nblk counts 1024-thread blocks)
   DG_CHECK_LAUNCH();
   (void)N;
   return DGCNN_OK;
@@ -847,7 +860,7 @@ int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s) {
   A.nseg = nseg;
   A.grads_base = segs[0].out;
   if (nb == 0) return DGCNN_OK;
-  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A, DgPrepRider{}, nb);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
