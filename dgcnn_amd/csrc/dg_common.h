@@ -165,7 +165,11 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
   // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
   R(adjbits, 4 * 31 * n);
-  R(dmap, 4 * (3080 + 3 * (n / 128 + b + 1)));      // item table: shares + records (dg_prep.h: dgd_table_ints)
+#if defined(DGD_ROWS) && DGD_ROWS == 64
+  R(dmap, 4 * (3080 + 3 * (n / 64 + b + 1)));
+#else
+  R(dmap, 4 * (3080 + 3 * (n / 128 + b + 1)));
+#endif      // item table: shares + records (dg_prep.h: dgd_table_ints)
 #undef R
   w->total = o;
   return DGCNN_OK;

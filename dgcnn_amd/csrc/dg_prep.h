@@ -37,7 +37,9 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 // built by ONE workgroup of graph preparation's second phase with a block-wide prefix sum over the graphs
 // (dg_prep_dense_plan); at most N/64 + B items.
 #define DGD_MAXN 512
+#ifndef DGD_ROWS
 #define DGD_ROWS 128
+#endif
 #define DGD_CLASSES 5
 #define DGD_SPLITS 3072
 #define DGD_REC0 (DGD_SPLITS + 8)

@@ -33,13 +33,17 @@
 #define DGD_SK 64                        // k rows per pipeline stage (64 or 128)
 #endif
 #define DGD_SW (DGD_SK / 32)             // bitmap words per stage
-#define DGD_KPT (DGD_SK / 16)            // consecutive k rows per thread in the staging (32 columns x 16 k-blocks = 512 threads)
+#define DGD_KPT (DGD_SK * 32 / (64 * DGD_WAVES))   // consecutive k rows per thread in the staging (32 columns x 16 k-blocks = 512 threads)
 #define DGD_HT_ROW (DGD_SK + 8)          // bf16 per column of a staged part: SK k + 8 pad (144 / 272 B: 16-B aligned, and the
                                          // 16 columns a b128 read group touches fall on distinct banks)
 #define DGD_HT_PART (32 * DGD_HT_ROW)    // one part: 32 columns
 #define DGD_BUF (3 * DGD_HT_PART)        // one stage buffer, in bf16 units: three parts (13.5 KiB)
 #define DGD_XT 36                        // row stride (floats) of the wave-private 16x32 tiles
-#define DGD_WAVES 8                      // one 16-row tile per wave: an item is 128 rows (DGD_ROWS, dg_prep.h)
+#ifndef DGD_WAVES
+#define DGD_WAVES 8                      // one 16-row tile per wave: an item is 128 rows (DGD_ROWS, dg_prep.h).  4 waves x 64-row
+#endif                                   // items (-DDGD_WAVES=4 -DDGD_ROWS=64 -DDGD_MAX_GRID=1024) measured: forward 25.6 -> 26.2,
+                                         // aggregate-first conv1 32 -> 43, backward 46.5 -> 44.0, conv4 backward 27.2 -> 23.2 us;
+                                         // 2048-graph step 430 -> 436 us
 #define DGD_THREADS (64 * DGD_WAVES)
 #ifndef DGD_MAX_GRID
 #define DGD_MAX_GRID 512                 // persistent forward grid: 2 workgroups of 8 waves per CU (must divide DGD_SPLITS; 768 = 3 per
