@@ -296,9 +296,10 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
  *      the step skips its own graph preparation, else it prepares in-stream first.
  *   2. if `next` != NULL: its graph structure (what dgcnn_model_prepare builds: CSR by target / by source, dinv,
  *      graph ranges -- a function of the batch only, never of the weights) is built DURING this step, by extra
- *      workgroups appended to the step's two graph-per-workgroup launches (SortPooling+tail forward carries
- *      phase A, its backward phase B): those launches occupy only B of the 256 CUs, the preparation runs on the
- *      idle ones.  Same stream, no events.  next->ws must differ from cur->ws.  (General edge lists without
+ *      workgroups appended to two of the step's launches (the SortPooling+tail forward carries phase A; phase B
+ *      rides on the tail backward or, when forward and backward of the tail ran as one launch, on the step's last
+ *      launch, the weight-gradient kernel): those launches leave most of the 256 CUs idle at the reference's batch
+ *      size, the preparation runs on the idle ones.  Same stream, no events.  next->ws must differ from cur->ws.  (General edge lists without
  *      DGCNN_FLAG_COALESCED_UNDIRECTED, or a step that took the fused forward, are prepared in-stream after
  *      the step instead: same results, no overlap.)
  * Every batch's preparation still runs exactly once inside the training loop; only its position changes.
