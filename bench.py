@@ -566,13 +566,24 @@ def main():
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_port"] = value / cpu["value"]
             out["speedup_vs_cpu_port_1_thread"] = value / cpu["value_1_thread"]
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if use_dist:
         try:
             tr.close()
         except Exception:                                     # noqa: BLE001
             pass
         dist.destroy_process_group()
+    if result_line is not None:
+        # the ONE result line goes out last and alone: RCCL writes a version banner through C stdio, which (piped) would
+        # otherwise be flushed at exit, after the JSON
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                     # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
