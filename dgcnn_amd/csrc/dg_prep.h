@@ -40,6 +40,10 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 #ifndef DGD_ROWS
 #define DGD_ROWS 128
 #endif
+#ifndef DGD_COST_STAGE
+#define DGD_COST_STAGE 3       // cost of an item = DGD_COST_STAGE * stages + 1.  (6 / 12 / 32 measured: same kernel times and the
+                               // same 5..10 stages per workgroup -- shares end at item boundaries, the item is the quantum)
+#endif
 #define DGD_CLASSES 5
 #define DGD_SPLITS 3072
 #define DGD_REC0 (DGD_SPLITS + 8)
@@ -67,7 +71,7 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
     n0 = 0; n = 0;
     if (g < B) { n0 = graph_ptr[g]; n = graph_ptr[g + 1] - n0; if (n > DGD_MAXN) n = DGD_MAXN; if (n < 0) n = 0; }
     items = (n + DGD_ROWS - 1) / DGD_ROWS;
-    ic = 3 * ((n + 63) / 64) + 1;                   // cost of one item (pipeline stages of 64 k-rows + epilogue)
+    ic = DGD_COST_STAGE * ((n + 63) / 64) + 1;      // cost of one item (pipeline stages of 64 k-rows + epilogue)
   };
   // pass 0: totals
   {
