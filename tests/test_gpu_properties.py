@@ -46,3 +46,37 @@ def test_node_relabelling_leaves_the_log_probabilities_unchanged(name, bs, agg):
     bad = int((diff > 1e-4).sum())
     assert bad <= max(1, bs // 200), f"{bad} of {bs} graphs changed by more than 1e-4 (max {float(diff.max()):.3e})"
     assert float(diff.median()) < 5e-6
+
+
+@pytest.mark.parametrize("name,bs,shard,agg", [("COLLAB", 2048, 256, "dense"), ("COLLAB", 256, 32, "sparse"),
+                                               ("DD", 50, 10, "sparse")])
+def test_gradient_of_the_full_batch_is_the_weighted_sum_of_its_shards(name, bs, shard, agg):
+    """NLL-mean gradients are additive over graphs (what data parallelism relies on, and what lets the large-batch backward
+    kernels -- persistent / two-stage / dense forms -- be checked against the small-batch ones the oracle covers): the
+    gradient of a batch equals sum_k (B_k / B) * gradient of shard k.  Eval mode (a dropout mask is drawn per batch
+    position); per-graph forwards are bit-identical across batch compositions, so SortPooling selects the same nodes."""
+    from parity_util import grads_close
+    sh = synth.SHAPES[name]
+    graphs = synth.make_graphs(name, bs, start=8000)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.agg_mode = agg
+    m.eval()
+
+    def grads_of(gs):
+        b = collate(gs).to("cuda")
+        loss = torch.nn.functional.nll_loss(m(b), b.y)
+        m.zero_grad(set_to_none=True)
+        loss.backward()
+        m.check_errors()
+        return {k: p.grad.detach().double().cpu().clone() for k, p in m.named_parameters()}
+
+    full = grads_of(graphs)
+    acc = {k: torch.zeros_like(v) for k, v in full.items()}
+    for k0 in range(0, bs, shard):
+        part = grads_of(graphs[k0:k0 + shard])
+        w = len(graphs[k0:k0 + shard]) / bs
+        for k in acc:
+            acc[k] += w * part[k]
+    for k in full:
+        ok, md, sc = grads_close(full[k].float(), acc[k])
+        assert ok, f"{k}: max diff {md:.3e} at scale {sc:.3e}"
