@@ -173,6 +173,9 @@ def self_launch(args) -> int:
 # ------------------------------------------------------------------------------------------------------
 # HBM traffic of the aggregation kernel from rocprofv3 PMC passes spawned by this run
 # ------------------------------------------------------------------------------------------------------
+LIVE_TRACE_US = {}       # kernel -> mean duration (us) from the kernel trace of the last live --pmc pass
+
+
 def live_pmc_traffic(argv_base, timeout_s=240):
     """Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: TCC slot limits) over a short run of this same
     bench (child mode: a few steps, no baseline/roofline); returns ({kernel: bytes per dispatch}, note) or (None, why)."""
@@ -203,11 +206,25 @@ def live_pmc_traffic(argv_base, timeout_s=240):
                 a[0] += float(row["Counter_Value"]); a[1] += 1
             for k, (v, n) in acc.items():
                 per.setdefault(k, {})[ctr] = v / n
+            # the same pass's kernel trace: device timestamps of every dispatch (what rocprofv3 --stats averages)
+            kt = glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True)
+            if kt and ctr == "WRITE_SIZE":
+                dur = {}
+                for row in csv.DictReader(open(kt[0])):
+                    try:
+                        d = dur.setdefault(row["Kernel_Name"], [0.0, 0])
+                        d[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); d[1] += 1
+                    except (KeyError, ValueError):
+                        break
+                for k, (v, n) in dur.items():
+                    per.setdefault(k, {})["trace_us"] = v / n * 1e-3
     except Exception as ex:                                   # noqa: BLE001 -- measurement side channel only
         return None, f"{type(ex).__name__}: {ex}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # KB per dispatch -> bytes; FETCH doubled (gfx950: FETCH_SIZE reports half the bytes of wide streaming reads)
+    LIVE_TRACE_US.clear()
+    LIVE_TRACE_US.update({k: d["trace_us"] for k, d in per.items() if "trace_us" in d})
     return {k: (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0 for k, d in per.items()}, None
 
 
@@ -490,7 +507,12 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": bpl, "avg_launch_us": avg_us, "launches_measured": nl,
-                    "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream",
+                    "avg_launch_us_kernel_trace": LIVE_TRACE_US.get(kname) if kname else None,
+                    "timing": "avg_launch_us (used for `achieved`): HIP events attached to the dispatch (hipExtLaunchKernelGGL) "
+                              "on the launch stream -- they bracket the dispatch packet, i.e. the kernel plus ~0.5-1 us of "
+                              "dispatch latency, which matters for a 5 us kernel; avg_launch_us_kernel_trace: device "
+                              "timestamps of the same kernel from the rocprofv3 --kernel-trace of this run's WRITE_SIZE pass "
+                              "(what profiles/*kernel_stats*.csv averages)",
                     "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at 50 graphs the launch "
                             "moves ~1.6 MB (0.2 us of HBM time) and is dispatch/latency-bound -- see roofline_large_batch and DESIGN.md"}
         # ---- the same kernel family where it is throughput-bound: a large batch ------------------
