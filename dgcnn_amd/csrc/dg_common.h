@@ -8,7 +8,11 @@
 #define DG_WAVE 64
 #define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
 #define DG_TILE_THREADS 1024  // 16 waves: one wave per destination node
-#define DG_MAX_PART 1024      // cap on per-workgroup partial-gradient slots
+#ifndef DG_MAX_PART
+#define DG_MAX_PART 512       // cap on per-workgroup partial-gradient slots = grid of the backward kernels: two 1024-thread
+                              // workgroups per CU.  (1024 measured: the weight-gradient kernel reads twice the partial rows --
+                              // step 131 -> 120 us at 256 graphs, 135 -> 125 DD batch 50, 429 -> 411 at 2048; 256: 124 / 129)
+#endif
 // per-graph partial weight gradients written by k_tail_bwd: conv5 W|b, conv6 W|b, classifier_2 W|b
 #define DG_PT_W5 0
 #define DG_PT_B5 (DGCNN_C5 * DGCNN_CAT)
