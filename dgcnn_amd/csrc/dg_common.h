@@ -95,8 +95,12 @@ static inline int dg_wg_two_stage_b() {
 #define DG_DENSE_MIN_NODES 28672   // ... and the batch has at least this many nodes (~375 COLLAB-shaped graphs; measured step,
                                    // gather vs dense: 256 graphs 120 vs 138 us, 400: 165 vs 154, 600: 231 vs 188)
 #endif
+#ifndef DG_WG_ROWS_PER_CHUNK
 #define DG_WG_ROWS_PER_CHUNK 32
+#endif
+#ifndef DG_WG_FC1_KCHUNK
 #define DG_WG_FC1_KCHUNK 128
+#endif
 static inline int dg_af_lfp(int F) { int l = 0; while ((1 << l) < F) ++l; return l; }   // log2 of lanes per neighbour row
 
 struct DgWs {
