@@ -444,7 +444,8 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
 // Training steps with labels: readout forward and readout backward of a graph need nothing of any other graph (the
 // NLL-mean scale 1/B is a constant), so ONE launch runs both per graph -- one dispatch and one cold-read chain fewer
 // per step (the backward's operands were written by this very workgroup, on this CU).  Rider range: phase A of the next
-// batch's graph preparation, as on k_readout_fwd; phase B then rides on the conv4-backward launch.
+// batch's graph preparation, as on k_readout_fwd; phase B then rides on the step's last launch, k_wgrad (conv4's backward when the
+// weight gradients take their two-stage form).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
