@@ -7,10 +7,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, os.cpu_count() or 1))))     # (inherited by the tests' subprocesses)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the fp64 oracle is thousands of tiny per-graph tensor ops: on the GPU box's 256 logical CPUs torch's default
+    # intra-op pool (one thread per core) spends its time in fork/join -- 8 threads are an order of magnitude faster
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    except Exception:                                         # noqa: BLE001
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
