@@ -32,6 +32,69 @@ __device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsi
       for (int j = 0; j < n; ++j) rank += keys[j] < my ? 1 : 0;
       if (rank < DGCNN_K) sel[rank] = tid;
     }
+  } else if (n <= SP_LDS_KEYS / 2) {
+    // Only the first K of the order are needed: RADIX SELECT of the K-th key's 32-bit value (four passes over 8-bit
+    // digits, an LDS histogram per pass), then the <= K + ties candidates at or below it are ranked among themselves.
+    // ~10 barriers in all, against the ~55 barrier-separated passes of a bitonic sort of 1024 keys (the largest graph of
+    // a DD batch, 661 nodes, spent 41.8 k of its 73 k readout cycles sorting).  Integer atomics only: deterministic.
+    // (scratch in the upper half of the key area -- every caller provides SP_LDS_KEYS slots: no static LDS of its own,
+    //  the graph-per-workgroup kernels have none to spare)
+    unsigned long long* cand = keys + SP_LDS_KEYS / 2;                               // [256]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(cand + 256);                // [256]
+    unsigned int& s_prefix = hist[256]; unsigned int& s_mask = hist[257];
+    unsigned int& s_need = hist[258]; unsigned int& s_cnt = hist[259];
+    for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
+    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = (unsigned)m; s_cnt = 0u; }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int b = tid; b < 256; b += T) hist[b] = 0u;
+      __syncthreads();
+      const unsigned int prefix = s_prefix, mask = s_mask, need = s_need;
+      for (int t = tid; t < n; t += T) {
+        const unsigned int u = (unsigned int)(keys[t] >> 32);
+        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {            // wave 0: lane l owns bins 4l .. 4l+3 (ascending digit = ascending key)
+        const unsigned int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+        const unsigned int sum = c0 + c1 + c2 + c3;
+        unsigned int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(incl, o); if (tid >= o) incl += a; }
+        const unsigned int excl = incl - sum;
+        if (excl < need && need <= incl) {             // exactly one lane
+          unsigned int before = excl, bin = 4 * tid;
+          if (before + c0 < need) { before += c0; ++bin;
+            if (before + c1 < need) { before += c1; ++bin;
+              if (before + c2 < need) { before += c2; ++bin; } } }
+          s_prefix = prefix | (bin << shift);
+          s_mask = mask | (255u << shift);
+          s_need = need - before;
+        }
+      }
+      __syncthreads();
+    }
+    const unsigned int ustar = s_prefix;                // value of the K-th key
+    for (int t = tid; t < n; t += T) {
+      const unsigned long long k = keys[t];
+      if ((unsigned int)(k >> 32) <= ustar) {
+        const unsigned int pos = atomicAdd(&s_cnt, 1u);
+        if (pos < 256u) cand[pos] = k;
+      }
+    }
+    __syncthreads();
+    const int cnt = (int)s_cnt;
+    if (cnt <= 256) {
+      if (tid < cnt) {
+        const unsigned long long my = cand[tid];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += cand[j] < my ? 1 : 0;
+        if (rank < DGCNN_K) sel[rank] = (int)(my & 0xffffffffull);
+      }
+    } else {                     // more than 256 - K keys tie with the K-th one: full sort
+      __syncthreads();
+      dg_block_bitonic<unsigned long long>(keys, n);
+      if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
+    }
   } else if (n <= SP_LDS_KEYS) {
     for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
     __syncthreads();

@@ -256,6 +256,23 @@ def test_sortpool_ties_lower_index_first_and_signed_zero():
     assert torch.equal(pooled, ref)
 
 
+@pytest.mark.parametrize("sizes", [[300], [1500, 257, 2048], [2049, 4096], [700, 40, 4500]])
+@pytest.mark.parametrize("levels", [1, 3, 40])
+def test_sortpool_heavy_ties_in_mid_size_graphs(sizes, levels):
+    """graphs of 257..2048 nodes go through the radix select: keys drawn from very few distinct values make hundreds of
+    nodes tie with the K-th key (candidate overflow -> the full-sort fallback) or exactly at a digit boundary; the
+    selection must still be the stable descending order (lower index first) of the oracle, bit for bit."""
+    g = torch.Generator().manual_seed(100 + levels)
+    N = sum(sizes)
+    x = torch.randn(N, 97, generator=g)
+    vals = torch.tensor([0.5, -0.25, 0.75, 1e-30, -1e-30] + [float(v) for v in torch.randn(40, generator=g)])[:max(levels, 1)]
+    x[:, 96] = vals[torch.randint(0, len(vals), (N,), generator=g)]
+    batch = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
+    pooled, perm, _ = run_sortpool(x, batch, len(sizes))
+    ref = ref_ops.sort_pool(x, batch, 30, len(sizes), stable=True)
+    assert torch.equal(pooled, ref)
+
+
 @pytest.mark.parametrize("kat", kats.sortpool_kats(), ids=lambda k: k.name)
 def test_sortpool_hand_kats_via_k30(kat):
     """The ABI fixes k=30; embed the D=2 KAT in channels (0, 96) and compare the first rows."""
