@@ -17,7 +17,7 @@ __device__ __forceinline__ unsigned long long dg_pack_key(float key, int idx) {
 
 // selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none).
 // Works for any workgroup size that is a multiple of 64 (<= 1024).
-__device__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
+__device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
                                unsigned long long* red, int* sel) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int m = n < DGCNN_K ? n : DGCNN_K;
