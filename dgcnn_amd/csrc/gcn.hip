@@ -40,6 +40,9 @@
 #define DG_SMALL_GRID_TILES 256       // = number of CUs: up to one workgroup per CU the deep form wins, beyond it the
 #endif                                // two-workgroups-per-CU forms do (measured at 232 / 300 / 470 tiles)
 #define DG_PERSIST_WGS 512           // persistent large-grid kernels: 2 workgroups per CU
+#ifndef DG_PERSIST_MIN_TILES
+#define DG_PERSIST_MIN_TILES (4 * DG_PERSIST_WGS)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // first linear: hs[i][c] = dinv[i] * sum_k x[i][k] W[c][k]   (x is the raw [N,F] input, F arbitrary)
@@ -359,7 +362,7 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
                                                      ev_start, ev_stop, 0, N, tiles, rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
   const bool small = tiles <= DG_SMALL_GRID_TILES;
   static const bool nopersist = dg_knob("DG_NO_PERSIST");     // A/B switch (DG_DEBUG_KNOBS builds only)
-  const bool persist = tiles >= 4 * DG_PERSIST_WGS && !nopersist;   // pays from ~4 tiles per workgroup (measured)
+  const bool persist = tiles >= DG_PERSIST_MIN_TILES && !nopersist;   // pays from ~4 tiles per workgroup (measured)
   if (mode == 0) { if (small) DG_FWD32_LAUNCH(0, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(0, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(0, DG_DEPTH_FWD_BIG); }
   else if (mode == 1) { if (small) DG_FWD32_LAUNCH(1, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(1, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(1, DG_DEPTH_FWD_BIG); }
   else { if (small) DG_FWD32_LAUNCH(2, DG_DEPTH_SMALL); else if (persist) DG_FWD32P_LAUNCH(2, DG_DEPTH_FWD_BIG); else DG_FWD32_LAUNCH(2, DG_DEPTH_FWD_BIG); }
