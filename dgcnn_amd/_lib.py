@@ -21,6 +21,8 @@ FLAG_FORCE_TILED = 4
 FLAG_PREPARED = 8
 FLAG_AGG_SPARSE = 16      # never use the dense per-graph block aggregation
 FLAG_AGG_DENSE = 32       # use it whenever the batch admits it (coalesced_undirected, max_nodes <= 512)
+FLAG_CHAIN = 128          # graph-chain kernels (conv1..conv4 of a graph inside one workgroup) whenever admissible
+FLAG_NO_CHAIN = 256       # never
 FLAG_BF16 = 64            # bf16 leg: pre-scaled linear outputs stored bf16, X.W on the bf16 matrix cores
 
 K = 30

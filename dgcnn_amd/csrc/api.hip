@@ -206,7 +206,7 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
   if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
   if (dgd_num_items(N, B) > 100000) return false;        // (a workgroup caches at most 128 item records: gcn_dense.hip)
-  if (flags & DGCNN_FLAG_AGG_DENSE) return true;
+  if (flags & (DGCNN_FLAG_AGG_DENSE | DGCNN_FLAG_CHAIN)) return true;
   if (flags & DGCNN_FLAG_BF16) return true;              // the bf16 leg exists in the dense form only
   // Automatic choice.  (1) The dense kernels are persistent pipelines with a fixed prologue (~2.5 us: item records,
   // first stage) and their bitmap costs extra graph-preparation work; below a few hundred work items per launch the
@@ -219,6 +219,13 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   kest = (kest / 64) * 64;
   if (kest < 64) kest = 64;
   return (int64_t)N * kest <= (int64_t)DG_DENSE_EDGE_COST * ((int64_t)E + N);
+}
+// Graph-chain kernels (gcn_chain.hip): a dense-form batch whose raw feature width admits the aggregate-first conv1 runs
+// conv1..conv4 of every graph inside one workgroup (one launch instead of four; hs never leaves the CU).
+static bool dg_use_chain(int F, int flags) {
+  if (flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) return false;
+  if (F > DG_AF_MAX_F) return false;
+  return true;
 }
 // the backward of a batch takes the form its forward took (same flags and max_nodes; the fused graph-per-workgroup
 // forward never builds the bitmap)
@@ -328,7 +335,12 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  if (dense) {
+  if (dense && dg_use_chain(F, flags)) {
+    DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
+                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, s, g_prof_which >= 0 ? g_prof_a : nullptr,
+                               g_prof_which >= 0 ? g_prof_b : nullptr));
+    g_prof_which = -1;
+  } else if (dense) {
     // dense per-graph block form (gcn_dense.hip): same four launches, A.H on the matrix cores from the bit-packed adjacency
     if (af) {
       DG_TRY(dg_launch_gcn_fwd_af_d(bf16, &G, F, dinv, hsA, params + pl.off[0], params + pl.off[1],

@@ -412,6 +412,11 @@ int dg_launch_gcn_bwd32d(const DgDense* G, const float* dinv, const float* gas, 
                          const float* ax = nullptr, int Fa = 0, float* part1 = nullptr);
 int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, const float* W4, const float* x3,
                         const float* gp3, float* gas3, float* pa4, int P1, hipStream_t s);
+// graph-chain kernels (gcn_chain.hip): conv1..conv4 of a graph in one workgroup, hs resident in LDS
+int dg_chain_max_nodes();
+int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
+                        const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
+                        float* x3, float* x4, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // graph-per-workgroup fused forward in the dense block form (gcn_dense.hip): conv1..conv4 + readout, one launch
 struct DgParams;
 int dg_fused_d_max_nodes();

@@ -1,0 +1,422 @@
+// gcn_chain.hip -- the four graph convolutions of one graph as ONE chain inside ONE workgroup (gfx950).
+//
+// Same layer arithmetic as gcn.hip / gcn_dense.hip (PyG GCNConv + tanh, /root/reference/model.py:13-16,30-33):
+//     x_l[i] = tanh( dinv[i] * sum_{j in N(i)+{i}} hs_l[j] + b_l ),      hs_l[j] = dinv[j] * (x_{l-1} W_l^T)[j]
+// evaluated per graph as dense block products (A+I)_g . HS_g on the bf16 matrix cores from the bit-packed adjacency
+// (exact in fp32 through the three-way bf16 split, see gcn_dense.hip), but the pre-scaled linear outputs hs_2, hs_3,
+// h4s NEVER LEAVE THE CU: a workgroup owns a graph, keeps hs in LDS, and walks conv1 -> conv2 -> conv3 -> conv4.
+// Per graph and layer the per-layer kernels pay a global round trip (rows of hs written by one launch, re-read, split
+// and staged by the next: ~10 k cycles per work item, profiles/r02); here a layer is LDS reads -> MFMAs -> epilogue.
+// HBM traffic: xs, bitmap, dinv in; ax, x1, x2, x3, x4 out (saved for backward and SortPooling).
+//
+// Everything is computed TRANSPOSED so that no operand ever needs an LDS round trip to change layout:
+//   * block product  out^T[c][m] = sum_k HS[k][c] * Adj[m][k]  on v_mfma_f32_16x16x32_bf16 with A := HS^T, B := Adj^T.
+//     The accumulator lane (nl = lane & 15, kq = lane >> 4) then holds, for node m = nl of the tile, the FOUR CONSECUTIVE
+//     output columns 4kq .. 4kq+3 (+16 for the second block): a 16-byte piece of the node's row -- row stores go straight
+//     from registers to global memory, 16 B per lane.
+//   * HS^T operand: hs lives in LDS ROW-MAJOR as three bf16 parts, [part][16-column plane][k][16] (32-byte rows), and is
+//     read with ds_read_b64_tr_b16 (hardware transpose read, tools/probes/tr16_probe.hip): two reads deliver the eight
+//     k-values of one column.  32 lanes read 8 consecutive rows = 256 contiguous bytes: conflict-free.  The sum over k
+//     is order-free, so lane group kg takes k = 4kg..4kg+3 and 16+4kg..16+4kg+3 of each 32-row word; the adjacency
+//     operand takes the matching two nibbles of the bitmap word.
+//   * next layer's linear step  hs^T[o][m] = sum_k W[o][k] * x[m][k]  on v_mfma_f32_16x16x4_f32 with A := W, B := x^T:
+//     step s of lane group kq consumes k = 16(s>>2) + 4kq + (s&3) -- exactly the activated values the lane already holds.
+//     The result lane again holds four consecutive columns of its node: split into three bf16 parts it is ONE 8-byte
+//     LDS store per part and plane into the next layer's row-major image (slot swizzled by (k>>2)&3: conflict-free).
+//   * conv4 (32 -> 1): the three parts of h4s are three COLUMNS of one B operand; one MFMA per bitmap word.
+// Results: deterministic, independent of batch composition (a graph's numbers depend on its own rows only); they differ
+// from the per-layer kernels by fp32 rounding (different k order inside the fp32 matrix instruction).
+#include "dg_common.h"
+#include "dg_prep.h"
+#include <hip/hip_ext.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define CH_LDS __attribute__((address_space(3)))
+
+struct ChW { const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4; };
+
+__device__ __forceinline__ void ch_split3(float h, unsigned& p0, unsigned& p1, unsigned& p2) {      // h = p0 + p1 + p2, exact
+  const unsigned u0 = __float_as_uint(h) & 0xffff0000u;
+  const float r1 = h - __uint_as_float(u0);
+  const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(u1);
+  p0 = u0 >> 16; p1 = u1 >> 16; p2 = __float_as_uint(r2) >> 16;
+}
+
+template <int WAVES, int TPW, bool PING>
+struct ChCfg {
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int ROWS = 16 * WAVES * TPW;        // node bound of the class
+  static constexpr int KW = ROWS / 32;                 // bitmap words per row
+  static constexpr int PS = ROWS * 32;                 // bytes of one (part, plane): ROWS rows of 16 bf16
+  static constexpr int BUF = 6 * PS;                   // three parts x two planes
+  static constexpr int NBUF = PING ? 2 : 1;
+  static constexpr int OFF_W1 = NBUF * BUF;            // operand-order weight tables [2 ob][8 s][64 lanes] fp32
+  static constexpr int OFF_W2 = OFF_W1 + 4096;
+  static constexpr int OFF_W3 = OFF_W2 + 4096;
+  static constexpr int OFF_BT = OFF_W3 + 4096;         // b1 | b2 | b3 | w4  (4 x 32 floats)
+  static constexpr int OFF_DV = OFF_BT + 512;          // dinv of the graph's nodes, 0 beyond n  [ROWS]
+  static constexpr int OFF_H4 = OFF_DV + 4 * ROWS;     // h4s as three bf16 parts [3][ROWS]
+  static constexpr int OFF_TAB = OFF_H4 + 6 * ROWS;    // nibble -> four bf16
+  static constexpr int TOTAL = OFF_TAB + 128;
+  static constexpr int STAGE_IT = (ROWS * 8 + THREADS - 1) / THREADS;     // xs staging items per thread (2 planes x 4 slots)
+};
+
+// one (part, plane) operand of a 32-row word: two transpose reads = the lane's eight k-values of its column
+__device__ __forceinline__ bf16x8 ch_read_hsT(const char* p) {
+  const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 CH_LDS*)(p));
+  const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 CH_LDS*)(p + 512));       // rows +16
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ bf16x8 ch_bits_operand(unsigned w, int kg, const uint2* __restrict__ tab) {
+  const uint2 lo = tab[(w >> (4 * kg)) & 15u], hi = tab[(w >> (16 + 4 * kg)) & 15u];
+  bf16x8 b;
+  unsigned* bu = reinterpret_cast<unsigned*>(&b);
+  bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+  return b;
+}
+
+template <int WAVES, int TPW, bool PING>
+__global__ void __launch_bounds__(64 * WAVES)
+k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits, const float* __restrict__ dinv,
+            const float* __restrict__ xs, ChW gw, float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2,
+            float* __restrict__ x3, float* __restrict__ x4, int nmin) {
+  using C = ChCfg<WAVES, TPW, PING>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  const int g = blockIdx.x;
+  const int n0 = graph_ptr[g], n = graph_ptr[g + 1] - n0;
+  if (n <= nmin || n > C::ROWS) return;                 // another size class' launch owns this graph (or: flagged by graph prep)
+  const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
+  const int S = 1 << dgd_class(n);
+  const int NBF = F > 16 ? 2 : 1;
+
+  char* H0 = smem;
+  char* H1 = PING ? smem + C::BUF : smem;
+  float* W1op = reinterpret_cast<float*>(smem + C::OFF_W1);
+  float* W2op = reinterpret_cast<float*>(smem + C::OFF_W2);
+  float* W3op = reinterpret_cast<float*>(smem + C::OFF_W3);
+  float* bt = reinterpret_cast<float*>(smem + C::OFF_BT);
+  float* dv = reinterpret_cast<float*>(smem + C::OFF_DV);
+  unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4);
+  uint2* tab = reinterpret_cast<uint2*>(smem + C::OFF_TAB);
+
+  // ---- prologue: every global load of the graph in flight at once ---------------------------------------------------
+  unsigned wb[TPW][C::KW];
+  {
+    const unsigned* bp = bits + (size_t)N * (S - 1) + (size_t)n0 * S;
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int m = 16 * (wave + ti * WAVES) + nl;
+#pragma unroll
+      for (int u = 0; u < C::KW; ++u) wb[ti][u] = (m < n && u < K32) ? bp[(size_t)m * S + u] : 0u;
+    }
+  }
+  float sv[C::STAGE_IT][4];
+#pragma unroll
+  for (int j = 0; j < C::STAGE_IT; ++j) {               // conv1 operand xs = dinv * x: item (plane, row k, 4-column slot q)
+    const int it = tid + j * C::THREADS;
+    const int nb = it >= 4 * RU ? 1 : 0, rem = it - nb * 4 * RU, k = rem >> 2, q = rem & 3;
+    const bool ok = it < 4 * RU * NBF && k < n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 16 * nb + 4 * q + i;
+      sv[j][i] = (ok && c < F) ? xs[(size_t)(n0 + k) * F + c] : 0.f;
+    }
+  }
+  for (int k = tid; k < C::ROWS; k += C::THREADS) dv[k] = k < n ? dinv[n0 + k] : 0.f;
+  for (int e = tid; e < 1024; e += C::THREADS) {        // weights in MFMA-operand order: [ob][s][lane] = W[16ob + (lane&15)][kappa(s, lane>>4)]
+    const int ob = e >> 9, s = (e >> 6) & 7, l = e & 63;
+    const int kap = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), o = 16 * ob + (l & 15);
+    W2op[e] = gw.W2[o * 32 + kap];
+    W3op[e] = gw.W3[o * 32 + kap];
+    W1op[e] = kap < F ? gw.W1[o * F + kap] : 0.f;
+  }
+  if (tid < 128) {
+    const int which = tid >> 5, idx = tid & 31;
+    const float* src = which == 0 ? gw.b1 : (which == 1 ? gw.b2 : (which == 2 ? gw.b3 : gw.W4));
+    bt[tid] = src[idx];
+  }
+  const float b4s = gw.b4[0];
+  if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
+                                      ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+  {   // rows 16T .. RU-1 (at most 16) are read by the block products but written by no tile: zero them once
+    const int gr = RU - 16 * T;
+    for (int it = tid; it < C::NBUF * 6 * gr * 2; it += C::THREADS) {
+      const int piece = it & 1, row = 16 * T + ((it >> 1) % gr), pp = (it >> 1) / gr;       // pp: (buffer, part, plane)
+      *reinterpret_cast<uint4*>(smem + (size_t)pp * C::PS + row * 32 + 16 * piece) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int it = tid; it < 3 * gr; it += C::THREADS) h4p[(it / gr) * C::ROWS + 16 * T + (it % gr)] = 0;
+  }
+  // xs -> H0 (all rows < RU of the planes conv1 reads, zeros where k >= n or column >= F)
+#pragma unroll
+  for (int j = 0; j < C::STAGE_IT; ++j) {
+    const int it = tid + j * C::THREADS;
+    const int nb = it >= 4 * RU ? 1 : 0, rem = it - nb * 4 * RU, k = rem >> 2, q = rem & 3;
+    if (it < 4 * RU * NBF) {
+      unsigned qq[3][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ch_split3(sv[j][i], qq[0][i], qq[1][i], qq[2][i]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(H0 + (p * 2 + nb) * C::PS + k * 32 + 8 * (q ^ ((k >> 2) & 3))) =
+            make_uint2(qq[p][0] | (qq[p][1] << 16), qq[p][2] | (qq[p][3] << 16));
+    }
+  }
+  __syncthreads();
+
+  // lane constants of the LDS addressing
+  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);        // transpose reads: row 4kg + i/4, slot (i%4) ^ kg
+  float dn[TPW];
+  int wroff[TPW];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int m = 16 * (wave + ti * WAVES) + nl;
+    dn[ti] = dv[m];
+    wroff[ti] = m * 32 + 8 * (kq ^ ((nl >> 2) & 3));
+  }
+  const float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // block product of tile ti with the hs image Hc: acc[nb] (nb < NBP planes)
+  auto product = [&](const char* Hc, int ti, int NBP, f32x4 (&acc)[2]) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* hp = Hc + rdoff;
+#pragma unroll
+    for (int u = 0; u < C::KW; ++u) {
+      if (u < K32) {
+        const unsigned w = wb[ti][u];
+        if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) {
+          const bf16x8 bop = ch_bits_operand(w, kq, tab);
+          if (NBP == 2) {
+            bf16x8 a[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop, acc[nb], 0, 0, 0);
+          } else {
+            bf16x8 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = ch_read_hsT(hp + (p * 2) * C::PS + u * 1024);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], bop, acc[0], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  // activated tile v (this lane: node m, columns 4kq..4kq+3 and 16+4kq..) -> its rows to global, then the next layer's
+  // pre-scaled linear output hs = dn * (v W^T) as registers (same layout)
+  auto rows_and_linear = [&](const f32x4 (&v)[2], int ti, float* __restrict__ xout, const float* __restrict__ Wop, f32x4 (&hs)[2]) {
+    const int m = 16 * (wave + ti * WAVES) + nl;
+    if (m < n) {
+      float* dst = xout + (size_t)(n0 + m) * 32 + 4 * kq;
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+      *reinterpret_cast<float4*>(dst + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+    }
+    float wv[2][8];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wv[ob][s] = Wop[(ob * 8 + s) * 64 + lane];
+    f32x4 d2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) d2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob][s], v[s >> 2][s & 3], d2[ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hs[ob][r] = dn[ti] * d2[ob][r];
+  };
+  auto write_hs = [&](char* Hn, int ti, const f32x4 (&hs)[2]) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      unsigned qq[3][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ch_split3(hs[ob][r], qq[0][r], qq[1][r], qq[2][r]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(Hn + (p * 2 + ob) * C::PS + wroff[ti]) =
+            make_uint2(qq[p][0] | (qq[p][1] << 16), qq[p][2] | (qq[p][3] << 16));
+    }
+  };
+  auto bias4 = [&](int which, int nb) { return *reinterpret_cast<const float4*>(bt + 32 * which + 16 * nb + 4 * kq); };
+
+  f32x4 hsv[TPW][2];
+  // ---- conv1, aggregate-first: ax = dn * (Adj . xs) (saved), x1 = tanh(ax W1^T + b1), hs2 = dn * (x1 W2^T) ------------
+  {
+    const float4 b0 = bias4(0, 0), b1v = bias4(0, 1);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int t = wave + ti * WAVES, m = 16 * t + nl;
+      if (t < T) {
+        f32x4 acc[2];
+        product(H0, ti, NBF, acc);
+        f32x4 axv[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            axv[nb][r] = dn[ti] * acc[nb][r];
+            const int c = 16 * nb + 4 * kq + r;
+            if (c < F && m < n) axg[(size_t)(n0 + m) * F + c] = axv[nb][r];
+          }
+        f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (16 * (s >> 2) + (s & 3) < F) {             // (uniform: the step's smallest k)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+              pre[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1op[(ob * 8 + s) * 64 + lane], axv[s >> 2][s & 3], pre[ob], 0, 0, 0);
+          }
+        f32x4 v[2];
+        v[0][0] = dg_tanh(pre[0][0] + b0.x); v[0][1] = dg_tanh(pre[0][1] + b0.y);
+        v[0][2] = dg_tanh(pre[0][2] + b0.z); v[0][3] = dg_tanh(pre[0][3] + b0.w);
+        v[1][0] = dg_tanh(pre[1][0] + b1v.x); v[1][1] = dg_tanh(pre[1][1] + b1v.y);
+        v[1][2] = dg_tanh(pre[1][2] + b1v.z); v[1][3] = dg_tanh(pre[1][3] + b1v.w);
+        rows_and_linear(v, ti, x1, W2op, hsv[ti]);
+      }
+    }
+    if (!PING) dg_lds_barrier();
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+      if (wave + ti * WAVES < T) write_hs(H1, ti, hsv[ti]);
+    dg_lds_barrier();
+  }
+  // ---- conv2: from H1; hs3 = dn * (x2 W3^T) -> H0 ---------------------------------------------------------------------
+  auto layer32 = [&](const char* Hc, int which, const f32x4& accA, const f32x4& accB, f32x4 (&v)[2], float dnv) {
+    const float4 b0 = bias4(which, 0), b1v = bias4(which, 1);
+    v[0][0] = dg_tanh(fmaf(dnv, accA[0], b0.x)); v[0][1] = dg_tanh(fmaf(dnv, accA[1], b0.y));
+    v[0][2] = dg_tanh(fmaf(dnv, accA[2], b0.z)); v[0][3] = dg_tanh(fmaf(dnv, accA[3], b0.w));
+    v[1][0] = dg_tanh(fmaf(dnv, accB[0], b1v.x)); v[1][1] = dg_tanh(fmaf(dnv, accB[1], b1v.y));
+    v[1][2] = dg_tanh(fmaf(dnv, accB[2], b1v.z)); v[1][3] = dg_tanh(fmaf(dnv, accB[3], b1v.w));
+  };
+  {
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+      if (wave + ti * WAVES < T) {
+        f32x4 acc[2], v[2];
+        product(H1, ti, 2, acc);
+        layer32(H1, 1, acc[0], acc[1], v, dn[ti]);
+        rows_and_linear(v, ti, x2, W3op, hsv[ti]);
+      }
+    if (!PING) dg_lds_barrier();
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+      if (wave + ti * WAVES < T) write_hs(H0, ti, hsv[ti]);
+    dg_lds_barrier();
+  }
+  // ---- conv3: from H0; the next linear step is 32 -> 1: h4s = dn * (x3 . w4) -> three bf16 parts -------------------------
+  {
+    const float4 w0 = bias4(3, 0), w1 = bias4(3, 1);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int t = wave + ti * WAVES, m = 16 * t + nl;
+      if (t < T) {
+        f32x4 acc[2], v[2];
+        product(H0, ti, 2, acc);
+        layer32(H0, 2, acc[0], acc[1], v, dn[ti]);
+        if (m < n) {
+          float* dst = x3 + (size_t)(n0 + m) * 32 + 4 * kq;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          *reinterpret_cast<float4*>(dst + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+        }
+        float p = v[0][0] * w0.x;
+        p = fmaf(v[0][1], w0.y, p); p = fmaf(v[0][2], w0.z, p); p = fmaf(v[0][3], w0.w, p);
+        p = fmaf(v[1][0], w1.x, p); p = fmaf(v[1][1], w1.y, p); p = fmaf(v[1][2], w1.z, p); p = fmaf(v[1][3], w1.w, p);
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        if (kq == 0) {
+          unsigned q0, q1, q2;
+          ch_split3(dn[ti] * p, q0, q1, q2);
+          h4p[m] = (unsigned short)q0; h4p[C::ROWS + m] = (unsigned short)q1; h4p[2 * C::ROWS + m] = (unsigned short)q2;
+        }
+      }
+    }
+    dg_lds_barrier();
+  }
+  // ---- conv4 (32 -> 1): the three parts of h4s are columns 0..2 of ONE B operand; x4 = tanh(dinv * sum + b4) ----------
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int t = wave + ti * WAVES;
+    if (t < T) {
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+      const unsigned short* hq = h4p + min(nl, 2) * C::ROWS + 4 * kq;
+#pragma unroll
+      for (int u = 0; u < C::KW; ++u) {
+        if (u < K32) {
+          const unsigned w = wb[ti][u];
+          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) {
+            const bf16x8 aop = ch_bits_operand(w, kq, tab);
+            uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
+            if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+            bf16x8 bop;
+            unsigned* bu = reinterpret_cast<unsigned*>(&bop);
+            bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop, a4, 0, 0, 0);
+          }
+        }
+      }
+      // lane (j = nl, kq) holds part j's sums for rows 4kq + r: total = (part0 + part1) + part2, gathered in lane j = 0
+      float tot[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = __shfl_xor(a4[r], 1), s2 = __shfl_xor(a4[r], 2);      // lane j = 0 receives lanes 1 and 2
+        tot[r] = (a4[r] + s1) + s2;       // (a DPP quad_perm form of this was mis-compiled by ROCm 7.2: one DPP move reused for all r)
+      }
+      if (nl == 0) {
+        const int mm = 16 * t + 4 * kq;
+        const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
+        const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mm + r < n) x4[n0 + mm + r] = dg_tanh(fmaf(dd[r], tot[r], b4s));
+      }
+    }
+  }
+  (void)bz;
+}
+
+// ---- host launcher ----------------------------------------------------------------------------------------------------
+// size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
+// workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
+// and leaves the other class' graphs alone; the second launch is skipped when the host's max_nodes hint rules it out.
+#define CH_SMALL_ROWS 128
+int dg_chain_max_nodes() { return 512; }
+
+int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
+                        const float* xs, const float* params, const DgParams* pl, float* ax, float* x1, float* x2, float* x3,
+                        float* x4, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (N <= 0 || B <= 0 || F < 1 || F > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !xs) return DGCNN_EINVAL;
+  ChW gw;
+  gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
+  gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
+  using CS = ChCfg<8, 1, true>;
+  using CL = ChCfg<16, 2, false>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CS::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CL::TOTAL) != hipSuccess)
+      return DGCNN_ELAUNCH;
+    attr_set = true;
+  }
+  hipExtLaunchKernelGGL((k_chain_fwd<8, 1, true>), dim3(B), dim3(CS::THREADS), CS::TOTAL, s, ev_start, ev_stop, 0, N, F, graph_ptr,
+                        bits, dinv, xs, gw, ax, x1, x2, x3, x4, 0);
+  DG_CHECK_LAUNCH();
+  if (max_nodes <= 0 || max_nodes > CH_SMALL_ROWS) {
+    hipLaunchKernelGGL((k_chain_fwd<16, 2, false>), dim3(B), dim3(CL::THREADS), CL::TOTAL, s, N, F, graph_ptr, bits, dinv, xs, gw,
+                       ax, x1, x2, x3, x4, CH_SMALL_ROWS);
+    DG_CHECK_LAUNCH();
+  }
+  return DGCNN_OK;
+}

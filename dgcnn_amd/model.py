@@ -266,7 +266,8 @@ class Model(nn.Module):
 
     def _mode_flags(self) -> int:
         """path overrides set as plain attributes (tests, sweeps, bench.py); every one defaults to the library's choice:
-        ``use_fused`` True/False, ``agg_mode`` "dense"/"sparse", ``compute_dtype`` "bf16" (BASELINE config 3's leg)."""
+        ``use_fused`` True/False, ``agg_mode`` "dense"/"sparse", ``use_chain`` True/False (graph-chain kernels),
+        ``compute_dtype`` "bf16" (BASELINE config 3's leg)."""
         d = self.__dict__
         f = 0
         uf = d.get("use_fused")
@@ -281,6 +282,11 @@ class Model(nn.Module):
             f |= _lib.FLAG_AGG_SPARSE
         if d.get("compute_dtype") == "bf16":
             f |= _lib.FLAG_BF16
+        uc = d.get("use_chain")
+        if uc is True:
+            f |= _lib.FLAG_CHAIN
+        elif uc is False:
+            f |= _lib.FLAG_NO_CHAIN
         return f
 
     def _flags_of(self, data) -> int:

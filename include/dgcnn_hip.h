@@ -71,6 +71,11 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
                                        (64-B rows) and X.W^T runs on v_mfma_f32_16x16x32_bf16; sums, activations, the
                                        SortPooling key channel and the whole backward stay fp32.  Dense block form only
                                        (DGCNN_EUNSUPPORTED otherwise).  Not the reference's arithmetic: a secondary leg. */
+#define DGCNN_FLAG_CHAIN       128   /* graph-chain kernels (gcn_chain.hip): conv1..conv4 of a graph run inside ONE workgroup, the
+                                       pre-scaled linear outputs never leave the CU (one launch instead of four; same for the
+                                       backward chain).  Needs what the dense block form needs plus num_features <= 32; this
+                                       flag asks for it whenever admissible ... */
+#define DGCNN_FLAG_NO_CHAIN    256   /* ... this one forbids it; neither: the library's cost model decides per batch */
 #define DGCNN_FUSED_MIN_GRAPHS (1 << 30) /* the fused path is never chosen automatically: the tiled kernels measured
                                             faster at every batch size (profiles/r01_sweep.txt); FORCE_FUSED selects it */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no

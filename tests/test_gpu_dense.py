@@ -55,7 +55,7 @@ def test_dense_structures_bit_exact(name, bs):
     if b.max_nodes > 512:
         pytest.skip("graph above the dense bound")
     m = make_model(sh.num_features, sh.num_classes)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     m.eval()
     with torch.no_grad():
         m(b.to("cuda"))
@@ -90,14 +90,14 @@ def test_dense_forward_backward_vs_oracle_and_vs_gather(name, bs):
         b = synth.make_batch(name, bs, start=start)
     m = make_model(sh.num_features, sh.num_classes)
     sd = cpu_state_dict(m)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     check_forward_parity(m, b, sd)
     xd = gpu_xcat(m)
     m.agg_mode = "sparse"
     check_forward_parity(m, b, sd)
     xs = gpu_xcat(m)
     assert float((xd - xs).abs().max()) <= 4e-6          # same sums, different order
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     check_backward_parity(m, b, sd)
 
 
@@ -108,7 +108,7 @@ def test_dense_raw_feature_widths(F):
     b = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
               base.coalesced_undirected, base.max_nodes, base.max_edges)
     m = make_model(F, 3)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     sd = cpu_state_dict(m)
     check_forward_parity(m, b, sd)
     check_backward_parity(m, b, sd)
@@ -118,7 +118,7 @@ def test_dense_results_do_not_depend_on_batch_composition_and_are_reproducible()
     sh = synth.SHAPES["COLLAB"]
     graphs = synth.make_graphs("COLLAB", 96, start=500)
     m = make_model(sh.num_features, sh.num_classes)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     m.eval()
     with torch.no_grad():
         big = collate(graphs).to("cuda")
@@ -146,13 +146,13 @@ def test_fused_dense_forward_vs_oracle_and_backward_through_it(name, bs):
         b = synth.make_batch(name, bs, start=start)
     m = make_model(sh.num_features, sh.num_classes)
     sd = cpu_state_dict(m)
-    m.use_fused, m.agg_mode = True, "dense"
+    m.use_fused, m.agg_mode, m.use_chain = True, "dense", False
     check_forward_parity(m, b, sd)
     xf = gpu_xcat(m)
     m.use_fused, m.agg_mode = False, "sparse"
     check_forward_parity(m, b, sd)
     assert float((xf - gpu_xcat(m)).abs().max()) <= 4e-6
-    m.use_fused, m.agg_mode = True, "dense"
+    m.use_fused, m.agg_mode, m.use_chain = True, "dense", False
     check_backward_parity(m, b, sd)          # backward (tiled kernels) from the activations the fused forward saved
 
 
@@ -163,7 +163,7 @@ def test_fused_dense_raw_feature_widths(F):
     b = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
               base.coalesced_undirected, base.max_nodes, base.max_edges)
     m = make_model(F, 3)
-    m.use_fused, m.agg_mode = True, "dense"
+    m.use_fused, m.agg_mode, m.use_chain = True, "dense", False
     sd = cpu_state_dict(m)
     check_forward_parity(m, b, sd)
     check_backward_parity(m, b, sd)
@@ -180,7 +180,7 @@ def test_fused_dense_reproducible_composition_independent_and_pipelined():
     m.eval()
     with torch.no_grad():
         full = collate(graphs).to("cuda")
-        m.use_fused, m.agg_mode = True, "dense"
+        m.use_fused, m.agg_mode, m.use_chain = True, "dense", False
         lp = m(full).clone()
         xa = gpu_xcat(m)
         assert torch.equal(m(full), lp) and torch.equal(gpu_xcat(m), xa)
@@ -193,7 +193,7 @@ def test_fused_dense_reproducible_composition_independent_and_pipelined():
     for look in (False, True):
         mm = make_model(sh.num_features, sh.num_classes)
         mm.train(); mm._seed_base, mm._fwd_count = 5, 0
-        mm.use_fused, mm.agg_mode = True, "dense"
+        mm.use_fused, mm.agg_mode, mm.use_chain = True, "dense", False
         tr = Trainer(mm)
         for k in range(6):
             tr.train_step(batches[k % 3], batches[k % 3].y, next_data=batches[(k + 1) % 3] if look else None)
@@ -216,7 +216,7 @@ def test_dense_form_detects_a_missing_reverse_edge(route):
     keep[ei.shape[1] // 2] = False                         # drop ONE directed edge: still sorted, no longer symmetric
     bad = Batch(good.x, ei[:, keep].contiguous(), good.batch, good.y, good.num_graphs, True, good.max_nodes, good.max_edges)
     m = make_model(sh.num_features, sh.num_classes)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     if route == "forward":
         m.eval()
         with torch.no_grad():
@@ -268,7 +268,7 @@ def test_dense_boundary_sizes_isolated_nodes_and_single_node_graphs(sizes, isola
     b = _sized_batch(sizes, seed=sum(sizes), isolated=isolated)
     m = make_model(3, 2)
     sd = cpu_state_dict(m)
-    m.agg_mode = "dense"
+    m.agg_mode, m.use_chain = "dense", False
     check_forward_parity(m, b, sd)
     xd = gpu_xcat(m)
     check_backward_parity(m, b, sd)
@@ -276,7 +276,7 @@ def test_dense_boundary_sizes_isolated_nodes_and_single_node_graphs(sizes, isola
     check_forward_parity(m, b, sd)
     assert float((xd - gpu_xcat(m)).abs().max()) <= 4e-6
     if max(sizes) <= 192:
-        m.agg_mode, m.use_fused = "dense", True
+        m.agg_mode, m.use_fused, m.use_chain = "dense", True, False
         check_forward_parity(m, b, sd)
         assert float((xd - gpu_xcat(m)).abs().max()) <= 4e-6
 
@@ -286,7 +286,7 @@ def test_dense_is_not_taken_above_512_nodes_and_the_bf16_leg_says_so():
     b = _sized_batch([513, 20], seed=7)
     m = make_model(3, 2)
     sd = cpu_state_dict(m)
-    m.agg_mode = "dense"                    # asked for, not admissible: the gather form runs, results stay right
+    m.agg_mode, m.use_chain = "dense", False                    # asked for, not admissible: the gather form runs, results stay right
     check_forward_parity(m, b, sd)
     m.compute_dtype = "bf16"
     m.eval()
