@@ -79,6 +79,8 @@ def parse(argv=None):
                     help="forward kernel family: library heuristic, graph-per-workgroup fused, or tiled")
     ap.add_argument("--agg", choices=["auto", "sparse", "dense"], default="auto",
                     help="aggregation form: library heuristic, CSR gather, or dense per-graph blocks on the matrix cores")
+    ap.add_argument("--chain", choices=["auto", "on", "off"], default="auto",
+                    help="graph-chain kernels (conv1..conv4 of a graph in one workgroup): library's choice / force / forbid")
     ap.add_argument("--exchange", choices=["auto", "rccl", "oneshot"], default="auto",
                     help="gradient exchange when --gpus > 1: RCCL all_reduce + Adam launch, or the one-shot peer-memory kernel "
                          "(dgcnn_allreduce_adam_step); auto = one-shot if it sets up and the replicas verify identical, else RCCL")
@@ -317,6 +319,8 @@ def main():
             model.agg_mode = args.agg
         if args.dtype == "bf16":
             model.compute_dtype = "bf16"
+        if args.chain != "auto":
+            model.use_chain = args.chain == "on"
         return Trainer(model, process_group=pg, force_collective=force, one_shot=exchange["mode"] == "oneshot")
 
     def replicas_identical(t):

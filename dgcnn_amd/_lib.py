@@ -189,7 +189,7 @@ def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
         "drop_mask": (torch.uint8, (B, HID1)), "dlogit": (torch.float32, (B, C)),
         "gp1": (torch.float32, (N, 32)), "gp2": (torch.float32, (N, 32)), "gp3": (torch.float32, (N, 32)),
         "gas4": (torch.float32, (N,)), "lossv": (torch.float32, (B, 2)), "ax": (torch.float32, (N, F)),
-        "adjbits": (torch.int32, (31 * N,)), "dmap": (torch.int32, (3080 + 3 * (N // 128 + B + 1),)),
+        "adjbits": (torch.int32, (31 * N,)), "dmap": (torch.int32, (3096 + 3 * (N // 128 + B + 1) + 2 * B + 4,)),
     }
     dt, shape = shapes[name]
     off = workspace_offset(name, N, E, B, F, C)

@@ -337,7 +337,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   if (dense && dg_use_chain(F, flags)) {
     DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
-                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, s, g_prof_which >= 0 ? g_prof_a : nullptr,
+                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<int32_t>(ws, wl.dmap), s,
+                               g_prof_which >= 0 ? g_prof_a : nullptr,
                                g_prof_which >= 0 ? g_prof_b : nullptr));
     g_prof_which = -1;
   } else if (dense) {

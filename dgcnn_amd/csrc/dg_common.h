@@ -175,9 +175,9 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
   R(adjbits, 4 * 31 * n);
 #if defined(DGD_ROWS) && DGD_ROWS == 64
-  R(dmap, 4 * (3080 + 3 * (n / 64 + b + 1)));
+  R(dmap, 4 * (3096 + 3 * (n / 64 + b + 1) + 2 * b + 4));
 #else
-  R(dmap, 4 * (3080 + 3 * (n / 128 + b + 1)));
+  R(dmap, 4 * (3096 + 3 * (n / 128 + b + 1) + 2 * b + 4));
 #endif      // item table: shares + records (dg_prep.h: dgd_table_ints)
 #undef R
   w->total = o;
@@ -416,7 +416,8 @@ int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, 
 int dg_chain_max_nodes();
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
-                        float* x3, float* x4, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                        float* x3, float* x4, int32_t* dmap, hipStream_t s, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);
 // graph-per-workgroup fused forward in the dense block form (gcn_dense.hip): conv1..conv4 + readout, one launch
 struct DgParams;
 int dg_fused_d_max_nodes();

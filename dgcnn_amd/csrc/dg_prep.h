@@ -33,6 +33,10 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 //                                (nearly) equal COST (cost of an item = 3 * its pipeline stages + 1, i.e. ~ n_g), so that
 //                                persistent workgroups that take equal numbers of shares finish together -- static,
 //                                hence reproducible, and contiguous, hence L2-friendly
+//   [dgd_sched0(N,B) + 2r ..]    graph SCHEDULE of the chain kernels (gcn_chain.hip): entry r = {first node, node count} of the
+//                                graph of rank r when the graphs are ordered by 16-row tile count, descending, ties by graph
+//                                index (a stable counting sort: deterministic).  Persistent workgroups deal themselves the
+//                                entries in snake order (w, 2G-1-w, 2G+w, ...): largest first, equal sums, no atomics
 //   [DGD_REC0 + 3w ..]           record of item w: {first node of its graph, node count, first row of the item}
 // built by ONE workgroup of graph preparation's second phase with a block-wide prefix sum over the graphs
 // (dg_prep_dense_plan); at most N/64 + B items.
@@ -46,9 +50,11 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 #endif
 #define DGD_CLASSES 5
 #define DGD_SPLITS 3072
-#define DGD_REC0 (DGD_SPLITS + 8)
+#define DGD_NBIG (DGD_SPLITS + 2)     // number of graphs above 128 nodes = first entry of the small graphs in the schedule
+#define DGD_REC0 (DGD_SPLITS + 24)
 static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }       // upper bound
-static inline int64_t dgd_table_ints(int N, int B) { return DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1); }
+static inline int64_t dgd_sched0(int N, int B) { return (DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1) + 1) & ~1LL; }
+static inline int64_t dgd_table_ints(int N, int B) { return dgd_sched0(N, B) + 2 * (int64_t)B + 2; }
 struct DgDense { const int* graph_ptr; const int* dmap; const unsigned* bits; int N, B, NW; };
 #include <type_traits>
 #ifdef __HIPCC__
@@ -73,6 +79,47 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
     items = (n + DGD_ROWS - 1) / DGD_ROWS;
     ic = DGD_COST_STAGE * ((n + 63) / 64) + 1;      // cost of one item (pipeline stages of 64 k-rows + epilogue)
   };
+  // ---- schedule of the chain kernels: stable counting sort of the graphs by tile count, descending --------------------
+  {
+    __shared__ int shist[33], sstart[33], scarry[33], swc[16][33];
+    const int N = graph_ptr[B];
+    int* sched = dmap + ((DGD_REC0 + 3 * (N / DGD_ROWS + B + 1) + 1) & ~1);
+    auto bin_of = [&](int g, int& n0, int& n) {
+      n0 = graph_ptr[g]; n = graph_ptr[g + 1] - n0;
+      int t = (max(n, 0) + 15) >> 4;
+      return 32 - min(t, 32);                 // bin 0: 32 tiles (or more: not admissible, flagged elsewhere) ... bin 32: empty graph
+    };
+    if (tid < 33) { shist[tid] = 0; scarry[tid] = 0; }
+    __syncthreads();
+    for (int g = tid; g < B; g += T) { int n0, n; atomicAdd(&shist[bin_of(g, n0, n)], 1); }     // (integer counts: order-free)
+    __syncthreads();
+    if (tid == 0) {
+      int a = 0;
+      for (int b = 0; b < 33; ++b) { sstart[b] = a; a += shist[b]; }
+      dmap[DGD_NBIG] = sstart[24];            // bins 0..23 = 32..9 tiles = graphs above 128 nodes
+    }
+    __syncthreads();
+    for (int base = 0; base < B; base += T) {
+      const int g = base + tid;
+      int n0 = 0, n = 0;
+      const int bin = g < B ? bin_of(g, n0, n) : 33;
+      int myrank = 0;
+      for (int b = 0; b < 33; ++b) {
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(bin == b);
+        if (bin == b) myrank = __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) swc[wave][b] = __builtin_popcountll(mk);
+      }
+      __syncthreads();
+      if (g < B) {
+        int off = sstart[bin] + scarry[bin] + myrank;
+        for (int w = 0; w < wave; ++w) off += swc[w][bin];
+        sched[2 * off] = n0; sched[2 * off + 1] = n;
+      }
+      __syncthreads();
+      if (tid < 33) { int a = 0; for (int w = 0; w < nw; ++w) a += swc[w][tid]; scarry[tid] += a; }
+      __syncthreads();
+    }
+  }
   // pass 0: totals
   {
     int sI = 0, sC = 0;

@@ -70,6 +70,28 @@ def test_chain_boundary_sizes_isolated_nodes_and_single_node_graphs(sizes, isola
     assert float((xc - gpu_xcat(m)).abs().max()) <= 4e-6
 
 
+def test_chain_schedule_is_the_stable_sort_by_tile_count():
+    """graph preparation's schedule (dg_prep.h): {first node, node count} of every graph, ordered by 16-row tile count
+    descending, ties by graph index; graphs above 128 nodes first, their number in the table header -- bit-exact"""
+    b = _sized_batch([5, 130, 64, 17, 16, 300, 128, 129, 1, 33, 48, 47, 200, 96], seed=3)
+    m = make_model(3, 2)
+    _chain(m)
+    m.eval()
+    with torch.no_grad():
+        m(b.to("cuda"))
+    m.check_errors()
+    N, B = b.num_nodes, b.num_graphs
+    ptr = np.searchsorted(b.batch.numpy(), np.arange(B + 1))
+    sizes = np.diff(ptr)
+    order = sorted(range(B), key=lambda g: (-((sizes[g] + 15) // 16), g))
+    tab = m.last_workspace_view("dmap").cpu().numpy()
+    s0 = (3096 + 3 * (N // 128 + B + 1) + 1) & ~1
+    got = tab[s0:s0 + 2 * B].reshape(B, 2)
+    want = np.array([[ptr[g], sizes[g]] for g in order])
+    np.testing.assert_array_equal(got, want)
+    assert tab[3074] == int((sizes > 128).sum())
+
+
 def test_chain_without_max_nodes_hint_runs_both_size_classes():
     b = _sized_batch([130, 20, 300, 64], seed=11)
     b = Batch(b.x, b.edge_index, b.batch, b.y, b.num_graphs, True, 512, b.max_edges)      # loose (but valid) bound

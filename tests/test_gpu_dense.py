@@ -65,7 +65,7 @@ def test_dense_structures_bit_exact(name, bs):
     tab = m.last_workspace_view("dmap").cpu().numpy()
     np.testing.assert_array_equal(tab[:3073], split)                       # equal-cost shares
     assert tab[3073] == len(recs)
-    np.testing.assert_array_equal(tab[3080:3080 + 3 * len(recs)].reshape(-1, 3), recs)
+    np.testing.assert_array_equal(tab[3096:3096 + 3 * len(recs)].reshape(-1, 3), recs)
     # only the words of each row's OWN stride class are defined content (the other classes are never written)
     ptr = np.searchsorted(b.batch.numpy(), np.arange(b.num_graphs + 1))
     N = b.num_nodes
