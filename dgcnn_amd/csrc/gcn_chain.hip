@@ -29,6 +29,7 @@
 #include "dg_common.h"
 #include "dg_prep.h"
 #include <hip/hip_ext.h>
+#include <cstdio>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -745,13 +746,432 @@ k_chain_fwd_p(int N, int B, int F, const int* __restrict__ sched, const int* __r
   }
 }
 
+// =================================================================================================================
+// The same persistent kernel with FOUR waves per workgroup and TWO 16-row tiles per wave (graphs of <= 128 nodes), one
+// LDS image of hs instead of two: 39 KB of LDS and <= 128 registers, i.e. FOUR workgroups = four graphs in flight per CU
+// instead of two (the per-layer time of a graph is a latency chain, ~2-3 k cycles, that barely stretches when more graphs
+// share the CU: profiles/r03 phase clocks).  A wave's two tiles share every HS^T operand it reads (half the LDS read
+// traffic per matrix instruction) and their dependent chains interleave.  The image is overwritten in place, so a layer
+// is  product -> barrier -> store next image -> barrier.
+// =================================================================================================================
+#ifndef CH_LOCKSTEP
+#define CH_LOCKSTEP 0         // 1: the epilogues of a wave's two tiles run in lock step (more overlap, ~20 more registers: three
+#endif                        // workgroups per CU instead of four)
+template <int W1S>
+struct ChQ {
+  static constexpr int THREADS = 256, ROWS = 128, PS = ROWS * 32, BUF = 6 * PS;
+  static constexpr int OFF_W1 = BUF, OFF_W2 = OFF_W1 + W1S * 512, OFF_W3 = OFF_W2 + 4096, OFF_BT = OFF_W3 + 4096;
+  static constexpr int OFF_DV = OFF_BT + 512;            // two sets (graph parity): dinv [ROWS] f32
+  static constexpr int OFF_H4 = OFF_DV + 2 * 4 * ROWS;   // two sets: h4s parts [3][ROWS] bf16
+  static constexpr int OFF_BL = OFF_H4 + 2 * 6 * ROWS;   // bitmap rows, <= 4 words each
+  static constexpr int OFF_TAB = OFF_BL + 16 * ROWS;
+  static constexpr int TOTAL = OFF_TAB + 128;
+};
+
+template <int XI, int W1S>      // XI: xs items (row, 4-column slot) per thread -- 1: F <= 8, 2: F <= 16, 4: F <= 32 (W1S = 8)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers: four workgroups per CU
+k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const unsigned* __restrict__ bits,
+              const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
+              float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
+              unsigned long long* __restrict__ dbg) {
+  using C = ChQ<W1S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  char* H = smem;
+  float* W1op = reinterpret_cast<float*>(smem + C::OFF_W1);
+  float* W2op = reinterpret_cast<float*>(smem + C::OFF_W2);
+  float* W3op = reinterpret_cast<float*>(smem + C::OFF_W3);
+  float* bt = reinterpret_cast<float*>(smem + C::OFF_BT);
+  unsigned* bl = reinterpret_cast<unsigned*>(smem + C::OFF_BL);
+  uint2* tab = reinterpret_cast<uint2*>(smem + C::OFF_TAB);
+#ifdef CH_TIMING
+  unsigned long long tprev_ = clock64();
+  if (dbg && tid == 0) { for (int k = 0; k < 16; ++k) dbg[blockIdx.x * 16 + k] = 0; dbg[blockIdx.x * 16 + 12] = wall_clock64(); }
+#endif
+  const int nbig = nbig_p[0], ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
+  auto entry_of = [&](int r) {               // {n0, n}; n = 0 past the end (load clamped, selected)
+    const int li = r * G + ((r & 1) ? G - 1 - w : w);
+    const int2 e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + min(li, max(ns - 1, 0))));
+    return make_int2(e.x, (li < ns && e.y <= C::ROWS) ? e.y : 0);
+  };
+  int2 eC = entry_of(0), eN = entry_of(1);
+  // ---- once per workgroup: weight tables in MFMA-operand order (coalesced loads, scattered on the LDS side) ------------
+  {
+    float w2[4], w3[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      w2[j] = gw.W2[e]; w3[j] = gw.W3[e]; w1[j] = e < 32 * F ? gw.W1[e] : 0.f;
+    }
+    float bv = 0.f;
+    if (tid < 128) {
+      const int which = tid >> 5, idx = tid & 31;
+      const float* src = which == 0 ? gw.b1 : (which == 1 ? gw.b2 : (which == 2 ? gw.b3 : gw.W4));
+      bv = src[idx];
+    }
+    // W[o][k] -> [ob = o >> 4][s = 4 (k >> 4) + (k & 3)][lane = (o & 15) + 16 ((k >> 2) & 3)], S steps per ob
+    auto slot_of = [](int o, int k, int S) {
+      return (((o >> 4) * S + ((k >> 4) << 2) + (k & 3)) << 6) + (o & 15) + (((k >> 2) & 3) << 4);
+    };
+    for (int e = tid; e < 2 * W1S * 64; e += 256) {      // conv1's table: entries with k >= F are zero
+      const int s_ = (e >> 6) % W1S, l = e & 63;
+      if (16 * (s_ >> 2) + 4 * (l >> 4) + (s_ & 3) >= F) W1op[e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      W2op[slot_of(e >> 5, e & 31, 8)] = w2[j]; W3op[slot_of(e >> 5, e & 31, 8)] = w3[j];
+      if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F, W1S)] = w1[j]; }
+    }
+    if (tid < 128) bt[tid] = bv;
+    if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
+                                        ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+  }
+  const float b4s = gw.b4[0];
+  __syncthreads();
+  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
+  const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
+  const int NBF = F > 16 ? 2 : 1;
+  unsigned pbit[2] = {0u, 0u}; float pdv = 0.f; float pxs[XI][4];
+  auto prefetch = [&](int pn0, int pn) {      // (unconditional loads on clamped addresses, selected when consumed)
+    const int pS = 1 << dgd_class(max(pn, 1));
+    const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
+    const int last = max(pn * pS - 1, 0);
+    pbit[0] = bp[min(tid, last)]; pbit[1] = bp[min(tid + 256, last)];
+    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int it = tid + 256 * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
+      const float* xr = xs + (size_t)(pn0 + k) * F;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pxs[j][i] = xr[min(4 * qq + i, F - 1)];
+    }
+  };
+  prefetch(n0, n);
+  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
+  const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 64;                 // this lane's node in tile wave / tile wave + 4
+  const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
+  int par = 0;
+  CH_T(0);                                                // 0: set-up
+  for (int r = 0; r * G < ns; ++r) {
+    float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
+    unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4) + par * 3 * C::ROWS;
+    const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
+    const int S = 1 << dgd_class(max(n, 1));
+    // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
+    if (tid < n * S) bl[tid] = pbit[0];
+    if (tid + 256 < n * S) bl[tid + 256] = pbit[1];
+    if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int it = tid + 256 * j, k = it >> lg, qq = it & ((1 << lg) - 1);
+      if (k < n) {
+        unsigned sp[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ch_split3(4 * qq + i < F ? pxs[j][i] : 0.f, sp[0][i], sp[1][i], sp[2][i]);
+        const int nb = qq >> 2, sl = qq & 3;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(H + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) =
+              make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+      }
+    }
+    {   // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
+      const int sh = NBF + 1;                              // 4 * NBF slots per row
+      for (int it = tid; it < (RU << sh); it += 256) {
+        const int k = it >> sh, qq = it & ((1 << sh) - 1);
+        if (!(k < n && qq < (1 << lg))) {
+          const int nb = qq >> 2, sl = qq & 3;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2*>(H + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) = make_uint2(0u, 0u);
+        }
+      }
+    }
+    if (RU > 16 * T) {   // rows 16T .. RU-1 (sixteen) of the planes conv1 does not use, and of h4s: written by no tile
+      if (tid < 192) {
+        const int piece = tid & 1, row = 16 * T + ((tid >> 1) & 15), pp = tid >> 5;
+        if ((pp & 1) >= NBF) *reinterpret_cast<uint4*>(H + pp * C::PS + row * 32 + 16 * piece) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (tid < 48) h4p[(tid >> 4) * C::ROWS + 16 * T + (tid & 15)] = 0;
+    }
+    CH_T(1);                                              // 1: wait for the prefetched data + staging stores
+    dg_lds_barrier();
+    CH_T(2);
+    const int n0N = __builtin_amdgcn_readfirstlane(eN.x), nN = __builtin_amdgcn_readfirstlane(eN.y);     // (requested a graph ago)
+    eN = entry_of(r + 2);
+    prefetch(n0N, nN);
+    unsigned wb[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wb[0][u] = (mrow0 < n && u < K32) ? bl[mrow0 * S + u] : 0u;
+      wb[1][u] = (mrow1 < n && u < K32) ? bl[mrow1 * S + u] : 0u;
+    }
+    const float dn[2] = {dv[mrow0], dv[mrow1]};
+    const int mrow[2] = {mrow0, mrow1};
+    CH_T(3);
+    const bool live0 = wave < T, live1 = wave + 4 < T;
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+
+    // block products of this wave's tiles with the image: every HS^T operand read once, used by both tiles; the reads of
+    // word u+1 are issued before the matrix instructions of word u
+    auto product = [&](auto nbc, f32x4 (&acc)[2][2]) {
+      constexpr int NBP = decltype(nbc)::value;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) { acc[ti][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const char* hp = H + rdoff;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < K32) {
+          const bf16x8 bop0 = ch_bits_operand(wb[0][u], kq, tab);
+          const bf16x8 bop1 = ch_bits_operand(wb[1][u], kq, tab);
+          bf16x8 a[3][NBP];
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nb = 0; nb < NBP; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop0, acc[0][nb], 0, 0, 0);
+          if (live1) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < NBP; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop1, acc[1][nb], 0, 0, 0);
+          }
+        }
+      }
+    };
+    auto bias4 = [&](int which, int nb) { return *reinterpret_cast<const float4*>(bt + 32 * which + 16 * nb + 4 * kq); };
+    // NT tiles in lock step: activated rows to global, next layer's pre-scaled linear output hs (registers, same layout)
+    auto rows_and_linear = [&](auto ntc, auto t0c, const f32x4 (&v)[2][2], float* __restrict__ xout, const float* __restrict__ Wop,
+                               f32x4 (&hs)[2][2]) {
+      constexpr int T0 = decltype(t0c)::value, NT = T0 + decltype(ntc)::value;       // tiles T0 .. NT-1
+#pragma unroll
+      for (int ti = T0; ti < NT; ++ti)
+        if (mrow[ti] < n) {
+          float* dst = xout + (size_t)(n0 + mrow[ti]) * 32 + 4 * kq;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[ti][0][0], v[ti][0][1], v[ti][0][2], v[ti][0][3]);
+          *reinterpret_cast<float4*>(dst + 16) = make_float4(v[ti][1][0], v[ti][1][1], v[ti][1][2], v[ti][1][3]);
+        }
+      float wv[2][8];
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wv[ob][s] = Wop[(ob * 8 + s) * 64 + lane];
+      // four independent accumulator chains per wave: (tile x output block) with two tiles, (output block x input half)
+      // with one -- the dependent-accumulator latency of the fp32 matrix instruction is 40 cycles, its issue interval 32
+      constexpr int NH = (NT - T0) == 2 ? 1 : 2;
+      f32x4 d2[2][2][NH];
+#pragma unroll
+      for (int ti = T0; ti < NT; ++ti)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) d2[ti][ob][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int ti = T0; ti < NT; ++ti)
+              d2[ti][ob][h % NH] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob][4 * h + s], v[ti][h][s], d2[ti][ob][h % NH], 0, 0, 0);
+#pragma unroll
+      for (int ti = T0; ti < NT; ++ti)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) hs[ti][ob][rr] = dn[ti] * (NH == 2 ? d2[ti][ob][0][rr] + d2[ti][ob][NH - 1][rr] : d2[ti][ob][0][rr]);
+    };
+    auto write_hs = [&](int ti, const f32x4 (&hs)[2]) {
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) {
+        unsigned sp[3][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ch_split3(hs[ob][rr], sp[0][rr], sp[1][rr], sp[2][rr]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(H + (p * 2 + ob) * C::PS + mrow[ti] * 32 + wsl) =
+              make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+      }
+    };
+    auto act32 = [&](auto ntc, auto t0c, int which, const f32x4 (&acc)[2][2], f32x4 (&v)[2][2]) {
+      constexpr int T0 = decltype(t0c)::value, NT = T0 + decltype(ntc)::value;
+      const float4 b0 = bias4(which, 0), b1v = bias4(which, 1);
+#pragma unroll
+      for (int ti = T0; ti < NT; ++ti) {
+        v[ti][0][0] = dg_tanh(fmaf(dn[ti], acc[ti][0][0], b0.x)); v[ti][0][1] = dg_tanh(fmaf(dn[ti], acc[ti][0][1], b0.y));
+        v[ti][0][2] = dg_tanh(fmaf(dn[ti], acc[ti][0][2], b0.z)); v[ti][0][3] = dg_tanh(fmaf(dn[ti], acc[ti][0][3], b0.w));
+        v[ti][1][0] = dg_tanh(fmaf(dn[ti], acc[ti][1][0], b1v.x)); v[ti][1][1] = dg_tanh(fmaf(dn[ti], acc[ti][1][1], b1v.y));
+        v[ti][1][2] = dg_tanh(fmaf(dn[ti], acc[ti][1][2], b1v.z)); v[ti][1][3] = dg_tanh(fmaf(dn[ti], acc[ti][1][3], b1v.w));
+      }
+    };
+    f32x4 hsv[2][2];
+    // ---- conv1 (aggregate-first): ax = dn (Adj xs) saved, x1 = tanh(ax W1^T + b1), hs2 = dn (x1 W2^T) ----------------------
+    if (live0) {
+      f32x4 acc[2][2];
+      if (NBF == 2) product(I2{}, acc); else product(I1{}, acc);
+      auto conv1_tail = [&](auto ntc, auto t0c) {
+        constexpr int T0 = decltype(t0c)::value, NT = T0 + decltype(ntc)::value;
+        const float4 b0 = bias4(0, 0), b1v = bias4(0, 1);
+        f32x4 axv[2][2], pre[2][2], v[2][2];
+#pragma unroll
+        for (int ti = T0; ti < NT; ++ti)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            pre[ti][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              axv[ti][nb][rr] = dn[ti] * acc[ti][nb][rr];
+              const int c = 16 * nb + 4 * kq + rr;
+              if (c < F && mrow[ti] < n) axg[(size_t)(n0 + mrow[ti]) * F + c] = axv[ti][nb][rr];
+            }
+          }
+#pragma unroll
+        for (int s = 0; s < W1S; ++s)
+          if (16 * (s >> 2) + (s & 3) < F) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+              const float wv = W1op[(ob * W1S + s) * 64 + lane];
+#pragma unroll
+              for (int ti = T0; ti < NT; ++ti)
+                pre[ti][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, axv[ti][s >> 2][s & 3], pre[ti][ob], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int ti = T0; ti < NT; ++ti) {
+          v[ti][0][0] = dg_tanh(pre[ti][0][0] + b0.x); v[ti][0][1] = dg_tanh(pre[ti][0][1] + b0.y);
+          v[ti][0][2] = dg_tanh(pre[ti][0][2] + b0.z); v[ti][0][3] = dg_tanh(pre[ti][0][3] + b0.w);
+          v[ti][1][0] = dg_tanh(pre[ti][1][0] + b1v.x); v[ti][1][1] = dg_tanh(pre[ti][1][1] + b1v.y);
+          v[ti][1][2] = dg_tanh(pre[ti][1][2] + b1v.z); v[ti][1][3] = dg_tanh(pre[ti][1][3] + b1v.w);
+        }
+        rows_and_linear(ntc, t0c, v, x1, W2op, hsv);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      if (CH_LOCKSTEP) { if (live1) conv1_tail(I2{}, I0{}); else conv1_tail(I1{}, I0{}); }
+      else { conv1_tail(I1{}, I0{}); if (live1) conv1_tail(I1{}, I1{}); }
+    }
+    CH_T(4);
+    dg_lds_barrier();                                     // every wave has read the image: it can be overwritten
+    if (live0) write_hs(0, hsv[0]);
+    if (live1) write_hs(1, hsv[1]);
+    dg_lds_barrier();
+    CH_T(5);
+    // ---- conv2 -----------------------------------------------------------------------------------------------------------
+    if (live0) {
+      f32x4 acc[2][2], v[2][2];
+      product(I2{}, acc);
+      using I0 = std::integral_constant<int, 0>;
+      if (CH_LOCKSTEP && live1) { act32(I2{}, I0{}, 1, acc, v); rows_and_linear(I2{}, I0{}, v, x2, W3op, hsv); }
+      else {
+        act32(I1{}, I0{}, 1, acc, v); rows_and_linear(I1{}, I0{}, v, x2, W3op, hsv);
+        if (live1) { act32(I1{}, I1{}, 1, acc, v); rows_and_linear(I1{}, I1{}, v, x2, W3op, hsv); }
+      }
+    }
+    CH_T(6);
+    dg_lds_barrier();
+    if (live0) write_hs(0, hsv[0]);
+    if (live1) write_hs(1, hsv[1]);
+    dg_lds_barrier();
+    CH_T(7);
+    // ---- conv3 (next linear step 32 -> 1: h4s = dn (x3 . w4), three bf16 parts in their own buffer) -------------------------
+    if (live0) {
+      const float4 w0 = bias4(3, 0), w1 = bias4(3, 1);
+      f32x4 acc[2][2], v[2][2];
+      product(I2{}, acc);
+      auto conv3_tail = [&](auto ntc) {
+        constexpr int NT = decltype(ntc)::value;
+        act32(ntc, std::integral_constant<int, 0>{}, 2, acc, v);
+        float pp[2];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+          if (mrow[ti] < n) {
+            float* dst = x3 + (size_t)(n0 + mrow[ti]) * 32 + 4 * kq;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[ti][0][0], v[ti][0][1], v[ti][0][2], v[ti][0][3]);
+            *reinterpret_cast<float4*>(dst + 16) = make_float4(v[ti][1][0], v[ti][1][1], v[ti][1][2], v[ti][1][3]);
+          }
+          float p = v[ti][0][0] * w0.x;
+          p = fmaf(v[ti][0][1], w0.y, p); p = fmaf(v[ti][0][2], w0.z, p); p = fmaf(v[ti][0][3], w0.w, p);
+          p = fmaf(v[ti][1][0], w1.x, p); p = fmaf(v[ti][1][1], w1.y, p); p = fmaf(v[ti][1][2], w1.z, p); p = fmaf(v[ti][1][3], w1.w, p);
+          pp[ti] = p;
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) pp[ti] += __shfl_xor(pp[ti], 16);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) pp[ti] += __shfl_xor(pp[ti], 32);
+        if (kq == 0) {
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) {
+            unsigned q0, q1, q2;
+            ch_split3(dn[ti] * pp[ti], q0, q1, q2);
+            h4p[mrow[ti]] = (unsigned short)q0; h4p[C::ROWS + mrow[ti]] = (unsigned short)q1; h4p[2 * C::ROWS + mrow[ti]] = (unsigned short)q2;
+          }
+        }
+      };
+      if (live1) conv3_tail(I2{}); else conv3_tail(I1{});
+    }
+    CH_T(8);
+    dg_lds_barrier();
+    CH_T(9);
+    // ---- conv4: the three parts of h4s are columns 0..2 of ONE B operand ---------------------------------------------------
+    if (live0) {
+      f32x4 a4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const unsigned short* hq = h4p + min(nl, 2) * C::ROWS + 4 * kq;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < K32) {
+          uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
+          if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+          bf16x8 bop;
+          unsigned* bu = reinterpret_cast<unsigned*>(&bop);
+          bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+          a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(wb[0][u], kq, tab), bop, a4[0], 0, 0, 0);
+          if (live1) a4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(wb[1][u], kq, tab), bop, a4[1], 0, 0, 0);
+        }
+      }
+      float s1[2][4], s2[2][4];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { s1[ti][rr] = __shfl_xor(a4[ti][rr], 1); s2[ti][rr] = __shfl_xor(a4[ti][rr], 2); }
+      if (nl == 0) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const int mm = 16 * (wave + 4 * ti) + 4 * kq;
+          const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
+          const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (mm + rr < n) x4[n0 + mm + rr] = dg_tanh(fmaf(dd[rr], (a4[ti][rr] + s1[ti][rr]) + s2[ti][rr], b4s));
+        }
+      }
+    }
+    CH_T(10);
+#ifdef CH_TIMING
+    if (dbg && tid == 0) dbg[blockIdx.x * 16 + 11] += 1;
+#endif
+    n0 = n0N; n = nN; par ^= 1;
+  }
+#ifdef CH_TIMING
+  if (dbg && tid == 0) dbg[blockIdx.x * 16 + 13] = wall_clock64();
+#endif
+}
+
 // ---- host launcher ----------------------------------------------------------------------------------------------------
 // size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
 // workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
 // and leaves the other class' graphs alone; the second launch is skipped when the host's max_nodes hint rules it out.
 #define CH_SMALL_ROWS 128
 #ifndef CH_GRID
-#define CH_GRID 512                      // persistent workgroups: two per CU (LDS 70 KB each)
+#define CH_GRID 512                      // eight-wave form: two persistent workgroups per CU (LDS 70 KB each)
+#endif
+#ifndef CH_GRID_Q
+#define CH_GRID_Q 1024                   // four-wave form: four per CU (LDS 39 KB each)
 #endif
 int dg_chain_max_nodes() { return 512; }
 
@@ -765,24 +1185,43 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   using CL = ChCfg<16, 2, false>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            ChP::TOTAL) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            ChP::TOTAL) != hipSuccess ||
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<4>::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<4>::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<8>::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CL::TOTAL) != hipSuccess)
       return DGCNN_ELAUNCH;
     attr_set = true;
   }
-  const int grid = B < CH_GRID ? B : CH_GRID;
   const int* sched = dmap + dgd_sched0(N, B);
   const int* nbig = dmap + DGD_NBIG;
+#ifdef CH_USE_P8        // measurement builds: the eight-wave, one-tile-per-wave form (two workgroups per CU)
+  const int grid = B < CH_GRID ? B : CH_GRID;
   if (F <= 16)
     hipExtLaunchKernelGGL((k_chain_fwd_p<1>), dim3(grid), dim3(512), ChP::TOTAL, s, ev_start, ev_stop, 0, N, B, F, sched, nbig,
                           bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer());
   else
     hipExtLaunchKernelGGL((k_chain_fwd_p<2>), dim3(grid), dim3(512), ChP::TOTAL, s, ev_start, ev_stop, 0, N, B, F, sched, nbig,
                           bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer());
+#else
+  const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
+#ifndef CH_LDS_CUT
+#define CH_LDS_CUT 0          // (measurement only: declare less LDS than the kernel uses, to probe the residency limit)
+#endif
+#define CH_LQ(XI, WS) hipExtLaunchKernelGGL((k_chain_fwd_q<XI, WS>), dim3(grid), dim3(256), ChQ<WS>::TOTAL - CH_LDS_CUT, s, ev_start, ev_stop, 0, N, B, F, \
+                                            sched, nbig, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
+#ifdef CH_TIMING
+  { static bool once = false; if (!once) { once = true; int nb = -1; hipFuncAttributes fa{};
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chain_fwd_q<1, 4>, 256, ChQ<4>::TOTAL - CH_LDS_CUT);
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_chain_fwd_q<1, 4>));
+      fprintf(stderr, "k_chain_fwd_q<1,4>: occupancy API %d blocks/CU, numRegs %d, static LDS %zu, scratch %zu, dyn LDS %d\n", nb, fa.numRegs,
+              fa.sharedSizeBytes, fa.localSizeBytes, ChQ<4>::TOTAL - CH_LDS_CUT); } }
+#endif
+  if (F <= 8) CH_LQ(1, 4); else if (F <= 16) CH_LQ(2, 4); else CH_LQ(4, 8);
+#undef CH_LQ
+#endif
   DG_CHECK_LAUNCH();
   if (max_nodes <= 0 || max_nodes > CH_SMALL_ROWS) {
     hipLaunchKernelGGL((k_chain_fwd<16, 2, false>), dim3(B), dim3(CL::THREADS), CL::TOTAL, s, N, F, graph_ptr, bits, dinv, xs, gw,

@@ -25,9 +25,15 @@ with torch.no_grad():
     L.dgcnn_debug_phase_clocks(None)
 d = dbg.cpu().numpy().reshape(-1, 16)
 d = d[(d[:, 11] > 0) & (d[:, :12].max(1) < 100_000_000)]       # (the readout kernels stamp the first words of the same buffer)
-names = ["setup", "stage(wait+stores)", "barrier0", "prefetch issue", "conv1", "bar1", "conv2", "bar2", "conv3", "bar3", "conv4"]
+names = ["setup", "stage(wait+stores)", "barrier0", "prefetch issue", "conv1", "bar1(+image store)", "conv2", "bar2(+image store)", "conv3", "bar3", "conv4"]
 tot = d[:, :11].sum(1)
 print(f"{len(d)} workgroups, graphs per WG mean {d[:,11].mean():.2f} max {d[:,11].max()}; cycles per WG mean {tot.mean():.0f} min {tot.min()} max {tot.max()}")
 ng = d[:, 11].sum()
 for k, n in enumerate(names):
     print(f"  {n:20s} per WG {d[:,k].mean():9.0f}  per graph {d[:,k].sum()/ng:8.0f}  share {100*d[:,k].sum()/tot.sum():5.1f} %")
+
+if d[:, 12].max() > 0:
+    t0 = d[:, 12].min()
+    st, en = (d[:, 12] - t0) / 100.0, (d[:, 13] - t0) / 100.0      # 100 MHz constant clock -> us
+    print(f"start (us): p50 {np.percentile(st,50):.2f} p75 {np.percentile(st,75):.2f} p90 {np.percentile(st,90):.2f} max {st.max():.2f};  end: p50 {np.percentile(en,50):.2f} max {en.max():.2f}")
+    print("  starts after 5 us:", int((st > 5).sum()), "of", len(st))
