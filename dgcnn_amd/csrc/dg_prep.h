@@ -50,7 +50,7 @@ static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {  
 #endif
 #define DGD_CLASSES 5
 #define DGD_SPLITS 3072
-#define DGD_NBIG (DGD_SPLITS + 2)     // number of graphs above 128 nodes = first entry of the small graphs in the schedule
+#define DGD_NBIG (DGD_SPLITS + 2)     // two words: number of graphs above 128 / above 256 nodes = first schedule entry of the rest
 #define DGD_REC0 (DGD_SPLITS + 24)
 static inline int dgd_num_items(int N, int B) { return N / DGD_ROWS + B; }       // upper bound
 static inline int64_t dgd_sched0(int N, int B) { return (DGD_REC0 + 3 * (int64_t)(dgd_num_items(N, B) + 1) + 1) & ~1LL; }
@@ -97,6 +97,7 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
       int a = 0;
       for (int b = 0; b < 33; ++b) { sstart[b] = a; a += shist[b]; }
       dmap[DGD_NBIG] = sstart[24];            // bins 0..23 = 32..9 tiles = graphs above 128 nodes
+      dmap[DGD_NBIG + 1] = sstart[16];        // bins 0..15 = 32..17 tiles = graphs above 256 nodes
     }
     __syncthreads();
     for (int base = 0; base < B; base += T) {

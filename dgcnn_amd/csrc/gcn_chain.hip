@@ -757,24 +757,28 @@ k_chain_fwd_p(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #ifndef CH_LOCKSTEP
 #define CH_LOCKSTEP 0         // 1: the epilogues of a wave's two tiles run in lock step (more overlap, ~20 more registers: three
 #endif                        // workgroups per CU instead of four)
-template <int W1S>
+template <int WAVES, int W1S>
 struct ChQ {
-  static constexpr int THREADS = 256, ROWS = 128, PS = ROWS * 32, BUF = 6 * PS;
+  static constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES, KW = WAVES, PS = ROWS * 32, BUF = 6 * PS;
+  static constexpr int PB = ROWS * KW / THREADS;         // bitmap words of a graph per thread
+  static constexpr int WJ = 1024 / THREADS;              // weight-matrix elements per thread
   static constexpr int OFF_W1 = BUF, OFF_W2 = OFF_W1 + W1S * 512, OFF_W3 = OFF_W2 + 4096, OFF_BT = OFF_W3 + 4096;
   static constexpr int OFF_DV = OFF_BT + 512;            // two sets (graph parity): dinv [ROWS] f32
   static constexpr int OFF_H4 = OFF_DV + 2 * 4 * ROWS;   // two sets: h4s parts [3][ROWS] bf16
-  static constexpr int OFF_BL = OFF_H4 + 2 * 6 * ROWS;   // bitmap rows, <= 4 words each
-  static constexpr int OFF_TAB = OFF_BL + 16 * ROWS;
+  static constexpr int OFF_BL = OFF_H4 + 2 * 6 * ROWS;   // bitmap rows, <= KW words each
+  static constexpr int OFF_TAB = OFF_BL + 4 * KW * ROWS;
   static constexpr int TOTAL = OFF_TAB + 128;
 };
 
-template <int XI, int W1S>      // XI: xs items (row, 4-column slot) per thread -- 1: F <= 8, 2: F <= 16, 4: F <= 32 (W1S = 8)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers: four workgroups per CU
+// WAVES = 4: graphs of <= 128 nodes, four workgroups per CU; WAVES = 8: <= 256 nodes (one LDS image of 48 KB), two per CU
+// XI: xs items (row, 4-column slot) per thread; W1S: k-steps of conv1's weight table (4: F <= 16, 8: F <= 32)
+template <int WAVES, int XI, int W1S>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers
 k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const unsigned* __restrict__ bits,
               const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
               float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
               unsigned long long* __restrict__ dbg) {
-  using C = ChQ<W1S>;
+  using C = ChQ<WAVES, W1S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -799,10 +803,10 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   int2 eC = entry_of(0), eN = entry_of(1);
   // ---- once per workgroup: weight tables in MFMA-operand order (coalesced loads, scattered on the LDS side) ------------
   {
-    float w2[4], w3[4], w1[4];
+    float w2[C::WJ], w3[C::WJ], w1[C::WJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + 256 * j;
+    for (int j = 0; j < C::WJ; ++j) {
+      const int e = tid + C::THREADS * j;
       w2[j] = gw.W2[e]; w3[j] = gw.W3[e]; w1[j] = e < 32 * F ? gw.W1[e] : 0.f;
     }
     float bv = 0.f;
@@ -815,13 +819,13 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     auto slot_of = [](int o, int k, int S) {
       return (((o >> 4) * S + ((k >> 4) << 2) + (k & 3)) << 6) + (o & 15) + (((k >> 2) & 3) << 4);
     };
-    for (int e = tid; e < 2 * W1S * 64; e += 256) {      // conv1's table: entries with k >= F are zero
+    for (int e = tid; e < 2 * W1S * 64; e += C::THREADS) {      // conv1's table: entries with k >= F are zero
       const int s_ = (e >> 6) % W1S, l = e & 63;
       if (16 * (s_ >> 2) + 4 * (l >> 4) + (s_ & 3) >= F) W1op[e] = 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + 256 * j;
+    for (int j = 0; j < C::WJ; ++j) {
+      const int e = tid + C::THREADS * j;
       W2op[slot_of(e >> 5, e & 31, 8)] = w2[j]; W3op[slot_of(e >> 5, e & 31, 8)] = w3[j];
       if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F, W1S)] = w1[j]; }
     }
@@ -834,16 +838,17 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
   const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
   const int NBF = F > 16 ? 2 : 1;
-  unsigned pbit[2] = {0u, 0u}; float pdv = 0.f; float pxs[XI][4];
+  unsigned pbit[C::PB]; float pdv = 0.f; float pxs[XI][4];
   auto prefetch = [&](int pn0, int pn) {      // (unconditional loads on clamped addresses, selected when consumed)
     const int pS = 1 << dgd_class(max(pn, 1));
     const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
     const int last = max(pn * pS - 1, 0);
-    pbit[0] = bp[min(tid, last)]; pbit[1] = bp[min(tid + 256, last)];
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
     pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-      const int it = tid + 256 * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
+      const int it = tid + C::THREADS * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
       const float* xr = xs + (size_t)(pn0 + k) * F;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pxs[j][i] = xr[min(4 * qq + i, F - 1)];
@@ -851,7 +856,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   };
   prefetch(n0, n);
   const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
-  const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 64;                 // this lane's node in tile wave / tile wave + 4
+  const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;         // this lane's node in tile wave / tile wave + WAVES
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
   int par = 0;
   CH_T(0);                                                // 0: set-up
@@ -861,12 +866,13 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
     // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
-    if (tid < n * S) bl[tid] = pbit[0];
-    if (tid + 256 < n * S) bl[tid + 256] = pbit[1];
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j)
+      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
     if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-      const int it = tid + 256 * j, k = it >> lg, qq = it & ((1 << lg) - 1);
+      const int it = tid + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
       if (k < n) {
         unsigned sp[3][4];
 #pragma unroll
@@ -880,7 +886,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     }
     {   // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
       const int sh = NBF + 1;                              // 4 * NBF slots per row
-      for (int it = tid; it < (RU << sh); it += 256) {
+      for (int it = tid; it < (RU << sh); it += C::THREADS) {
         const int k = it >> sh, qq = it & ((1 << sh) - 1);
         if (!(k < n && qq < (1 << lg))) {
           const int nb = qq >> 2, sl = qq & 3;
@@ -903,16 +909,14 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     const int n0N = __builtin_amdgcn_readfirstlane(eN.x), nN = __builtin_amdgcn_readfirstlane(eN.y);     // (requested a graph ago)
     eN = entry_of(r + 2);
     prefetch(n0N, nN);
-    unsigned wb[2][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wb[0][u] = (mrow0 < n && u < K32) ? bl[mrow0 * S + u] : 0u;
-      wb[1][u] = (mrow1 < n && u < K32) ? bl[mrow1 * S + u] : 0u;
-    }
+    // this lane's bitmap rows stay in LDS (re-read per layer: 2 x K32 words; in registers they cost 16 at eight waves)
+    const unsigned* bl0 = bl + min(mrow0, max(n - 1, 0)) * S;
+    const unsigned* bl1 = bl + min(mrow1, max(n - 1, 0)) * S;
+    const bool rv0 = mrow0 < n, rv1 = mrow1 < n;
     const float dn[2] = {dv[mrow0], dv[mrow1]};
     const int mrow[2] = {mrow0, mrow1};
     CH_T(3);
-    const bool live0 = wave < T, live1 = wave + 4 < T;
+    const bool live0 = wave < T, live1 = wave + WAVES < T;
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 
     // block products of this wave's tiles with the image: every HS^T operand read once, used by both tiles; the reads of
@@ -923,10 +927,10 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
       for (int ti = 0; ti < 2; ++ti) { acc[ti][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       const char* hp = H + rdoff;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < C::KW; ++u) {
         if (u < K32) {
-          const bf16x8 bop0 = ch_bits_operand(wb[0][u], kq, tab);
-          const bf16x8 bop1 = ch_bits_operand(wb[1][u], kq, tab);
+          const bf16x8 bop0 = ch_bits_operand(rv0 ? bl0[u] : 0u, kq, tab);
+          const bf16x8 bop1 = ch_bits_operand(rv1 ? bl1[u] : 0u, kq, tab);
           bf16x8 a[3][NBP];
 #pragma unroll
           for (int p = 0; p < 3; ++p)
@@ -1123,15 +1127,15 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
       f32x4 a4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       const unsigned short* hq = h4p + min(nl, 2) * C::ROWS + 4 * kq;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < C::KW; ++u) {
         if (u < K32) {
           uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
           if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
           bf16x8 bop;
           unsigned* bu = reinterpret_cast<unsigned*>(&bop);
           bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
-          a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(wb[0][u], kq, tab), bop, a4[0], 0, 0, 0);
-          if (live1) a4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(wb[1][u], kq, tab), bop, a4[1], 0, 0, 0);
+          a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(rv0 ? bl0[u] : 0u, kq, tab), bop, a4[0], 0, 0, 0);
+          if (live1) a4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(rv1 ? bl1[u] : 0u, kq, tab), bop, a4[1], 0, 0, 0);
         }
       }
       float s1[2][4], s2[2][4];
@@ -1142,7 +1146,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
       if (nl == 0) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-          const int mm = 16 * (wave + 4 * ti) + 4 * kq;
+          const int mm = 16 * (wave + WAVES * ti) + 4 * kq;
           const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
           const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
@@ -1166,13 +1170,16 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 // size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
 // workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
 // and leaves the other class' graphs alone; the second launch is skipped when the host's max_nodes hint rules it out.
-#define CH_SMALL_ROWS 128
 #ifndef CH_GRID
 #define CH_GRID 512                      // eight-wave form: two persistent workgroups per CU (LDS 70 KB each)
 #endif
+#ifndef CH_QW
+#define CH_QW 8                          // waves per workgroup of the two-tile form: 8 -> graphs of <= 256 nodes, two workgroups per CU;
+#endif                                   // 4 -> <= 128 nodes, four per CU (measured: ...)
 #ifndef CH_GRID_Q
-#define CH_GRID_Q 1024                   // four-wave form: four per CU (LDS 39 KB each)
+#define CH_GRID_Q (CH_QW == 8 ? 512 : 1024)
 #endif
+#define CH_SMALL_ROWS (32 * CH_QW)
 int dg_chain_max_nodes() { return 512; }
 
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
@@ -1185,9 +1192,9 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   using CL = ChCfg<16, 2, false>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<4>::TOTAL) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<4>::TOTAL) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<8>::TOTAL) != hipSuccess ||
+#define CH_ATTR(W, XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS>), \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess)
+    if (CH_ATTR(CH_QW, 1, 4) || CH_ATTR(CH_QW, 2, 4) || CH_ATTR(CH_QW, 4, 8) ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1196,7 +1203,7 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
     attr_set = true;
   }
   const int* sched = dmap + dgd_sched0(N, B);
-  const int* nbig = dmap + DGD_NBIG;
+  const int* nbig = dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0);      // graphs above the size class = first entry of the class
 #ifdef CH_USE_P8        // measurement builds: the eight-wave, one-tile-per-wave form (two workgroups per CU)
   const int grid = B < CH_GRID ? B : CH_GRID;
   if (F <= 16)
@@ -1207,18 +1214,9 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
                           bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer());
 #else
   const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
-#ifndef CH_LDS_CUT
-#define CH_LDS_CUT 0          // (measurement only: declare less LDS than the kernel uses, to probe the residency limit)
-#endif
-#define CH_LQ(XI, WS) hipExtLaunchKernelGGL((k_chain_fwd_q<XI, WS>), dim3(grid), dim3(256), ChQ<WS>::TOTAL - CH_LDS_CUT, s, ev_start, ev_stop, 0, N, B, F, \
-                                            sched, nbig, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
-#ifdef CH_TIMING
-  { static bool once = false; if (!once) { once = true; int nb = -1; hipFuncAttributes fa{};
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chain_fwd_q<1, 4>, 256, ChQ<4>::TOTAL - CH_LDS_CUT);
-      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_chain_fwd_q<1, 4>));
-      fprintf(stderr, "k_chain_fwd_q<1,4>: occupancy API %d blocks/CU, numRegs %d, static LDS %zu, scratch %zu, dyn LDS %d\n", nb, fa.numRegs,
-              fa.sharedSizeBytes, fa.localSizeBytes, ChQ<4>::TOTAL - CH_LDS_CUT); } }
-#endif
+  // XI = xs items per thread: rows x 4-column slots with data / threads = 2^lg / 2 (at least 1)
+#define CH_LQ(XI, WS) hipExtLaunchKernelGGL((k_chain_fwd_q<CH_QW, XI, WS>), dim3(grid), dim3(64 * CH_QW), ChQ<CH_QW, WS>::TOTAL, s, ev_start, \
+                                            ev_stop, 0, N, B, F, sched, nbig, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
   if (F <= 8) CH_LQ(1, 4); else if (F <= 16) CH_LQ(2, 4); else CH_LQ(4, 8);
 #undef CH_LQ
 #endif
