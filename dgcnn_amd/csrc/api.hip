@@ -206,7 +206,7 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
   if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
   if (dgd_num_items(N, B) > 100000) return false;        // (a workgroup caches at most 128 item records: gcn_dense.hip)
-  if (flags & (DGCNN_FLAG_AGG_DENSE | DGCNN_FLAG_CHAIN)) return true;
+  if (flags & DGCNN_FLAG_AGG_DENSE) return true;
   if (flags & DGCNN_FLAG_BF16) return true;              // the bf16 leg exists in the dense form only
   // Automatic choice.  (1) The dense kernels are persistent pipelines with a fixed prologue (~2.5 us: item records,
   // first stage) and their bitmap costs extra graph-preparation work; below a few hundred work items per launch the
@@ -220,12 +220,30 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
   if (kest < 64) kest = 64;
   return (int64_t)N * kest <= (int64_t)DG_DENSE_EDGE_COST * ((int64_t)E + N);
 }
-// Graph-chain kernels (gcn_chain.hip): a dense-form batch whose raw feature width admits the aggregate-first conv1 runs
-// conv1..conv4 of every graph inside one workgroup (one launch instead of four; hs never leaves the CU).
-static bool dg_use_chain(int F, int flags) {
-  if (flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) return false;
+// Graph-chain forward (gcn_chain.hip): conv1..conv4 of every graph inside one workgroup, one launch instead of four, hs never
+// leaves the CU.  Needs the bitmap + graph schedule of the dense structures (so: the coalesced + undirected promise and
+// a node bound <= 512) and a raw feature width that admits the aggregate-first conv1; independent of the form the
+// BACKWARD takes (dense per-layer kernels for large batches, CSR gather for small ones: dg_use_dense).
+static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
+  if (flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16 | DGCNN_FLAG_AGG_SPARSE | DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED))
+    return false;      // (each of these names another kernel family)
   if (F > DG_AF_MAX_F) return false;
-  return true;
+  if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
+  if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
+  if (dgd_num_items(N, B) > 100000) return false;
+  if (flags & DGCNN_FLAG_CHAIN) return true;
+  // graphs above the persistent kernel's size class take a second launch: worth it for large batches only
+  return max_nodes <= dg_chain_small_rows() || N >= DG_DENSE_MIN_NODES;
+}
+struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
+static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
+  DgForm f;
+  f.dense = dg_use_dense(N, E, B, flags, max_nodes);
+  f.chain = dg_use_chain(N, E, B, F, flags, max_nodes);
+  f.bitmap = f.dense || f.chain;
+  f.plan = f.dense || (f.chain && dg_chain_needs_schedule(B));      // item table + graph schedule (one workgroup of phase B)
+  f.edge_check = (f.bitmap && !f.dense) ? 1 : 0;       // chain forward over a gather backward: phase B keeps the per-edge check
+  return f;
 }
 // the backward of a batch takes the form its forward took (same flags and max_nodes; the fused graph-per-workgroup
 // forward never builds the bitmap)
@@ -248,13 +266,15 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
   DgWs wl;
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
   DgLinFirst lf; lf.x = x; lf.W = nullptr; lf.hs = dg_ptr<float>(ws, wl.hsA); lf.F = F;
-  const bool dense = dg_use_dense(N, E, B, flags, max_nodes);
+  const DgForm fm = dg_form(N, E, B, F, flags, max_nodes);
+  const bool dense = fm.bitmap;
   return dg_launch_prep(edge_index, E, batch, N, B, dg_ptr<int32_t>(ws, wl.rowptr), dg_ptr<int32_t>(ws, wl.colidx),
                         dg_ptr<int32_t>(ws, wl.rowptr_t), dg_ptr<int32_t>(ws, wl.colidx_t), dg_ptr<float>(ws, wl.dinv),
                         dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out), dg_ptr<int32_t>(ws, wl.err),
                         flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr,
-                        dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, dense ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr);
+                        dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr,
+                        fm.edge_check);
 }
 
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
@@ -294,7 +314,10 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                      max_nodes <= dg_fused_d_max_nodes();
   const bool fused_d = fd_ok && (((flags & DGCNN_FLAG_FORCE_FUSED) && (flags & DGCNN_FLAG_AGG_DENSE)) ||
                                  (!(flags & (DGCNN_FLAG_AGG_SPARSE | DGCNN_FLAG_AGG_DENSE)) && B <= DG_FUSED_D_MAX_B));
-  const bool dense = !fused && !fused_d && dg_use_dense(N, E, B, flags, max_nodes);
+  const DgForm fm = dg_form(N, E, B, F, flags, max_nodes);
+  const bool dense = !fused && !fused_d && fm.dense;
+  const bool chain = !fused && !fused_d && fm.chain;
+  const bool bitmap = dense || chain;
   const int bf16 = (flags & DGCNN_FLAG_BF16) ? 1 : 0;
   if (bf16 && !dense) return DGCNN_EUNSUPPORTED;          // the bf16 leg runs in the dense block form only
   const DgDense G = dg_dense_view(ws, wl, N, B);
@@ -308,7 +331,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                         dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
-                        dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, dense ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr));
+                        bitmap ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr,
+                        (bitmap && fm.plan) ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, fm.edge_check));
   if (fused_d) {
     DG_TRY(dg_launch_fused_fwd_d(N, B, F, C, params, &pl, x, rowptr, colidx, dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                                  dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
@@ -335,9 +359,9 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  if (dense && dg_use_chain(F, flags)) {
+  if (chain) {
     DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
-                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<int32_t>(ws, wl.dmap), s,
+                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s,
                                g_prof_which >= 0 ? g_prof_a : nullptr,
                                g_prof_which >= 0 ? g_prof_b : nullptr));
     g_prof_which = -1;
@@ -557,8 +581,10 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     const bool naf = next->F <= DG_AF_MAX_F;
     rd.x = naf ? next->x : nullptr; rd.xs = naf ? dg_ptr<float>(next->ws, nl.hsA) : nullptr; rd.F = next->F;
     rd.epoch = next->epoch;
-    if (dg_use_dense(next->N, next->E, next->B, next->flags, next->max_nodes)) {
-      rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = dg_ptr<int>(next->ws, nl.dmap);
+    const DgForm nf = dg_form(next->N, next->E, next->B, next->F, next->flags, next->max_nodes);
+    if (nf.bitmap) {
+      rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = nf.plan ? dg_ptr<int>(next->ws, nl.dmap) : nullptr;
+      rd.edge_check = nf.edge_check;
     }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
     rider = &rd;
@@ -580,7 +606,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
                                 dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr,
                                 tail_done != 0));
-  if (next && rode && rd.bits)      // dense next batch: its reverse-edge check on the bitmap the riders just built
+  if (next && rode && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
     DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
                               reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));
   if (next) {

@@ -414,6 +414,8 @@ int dg_launch_gcn_bwd1d(const DgDense* G, const float* dinv, const float* gas4, 
                         const float* gp3, float* gas3, float* pa4, int P1, hipStream_t s);
 // graph-chain kernels (gcn_chain.hip): conv1..conv4 of a graph in one workgroup, hs resident in LDS
 int dg_chain_max_nodes();
+int dg_chain_small_rows();
+int dg_chain_needs_schedule(int B);
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                         float* x3, float* x4, int32_t* dmap, hipStream_t s, hipEvent_t ev_start = nullptr,
@@ -439,7 +441,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
-                   int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr);
+                   int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr, int edge_check = 0);
 int dg_launch_prep_sym(const int64_t* edge_index, int E, int N, int B, const int64_t* batch, const int32_t* graph_ptr,
                        const uint32_t* bits, int32_t* err, uint32_t epoch, hipStream_t s);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,

@@ -16,6 +16,8 @@ struct DgPrepRider {
   unsigned int epoch;
   int nblk;        // rider workgroups appended to the host kernel's grid (0 = none)
   unsigned int* bits; int* dmap;   // dense per-graph block structures (dg_dense.h); bits == nullptr: not built
+  int edge_check;  // 1: the reverse-edge check stays the per-edge binary search of phase B although the bitmap is built
+                   // (small batches that take only the chain forward from it: no third launch for the bitmap's symmetry check)
 };
 static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {      // threads of phase A / phase B
   int work = E > N + 1 ? E : N + 1;
@@ -220,7 +222,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     float* __restrict__ xs = nullptr, int F = 0,
                                                     const int64_t* __restrict__ batch = nullptr,
                                                     unsigned int* __restrict__ bits = nullptr,
-                                                    int* __restrict__ dmap = nullptr) {
+                                                    int* __restrict__ dmap = nullptr, bool edge_check = false) {
   if (bits) {
     // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
     // per row: lane l takes neighbours l, l + 8, ... of the row (int32 colidx copy of phase A; the 8 lanes read 8
@@ -286,7 +288,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
     }
   }
   if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
-  if (t < E && !bits) {      // (dense batches verify the reverse edges on the bitmap afterwards: dg_prep_sym_body)
+  if (t < E && (!bits || edge_check)) {      // (dense batches verify the reverse edges on the bitmap afterwards: dg_prep_sym_body)
     const int64_t s = ei[t], d = ei[(int64_t)E + t];
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
       const int end = rowptr[d + 1];

@@ -774,7 +774,8 @@ struct ChQ {
 // XI: xs items (row, 4-column slot) per thread; W1S: k-steps of conv1's weight table (4: F <= 16, 8: F <= 32)
 template <int WAVES, int XI, int W1S>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers
-k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const unsigned* __restrict__ bits,
+k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
+              const unsigned* __restrict__ bits,
               const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
               float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
               unsigned long long* __restrict__ dbg) {
@@ -794,13 +795,36 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   unsigned long long tprev_ = clock64();
   if (dbg && tid == 0) { for (int k = 0; k < 16; ++k) dbg[blockIdx.x * 16 + k] = 0; dbg[blockIdx.x * 16 + 12] = wall_clock64(); }
 #endif
-  const int nbig = nbig_p[0], ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
+  // sched == null (batches of at most one graph per workgroup: no schedule was built): entry r = graph r*G + w of graph_ptr
+  const int nbig = sched ? nbig_p[0] : 0, ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
   auto entry_of = [&](int r) {               // {n0, n}; n = 0 past the end (load clamped, selected)
-    const int li = r * G + ((r & 1) ? G - 1 - w : w);
-    const int2 e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + min(li, max(ns - 1, 0))));
+    const int li = r * G + ((r & 1) ? G - 1 - w : w), lc = min(li, max(ns - 1, 0));
+    int2 e;
+    if (sched) e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + lc));
+    else { e.x = graph_ptr[lc]; e.y = graph_ptr[lc + 1] - e.x; }
     return make_int2(e.x, (li < ns && e.y <= C::ROWS) ? e.y : 0);
   };
   int2 eC = entry_of(0), eN = entry_of(1);
+  const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
+  const int NBF = F > 16 ? 2 : 1;
+  unsigned pbit[C::PB]; float pdv = 0.f; float pxs[XI][4];
+  auto prefetch = [&](int pn0, int pn) {      // (unconditional loads on clamped addresses, selected when consumed)
+    const int pS = 1 << dgd_class(max(pn, 1));
+    const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
+    const int last = max(pn * pS - 1, 0);
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
+    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int it = tid + C::THREADS * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
+      const float* xr = xs + (size_t)(pn0 + k) * F;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pxs[j][i] = xr[min(4 * qq + i, F - 1)];
+    }
+  };
+  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
+  prefetch(n0, n);                            // the first graph's data travels while the weight tables are set up
   // ---- once per workgroup: weight tables in MFMA-operand order (coalesced loads, scattered on the LDS side) ------------
   {
     float w2[C::WJ], w3[C::WJ], w1[C::WJ];
@@ -835,26 +859,6 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   }
   const float b4s = gw.b4[0];
   __syncthreads();
-  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
-  const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
-  const int NBF = F > 16 ? 2 : 1;
-  unsigned pbit[C::PB]; float pdv = 0.f; float pxs[XI][4];
-  auto prefetch = [&](int pn0, int pn) {      // (unconditional loads on clamped addresses, selected when consumed)
-    const int pS = 1 << dgd_class(max(pn, 1));
-    const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
-    const int last = max(pn * pS - 1, 0);
-#pragma unroll
-    for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
-    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-      const int it = tid + C::THREADS * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
-      const float* xr = xs + (size_t)(pn0 + k) * F;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pxs[j][i] = xr[min(4 * qq + i, F - 1)];
-    }
-  };
-  prefetch(n0, n);
   const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
   const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;         // this lane's node in tile wave / tile wave + WAVES
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
@@ -865,6 +869,9 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4) + par * 3 * C::ROWS;
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
+    // graphs of <= ROWS/2 nodes keep TWO images, rows [0, ROWS/2) and [ROWS/2, ROWS) of every plane, and alternate between
+    // them: a layer's output image is not the one still being read, so the barrier in front of its stores is not needed
+    const int pong = (2 * n <= C::ROWS) ? (C::ROWS / 2) * 32 : 0;
     // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
@@ -902,6 +909,8 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
         if ((pp & 1) >= NBF) *reinterpret_cast<uint4*>(H + pp * C::PS + row * 32 + 16 * piece) = make_uint4(0u, 0u, 0u, 0u);
       }
       if (tid < 48) h4p[(tid >> 4) * C::ROWS + 16 * T + (tid & 15)] = 0;
+      if (pong && tid < 192)
+        *reinterpret_cast<uint4*>(H + pong + (tid >> 5) * C::PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
     }
     CH_T(1);                                              // 1: wait for the prefetched data + staging stores
     dg_lds_barrier();
@@ -921,11 +930,11 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 
     // block products of this wave's tiles with the image: every HS^T operand read once, used by both tiles; the reads of
     // word u+1 are issued before the matrix instructions of word u
-    auto product = [&](auto nbc, f32x4 (&acc)[2][2]) {
+    auto product = [&](auto nbc, const char* Hc, f32x4 (&acc)[2][2]) {
       constexpr int NBP = decltype(nbc)::value;
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) { acc[ti][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      const char* hp = H + rdoff;
+      const char* hp = Hc + rdoff;
 #pragma unroll
       for (int u = 0; u < C::KW; ++u) {
         if (u < K32) {
@@ -992,7 +1001,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) hs[ti][ob][rr] = dn[ti] * (NH == 2 ? d2[ti][ob][0][rr] + d2[ti][ob][NH - 1][rr] : d2[ti][ob][0][rr]);
     };
-    auto write_hs = [&](int ti, const f32x4 (&hs)[2]) {
+    auto write_hs = [&](char* Hn, int ti, const f32x4 (&hs)[2]) {
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob) {
         unsigned sp[3][4];
@@ -1000,7 +1009,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
         for (int rr = 0; rr < 4; ++rr) ch_split3(hs[ob][rr], sp[0][rr], sp[1][rr], sp[2][rr]);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(H + (p * 2 + ob) * C::PS + mrow[ti] * 32 + wsl) =
+          *reinterpret_cast<uint2*>(Hn + (p * 2 + ob) * C::PS + mrow[ti] * 32 + wsl) =
               make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
       }
     };
@@ -1019,7 +1028,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     // ---- conv1 (aggregate-first): ax = dn (Adj xs) saved, x1 = tanh(ax W1^T + b1), hs2 = dn (x1 W2^T) ----------------------
     if (live0) {
       f32x4 acc[2][2];
-      if (NBF == 2) product(I2{}, acc); else product(I1{}, acc);
+      if (NBF == 2) product(I2{}, H, acc); else product(I1{}, H, acc);
       auto conv1_tail = [&](auto ntc, auto t0c) {
         constexpr int T0 = decltype(t0c)::value, NT = T0 + decltype(ntc)::value;
         const float4 b0 = bias4(0, 0), b1v = bias4(0, 1);
@@ -1061,15 +1070,15 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
       else { conv1_tail(I1{}, I0{}); if (live1) conv1_tail(I1{}, I1{}); }
     }
     CH_T(4);
-    dg_lds_barrier();                                     // every wave has read the image: it can be overwritten
-    if (live0) write_hs(0, hsv[0]);
-    if (live1) write_hs(1, hsv[1]);
+    if (!pong) dg_lds_barrier();                          // every wave has read the image: it can be overwritten
+    if (live0) write_hs(H + pong, 0, hsv[0]);
+    if (live1) write_hs(H + pong, 1, hsv[1]);
     dg_lds_barrier();
     CH_T(5);
     // ---- conv2 -----------------------------------------------------------------------------------------------------------
     if (live0) {
       f32x4 acc[2][2], v[2][2];
-      product(I2{}, acc);
+      product(I2{}, H + pong, acc);
       using I0 = std::integral_constant<int, 0>;
       if (CH_LOCKSTEP && live1) { act32(I2{}, I0{}, 1, acc, v); rows_and_linear(I2{}, I0{}, v, x2, W3op, hsv); }
       else {
@@ -1078,16 +1087,16 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
       }
     }
     CH_T(6);
-    dg_lds_barrier();
-    if (live0) write_hs(0, hsv[0]);
-    if (live1) write_hs(1, hsv[1]);
+    if (!pong) dg_lds_barrier();
+    if (live0) write_hs(H, 0, hsv[0]);
+    if (live1) write_hs(H, 1, hsv[1]);
     dg_lds_barrier();
     CH_T(7);
     // ---- conv3 (next linear step 32 -> 1: h4s = dn (x3 . w4), three bf16 parts in their own buffer) -------------------------
     if (live0) {
       const float4 w0 = bias4(3, 0), w1 = bias4(3, 1);
       f32x4 acc[2][2], v[2][2];
-      product(I2{}, acc);
+      product(I2{}, H, acc);
       auto conv3_tail = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;
         act32(ntc, std::integral_constant<int, 0>{}, 2, acc, v);
@@ -1181,11 +1190,16 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #endif
 #define CH_SMALL_ROWS (32 * CH_QW)
 int dg_chain_max_nodes() { return 512; }
+int dg_chain_small_rows() { return CH_SMALL_ROWS; }
+// batches of at most one graph per persistent workgroup need no schedule (and graph preparation no planning pass)
+int dg_chain_needs_schedule(int B) { return B > CH_GRID_Q ? 1 : 0; }
 
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const DgParams* pl, float* ax, float* x1, float* x2, float* x3,
                         float* x4, int32_t* dmap, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (N <= 0 || B <= 0 || F < 1 || F > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !xs || !dmap) return DGCNN_EINVAL;
+  // dmap == null: no schedule was built (dg_chain_needs_schedule(B) == 0): one graph per workgroup straight from graph_ptr
+  if (N <= 0 || B <= 0 || F < 1 || F > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !xs) return DGCNN_EINVAL;
+  if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
   ChW gw;
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
@@ -1202,8 +1216,8 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
       return DGCNN_ELAUNCH;
     attr_set = true;
   }
-  const int* sched = dmap + dgd_sched0(N, B);
-  const int* nbig = dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0);      // graphs above the size class = first entry of the class
+  const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
+  const int* nbig = dmap ? dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0) : nullptr;      // graphs above the size class = first entry of the class
 #ifdef CH_USE_P8        // measurement builds: the eight-wave, one-tile-per-wave form (two workgroups per CU)
   const int grid = B < CH_GRID ? B : CH_GRID;
   if (F <= 16)
@@ -1216,7 +1230,7 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
   // XI = xs items per thread: rows x 4-column slots with data / threads = 2^lg / 2 (at least 1)
 #define CH_LQ(XI, WS) hipExtLaunchKernelGGL((k_chain_fwd_q<CH_QW, XI, WS>), dim3(grid), dim3(64 * CH_QW), ChQ<CH_QW, WS>::TOTAL, s, ev_start, \
-                                            ev_stop, 0, N, B, F, sched, nbig, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
+                                            ev_stop, 0, N, B, F, sched, nbig, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
   if (F <= 8) CH_LQ(1, 4); else if (F <= 16) CH_LQ(2, 4); else CH_LQ(4, 8);
 #undef CH_LQ
 #endif

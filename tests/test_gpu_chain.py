@@ -70,6 +70,44 @@ def test_chain_boundary_sizes_isolated_nodes_and_single_node_graphs(sizes, isola
     assert float((xc - gpu_xcat(m)).abs().max()) <= 4e-6
 
 
+@pytest.mark.parametrize("name,bs", [("MUTAG", 50), ("PROTEINS", 24), ("COLLAB", 50), ("IMDB", 20)])
+def test_chain_forward_with_gather_backward(name, bs):
+    """small batches: the chain forward (bitmap + schedule built, reverse edges checked per edge in graph prep) feeding the
+    CSR-gather backward kernels -- the library's own choice when neither aggregation form is forced"""
+    sh = synth.SHAPES[name]
+    start = 2000
+    b = synth.make_batch(name, bs, start=start)
+    while b.max_nodes > 512:
+        start += bs
+        b = synth.make_batch(name, bs, start=start)
+    m = make_model(sh.num_features, sh.num_classes)
+    sd = cpu_state_dict(m)
+    m.use_chain = True
+    check_forward_parity(m, b, sd)
+    xc = gpu_xcat(m)
+    check_backward_parity(m, b, sd)
+    m.use_chain = False
+    check_forward_parity(m, b, sd)
+    assert float((xc - gpu_xcat(m)).abs().max()) <= 4e-6
+
+
+def test_chain_forward_flags_a_missing_reverse_edge_without_the_bitmap_check():
+    from dgcnn_amd import _lib
+    good = synth.make_batch("COLLAB", 12, start=900)
+    ei = good.edge_index
+    keep = torch.ones(ei.shape[1], dtype=torch.bool)
+    keep[ei.shape[1] // 2] = False
+    bad = Batch(good.x, ei[:, keep].contiguous(), good.batch, good.y, good.num_graphs, True, good.max_nodes, good.max_edges)
+    m = make_model(1, 3)
+    m.use_chain = True
+    m.eval()
+    with torch.no_grad():
+        m(good.to("cuda")); m.check_errors()
+        m(bad.to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+
+
 def test_chain_schedule_is_the_stable_sort_by_tile_count():
     """graph preparation's schedule (dg_prep.h): {first node, node count} of every graph, ordered by 16-row tile count
     descending, ties by graph index; graphs above 128 nodes first, their number in the table header -- bit-exact"""
