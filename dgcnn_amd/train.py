@@ -21,6 +21,8 @@ from __future__ import annotations
 
 from typing import Iterable, Optional, Tuple
 
+import math
+
 import torch
 
 from . import _lib
@@ -99,7 +101,12 @@ class Trainer:
     def _slot_ws(self, k, need, device):
         sl = self._slots[k]
         if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != device:
+            if sl["ws"] is not None and sl.get("dims"):
+                # the buffer about to be dropped carries the sticky error words of every batch it served since the last
+                # check: surface them now (one small copy; growth is rare) instead of losing them with the buffer
+                self.model.check_errors([(sl["ws"], sl["dims"])], since=self._err_checked)
             sl["ws"] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+            sl["ws"][:16].zero_()          # error words of a fresh buffer: no stale tag can pass for a real one
             sl["bytes"] = sl["ws"].numel()
             sl["ptr"] = sl["ws"].data_ptr()
         return sl["ws"]
@@ -175,7 +182,7 @@ class Trainer:
         """cached ``dgcnn_step_args`` of a batch object: sizes, input pointers, layout flags and the optimizer's
         constants are filled ONCE per batch object; a step only touches epoch / seed / step / ws."""
         ent = self._args_cache.get(id(data))
-        if ent is not None and ent[0] is data and ent[1] is y:
+        if ent is not None and ent[0] is data and ent[1] is y and self._same_tensors(ent, data):
             return ent
         m = self.model
         N, E, B, F, C = self._dims(data)
@@ -191,9 +198,17 @@ class Trainer:
         if len(self._args_cache) >= self.ARGS_CACHE_MAX:      # bounded: every entry keeps its batch's tensors alive
             self._args_cache.clear()
         ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C), _lib.ctypes.byref(a), x.device,
-               _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0)
+               _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0,
+               (data.x, data.edge_index, data.batch))
         self._args_cache[id(data)] = ent
         return ent
+
+    @staticmethod
+    def _same_tensors(ent, data) -> bool:
+        """the cached pointers still describe ``data``: a caller (a PyG-style transform, say) may have REBOUND ``data.x`` /
+        ``edge_index`` / ``batch`` to new tensors on the same batch object -- three identity compares per step"""
+        src = ent[9]
+        return data.x is src[0] and data.edge_index is src[1] and data.batch is src[2]
 
     def _bind_static(self, a) -> None:
         """pointers that are constant for this trainer (re-bound only if a buffer was re-allocated)"""
@@ -208,7 +223,7 @@ class Trainer:
         lookup and a handful of field stores (the host must stay ahead of a ~60 us GPU step)."""
         m = self.model
         ent = self._args_cache.get(id(data))
-        if ent is None or ent[0] is not data or ent[1] is not y:
+        if ent is None or ent[0] is not data or ent[1] is not y or not self._same_tensors(ent, data):
             ent = self._step_args(data, y)
         a, need, dims, aref, dev = ent[2], ent[3], ent[5], ent[6], ent[7]
         if self._pipe is None:
@@ -222,7 +237,7 @@ class Trainer:
             self._p_flat, self._p_grads, self._p_metrics = flat.data_ptr(), self.grads.data_ptr(), self.metrics.data_ptr()
             self._p_m, self._p_v = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         pe = self._prep_ent
-        prepared = pe is not None and pe[0] is data
+        prepared = pe is ent          # the very cache entry that was prepared: same batch object AND the same tensors
         if prepared:
             slot = self._prep_slot               # its workspace was sized when it was handed in as `next`
             m.__dict__["_epoch"] = a.epoch
@@ -259,7 +274,7 @@ class Trainer:
         if next_data is not None and next_data is not data:
             ny = next_y if next_y is not None else next_data.y
             nent = self._args_cache.get(id(next_data))
-            if nent is None or nent[0] is not next_data or nent[1] is not ny:
+            if nent is None or nent[0] is not next_data or nent[1] is not ny or not self._same_tensors(nent, next_data):
                 nent = self._step_args(next_data, ny)
             na = nent[2]
             nsl = self._slots[1 - slot]
@@ -321,7 +336,7 @@ class Trainer:
         if global_batch is None and self._dp_world > 1 and self._allreduce is not None:
             global_batch = self._allreduce.global_batch(_batch_size_of(data), data.x.device)
         ent = self._args_cache.get(id(data))
-        if ent is None or ent[0] is not data or ent[1] is not y:
+        if ent is None or ent[0] is not data or ent[1] is not y or not self._same_tensors(ent, data):
             ent = self._step_args(data, y)
         a, need, dims, aref, dev = ent[2], ent[3], ent[5], ent[6], ent[7]
         flat = m.flat_params_fast()
@@ -370,8 +385,13 @@ class Trainer:
         m = self.metrics
         if self.pg is not None and self._dp_world > 1:
             import torch.distributed as dist
-            m = m.clone()
+            local = m.clone()
+            m = local.clone()
             dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.pg)
+            lv = float(local[0])
+            if not math.isfinite(lv):      # name the shard: after the reduction every rank sees the same poisoned sum
+                raise _lib.DgcnnError(f"non-finite loss on rank {dist.get_rank(self.pg)}: a label outside [0, num_classes) "
+                                      "or diverged parameters")
         v = m.tolist()
         dims = self.model._last_dims
         if dims is not None:
@@ -380,7 +400,7 @@ class Trainer:
             self._err_checked = self.model._epoch
         if self._peer is not None:
             self._peer.check()
-        if v[0] != v[0]:
+        if not math.isfinite(v[0]):          # NaN (poisoned label) and +-inf (divergence) alike
             raise _lib.DgcnnError("non-finite loss: a label outside [0, num_classes) or diverged parameters")
         return float(v[0]), float(v[1])
 

@@ -617,3 +617,33 @@ def test_two_stage_weight_gradient_reduction_in_a_subprocess():
     env = dict(os.environ, DG_WG_TWO_STAGE_B="128")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "TWO_STAGE_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_trainer_uses_tensors_rebound_on_a_cached_batch_object():
+    """the Trainer caches the argument block of a batch object (pointers included); a caller that assigns NEW tensors to
+    ``batch.x`` / ``batch.edge_index`` on the same object (PyG-style transforms do) must get the new values, on the
+    current batch and on the look-ahead batch alike"""
+    from dgcnn_amd.batch import Batch
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["PROTEINS"]
+    b1 = synth.make_batch("PROTEINS", 8, start=11).to("cuda")
+    b2 = synth.make_batch("PROTEINS", 8, start=40).to("cuda")
+    x_new = (b1.x * 0.5 + 0.25).contiguous()
+    res = []
+    for rebind in (True, False):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 9, 0
+        tr = Trainer(m)
+        a = Batch(b1.x, b1.edge_index, b1.batch, b1.y, b1.num_graphs, b1.coalesced_undirected, b1.max_nodes, b1.max_edges)
+        tr.train_step(a, a.y, next_data=b2)
+        tr.train_step(b2, b2.y, next_data=a)            # `a` is cached twice over: as a current and as a look-ahead batch
+        if rebind:
+            a.x = x_new                                  # same object, new tensor
+            nxt = a
+        else:
+            nxt = Batch(x_new, b1.edge_index, b1.batch, b1.y, b1.num_graphs, b1.coalesced_undirected, b1.max_nodes, b1.max_edges)
+        tr.train_step(nxt, nxt.y)
+        torch.cuda.synchronize()
+        tr.read_metrics()
+        res.append(m.flat_params.clone())
+    assert torch.equal(res[0], res[1])
