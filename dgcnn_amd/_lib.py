@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 14
+ABI_VERSION = 15
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -89,6 +89,8 @@ SIGNATURES = {
     "dgcnn_accumulate_metrics": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dgcnn_peer_alloc": (c_int, [c_int64, ctypes.POINTER(c_void_p), c_void_p]),
     "dgcnn_peer_open": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "dgcnn_peer_set_timeout_ms": (c_int, [c_int]),
+    "dgcnn_peer_last_alloc_finegrained": (c_int, []),
     "dgcnn_peer_close": (c_int, [c_void_p]),
     "dgcnn_peer_free": (c_int, [c_void_p]),
     "dgcnn_allreduce_adam_step": (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,

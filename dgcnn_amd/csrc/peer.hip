@@ -8,7 +8,7 @@
 // same mapping between two processes of one GPU), and ONE kernel per rank
 //     publishes "my gradient of step s is complete"      (system-scope release store of the step tag; the gradient was
 //                                                          written by the previous kernel of this stream)
-//     waits for the same tag of every peer                (bounded poll, acquire)
+//     waits for the same tag of every peer                (bounded poll, acquire; the timeout verdict is agreed by all ranks)
 //     sums the R gradients in RANK ORDER                  (every rank forms the identical fp32 sum: replicas stay bit-equal)
 //     applies Adam to its replica                         (same arithmetic as k_adam, tail.hip)
 // Gradient buffers are double-buffered by step parity: a rank that runs ahead writes step s+1's gradient into the other
@@ -20,28 +20,63 @@
 #define DG_PEER_MAX 16
 struct DgPeers {
   const float* grad[DG_PEER_MAX];
-  unsigned int* flag[DG_PEER_MAX];
+  unsigned int* flag[DG_PEER_MAX];       // each rank's flag block (64 B): see the word list below
 };
+// flag block words (fine-grained, mapped by every rank):
+//   [0] READY   : tag of the newest gradient this rank has completed
+//   [1] DECIDED : tag of the newest step for which this rank has decided go / abort
+//   [2] GO      : this rank's own grid-wide verdict for the step, tag | (abort << 31) -- polled by its other workgroups
+//   [3] ABORTED : tag of the newest step this rank aborted (0: never)
+#define DG_PW_READY 0
+#define DG_PW_DECIDED 1
+#define DG_PW_GO 2
+#define DG_PW_ABORTED 3
 
+static unsigned int g_peer_spins = 20u * 1000u * 1000u;      // bounded wait, ~1 us per spin: 20 s (dgcnn_peer_set_timeout_ms)
+static int g_peer_last_finegrained = 0;
+
+// The wait is bounded (a lost peer must not hang the GPU), and the timeout decision is taken ONCE PER STEP AND AGREED BY ALL
+// RANKS: workgroup 0 of every rank waits for the peers' gradients, publishes its verdict, waits for the peers' verdicts,
+// and aborts if ANY rank aborted (a late peer that finds our gradient in place still learns that we gave up on the step,
+// and gives up too); its other workgroups take the verdict from workgroup 0.  On abort nobody touches parameters or Adam
+// state -- replicas stay identical -- and err[0] carries the tag on every rank (Trainer.read_metrics raises everywhere).
 __global__ void __launch_bounds__(256)
 k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __restrict__ params, float* __restrict__ m,
                  float* __restrict__ v, float* __restrict__ gsum_out, int64_t n, float lr, float b1, float b2, float eps,
-                 float bc1, float bc2_sqrt, unsigned int* __restrict__ err) {
+                 float bc1, float bc2_sqrt, unsigned int* __restrict__ err, unsigned int max_spins) {
   __shared__ int ok;
   if (threadIdx.x == 0) {
-    if (blockIdx.x == 0)
-      __hip_atomic_store(P.flag[rank], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned int* mine = P.flag[rank];
     int good = 1;
-    for (int r = 0; r < world; ++r) {
-      if (r == rank) continue;
-      int spins = 0;
-      // tags only grow: wait until the peer's tag has reached ours (a peer may already be one step ahead)
-      while ((int)(__hip_atomic_load(P.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
+    if (blockIdx.x == 0) {
+      __hip_atomic_store(mine + DG_PW_READY, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      auto wait_for = [&](int word) {        // every peer's `word` has reached this step's tag (tags only grow)
+        for (int r = 0; r < world; ++r) {
+          if (r == rank) continue;
+          unsigned int spins = 0;
+          while ((int)(__hip_atomic_load(P.flag[r] + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > max_spins) return false;
+          }
+        }
+        return true;
+      };
+      if (!wait_for(DG_PW_READY)) good = 0;
+      if (!good) __hip_atomic_store(mine + DG_PW_ABORTED, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(mine + DG_PW_DECIDED, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!wait_for(DG_PW_DECIDED)) good = 0;
+      for (int r = 0; r < world && good; ++r)
+        if (r != rank && __hip_atomic_load(P.flag[r] + DG_PW_ABORTED, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag) good = 0;
+      if (!good) err[0] = tag;
+      __hip_atomic_store(mine + DG_PW_GO, good ? tag : (tag | 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned int spins = 0, g;
+      while (((g = __hip_atomic_load(mine + DG_PW_GO, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & 0x7fffffffu) != tag) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1 << 21)) { good = 0; break; }         // bounded (~2 s): a lost peer must not hang the GPU
+        if (++spins > 4u * max_spins + 1024u) { g = 0x80000000u; err[1] = tag; break; }    // (workgroup 0 always decides first)
       }
+      good = (g >> 31) ? 0 : 1;
     }
-    if (!good) err[0] = tag;
     ok = good;
   }
   __syncthreads();
@@ -61,12 +96,21 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
 
 extern "C" {
 
+int dgcnn_peer_set_timeout_ms(int ms) {
+  if (ms < 1) return DGCNN_EINVAL;
+  g_peer_spins = ms > 2000000 ? 2000000000u : (unsigned int)ms * 1000u;
+  return DGCNN_OK;
+}
+int dgcnn_peer_last_alloc_finegrained(void) { return g_peer_last_finegrained; }
+
 int dgcnn_peer_alloc(int64_t bytes, void** dev_ptr, void* ipc_handle64) {
   if (bytes <= 0 || !dev_ptr || !ipc_handle64) return DGCNN_EINVAL;
   static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle fits the 64-byte slot");
   void* p = nullptr;
+  g_peer_last_finegrained = 1;
   if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
     (void)hipGetLastError();
+    g_peer_last_finegrained = 0;         // coarse-grained: flag polling across DEVICES is not guaranteed coherent -- the caller decides
     if (hipMalloc(&p, (size_t)bytes) != hipSuccess) return DGCNN_ELAUNCH;
   }
   if (hipMemset(p, 0, (size_t)bytes) != hipSuccess) { (void)hipFree(p); return DGCNN_ELAUNCH; }
@@ -115,7 +159,7 @@ int dgcnn_allreduce_adam_step(int world, int rank, const float* const* peer_grad
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(k_allreduce_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, world, rank,
                      tag, params, exp_avg, exp_avg_sq, grad_sum_out, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
-                     err);
+                     err, g_peer_spins);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

@@ -118,6 +118,11 @@ class _RawCudaBuffer:
         self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
+def _host_id() -> str:
+    import socket
+    return socket.gethostname()
+
+
 class PeerExchange:
     """One-shot gradient all-reduce + Adam over peer-mapped memory (``dgcnn_allreduce_adam_step``, csrc/peer.hip).
 
@@ -143,25 +148,52 @@ class PeerExchange:
         self.stride = ((self.numel * 4 + 255) // 256) * 256
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
         nbytes = self.HDR + 2 * self.stride
+        self._own, self._opened, self._bases = None, [], []
+        # set-up is collective but its failures are local: every phase ends with an exchange of success flags, and a
+        # failure on ANY rank releases what was mapped and raises on EVERY rank (nobody is left waiting in a barrier)
         own = ctypes.c_void_p()
         handle = ctypes.create_string_buffer(64)
-        _lib.check(L.dgcnn_peer_alloc(nbytes, ctypes.byref(own), handle), "dgcnn_peer_alloc")
-        self._own = own.value
-        handles = [None] * self.world
-        if self.world > 1:
-            dist.all_gather_object(handles, bytes(handle.raw), group=process_group)
+        fail = None
+        rc = L.dgcnn_peer_alloc(nbytes, ctypes.byref(own), handle)
+        if rc != 0:
+            fail = f"dgcnn_peer_alloc failed ({rc}) on rank {self.rank}"
         else:
-            handles[0] = bytes(handle.raw)
-        self._bases, self._opened = [], []
-        for r in range(self.world):
-            if r == self.rank:
-                self._bases.append(self._own)
-                continue
-            p = ctypes.c_void_p()
-            hb = ctypes.create_string_buffer(handles[r], 64)
-            _lib.check(L.dgcnn_peer_open(hb, ctypes.byref(p)), f"dgcnn_peer_open(rank {r})")
-            self._bases.append(p.value)
-            self._opened.append(p.value)
+            self._own = own.value
+            self.fine_grained = bool(L.dgcnn_peer_last_alloc_finegrained())
+        infos = [None] * self.world
+        mine = (bytes(handle.raw), fail, int(self.device.index if self.device.index is not None else torch.cuda.current_device()),
+                bool(getattr(self, "fine_grained", False)), _host_id())
+        if self.world > 1:
+            dist.all_gather_object(infos, mine, group=process_group)
+        else:
+            infos[0] = mine
+        fails = [i[1] for i in infos if i[1]]
+        # coarse-grained exchange memory is only coherent for flag polling between processes of ONE device
+        if not fails and len({(i[4], i[2]) for i in infos}) > 1 and not all(i[3] for i in infos):
+            fails.append("fine-grained device memory is unavailable on a rank and the ranks span more than one device: "
+                         "the one-shot exchange cannot poll its flags coherently (use the collective route)")
+        if not fails:
+            for r in range(self.world):
+                if r == self.rank:
+                    self._bases.append(self._own)
+                    continue
+                p = ctypes.c_void_p()
+                hb = ctypes.create_string_buffer(infos[r][0], 64)
+                rc = L.dgcnn_peer_open(hb, ctypes.byref(p))
+                if rc != 0:
+                    fail = f"dgcnn_peer_open(rank {r}) failed ({rc}) on rank {self.rank}"
+                    break
+                self._bases.append(p.value)
+                self._opened.append(p.value)
+            oks = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(oks, fail, group=process_group)
+            else:
+                oks[0] = fail
+            fails = [f for f in oks if f]
+        if fails:
+            self.release_local()
+            raise _lib.DgcnnError("one-shot exchange set-up failed: " + "; ".join(fails))
         arr = ctypes.c_void_p * self.world
         self._flags = arr(*[b for b in self._bases])
         self._grads = [arr(*[b + self.HDR + par * self.stride for b in self._bases]) for par in (0, 1)]
@@ -187,9 +219,27 @@ class PeerExchange:
         self._lib.check(rc, "dgcnn_allreduce_adam_step")
 
     def check(self) -> None:
-        """host-side check (a sync): did a peer fail to arrive within the kernel's bounded wait?"""
+        """host-side check (a sync): did a step of the exchange time out?  The kernel's verdict is agreed by all ranks (a
+        step any rank gave up on is applied by none), so every rank raises here for the same step."""
         if int(self.err[0].item()) != 0:
-            raise self._lib.DgcnnError("one-shot all-reduce: a peer never published its gradient (lost rank?)")
+            raise self._lib.DgcnnError("one-shot all-reduce: a peer did not publish its gradient within the bounded wait "
+                                       "(lost or stalled rank); the step was applied on NO rank "
+                                       "(dgcnn_peer_set_timeout_ms raises the bound)")
+
+    def release_local(self) -> None:
+        """unmap the peers and free the own block WITHOUT any collective (error paths, ``__del__``)"""
+        L = self._lib.lib()
+        for p in getattr(self, "_opened", []):
+            L.dgcnn_peer_close(p)
+        if getattr(self, "_own", None) is not None:
+            L.dgcnn_peer_free(self._own)
+        self._own, self._opened = None, []
+
+    def __del__(self):
+        try:
+            self.release_local()
+        except Exception:
+            pass
 
     def close(self) -> None:
         L = self._lib.lib()
@@ -198,7 +248,4 @@ class PeerExchange:
         torch.cuda.synchronize(self.device)
         if self.world > 1:
             dist.barrier(group=self.pg)                # nobody still reads a buffer that is about to go away
-        for p in self._opened:
-            L.dgcnn_peer_close(p)
-        L.dgcnn_peer_free(self._own)
-        self._own, self._opened = None, []
+        self.release_local()

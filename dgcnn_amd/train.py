@@ -94,6 +94,9 @@ class Trainer:
             if self._pipe is not None:
                 _lib.lib().dgcnn_pipeline_destroy(self._pipe)
                 self._pipe = None
+            if self._peer is not None:           # local unmap / free only: a destructor must not enter a collective
+                self._peer.release_local()
+                self._peer = None
         except Exception:
             pass
 

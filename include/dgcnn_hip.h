@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 14
+#define DGCNN_ABI_VERSION 15
 
 /* error codes */
 #define DGCNN_OK            0
@@ -390,6 +390,12 @@ int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_
  * The own gradient must have been written by earlier work on `stream`.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_peer_alloc(int64_t bytes, void** dev_ptr, void* ipc_handle64);
+/* bound of the exchange kernel's waits (default 20 000 ms).  The timeout verdict of a step is taken once per rank and agreed
+ * by all ranks (a step that any rank gave up on is applied by NO rank); err[0] = tag on every rank afterwards. */
+int dgcnn_peer_set_timeout_ms(int ms);
+/* 1 if the last dgcnn_peer_alloc of this process got fine-grained memory, 0 if it fell back to coarse-grained memory
+ * (fine between processes of ONE device; across devices the flag polling is not guaranteed coherent). */
+int dgcnn_peer_last_alloc_finegrained(void);
 int dgcnn_peer_open(const void* ipc_handle64, void** dev_ptr);
 int dgcnn_peer_close(void* dev_ptr);
 int dgcnn_peer_free(void* dev_ptr);

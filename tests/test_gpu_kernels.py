@@ -467,3 +467,62 @@ def test_gcn_fwd_dense_and_bf16_storage_flag():
     assert float((outs["dense"].double() - ref).abs().max()) <= 3e-6
     e = float((outs["bf16"].double() - ref).abs().max())
     assert 1e-5 < e <= 1e-2, e
+
+
+# ---- one-shot gradient exchange (csrc/peer.hip): the bounded wait and its all-rank verdict, driven through the C ABI ----
+def _peer_call(L, world, rank, grads, flags, tag, params, m, v, err, stream=0, step=1):
+    import ctypes
+    arr = ctypes.c_void_p * world
+    return L.dgcnn_allreduce_adam_step(world, rank, arr(*[g.data_ptr() for g in grads]), arr(*[f.data_ptr() for f in flags]), tag,
+                                       params.data_ptr(), m.data_ptr(), v.data_ptr(), None, params.numel(), step, 1e-3, 0.9,
+                                       0.999, 1e-8, err.data_ptr(), stream)
+
+
+def test_one_shot_exchange_times_out_consistently_and_applies_the_step_on_no_rank():
+    """a rank that never publishes: the waiting rank gives up after the bounded wait (no hang), flags err[0], and leaves its
+    replica untouched; the LATE rank then finds the gradient in place but also the other's abort verdict and skips the step
+    too -- replicas stay identical, both ranks report the error"""
+    L = _lib.lib()
+    n = 5000
+    dev = "cuda"
+    torch.manual_seed(0)
+    grads = [torch.randn(n, device=dev), torch.randn(n, device=dev)]
+    flags = [torch.zeros(16, dtype=torch.int32, device=dev) for _ in range(2)]
+    p0 = torch.randn(n, device=dev); p1 = p0.clone()
+    st = [(torch.zeros(n, device=dev), torch.zeros(n, device=dev)) for _ in range(2)]
+    errs = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(2)]
+    keep = p0.clone()
+    assert L.dgcnn_peer_set_timeout_ms(30) == 0
+    try:
+        assert _peer_call(L, 2, 0, grads, flags, 1, p0, st[0][0], st[0][1], errs[0]) == 0
+        torch.cuda.synchronize()                                   # returns: the wait is bounded
+        assert int(errs[0][0]) == 1 and torch.equal(p0, keep) and float(st[0][0].abs().sum()) == 0.0
+        assert _peer_call(L, 2, 1, grads, flags, 1, p1, st[1][0], st[1][1], errs[1]) == 0      # the late rank
+        torch.cuda.synchronize()
+        assert int(errs[1][0]) == 1 and torch.equal(p1, keep)
+    finally:
+        L.dgcnn_peer_set_timeout_ms(20000)
+
+
+def test_one_shot_exchange_two_ranks_on_two_streams_apply_the_identical_step():
+    L = _lib.lib()
+    n = 52000
+    dev = "cuda"
+    torch.manual_seed(1)
+    grads = [torch.randn(n, device=dev), torch.randn(n, device=dev)]
+    flags = [torch.zeros(16, dtype=torch.int32, device=dev) for _ in range(2)]
+    p = [torch.randn(n, device=dev)]; p.append(p[0].clone())
+    st = [(torch.zeros(n, device=dev), torch.zeros(n, device=dev)) for _ in range(2)]
+    errs = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(2)]
+    ref = p[0].clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    ref.grad = grads[0] + grads[1]
+    opt.step()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    assert _peer_call(L, 2, 0, grads, flags, 1, p[0], st[0][0], st[0][1], errs[0], stream=s0.cuda_stream) == 0
+    assert _peer_call(L, 2, 1, grads, flags, 1, p[1], st[1][0], st[1][1], errs[1], stream=s1.cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert int(errs[0][0]) == 0 and int(errs[1][0]) == 0
+    assert torch.equal(p[0], p[1])
+    assert torch.allclose(p[0], ref.detach(), rtol=1e-5, atol=1e-7)
