@@ -15,7 +15,7 @@ Inputs (x, edge_index, batch, y of every batch) are resident in HBM before the t
 
 Timing protocol: W untimed warm-up steps, then the K-step timed loop -- bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks -- is REPEATED until at least
-``--min-seconds`` (0.25 s) of timed work exists (at least 3 repeats); ``ms_per_step`` / ``value`` are the
+``--min-seconds`` (3 s: long enough for an outside GPU-busy sampler to see the work) of timed work exists (at least 3 repeats); ``ms_per_step`` / ``value`` are the
 MEDIAN repeat (every repeat's ms/step is listed under "repeats_ms_per_step").
 
 Scaling modes (BASELINE config 5 asks for both):
@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-AGG_KERNELS = ("k_gcn_fwd32d", "k_gcn_fwd32p", "k_gcn_fwd32")     # dense-block / persistent / tiled forms
+AGG_KERNELS = ("k_chain_fwd_q", "k_gcn_fwd32d", "k_gcn_fwd32p", "k_gcn_fwd32")     # graph-chain / dense-block / persistent / tiled forms
 
 
 def parse(argv=None):
@@ -66,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--global-batch", type=int, default=256,
                     help="strong scaling: graphs per step over ALL GPUs (BASELINE config 5: 256)")
     ap.add_argument("--pool", type=int, default=40, help="distinct batches resident in HBM per GPU")
-    ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed loop until this much is timed")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed loop until this much is timed")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE config 3's secondary leg (hs stored bf16, X.W on bf16 MFMA); never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +95,25 @@ def algorithmic_bytes_agg(N: int, E_noself: int, F: int = 32, s: int = 4) -> int
     E~ = non-self-loop edges + N self loops.  Each array counted once (compulsory traffic)."""
     Et = E_noself + N
     return 4 * Et + 4 * (N + 1) + 4 * N + 2 * s * N * F
+
+
+def algorithmic_bytes_chain_fwd(N: int, E_noself: int) -> int:
+    """the graph-chain forward launch processes FOUR aggregation calls (conv1..conv4) of SURVEY D4's model
+    ("fwd uses F = 32,32,32,1": 106 KB per COLLAB-cfg graph): the units of one launch x the per-unit figure"""
+    return 3 * algorithmic_bytes_agg(N, E_noself, 32) + algorithmic_bytes_agg(N, E_noself, 1)
+
+
+def algorithmic_bytes_readout_tail(N: int, B: int, C: int) -> int:
+    """SURVEY D4 sort-pool model + the dense tail, forward and backward in the one k_readout_tail launch: keys 4N, graph
+    pointers, the gathered rows 4*97*30*B, pooled [B,2910] written (forward) and read (backward), the tail weights
+    (conv5, conv6, classifier_1, classifier_2: read by both halves, L2-resident), saved activations (conv5 480, conv6 352,
+    fc1 128 floats per graph) written and read, per-graph weight-gradient partials written, and the SortPooling gradient
+    scattered into the dense slabs gp1..gp3 [N,32] + gas4 [N] (zero-filled: every word written once)."""
+    wts = 4 * (16 * 97 + 16 + 32 * 16 * 5 + 32 + 128 * 352 + 128 + C * 128 + C)
+    ptail = 4 * (16 * 97 + 16 + 32 * 16 * 5 + 32 + C * 128 + C)
+    fwd = 4 * N + 4 * (B + 1) + 4 * 97 * 30 * B + 4 * 2910 * B + wts + 4 * (480 + 352 + 128) * B + 128 * B
+    bwd = 4 * 2910 * B + wts + 4 * (480 + 352 + 128) * B + ptail * B + 4 * (128 + 352) * B + 4 * N * 97
+    return fwd + bwd
 
 
 def algorithmic_bytes_fused_fwd(N: int, E_noself: int, B: int, F: int) -> int:
@@ -416,7 +435,7 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
     reps, total, k0 = [], 0.0, args.warmup
-    while len(reps) < 3 or (total < args.min_seconds and len(reps) < 200):
+    while len(reps) < 3 or (total < args.min_seconds and len(reps) < 100000):
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -463,70 +482,111 @@ def main():
         Bl = bl_cpu[0].num_graphs
         fused = args.path == "fused" and bool(L.dgcnn_fused_fits(max(b.max_nodes for b in bl_cpu),
                                                                   max(b.max_edges for b in bl_cpu), F))
+        mflags = trainer.model._mode_flags()
+
+        def form_of(b):        # which kernel family the library takes for this batch (pure function of host-known numbers)
+            fl = mflags | (_lib.FLAG_COALESCED_UNDIRECTED if getattr(b, "coalesced_undirected", False) else 0)
+            return L.dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, F, fl, int(b.max_nodes or 0))
+        chain_n = 0
         for i in range(nprof):
             a, bb = ev(), ev()
             which = 1 + i % 2 if F <= 32 else i % 3
             _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")
             b = bl[i % len(bl)]
             trainer.train_step(b, b.y, global_batch=gb) if not use_dist else trainer.forward_backward(b, b.y, global_batch=gb)
-            pairs.append((a, bb, b.num_nodes, b.num_edges))
+            ch = (not fused) and bool(form_of(bl_cpu[i % len(bl)]) & 2)
+            chain_n += 1 if ch else 0
+            pairs.append((a, bb, b.num_nodes, b.num_edges, ch))
         torch.cuda.synchronize(dev)
         tot_us = tot_bytes = tot_extra = 0.0
-        for k, (a, bb, n_, e_) in enumerate(pairs):
+        for k, (a, bb, n_, e_, ch) in enumerate(pairs):
             _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
-            tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else algorithmic_bytes_agg(n_, e_)
+            tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else \
+                (algorithmic_bytes_chain_fwd(n_, e_) if ch else algorithmic_bytes_agg(n_, e_))
             # the next layer's pre-scaled linear output this launch also writes (not part of SURVEY's one-layer model):
             # [N,32] fp32 behind conv1 / conv2, [N] behind conv3
             which = 1 + k % 2 if F <= 32 else k % 3
-            tot_extra += 0.0 if fused else (4.0 * n_ if which == 2 else 4.0 * n_ * 32)
+            tot_extra += 0.0 if (fused or ch) else (4.0 * n_ if which == 2 else 4.0 * n_ * 32)
             L.dgcnn_event_destroy(a); L.dgcnn_event_destroy(bb)
         avg_us = max(tot_us / len(pairs), 1e-3)
         bytes_per_launch = tot_bytes / len(pairs)
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
         FUSED_EXTRA["bytes"] = tot_extra / len(pairs)
+        FUSED_EXTRA["chain_frac"] = chain_n / len(pairs)
         return fused, avg_us, bytes_per_launch, achieved, len(pairs)
 
     kernel_note = ("32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA; the library picks per batch between the "
                    "CSR-gather forms (k_gcn_fwd32 / k_gcn_fwd32p) and the dense per-graph block form on the matrix cores "
                    "(k_gcn_fwd32d)")
+    chain_note = ("k_chain_fwd_q (gcn_chain.hip): conv1..conv4 of every graph inside one persistent workgroup -- FOUR aggregation "
+                  "calls per launch as dense block products on v_mfma_f32_16x16x32_bf16 (exact in fp32 via the bf16x3 split) "
+                  "from the bit-packed adjacency, the pre-scaled linear outputs resident in LDS (transpose-read layout), "
+                  "next X.W on the fp32 matrix cores; graphs dealt from a sorted static schedule")
+    byte_note_agg = "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per aggregation call (SURVEY D4)"
+    byte_note_chain = ("SURVEY D4's per-call model x the FOUR aggregation calls one launch processes (F = 32, 32, 32, 1: 106 KB per "
+                       "COLLAB-cfg graph).  The launch's real HBM traffic (`traffic`) is far BELOW this figure -- that is the "
+                       "point of the kernel: hs_2, hs_3, h4s never leave the CU and the adjacency is read once as a bitmap -- so "
+                       "`frac` measures work per time on the survey's byte model, not bytes actually moved; "
+                       "`frac_of_peak_on_measured_traffic` is the physical bandwidth fraction")
+
+    def pmc_pick(per, fused):
+        for kn in (("k_fused_fwd",) if fused else AGG_KERNELS):
+            if kn in per:
+                return kn, per[kn]
+        return None, None
+
     if rank == 0 and not args.no_roofline:
         fused, avg_us, bpl, achieved, nl = measure_agg(tr, batches, batches_cpu, max(200, min(args.steps, 400)))
-        extra_small = FUSED_EXTRA["bytes"]
+        extra_small, chain_small = FUSED_EXTRA["bytes"], FUSED_EXTRA.get("chain_frac", 0.0)
         traffic = traffic_src = kname = None
+        per_small = None
+        base_common = ["--workload", args.workload, "--scaling", args.scaling, "--global-batch", str(args.global_batch),
+                       "--pool", "8", "--path", args.path, "--agg", args.agg, "--chain", args.chain, "--dtype", args.dtype] + \
+                      ([] if args.pipeline else ["--no-pipeline"])
         if not args.no_pmc and world == 1:
-            base = ["--workload", args.workload, "--batch", str(args.batch), "--scaling", args.scaling,
-                    "--global-batch", str(args.global_batch), "--pool", "8", "--path", args.path, "--agg", args.agg,
-                    "--dtype", args.dtype] + ([] if args.pipeline else ["--no-pipeline"])
-            per, why = live_pmc_traffic(base)
-            if per:
-                for kn in (("k_fused_fwd",) if fused else AGG_KERNELS):
-                    if kn in per:
-                        kname, traffic = kn, per[kn]
-                        traffic_src = ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) "
-                                       f"spawned by this run over 12 steps of the same workload; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                                       f"per {kn} dispatch; includes the fused next-layer X.W write (4*N*32 B) the algorithmic "
-                                       "model does not count")
-                        break
+            per_small, why = live_pmc_traffic(base_common + ["--batch", str(args.batch)])
+            if per_small:
+                kname, traffic = pmc_pick(per_small, fused)
+                if kname:
+                    traffic_src = ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) "
+                                   f"spawned by this run over 12 steps of the same workload; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                                   f"per {kname} dispatch")
             else:
                 extra["pmc_note"] = why
+        trace_small = dict(LIVE_TRACE_US)
         if traffic is None:
             kname, traffic, src = committed_pmc_traffic(int(Bavg))
             traffic_src = None if traffic is None else f"committed {src}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes"
+        chain = chain_small > 0.5
         roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup forward, LDS-resident)" if fused else
-                    (f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
+                    (chain_note if chain else f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
+                    "frac_of_peak_on_measured_traffic": None if traffic is None else traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": bpl, "avg_launch_us": avg_us, "launches_measured": nl,
-                    "avg_launch_us_kernel_trace": LIVE_TRACE_US.get(kname) if kname else None,
+                    "aggregation_calls_per_launch": 4 if chain else 1, "launches_in_chain_form": chain_small,
+                    "avg_launch_us_kernel_trace": trace_small.get(kname) if kname else None,
                     "frac_counting_fused_output": (bpl + extra_small) / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "timing": "avg_launch_us (used for `achieved`): HIP events attached to the dispatch (hipExtLaunchKernelGGL) "
                               "on the launch stream -- they bracket the dispatch packet, i.e. the kernel plus ~0.5-1 us of "
-                              "dispatch latency, which matters for a 5 us kernel; avg_launch_us_kernel_trace: device "
+                              "dispatch latency, which matters for a short kernel; avg_launch_us_kernel_trace: device "
                               "timestamps of the same kernel from the rocprofv3 --kernel-trace of this run's WRITE_SIZE pass "
                               "(what profiles/*kernel_stats*.csv averages)",
-                    "note": "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per launch (SURVEY D4); at 50 graphs the launch "
-                            "moves ~1.6 MB (0.2 us of HBM time) and is dispatch/latency-bound -- see roofline_large_batch and DESIGN.md"}
+                    "note": (byte_note_chain if chain else byte_note_agg) + "; at 50 graphs a launch is latency-bound (one graph per "
+                            "workgroup, the largest graph sets its duration) -- see roofline_large_batch and DESIGN.md"}
+        # ---- the step's dominant kernel BY TIME at this batch size: the fused readout (SortPooling + dense tail, fwd + bwd) ----
+        if per_small and "k_readout_tail" in per_small and trace_small.get("k_readout_tail"):
+            t_us = trace_small["k_readout_tail"]
+            rb = algorithmic_bytes_readout_tail(int(avgN), int(Bavg), C)
+            extra["roofline_readout"] = {
+                "bound": "hbm", "kernel": "k_readout_tail (SortPooling top-30 + conv5/pool/conv6/MLP/log_softmax forward AND backward of "
+                                          "one graph per 1024-thread workgroup, one launch)",
+                "achieved": rb / (t_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "traffic": per_small["k_readout_tail"], "algorithmic_bytes_per_launch": rb, "avg_launch_us_kernel_trace": t_us,
+                "note": "byte model: bench.py algorithmic_bytes_readout_tail (SURVEY D4 sort-pool formula + tail weights, activations, "
+                        "per-graph gradient partials, SortPooling-gradient slabs); duration and traffic from the live rocprofv3 passes of "
+                        "this run; latency-bound per-graph chain (B workgroups on B of 256 CUs)"}
         # ---- the same kernel family where it is throughput-bound: a large batch ------------------
         if args.large_batch and world == 1 and not strong and args.large_batch > args.batch:
             LB = args.large_batch
@@ -545,20 +605,35 @@ def main():
             torch.cuda.synchronize(dev)
             ms_large = 1e3 * (time.perf_counter() - t1) / nl2
             _, avg2, bpl2, ach2, n2_ = measure_agg(tr2, lb, lb_cpu, 60)
-            extra_large = FUSED_EXTRA["bytes"]
+            extra_large, chain_large = FUSED_EXTRA["bytes"], FUSED_EXTRA.get("chain_frac", 0.0) > 0.5
             gb = gb_keep
-            kn2, tr2_, src2 = committed_pmc_traffic(LB)
-            roofline_large = {"bound": "hbm", "batch": LB, "kernel": "k_gcn_fwd32d (dense per-graph block form: bit-packed adjacency x bf16x3-split rows on "
+            kn2 = tr2_ = src2 = None
+            if not args.no_pmc:
+                per_l, why_l = live_pmc_traffic(base_common + ["--batch", str(LB)], timeout_s=300)
+                if per_l:
+                    kn2, tr2_ = pmc_pick(per_l, False)
+                    src2 = (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) spawned by this run "
+                            f"over 12 steps of {LB} graphs; (2*FETCH_SIZE + WRITE_SIZE)*1024 per {kn2} dispatch")
+                else:
+                    extra["pmc_note_large_batch"] = why_l
+            trace_large = LIVE_TRACE_US.get(kn2) if kn2 else None
+            if tr2_ is None:
+                kn2, tr2_, src2c = committed_pmc_traffic(LB)
+                src2 = None if tr2_ is None else f"committed {src2c}, kernel {kn2}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch"
+            roofline_large = {"bound": "hbm", "batch": LB,
+                              "kernel": chain_note if chain_large else
+                              "k_gcn_fwd32d (dense per-graph block form: bit-packed adjacency x bf16x3-split rows on "
                               "v_mfma_f32_16x16x32_bf16, exact in fp32) when the library's cost model picks it, else k_gcn_fwd32p",
-                              "traffic": tr2_, "traffic_source": None if tr2_ is None else f"committed {src2}, kernel {kn2}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch",
+                              "traffic": tr2_, "traffic_source": src2,
+                              "frac_of_peak_on_measured_traffic": None if tr2_ is None else tr2_ / (avg2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
                               "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl2, "avg_launch_us": avg2,
+                              "avg_launch_us_kernel_trace": trace_large,
+                              "aggregation_calls_per_launch": 4 if chain_large else 1,
                               "frac_counting_fused_output": (bpl2 + extra_large) / (avg2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "fused_output_note": "secondary: the launch also computes and writes the NEXT layer's pre-scaled linear "
-                                                   "output ([N,32] fp32 behind conv2, [N] behind conv3), which SURVEY's one-layer byte "
-                                                   "model leaves out; `frac` does not count it",
                               "launches_measured": n2_, "step_ms": ms_large, "graphs_per_s": LB / (ms_large * 1e-3),
-                              "note": f"same code, {LB} {args.workload}-shape graphs per step (secondary figure; the headline "
+                              "note": (byte_note_chain if chain_large else byte_note_agg) +
+                                      f"; same code, {LB} {args.workload}-shape graphs per step (secondary figure; the headline "
                                       f"metric stays batch {args.batch})"}
             del tr2, lb
 

@@ -152,6 +152,9 @@ int dgcnn_gcn_bwd(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const
   float* part1 = part + (size_t)P * 1056;
   const bool use_dense = dense != nullptr;
   if (use_dense && !dg_view_ok(dense)) return DGCNN_EINVAL;
+  // the gather kernels walk the transposed CSR: every branch of the gather form, and conv1's own backward (`first`) in
+  // BOTH forms (its operand is the raw [N,Fin] input, there is no dense kernel for it)
+  if (!colidx_t && (!use_dense || first)) return DGCNN_EINVAL;
   DgDense G{};
   if (use_dense) G = dg_dense_of(dense, N);
   if (Fout == 1) {                                 // conv4 form: k_gcn_bwd1 / k_gcn_bwd1d
@@ -256,6 +259,12 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
   G.graph_ptr = dg_cptr<int32_t>(ws, wl.graph_ptr); G.dmap = dg_cptr<int32_t>(ws, wl.dmap);
   G.bits = dg_cptr<uint32_t>(ws, wl.adjbits); G.N = N; G.B = B; G.NW = dgd_num_items(N, B);
   return G;
+}
+
+int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
+  if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
+  const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
+  return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0);
 }
 
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,

@@ -178,7 +178,8 @@ int dgcnn_gcn_fwd(int N, const int32_t* rowptr, const int32_t* colidx, const flo
  *   Fout = 1  (conv4 form): W [1,32]; gW [32], gb_prev [32], gas_prev [N,32] as above
  *   dense : NULL = CSR gather kernels on rowptr_t / colidx_t (CSR by source); else the dense block kernels
  *   scratch : dgcnn_gcn_bwd_scratch_bytes(N, Fin, Fout) bytes (per-workgroup partial rows; reduced in a fixed order)
- * ---------------------------------------------------------------------------------- */
+ * ----------------------------------------------------------------------------------  * colidx_t may be NULL only with `dense` and first == 0 (conv1's own backward, first != 0, always runs the gather kernel on
+ * the transposed CSR); DGCNN_EINVAL otherwise. */
 int64_t dgcnn_gcn_bwd_scratch_bytes(int N, int Fin, int Fout);
 int dgcnn_gcn_bwd(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv, const float* gas, int Fout,
                   const float* W, const float* x_prev, int Fin, int first, const float* gp_prev, float* gas_prev,
@@ -231,6 +232,14 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,
                         void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                         int max_edges, uint32_t epoch, dgcnn_stream_t stream);
+/* Which kernel families dgcnn_model_forward / the training step take for a batch of these sizes, flags and max_nodes
+ * (a pure function of host-known numbers): DGCNN_FORM_CHAIN = conv1..conv4 as ONE graph-chain launch (gcn_chain.hip),
+ * DGCNN_FORM_DENSE = dense per-graph block kernels for the per-layer forward (when not chained) and the backward
+ * (gcn_dense.hip); neither = CSR gather kernels (gcn.hip).  Negative: error code. */
+#define DGCNN_FORM_DENSE 1
+#define DGCNN_FORM_CHAIN 2
+int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
+
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
  * forward that depends on the batch only, not on the parameters -- CSR by target / by source, dinv, graph ranges and
  * (for F <= 32, where conv1 runs aggregate-first) the pre-scaled raw features dinv*x, which is why `x` is an input
