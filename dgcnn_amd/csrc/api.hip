@@ -235,8 +235,9 @@ static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
   if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
   if (dgd_num_items(N, B) > 100000) return false;
   if (flags & DGCNN_FLAG_CHAIN) return true;
-  // graphs above the persistent kernel's size class take a second launch: worth it for large batches only
-  return max_nodes <= dg_chain_small_rows() || N >= DG_DENSE_MIN_NODES;
+  // small batches (one workgroup per graph): a graph above 256 nodes would run two tiles per wave and set the launch's
+  // duration; large batches: graphs above the persistent kernel's size class take a second launch, worth it there
+  return max_nodes <= 256 || N >= DG_DENSE_MIN_NODES;
 }
 struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
 static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
@@ -368,6 +369,23 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
+  if (chain && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+      max_nodes <= dg_chain_train_max_nodes()) {
+    // small training batch: chain forward + readout forward + readout backward of every graph in ONE launch
+    DG_TRY(dg_launch_chain_readout_tail(N, B, F, C, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
+                                        dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
+                                        dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
+                                        dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, tt->y,
+                                        tt->loss_scale, dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1),
+                                        dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.gz5), dg_ptr<float>(ws, wl.gp1),
+                                        dg_ptr<float>(ws, wl.gp2), dg_ptr<float>(ws, wl.gp3), dg_ptr<float>(ws, wl.gas4),
+                                        dg_ptr<float>(ws, wl.gb4p), dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
+                                        dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
+    g_prof_which = -1;
+    *tail_done = 1;
+    if (rider_a && rode) *rode = 1;
+    return DGCNN_OK;
+  }
   if (chain) {
     DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
                                dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s,

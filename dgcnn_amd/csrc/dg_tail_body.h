@@ -1,0 +1,297 @@
+// dg_tail_body.h -- body of the readout backward for one graph (one workgroup of RD_THREADS threads), shared by k_tail_bwd,
+// the merged training kernel k_readout_tail (tail.hip) and the graph-chain training kernel (gcn_chain.hip).
+#pragma once
+#include "dg_common.h"
+#include "dg_readout.h"
+
+// ---------------------------------------------------------------------------------------------
+// readout backward (data gradients), one workgroup of 1024 threads per graph.  Also scatters the
+// SortPooling gradient to dense per-node slabs gp1..gp3 [N,32] and produces
+// gas4 = dinv * dL/d(pre-activation of conv4).
+// ---------------------------------------------------------------------------------------------
+// BIG (many graphs): classifier_1's weights are NOT prefetched into 64 registers at kernel start but read in 4-row
+// chunks at their use (they are L2-resident when thousands of workgroups stream the same 180 KB), and the registers
+// are capped at 64 so that two workgroups share a CU.  Same arithmetic order: bit-identical results.
+// body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
+// training kernel k_readout_tail (forward readout + this, one launch)
+struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb; };      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+template <bool BIG, bool MERGED = false>
+__device__ __forceinline__ void dg_tail_bwd_body(
+    int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+    const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
+    const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
+    const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
+    float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
+    float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
+    float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
+    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{}) {
+#define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+  TB_MARK(0);
+  // MERGED (k_readout_tail): conv5 / conv6 weights, the pooled rows and the log-probabilities are still in the forward
+  // body's LDS -- no reload, and the first barrier no longer waits for a global round trip
+  __shared__ float W5s_own[MERGED ? 1 : NW5];
+  __shared__ float a1ds[DGCNN_HID1];
+  __shared__ float p5s[DGCNN_C5 * DGCNN_T5];
+  __shared__ float sps_own[MERGED ? 1 : KCAT];            // this graph's pooled rows (conv5's weight-gradient operand)
+  __shared__ float W6s_own[MERGED ? 1 : NW6];
+  const float* W5s = MERGED ? ext.W5s : W5s_own;
+  const float* W6s = MERGED ? ext.W6s : W6s_own;
+  const float* sps = MERGED ? ext.sp : sps_own;
+  __shared__ float dl[DGCNN_MAX_C];
+  __shared__ float gz1s[DGCNN_HID1];
+  __shared__ __attribute__((aligned(16))) float gfh[8][DGCNN_FLAT];
+  __shared__ float gz6s[DGCNN_FLAT];
+  __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
+  __shared__ float gp5q[4][DGCNN_C5 * DGCNN_T5];
+  __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
+  __shared__ float ga4s[DGCNN_K];
+  __shared__ int selS[DGCNN_K];
+  __shared__ float x4S[DGCNN_K], dvS[DGCNN_K];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  const int msel = n < DGCNN_K ? n : DGCNN_K;
+
+  // ---- every small global load of steps 0-2 first (VMEM loads complete in order) ----
+  DgStage<NW5, RD_THREADS> st5;
+  DgStage<NW6, RD_THREADS> st6;
+  DgStage<KCAT, RD_THREADS> stp;
+  if (!MERGED) { st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)blockIdx.x * KCAT, tid); }
+  float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
+  int yb_ = 0;
+  if (wv == 0) {
+    if (MERGED) lp_ = lane < C ? ext.lg[lane] : -INFINITY;
+    else lp_ = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
+    if (glogp) g_ = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
+    else yb_ = MERGED ? ext.yb : (int)y[b];
+  }
+  // operands of the later steps that live in global memory: loaded NOW (their round trips overlap steps 1-2)
+  float a6_ = 0.f, a5a_ = 0.f, a5b_ = 0.f;
+  if (tid < DGCNN_FLAT) a6_ = MERGED ? ext.flat[tid] : a6g[(size_t)b * DGCNN_FLAT + tid];          // step 3: ReLU mask of conv6
+  if (tid < DGCNN_C5 * DGCNN_T5) {                                                     // step 5: MaxPool argmax
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+    const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
+    if (MERGED) { a5a_ = ext.a5s[c * DGCNN_K + 2 * u]; a5b_ = ext.a5s[c * DGCNN_K + 2 * u + 1]; }
+    else { a5a_ = a5g[base]; a5b_ = a5g[base + 1]; }
+  }
+  int node_ = -1;                                                                      // step 6: scatter targets
+  if (tid >= 64 && tid < 64 + DGCNN_K) {
+    if (MERGED) { const int ls = ext.sel[tid - 64]; node_ = ls >= 0 ? n0 + ls : -1; }
+    else node_ = perm[b * DGCNN_K + (tid - 64)];
+  }
+  float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
+  if (tid < DGCNN_HID1) {
+    a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
+  }
+  // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
+  // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only
+  // LDS-only barriers and no further global load, so they land while steps 1-2 run. ----
+  // 704 threads = 8 row groups (16 rows each) x 88 column quads: 16 x 16-byte loads per thread (one quarter of the
+  // vector-memory instructions a dword-per-lane mapping needs for the same 180 KB)
+  float4 wpre[BIG ? 1 : 16];
+  if (!BIG && tid < 2 * DGCNN_FLAT) {
+    const int rg = tid / 88, mq = tid - rg * 88;
+    const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
+#pragma unroll
+    for (int j = 0; j < (BIG ? 1 : 16); ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
+  }
+  if (!MERGED) { st5.store(W5s_own, tid); st6.store(W6s_own, tid); stp.store(sps_own, tid); }     // (waits only for the small loads above)
+  // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
+  for (int t = tid; t < n * 32; t += RD_THREADS) {
+    gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
+  }
+  for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
+  if (tid < DGCNN_K) ga4s[tid] = 0.f;
+
+  // 1. d(loss)/d(logits) from the upstream gradient wrt log-probs (or from labels: NLL mean)
+  if (wv == 0) {
+    const float lp = lp_;
+    float g = g_;
+    if (!glogp) {
+      const float sc = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;
+      // a label outside [0, C) (the reference's NLLLoss raises for it): clamp for memory safety and poison this
+      // graph's loss with NaN, which sticks in the metrics accumulator until Trainer.read_metrics raises
+      const bool ybad = (unsigned)yb_ >= (unsigned)C;
+      const int yb = ybad ? 0 : yb_;
+      g = (lane == yb) ? -sc : 0.f;
+      // loss and accuracy bookkeeping (train.py:44-45): first max index like torch.argmax
+      float mx = lp;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const unsigned long long ball = __ballot(lane < C && lp == mx);
+      const int am = __ffsll((long long)ball) - 1;
+      const float lpy = __shfl(lp, yb);
+      if (lane == 0) { lossv[2 * b] = ybad ? __builtin_nanf("") : -lpy * sc; lossv[2 * b + 1] = (am == yb) ? 1.f : 0.f; }
+    }
+    const float sg = dg_wave_sum(g);
+    const float d = lane < C ? g - expf(lp) * sg : 0.f;
+    if (lane < C) { dl[lane] = d; dlogit[(size_t)b * C + lane] = d; }
+  }
+  dg_lds_barrier();
+  TB_MARK(1);
+  float x4n_ = 0.f, dvn_ = 0.f;             // conv4 output / dst scale of the selected nodes (wave 1; used in step 6)
+  if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
+  // 2. through classifier_2, dropout, ReLU
+  if (tid < DGCNN_HID1) {
+    float ga = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) ga = fmaf(dl[c], wf2_[c], ga);
+    for (int c = 8; c < C; ++c) ga = fmaf(dl[c], w.Wf2[c * DGCNN_HID1 + tid], ga);
+    const float a = a1_;
+    const float gz = (a != 0.f) ? (training ? ga * 2.0f : ga) : 0.f;
+    gz1s[tid] = gz;
+    a1ds[tid] = a;
+    gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
+  }
+  dg_lds_barrier();
+  // per-graph partial of classifier_2's weight gradient: dl[c] * a1d[j]  (and bias = dl[c])
+  float* pt = ptail + (size_t)b * DG_PTAIL(C);
+  for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
+    const int c = t / DGCNN_HID1, j = t - c * DGCNN_HID1;
+    pt[DG_PT_WF2 + t] = dl[c] * a1ds[j];
+  }
+  if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
+  TB_MARK(2);
+  // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads); the
+  //    weights were prefetched into registers at kernel start
+  if (tid < 2 * DGCNN_FLAT) {
+    const int rg = tid / 88, mq = tid - rg * 88;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BIG) {
+      const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
+#pragma unroll 1
+      for (int j0 = 0; j0 < 16; j0 += 4) {
+        float4 wq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wq[u] = *reinterpret_cast<const float4*>(wc + (size_t)(j0 + u) * DGCNN_FLAT);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float z = gz1s[rg * 16 + j0 + u];
+          g.x = fmaf(z, wq[u].x, g.x); g.y = fmaf(z, wq[u].y, g.y);
+          g.z = fmaf(z, wq[u].z, g.z); g.w = fmaf(z, wq[u].w, g.w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (BIG ? 1 : 16); ++j) {
+        const float z = gz1s[rg * 16 + j];
+        g.x = fmaf(z, wpre[j].x, g.x); g.y = fmaf(z, wpre[j].y, g.y);
+        g.z = fmaf(z, wpre[j].z, g.z); g.w = fmaf(z, wpre[j].w, g.w);
+      }
+    }
+    *reinterpret_cast<float4*>(&gfh[rg][4 * mq]) = g;
+  }
+  __syncthreads();
+  if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
+    const float gf = ((gfh[0][tid] + gfh[1][tid]) + (gfh[2][tid] + gfh[3][tid])) +
+                     ((gfh[4][tid] + gfh[5][tid]) + (gfh[6][tid] + gfh[7][tid]));
+    const float g6 = a6_ > 0.f ? gf : 0.f;
+    gz6s[tid] = g6;
+    gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
+  }
+  __syncthreads();
+  TB_MARK(3);
+  // 4. conv6 data gradient on the matrix cores: gp5[c][u] = sum_{oc,d} W6[oc][c][d] gz6[oc][u-d]
+  //    -> [16 x 16(15)] = [16 x 160] . [160 x 16]; K split over 4 waves (40 each), combined in a fixed order
+  if (wv < 4) {
+    const int kbase = wv * 40;
+    dg_mfma_tile16(
+        0, 0, 40, lane,
+        [&](int c, int kk) { const int k = kbase + kk; return W6s[((k / DGCNN_KW6) * DGCNN_C5 + c) * DGCNN_KW6 + (k % DGCNN_KW6)]; },
+        [&](int kk, int u) {
+          const int k = kbase + kk;
+          const int tt = u - (k % DGCNN_KW6);
+          return (u < DGCNN_T5 && tt >= 0 && tt < DGCNN_T6) ? gz6s[(k / DGCNN_KW6) * DGCNN_T6 + tt] : 0.f;
+        },
+        [&](int c, int u, float v) { if (u < DGCNN_T5) gp5q[wv][c * DGCNN_T5 + u] = v; });
+  }
+  __syncthreads();
+  if (tid < DGCNN_C5 * DGCNN_T5) gp5[tid] = (gp5q[0][tid] + gp5q[1][tid]) + (gp5q[2][tid] + gp5q[3][tid]);
+  __syncthreads();
+  TB_MARK(4);
+  // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
+  if (tid < DGCNN_C5 * DGCNN_T5) {
+    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
+    const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
+    const float a0 = a5a_, a1 = a5b_;
+    p5s[tid] = fmaxf(a0, a1);                      // MaxPool1d output, needed for conv6's weight gradient
+    const float gp = gp5[tid];
+    const bool first = !(a1 > a0);
+    const float g0 = (first && a0 > 0.f) ? gp : 0.f;
+    const float g1 = (!first && a1 > 0.f) ? gp : 0.f;
+    gz5s[c * DGCNN_K + 2 * u] = g0;
+    gz5s[c * DGCNN_K + 2 * u + 1] = g1;
+    gz5g[base] = g0;
+    gz5g[base + 1] = g1;
+  }
+  if (tid >= 64 && tid < 64 + DGCNN_K) { selS[tid - 64] = node_; x4S[tid - 64] = x4n_; dvS[tid - 64] = dvn_; }
+  __syncthreads();
+  TB_MARK(5);
+  // 5b. per-graph partial weight gradients of conv6 and conv5 (everything they need is in LDS / this graph's
+  //     pooled rows); k_wgrad then only sums B contiguous partials per element (coalesced)
+  // conv6: pW6[oc][(c,d)] = sum_t gz6[oc][t] p5[c][t+d]   -> [32 x 80] = [32 x 12(11)] . [12 x 80]   (10 tiles)
+  // conv5: pW5[o][m]      = sum_s gz5[o][s] sp[s][m]       -> [16 x 112(97)] = [16 x 32(30)] . [32 x 112] (7 tiles)
+  for (int job = wv; job < 17; job += RD_THREADS / 64) {
+    if (job < 10) {
+      const int mt = job / 5, nt = job - mt * 5;
+      dg_mfma_tile16(
+          mt * 16, nt * 16, 12, lane,
+          [&](int oc, int t) { return t < DGCNN_T6 ? gz6s[oc * DGCNN_T6 + t] : 0.f; },
+          [&](int t, int n) { return t < DGCNN_T6 ? p5s[(n / DGCNN_KW6) * DGCNN_T5 + t + (n % DGCNN_KW6)] : 0.f; },
+          [&](int oc, int n, float v) { pt[DG_PT_W6 + oc * (DGCNN_C5 * DGCNN_KW6) + n] = v; });
+    } else {
+      const int nt = job - 10;
+      dg_mfma_tile16(
+          0, nt * 16, 32, lane,
+          [&](int o, int sl) { return sl < DGCNN_K ? gz5s[o * DGCNN_K + sl] : 0.f; },
+          [&](int sl, int m) { return (sl < DGCNN_K && m < DGCNN_CAT) ? sps[sl * DGCNN_CAT + m] : 0.f; },
+          [&](int o, int m, float v) { if (m < DGCNN_CAT) pt[DG_PT_W5 + o * DGCNN_CAT + m] = v; });
+    }
+  }
+  if (tid < DGCNN_C6) {
+    float acc = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < DGCNN_T6; ++tt) acc += gz6s[tid * DGCNN_T6 + tt];
+    pt[DG_PT_B6 + tid] = acc;
+  }
+  if (tid >= 512 && tid < 512 + DGCNN_C5) {
+    const int o = tid - 512;
+    float acc = 0.f;
+    for (int sl = 0; sl < DGCNN_K; ++sl) acc += gz5s[o * DGCNN_K + sl];
+    pt[DG_PT_B5 + o] = acc;
+  }
+  TB_MARK(6);
+  // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
+  // gsp[s][c] = sum_oc gz5[oc][s] W5[oc][c]  -> [32(30) x 112(97)] = [32 x 16] . [16 x 112]  (14 tiles, one wave each)
+  for (int job = wv; job < 14; job += RD_THREADS / 64) {
+    const int mt = job / 7, nt = job - mt * 7;
+    dg_mfma_tile16(
+        mt * 16, nt * 16, DGCNN_C5, lane,
+        [&](int sl, int oc) { return sl < DGCNN_K ? gz5s[oc * DGCNN_K + sl] : 0.f; },
+        [&](int oc, int c) { return c < DGCNN_CAT ? W5s[oc * DGCNN_CAT + c] : 0.f; },
+        [&](int sl, int c, float v) {
+          if (sl < msel && c < DGCNN_CAT) {
+            const int node = selS[sl];
+            if (c < 32) gp1[(size_t)node * 32 + c] = v;
+            else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
+            else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;
+            else {
+              const float xv = x4S[sl];
+              const float ga = v * (1.f - xv * xv);      // tanh'
+              gas4[node] = dvS[sl] * ga;
+              ga4s[sl] = ga;
+            }
+          }
+        });
+  }
+  __syncthreads();
+  TB_MARK(7);
+  if (tid == 0) {     // db4 partial of this graph, fixed order
+    float sum = 0.f;
+    for (int s = 0; s < DGCNN_K; ++s) sum += ga4s[s];
+    gb4p[b] = sum;
+  }
+}
+

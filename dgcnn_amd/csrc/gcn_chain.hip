@@ -28,6 +28,8 @@
 // from the per-layer kernels by fp32 rounding (different k order inside the fp32 matrix instruction).
 #include "dg_common.h"
 #include "dg_prep.h"
+#include "dg_readout.h"
+#include "dg_tail_body.h"
 #include <hip/hip_ext.h>
 #include <cstdio>
 
@@ -393,7 +395,7 @@ k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __r
 }
 
 // =================================================================================================================
-// PERSISTENT form for graphs of <= 128 nodes (the bulk of every TU-shaped batch): workgroups stay resident, stage the
+// PERSISTENT form: workgroups stay resident, stage the
 // weight tables ONCE, and deal themselves graphs from the SCHEDULE graph preparation left behind (dg_prep.h: graphs ranked
 // by tile count, largest first; workgroup w of G takes ranks w, 2G-1-w, 2G+w, ... -- snake order, equal sums, no atomics,
 // and the same assignment every run).  Everything a graph needs from global memory (its block of the bitmap, dinv, xs)
@@ -408,378 +410,41 @@ k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __r
 #else
 #define CH_T(k) do { } while (0)
 #endif
-struct ChP {
-  static constexpr int THREADS = 512, ROWS = 128, KW = 4, PS = ROWS * 32, BUF = 6 * PS;
-  static constexpr int OFF_W1 = 2 * BUF, OFF_W2 = OFF_W1 + 4096, OFF_W3 = OFF_W2 + 4096, OFF_BT = OFF_W3 + 4096;
-  static constexpr int OFF_DV = OFF_BT + 512;            // two sets (graph parity) of: dinv [ROWS] f32
-  static constexpr int OFF_H4 = OFF_DV + 2 * 4 * ROWS;   //                           h4s parts [3][ROWS] bf16
-  static constexpr int OFF_BL = OFF_H4 + 2 * 6 * ROWS;   //                           bitmap rows [ROWS][4] u32
-  static constexpr int OFF_TAB = OFF_BL + 2 * 16 * ROWS;
-  static constexpr int OFF_CTL = OFF_TAB + 128;
-  static constexpr int TOTAL = OFF_CTL + 64;
-};
-
-template <int XI>      // xs items (row, 4-column slot) per thread: 1 covers F <= 16, 2 covers F <= 32
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))       // <= 128 registers: two workgroups per CU
-k_chain_fwd_p(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const unsigned* __restrict__ bits,
-              const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
-              float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
-              unsigned long long* __restrict__ dbg) {
-  using C = ChP;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nl = lane & 15, kq = lane >> 4;
-  char* H0 = smem;
-  char* H1 = smem + C::BUF;
-  float* W1op = reinterpret_cast<float*>(smem + C::OFF_W1);
-  float* W2op = reinterpret_cast<float*>(smem + C::OFF_W2);
-  float* W3op = reinterpret_cast<float*>(smem + C::OFF_W3);
-  float* bt = reinterpret_cast<float*>(smem + C::OFF_BT);
-  uint2* tab = reinterpret_cast<uint2*>(smem + C::OFF_TAB);
-  int* ctl = reinterpret_cast<int*>(smem + C::OFF_CTL);
-#ifdef CH_TIMING
-  unsigned long long tprev_ = clock64();
-  if (dbg && tid == 0) for (int k = 0; k < 16; ++k) dbg[blockIdx.x * 16 + k] = 0;
-#endif
-  // ---- schedule: entries [nbig, B) are the graphs of this size class; entry of round r for this workgroup -----------------
-  const int nbig = nbig_p[0], ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
-  auto entry_of = [&](int r) {               // {n0, n}; n = 0 past the end (load clamped, selected)
-    const int li = r * G + ((r & 1) ? G - 1 - w : w);
-    const int2 e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + min(li, max(ns - 1, 0))));
-    return make_int2(e.x, (li < ns && e.y <= ChP::ROWS) ? e.y : 0);
-  };
-  int2 eC = entry_of(0), eN = entry_of(1);
-  // ---- once per workgroup: weight tables in MFMA-operand order, biases, nibble table -----------------------------------
-  // (COALESCED loads -- thread e takes element e -- scattered into operand order [ob][s][lane] on the LDS side: 512
-  //  workgroups gathering the same 12 KB in operand order at the same moment took 17 us of set-up)
-  {
-    float w2[2], w3[2], w1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + 512 * j;
-      w2[j] = gw.W2[e]; w3[j] = gw.W3[e]; w1[j] = e < 32 * F ? gw.W1[e] : 0.f;
-    }
-    float bv = 0.f;
-    if (tid < 128) {
-      const int which = tid >> 5, idx = tid & 31;
-      const float* src = which == 0 ? gw.b1 : (which == 1 ? gw.b2 : (which == 2 ? gw.b3 : gw.W4));
-      bv = src[idx];
-    }
-    auto slot_of = [](int o, int k) {       // W[o][k] -> [ob = o >> 4][s = 4 (k >> 4) + (k & 3)][lane = (o & 15) + 16 ((k >> 2) & 3)]
-      return (((o >> 4) * 8 + ((k >> 4) << 2) + (k & 3)) << 6) + (o & 15) + (((k >> 2) & 3) << 4);
-    };
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {           // conv1's table: entries with k >= F are zero (written here, by destination index)
-      const int e = tid + 512 * j, s_ = (e >> 6) & 7, l = e & 63;
-      if (16 * (s_ >> 2) + 4 * (l >> 4) + (s_ & 3) >= F) W1op[e] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + 512 * j;
-      W2op[slot_of(e >> 5, e & 31)] = w2[j]; W3op[slot_of(e >> 5, e & 31)] = w3[j];
-      if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F)] = w1[j]; }
-    }
-    if (tid < 128) bt[tid] = bv;
-    if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
-                                        ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
-  }
-  const float b4s = gw.b4[0];
-  __syncthreads();
-  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
-  const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
-  const int NBF = F > 16 ? 2 : 1;
-  // prefetch registers of the graph about to be staged
-  unsigned pbit = 0u; float pdv = 0.f; float pxs[XI][4];
-  // (loads are issued UNCONDITIONALLY on clamped addresses and selected when they are consumed: behind a per-lane `if` the
-  //  compiler loads into temporaries and waits for them on the spot -- the prefetch would not be one)
-  auto prefetch = [&](int pn0, int pn) {
-    const int pS = 1 << dgd_class(max(pn, 1));
-    pbit = bits[(size_t)N * (pS - 1) + (size_t)pn0 * pS + min(tid, max(pn * pS - 1, 0))];
-    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-      const int it = tid + 512 * j, k = min(it >> lg, max(pn - 1, 0)), qq = it & ((1 << lg) - 1);
-      const float* xr = xs + (size_t)(pn0 + k) * F;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pxs[j][i] = xr[min(4 * qq + i, F - 1)];
-    }
-  };
-  prefetch(n0, n);
-  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
-  const int mrow = 16 * wave + nl;
-  const int wroff = mrow * 32 + 8 * (kq ^ ((nl >> 2) & 3));
-  int par = 0;
-  CH_T(0);                                                // 0: set-up (tables, first tickets)
-  for (int r = 0; r * G < ns; ++r) {
-    float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
-    unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4) + par * 3 * C::ROWS;
-    unsigned* bl = reinterpret_cast<unsigned*>(smem + C::OFF_BL) + par * 4 * C::ROWS;
-    const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
-    const int S = 1 << dgd_class(max(n, 1));
-    // ---- stage the graph: registers -> LDS images ---------------------------------------------------------------------
-    if (tid < n * S) bl[tid] = pbit;                      // bitmap rows, stride S words
-    if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;     // (0 beyond n)
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-      const int it = tid + 512 * j, k = it >> lg, qq = it & ((1 << lg) - 1);
-      if (k < n) {
-        unsigned sp[3][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ch_split3(4 * qq + i < F ? pxs[j][i] : 0.f, sp[0][i], sp[1][i], sp[2][i]);
-        const int nb = qq >> 2, sl = qq & 3;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(H0 + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) =
-              make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
-      }
-    }
-    // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
-    for (int it = tid; it < RU * 4 * NBF; it += 512) {
-      const int k = it / (4 * NBF), qq = it - k * 4 * NBF;
-      if (!(k < n && qq < (1 << lg))) {
-        const int nb = qq >> 2, sl = qq & 3;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(H0 + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) = make_uint2(0u, 0u);
-      }
-    }
-    {   // rows 16T .. RU-1 of every later image (H1 whole, H0's planes conv1 does not use, h4s): written by no tile
-      const int gr = RU - 16 * T;
-      for (int it = tid; it < 12 * gr * 2; it += 512) {
-        const int piece = it & 1, row = 16 * T + ((it >> 1) % gr), pp = (it >> 1) / gr;
-        if (pp >= 6 || (pp & 1) >= NBF)
-          *reinterpret_cast<uint4*>(smem + (size_t)pp * C::PS + row * 32 + 16 * piece) = make_uint4(0u, 0u, 0u, 0u);
-      }
-      for (int it = tid; it < 3 * gr; it += 512) h4p[(it / gr) * C::ROWS + 16 * T + (it % gr)] = 0;
-    }
-    CH_T(1);                                              // 1: wait for the prefetched data + staging stores
-    dg_lds_barrier();
-    CH_T(2);                                              // 2: barrier
-    const int n0N = __builtin_amdgcn_readfirstlane(eN.x), nN = __builtin_amdgcn_readfirstlane(eN.y);     // (requested a graph ago)
-    eN = entry_of(r + 2);
-    prefetch(n0N, nN);
-    unsigned wb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wb[u] = (mrow < n && u < K32) ? bl[mrow * S + u] : 0u;
-    const float dn = dv[mrow];
-    CH_T(3);                                              // 3: issue of the next graph's loads
-    const bool live = wave < T;
-    // block product of this wave's tile with the image Hc.  Straight-line code per word count (no per-word branch: the
-    // reads of word u+1 are scheduled under the matrix instructions of word u)
-    auto productK = [&](auto kc, auto nbc, const char* Hc, f32x4 (&acc)[2]) {
-      constexpr int KC = decltype(kc)::value, NBP = decltype(nbc)::value;
-      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const char* hp = Hc + rdoff;
-      bf16x8 bop[KC];
-#pragma unroll
-      for (int u = 0; u < KC; ++u) bop[u] = ch_bits_operand(wb[u], kq, tab);
-#pragma unroll
-      for (int u = 0; u < KC; ++u) {
-        bf16x8 a[3][NBP];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int nb = 0; nb < NBP; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int nb = 0; nb < NBP; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop[u], acc[nb], 0, 0, 0);
-      }
-    };
-    auto product = [&](const char* Hc, int NBP, f32x4 (&acc)[2]) {
-      using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
-      if (NBP == 2) {
-        if (K32 == 1) productK(I1{}, I2{}, Hc, acc); else if (K32 == 2) productK(I2{}, I2{}, Hc, acc);
-        else if (K32 == 3) productK(I3{}, I2{}, Hc, acc); else productK(I4{}, I2{}, Hc, acc);
-      } else {
-        if (K32 == 1) productK(I1{}, I1{}, Hc, acc); else if (K32 == 2) productK(I2{}, I1{}, Hc, acc);
-        else if (K32 == 3) productK(I3{}, I1{}, Hc, acc); else productK(I4{}, I1{}, Hc, acc);
-      }
-    };
-    auto rows_and_linear = [&](const f32x4 (&v)[2], float* __restrict__ xout, const float* __restrict__ Wop, char* Hn) {
-      if (mrow < n) {
-        float* dst = xout + (size_t)(n0 + mrow) * 32 + 4 * kq;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-        *reinterpret_cast<float4*>(dst + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
-      }
-      float wv[2][8];
-#pragma unroll
-      for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) wv[ob][s] = Wop[(ob * 8 + s) * 64 + lane];
-      // four independent accumulator chains (k-steps of the first / second 16 input columns), combined at the end: the
-      // dependent-accumulator latency of the fp32 matrix instruction is 40 cycles, its issue interval 32
-      f32x4 d2[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int ob = 0; ob < 2; ++ob)
-            d2[ob][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob][4 * h + s], v[h][s], d2[ob][h], 0, 0, 0);
-#pragma unroll
-      for (int ob = 0; ob < 2; ++ob) {
-        unsigned sp[3][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ch_split3(dn * (d2[ob][0][r] + d2[ob][1][r]), sp[0][r], sp[1][r], sp[2][r]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(Hn + (p * 2 + ob) * C::PS + wroff) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
-      }
-    };
-    auto bias4 = [&](int which, int nb) { return *reinterpret_cast<const float4*>(bt + 32 * which + 16 * nb + 4 * kq); };
-    auto act32 = [&](int which, const f32x4 (&acc)[2], f32x4 (&v)[2]) {
-      const float4 b0 = bias4(which, 0), b1v = bias4(which, 1);
-      v[0][0] = dg_tanh(fmaf(dn, acc[0][0], b0.x)); v[0][1] = dg_tanh(fmaf(dn, acc[0][1], b0.y));
-      v[0][2] = dg_tanh(fmaf(dn, acc[0][2], b0.z)); v[0][3] = dg_tanh(fmaf(dn, acc[0][3], b0.w));
-      v[1][0] = dg_tanh(fmaf(dn, acc[1][0], b1v.x)); v[1][1] = dg_tanh(fmaf(dn, acc[1][1], b1v.y));
-      v[1][2] = dg_tanh(fmaf(dn, acc[1][2], b1v.z)); v[1][3] = dg_tanh(fmaf(dn, acc[1][3], b1v.w));
-    };
-    // ---- conv1 (aggregate-first) ---------------------------------------------------------------------------------------
-    if (live) {
-      const float4 b0 = bias4(0, 0), b1v = bias4(0, 1);
-      f32x4 acc[2];
-      product(H0, NBF, acc);
-      f32x4 axv[2];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          axv[nb][r] = dn * acc[nb][r];
-          const int c = 16 * nb + 4 * kq + r;
-          if (c < F && mrow < n) axg[(size_t)(n0 + mrow) * F + c] = axv[nb][r];
-        }
-      f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        if (16 * (s >> 2) + (s & 3) < F) {
-#pragma unroll
-          for (int ob = 0; ob < 2; ++ob)
-            pre[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1op[(ob * 8 + s) * 64 + lane], axv[s >> 2][s & 3], pre[ob], 0, 0, 0);
-        }
-      f32x4 v[2];
-      v[0][0] = dg_tanh(pre[0][0] + b0.x); v[0][1] = dg_tanh(pre[0][1] + b0.y);
-      v[0][2] = dg_tanh(pre[0][2] + b0.z); v[0][3] = dg_tanh(pre[0][3] + b0.w);
-      v[1][0] = dg_tanh(pre[1][0] + b1v.x); v[1][1] = dg_tanh(pre[1][1] + b1v.y);
-      v[1][2] = dg_tanh(pre[1][2] + b1v.z); v[1][3] = dg_tanh(pre[1][3] + b1v.w);
-      rows_and_linear(v, x1, W2op, H1);
-    }
-    CH_T(4);
-    dg_lds_barrier();
-    CH_T(5);
-    // ---- conv2 ---------------------------------------------------------------------------------------------------------
-    if (live) {
-      f32x4 acc[2], v[2];
-      product(H1, 2, acc);
-      act32(1, acc, v);
-      rows_and_linear(v, x2, W3op, H0);
-    }
-    CH_T(6);
-    dg_lds_barrier();
-    CH_T(7);
-    // ---- conv3 (next linear step 32 -> 1) --------------------------------------------------------------------------------
-    if (live) {
-      const float4 w0 = bias4(3, 0), w1 = bias4(3, 1);
-      f32x4 acc[2], v[2];
-      product(H0, 2, acc);
-      act32(2, acc, v);
-      if (mrow < n) {
-        float* dst = x3 + (size_t)(n0 + mrow) * 32 + 4 * kq;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-        *reinterpret_cast<float4*>(dst + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
-      }
-      float p = v[0][0] * w0.x;
-      p = fmaf(v[0][1], w0.y, p); p = fmaf(v[0][2], w0.z, p); p = fmaf(v[0][3], w0.w, p);
-      p = fmaf(v[1][0], w1.x, p); p = fmaf(v[1][1], w1.y, p); p = fmaf(v[1][2], w1.z, p); p = fmaf(v[1][3], w1.w, p);
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
-      if (kq == 0) {
-        unsigned q0, q1, q2;
-        ch_split3(dn * p, q0, q1, q2);
-        h4p[mrow] = (unsigned short)q0; h4p[C::ROWS + mrow] = (unsigned short)q1; h4p[2 * C::ROWS + mrow] = (unsigned short)q2;
-      }
-    }
-    CH_T(8);
-    dg_lds_barrier();
-    CH_T(9);
-    // ---- conv4 -----------------------------------------------------------------------------------------------------------
-    if (live) {
-      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-      const unsigned short* hq = h4p + min(nl, 2) * C::ROWS + 4 * kq;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u < K32) {
-          const unsigned w = wb[u];
-          if (__builtin_amdgcn_ballot_w64(w != 0u) != 0ull) {
-            const bf16x8 aop = ch_bits_operand(w, kq, tab);
-            uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
-            if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
-            bf16x8 bop;
-            unsigned* bu = reinterpret_cast<unsigned*>(&bop);
-            bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
-            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop, a4, 0, 0, 0);
-          }
-        }
-      }
-      float tot[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s1 = __shfl_xor(a4[r], 1), s2 = __shfl_xor(a4[r], 2);
-        tot[r] = (a4[r] + s1) + s2;
-      }
-      if (nl == 0) {
-        const int mm = 16 * wave + 4 * kq;
-        const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
-        const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (mm + r < n) x4[n0 + mm + r] = dg_tanh(fmaf(dd[r], tot[r], b4s));
-      }
-    }
-    CH_T(10);
-#ifdef CH_TIMING
-    if (dbg && tid == 0) dbg[blockIdx.x * 16 + 11] += 1;
-#endif
-    n0 = n0N; n = nN; par ^= 1;
-  }
-}
-
 // =================================================================================================================
-// The same persistent kernel with FOUR waves per workgroup and TWO 16-row tiles per wave (graphs of <= 128 nodes), one
-// LDS image of hs instead of two: 39 KB of LDS and <= 128 registers, i.e. FOUR workgroups = four graphs in flight per CU
-// instead of two (the per-layer time of a graph is a latency chain, ~2-3 k cycles, that barely stretches when more graphs
-// share the CU: profiles/r03 phase clocks).  A wave's two tiles share every HS^T operand it reads (half the LDS read
-// traffic per matrix instruction) and their dependent chains interleave.  The image is overwritten in place, so a layer
-// is  product -> barrier -> store next image -> barrier.
+// WAVES waves per workgroup, up to TWO 16-row tiles per wave (tiles `wave` and `wave + WAVES`): graphs of up to 32*WAVES
+// nodes.  A wave's two tiles share every HS^T operand it reads.  Graphs of at most half that size keep two images (the
+// two halves of every plane) and alternate; larger ones overwrite the one image in place:
+// product -> barrier -> store next image -> barrier.  Instantiations: 8 waves (<= 256 nodes, two workgroups per CU:
+// the persistent form for large batches), 16 waves (<= 512 nodes, one workgroup per CU: small batches, one graph per
+// workgroup, where the largest graph's critical path is the kernel's duration -- one tile per wave up to 256 nodes),
+// 4 waves (<= 128 nodes, four per CU: measured no faster than 8, kept as a measurement build).
 // =================================================================================================================
 #ifndef CH_LOCKSTEP
 #define CH_LOCKSTEP 0         // 1: the epilogues of a wave's two tiles run in lock step (more overlap, ~20 more registers: three
 #endif                        // workgroups per CU instead of four)
-template <int WAVES, int W1S>
+template <int WAVES, int W1S, int MAXN = 32 * WAVES>     // MAXN: largest graph admitted (sizes the bitmap image; <= 32 * WAVES)
 struct ChQ {
-  static constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES, KW = WAVES, PS = ROWS * 32, BUF = 6 * PS;
-  static constexpr int PB = ROWS * KW / THREADS;         // bitmap words of a graph per thread
+  static constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES, KW = MAXN / 32, PS = ROWS * 32, BUF = 6 * PS;
+  static constexpr int PB = (MAXN * KW + THREADS - 1) / THREADS;         // bitmap words of a graph per thread
   static constexpr int WJ = 1024 / THREADS;              // weight-matrix elements per thread
   static constexpr int OFF_W1 = BUF, OFF_W2 = OFF_W1 + W1S * 512, OFF_W3 = OFF_W2 + 4096, OFF_BT = OFF_W3 + 4096;
   static constexpr int OFF_DV = OFF_BT + 512;            // two sets (graph parity): dinv [ROWS] f32
   static constexpr int OFF_H4 = OFF_DV + 2 * 4 * ROWS;   // two sets: h4s parts [3][ROWS] bf16
   static constexpr int OFF_BL = OFF_H4 + 2 * 6 * ROWS;   // bitmap rows, <= KW words each
-  static constexpr int OFF_TAB = OFF_BL + 4 * KW * ROWS;
+  static constexpr int OFF_TAB = OFF_BL + 4 * KW * MAXN;
   static constexpr int TOTAL = OFF_TAB + 128;
 };
 
 // WAVES = 4: graphs of <= 128 nodes, four workgroups per CU; WAVES = 8: <= 256 nodes (one LDS image of 48 KB), two per CU
 // XI: xs items (row, 4-column slot) per thread; W1S: k-steps of conv1's weight table (4: F <= 16, 8: F <= 32)
-template <int WAVES, int XI, int W1S>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers
-k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
+template <int WAVES, int XI, int W1S, bool LOOP, int MAXN = 32 * WAVES>      // LOOP = false: exactly one graph per workgroup (grid = B), nothing is prefetched
+__device__ __forceinline__ void
+ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
               const unsigned* __restrict__ bits,
-              const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
+              const float* __restrict__ dinv, const float* __restrict__ xs, const ChW& gw, float* __restrict__ axg,
               float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
               unsigned long long* __restrict__ dbg) {
-  using C = ChQ<WAVES, W1S>;
+  using C = ChQ<WAVES, W1S, MAXN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -802,9 +467,9 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     int2 e;
     if (sched) e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + lc));
     else { e.x = graph_ptr[lc]; e.y = graph_ptr[lc + 1] - e.x; }
-    return make_int2(e.x, (li < ns && e.y <= C::ROWS) ? e.y : 0);
+    return make_int2(e.x, (li < ns && e.y <= MAXN) ? e.y : 0);
   };
-  int2 eC = entry_of(0), eN = entry_of(1);
+  int2 eC = entry_of(0), eN = LOOP ? entry_of(1) : make_int2(0, 0);
   const int lg = F <= 4 ? 0 : (F <= 8 ? 1 : (F <= 16 ? 2 : 3));      // 4-column slots with data per row: 2^lg
   const int NBF = F > 16 ? 2 : 1;
   unsigned pbit[C::PB]; float pdv = 0.f; float pxs[XI][4];
@@ -864,7 +529,7 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
   int par = 0;
   CH_T(0);                                                // 0: set-up
-  for (int r = 0; r * G < ns; ++r) {
+  for (int r = 0; LOOP ? r * G < ns : r < 1; ++r) {
     float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
     unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4) + par * 3 * C::ROWS;
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
@@ -915,9 +580,12 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
     CH_T(1);                                              // 1: wait for the prefetched data + staging stores
     dg_lds_barrier();
     CH_T(2);
-    const int n0N = __builtin_amdgcn_readfirstlane(eN.x), nN = __builtin_amdgcn_readfirstlane(eN.y);     // (requested a graph ago)
-    eN = entry_of(r + 2);
-    prefetch(n0N, nN);
+    int n0N = 0, nN = 0;
+    if (LOOP) {
+      n0N = __builtin_amdgcn_readfirstlane(eN.x); nN = __builtin_amdgcn_readfirstlane(eN.y);     // (requested a graph ago)
+      eN = entry_of(r + 2);
+      prefetch(n0N, nN);
+    }
     // this lane's bitmap rows stay in LDS (re-read per layer: 2 x K32 words; in registers they cost 16 at eight waves)
     const unsigned* bl0 = bl + min(mrow0, max(n - 1, 0)) * S;
     const unsigned* bl1 = bl + min(mrow1, max(n - 1, 0)) * S;
@@ -1175,22 +843,80 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #endif
 }
 
+template <int WAVES, int XI, int W1S, bool LOOP>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers
+k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
+              const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw,
+              float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
+              unsigned long long* __restrict__ dbg) {
+  ch_chain_body<WAVES, XI, W1S, LOOP>(N, B, F, sched, nbig_p, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, dbg);
+}
+
+// =================================================================================================================
+// Training step of a SMALL batch (one graph per workgroup): the graph-chain forward, the readout forward (SortPooling +
+// dense tail, dg_readout.h) and the readout backward (dg_tail_body.h) of a graph in ONE launch -- all three are per-graph
+// chains on the same 1024 threads; the x1..x4 rows the chain just wrote are read back by the workgroup that wrote them.
+// Rider range (blocks >= B): phase A of the next batch's graph preparation, as on k_readout_tail.
+// =================================================================================================================
+#define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
+struct ChTail {
+  unsigned int* err; unsigned int epoch;
+  int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
+  const int64_t* y; float loss_scale; float *dlogit, *gz1g, *gz6g, *gz5g, *gp1, *gp2, *gp3, *gas4, *gb4p, *lossv, *ptail;
+};
+template <int XI, int W1S>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits,
+                     const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
+                     float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChTail t,
+                     unsigned long long* __restrict__ dbg, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) {
+    dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
+                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
+    return;
+  }
+  const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
+  if (threadIdx.x == 0 && graph_ptr[blockIdx.x + 1] - graph_ptr[blockIdx.x] > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
+  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, nullptr);
+  __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TbExt ext;
+  {
+    const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
+    const float* sp = reinterpret_cast<const float*>(M.region0);
+    ext.sp = sp; ext.W5s = sp + 2912; ext.W6s = sp + 2912 + NW5; ext.lg = M.lg;
+    ext.flat = M.flat; ext.a5s = M.a5s; ext.a1s = M.a1s; ext.sel = M.sel;
+    ext.yb = yb;
+    const int b = blockIdx.x;
+    const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
+    dg_readout_fwd_body(M, b, n0, n, t.C, t.w, x4, n0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
+                        t.training, t.seed, dbg);
+  }
+  __syncthreads();
+  dg_tail_bwd_body<false, true>(B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
+                                t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
+                                t.pooled, dbg, ext);
+}
+
 // ---- host launcher ----------------------------------------------------------------------------------------------------
 // size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
 // workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
 // and leaves the other class' graphs alone; the second launch is skipped when the host's max_nodes hint rules it out.
-#ifndef CH_GRID
-#define CH_GRID 512                      // eight-wave form: two persistent workgroups per CU (LDS 70 KB each)
-#endif
 #ifndef CH_QW
-#define CH_QW 8                          // waves per workgroup of the two-tile form: 8 -> graphs of <= 256 nodes, two workgroups per CU;
-#endif                                   // 4 -> <= 128 nodes, four per CU (measured: ...)
+#define CH_QW 8                          // waves per workgroup of the persistent form: 8 -> graphs of <= 256 nodes, two workgroups per CU
+#endif                                   // (4 -> <= 128 nodes, four per CU: measurement build; 2048 COLLAB graphs 37 + 19 us for the
+                                         // larger graphs' launch against 46 us for everything in one launch at 8)
 #ifndef CH_GRID_Q
 #define CH_GRID_Q (CH_QW == 8 ? 512 : 1024)
 #endif
+#ifndef CH_ONESHOT_MAX_B
+#define CH_ONESHOT_MAX_B 256             // up to this many graphs: one 16-wave workgroup per graph (<= 512 nodes, no schedule)
+#endif
 #define CH_SMALL_ROWS (32 * CH_QW)
 int dg_chain_max_nodes() { return 512; }
-int dg_chain_small_rows() { return CH_SMALL_ROWS; }
+// largest graph the single-launch forms take (above it the size-class kernel runs as a second launch)
+int dg_chain_small_rows(int B) { return B <= CH_ONESHOT_MAX_B ? 512 : CH_SMALL_ROWS; }
 // batches of at most one graph per persistent workgroup need no schedule (and graph preparation no planning pass)
 int dg_chain_needs_schedule(int B) { return B > CH_GRID_Q ? 1 : 0; }
 
@@ -1206,11 +932,10 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   using CL = ChCfg<16, 2, false>;
   static bool attr_set = false;
   if (!attr_set) {
-#define CH_ATTR(W, XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS>), \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess)
-    if (CH_ATTR(CH_QW, 1, 4) || CH_ATTR(CH_QW, 2, 4) || CH_ATTR(CH_QW, 4, 8) ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ChP::TOTAL) != hipSuccess ||
+#define CH_ATTR(W, XI, WS, LP) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess)
+    if (CH_ATTR(CH_QW, 1, 4, true) || CH_ATTR(CH_QW, 2, 4, true) || CH_ATTR(CH_QW, 4, 8, true) ||
+        CH_ATTR(16, 1, 4, false) || CH_ATTR(16, 2, 4, false) || CH_ATTR(16, 4, 8, false) ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CL::TOTAL) != hipSuccess)
       return DGCNN_ELAUNCH;
@@ -1218,27 +943,63 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   }
   const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
   const int* nbig = dmap ? dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0) : nullptr;      // graphs above the size class = first entry of the class
-#ifdef CH_USE_P8        // measurement builds: the eight-wave, one-tile-per-wave form (two workgroups per CU)
-  const int grid = B < CH_GRID ? B : CH_GRID;
-  if (F <= 16)
-    hipExtLaunchKernelGGL((k_chain_fwd_p<1>), dim3(grid), dim3(512), ChP::TOTAL, s, ev_start, ev_stop, 0, N, B, F, sched, nbig,
-                          bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer());
-  else
-    hipExtLaunchKernelGGL((k_chain_fwd_p<2>), dim3(grid), dim3(512), ChP::TOTAL, s, ev_start, ev_stop, 0, N, B, F, sched, nbig,
-                          bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer());
-#else
-  const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
   // XI = xs items per thread: rows x 4-column slots with data / threads = 2^lg / 2 (at least 1)
-#define CH_LQ(XI, WS) hipExtLaunchKernelGGL((k_chain_fwd_q<CH_QW, XI, WS>), dim3(grid), dim3(64 * CH_QW), ChQ<CH_QW, WS>::TOTAL, s, ev_start, \
-                                            ev_stop, 0, N, B, F, sched, nbig, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
-  if (F <= 8) CH_LQ(1, 4); else if (F <= 16) CH_LQ(2, 4); else CH_LQ(4, 8);
+#define CH_LQ(W, XI, WS, LP, GRID, SCH) hipExtLaunchKernelGGL((k_chain_fwd_q<W, XI, WS, LP>), dim3(GRID), dim3(64 * W), ChQ<W, WS>::TOTAL, s, \
+    ev_start, ev_stop, 0, N, B, F, SCH, nbig, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
+  if (B <= CH_ONESHOT_MAX_B) {           // one 16-wave workgroup per graph, straight from graph_ptr (graphs of <= 512 nodes)
+    const int* none = nullptr;
+    if (F <= 8) CH_LQ(16, 1, 4, false, B, none); else if (F <= 16) CH_LQ(16, 2, 4, false, B, none); else CH_LQ(16, 4, 8, false, B, none);
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
+  const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
+  if (F <= 8) CH_LQ(CH_QW, 1, 4, true, grid, sched); else if (F <= 16) CH_LQ(CH_QW, 2, 4, true, grid, sched); else CH_LQ(CH_QW, 4, 8, true, grid, sched);
 #undef CH_LQ
-#endif
   DG_CHECK_LAUNCH();
   if (max_nodes <= 0 || max_nodes > CH_SMALL_ROWS) {
     hipLaunchKernelGGL((k_chain_fwd<16, 2, false>), dim3(B), dim3(CL::THREADS), CL::TOTAL, s, N, F, graph_ptr, bits, dinv, xs, gw,
                        ax, x1, x2, x3, x4, CH_SMALL_ROWS, sched, nbig);
     DG_CHECK_LAUNCH();
   }
+  return DGCNN_OK;
+}
+
+int dg_chain_train_max_b() { return CH_ONESHOT_MAX_B; }
+int dg_chain_train_max_nodes() { return CH_TRAIN_MAXN; }
+
+// chain forward + readout forward + readout backward of a small batch in one launch (training step with labels)
+int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
+                                 const float* xs, const float* params, const DgParams* pl, float* ax, float* x1, float* x2, float* x3,
+                                 float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask,
+                                 float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit, float* gz1,
+                                 float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
+                                 float* ptail, int32_t* err, uint32_t epoch, hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start,
+                                 hipEvent_t ev_stop) {
+  if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
+      !dinv || !xs || !y)
+    return DGCNN_EINVAL;
+  ChW gw;
+  gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
+  gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
+  ChTail t;
+  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
+  t.C = C; t.w = dg_tail_w(params, pl); t.pooled = pooled; t.perm = perm; t.a5g = a5; t.a6g = a6; t.a1dg = a1d; t.maskg = drop_mask;
+  t.logp = logp; t.training = training; t.seed = seed; t.y = y; t.loss_scale = loss_scale; t.dlogit = dlogit; t.gz1g = gz1;
+  t.gz6g = gz6; t.gz5g = gz5; t.gp1 = gp1; t.gp2 = gp2; t.gp3 = gp3; t.gas4 = gas4; t.gb4p = gb4p; t.lossv = lossv; t.ptail = ptail;
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  static_assert(ChQ<16, 4, CH_TRAIN_MAXN>::TOTAL >= RD_REGION0_BYTES + RD_SMALL_BYTES, "the readout's LDS plan aliases the chain's images");
+  static bool attr_set = false;
+  if (!attr_set) {
+#define CH_ATTR2(XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS>), \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL) != hipSuccess)
+    if (CH_ATTR2(1, 4) || CH_ATTR2(2, 4) || CH_ATTR2(4, 8)) return DGCNN_ELAUNCH;
+    attr_set = true;
+  }
+#define CH_LT(XI, WS) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS>), dim3(B + rd.nblk), dim3(1024), ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL, s, ev_start, \
+                                            ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
+  if (F <= 8) CH_LT(1, 4); else if (F <= 16) CH_LT(2, 4); else CH_LT(4, 8);
+#undef CH_LT
+  DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
