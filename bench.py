@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-AGG_KERNELS = ("k_chain_fwd_q", "k_gcn_fwd32d", "k_gcn_fwd32p", "k_gcn_fwd32")     # graph-chain / dense-block / persistent / tiled forms
+AGG_KERNELS = ("k_chain_readout_tail", "k_chain_fwd_q", "k_gcn_fwd32d", "k_gcn_fwd32p", "k_gcn_fwd32")     # graph-chain / dense-block / persistent / tiled forms
 
 
 def parse(argv=None):
@@ -487,15 +487,17 @@ def main():
         def form_of(b):        # which kernel family the library takes for this batch (pure function of host-known numbers)
             fl = mflags | (_lib.FLAG_COALESCED_UNDIRECTED if getattr(b, "coalesced_undirected", False) else 0)
             return L.dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, F, fl, int(b.max_nodes or 0))
-        chain_n = 0
+        chain_n, tail_n = 0, [0]
         for i in range(nprof):
             a, bb = ev(), ev()
             which = 1 + i % 2 if F <= 32 else i % 3
             _lib.check(L.dgcnn_profile_next_forward(which, a, bb), "profile_next_forward")
             b = bl[i % len(bl)]
             trainer.train_step(b, b.y, global_batch=gb) if not use_dist else trainer.forward_backward(b, b.y, global_batch=gb)
-            ch = (not fused) and bool(form_of(bl_cpu[i % len(bl)]) & 2)
+            fm = 0 if fused else form_of(bl_cpu[i % len(bl)])
+            ch = 2 if (fm & 4 and not use_dist) else (1 if fm & 2 else 0)     # 2: the one-launch chain + readout training kernel
             chain_n += 1 if ch else 0
+            tail_n[0] += 1 if ch == 2 else 0
             pairs.append((a, bb, b.num_nodes, b.num_edges, ch))
         torch.cuda.synchronize(dev)
         tot_us = tot_bytes = tot_extra = 0.0
@@ -503,7 +505,8 @@ def main():
             _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
             tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else \
-                (algorithmic_bytes_chain_fwd(n_, e_) if ch else algorithmic_bytes_agg(n_, e_))
+                (algorithmic_bytes_chain_fwd(n_, e_) + (algorithmic_bytes_readout_tail(n_, Bl, C) if ch == 2 else 0)
+                 if ch else algorithmic_bytes_agg(n_, e_))
             # the next layer's pre-scaled linear output this launch also writes (not part of SURVEY's one-layer model):
             # [N,32] fp32 behind conv1 / conv2, [N] behind conv3
             which = 1 + k % 2 if F <= 32 else k % 3
@@ -514,6 +517,7 @@ def main():
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
         FUSED_EXTRA["bytes"] = tot_extra / len(pairs)
         FUSED_EXTRA["chain_frac"] = chain_n / len(pairs)
+        FUSED_EXTRA["tail_frac"] = tail_n[0] / len(pairs)
         return fused, avg_us, bytes_per_launch, achieved, len(pairs)
 
     kernel_note = ("32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA; the library picks per batch between the "
@@ -523,6 +527,9 @@ def main():
                   "calls per launch as dense block products on v_mfma_f32_16x16x32_bf16 (exact in fp32 via the bf16x3 split) "
                   "from the bit-packed adjacency, the pre-scaled linear outputs resident in LDS (transpose-read layout), "
                   "next X.W on the fp32 matrix cores; graphs dealt from a sorted static schedule")
+    tail_note = ("k_chain_readout_tail (gcn_chain.hip): the graph-chain forward (conv1..conv4, four aggregation calls: see "
+                 "k_chain_fwd_q) AND the SortPooling readout + dense tail, forward and backward, of one graph per 16-wave "
+                 "workgroup in ONE launch -- the step's dominant kernel by time at this batch size")
     byte_note_agg = "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per aggregation call (SURVEY D4)"
     byte_note_chain = ("SURVEY D4's per-call model x the FOUR aggregation calls one launch processes (F = 32, 32, 32, 1: 106 KB per "
                        "COLLAB-cfg graph).  The launch's real HBM traffic (`traffic`) is far BELOW this figure -- that is the "
@@ -539,6 +546,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         fused, avg_us, bpl, achieved, nl = measure_agg(tr, batches, batches_cpu, max(200, min(args.steps, 400)))
         extra_small, chain_small = FUSED_EXTRA["bytes"], FUSED_EXTRA.get("chain_frac", 0.0)
+        tail_small = FUSED_EXTRA.get("tail_frac", 0.0) > 0.5
         traffic = traffic_src = kname = None
         per_small = None
         base_common = ["--workload", args.workload, "--scaling", args.scaling, "--global-batch", str(args.global_batch),
@@ -560,7 +568,7 @@ def main():
             traffic_src = None if traffic is None else f"committed {src}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes"
         chain = chain_small > 0.5
         roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup forward, LDS-resident)" if fused else
-                    (chain_note if chain else f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
+                    ((tail_note if tail_small else chain_note) if chain else f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "frac_of_peak_on_measured_traffic": None if traffic is None else traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -573,7 +581,9 @@ def main():
                               "dispatch latency, which matters for a short kernel; avg_launch_us_kernel_trace: device "
                               "timestamps of the same kernel from the rocprofv3 --kernel-trace of this run's WRITE_SIZE pass "
                               "(what profiles/*kernel_stats*.csv averages)",
-                    "note": (byte_note_chain if chain else byte_note_agg) + "; at 50 graphs a launch is latency-bound (one graph per "
+                    "note": (byte_note_chain if chain else byte_note_agg) +
+                            ("; plus bench.py algorithmic_bytes_readout_tail for the readout half of the launch" if tail_small else "") +
+                            "; at 50 graphs a launch is latency-bound (one graph per "
                             "workgroup, the largest graph sets its duration) -- see roofline_large_batch and DESIGN.md"}
         # ---- the step's dominant kernel BY TIME at this batch size: the fused readout (SortPooling + dense tail, fwd + bwd) ----
         if per_small and "k_readout_tail" in per_small and trace_small.get("k_readout_tail"):

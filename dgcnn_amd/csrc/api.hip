@@ -265,7 +265,9 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
-  return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0);
+  const bool chain_tail = f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+                          max_nodes <= dg_chain_train_max_nodes();
+  return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0);
 }
 
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,

@@ -238,6 +238,7 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
  * (gcn_dense.hip); neither = CSR gather kernels (gcn.hip).  Negative: error code. */
 #define DGCNN_FORM_DENSE 1
 #define DGCNN_FORM_CHAIN 2
+#define DGCNN_FORM_CHAIN_TAIL 4   /* a TRAINING step with labels runs chain forward + readout forward + readout backward as one launch */
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
 
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-3 evidence set (GPU box): bench lines, rocprofv3 kernel stats and PMC summaries -> gpurun_out/, to be copied to profiles/
+# usage: GIT_HASH=<hash> bash tools/profile_r03.sh [tag]     (tag defaults to r03)
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; cd $R
+T=${1:-r03}
+export GIT_HASH=${GIT_HASH:-unknown}
+python bench.py > $OUT/${T}_bench.json 2> $OUT/${T}_bench.err
+python bench.py --batch 2048 --steps 100 --warmup 20 --pool 8 --min-seconds 1 --no-cpu-baseline --no-pmc --large-batch 0 > $OUT/${T}_bench_b2048.json 2>> $OUT/${T}_bench.err
+python bench.py --batch 256 --steps 200 --warmup 20 --pool 8 --min-seconds 1 --no-cpu-baseline --no-pmc --large-batch 0 > $OUT/${T}_bench_b256.json 2>> $OUT/${T}_bench.err
+for W in MUTAG PROTEINS DD; do
+  python bench.py --workload $W --steps 200 --warmup 20 --min-seconds 1 --no-cpu-baseline --no-pmc --large-batch 0 > $OUT/${T}_bench_$(echo $W | tr A-Z a-z).json 2>> $OUT/${T}_bench.err
+done
+bash tools/kstats.sh ${T}_b50 > /dev/null
+bash tools/kstats.sh ${T}_b2048 --batch 2048 --pool 8 > /dev/null
+bash tools/pmc.sh ${T}_b50 > $OUT/${T}_pmc_b50.txt 2>&1
+bash tools/pmc.sh ${T}_b2048 --batch 2048 > $OUT/${T}_pmc_b2048.txt 2>&1
+bash tools/pmc_sq.sh ${T}_b2048 "--batch 2048" "k_chain_fwd_q|k_gcn_bwd32d|k_gcn_bwd1d|k_readout_fwd|k_tail_bwd" > $OUT/${T}_sq_b2048.txt 2>&1
+bash tools/pmc_sq.sh ${T}_b50 "" "k_chain_readout_tail|k_gcn_bwd32|k_gcn_bwd1|k_wgrad" > $OUT/${T}_sq_b50.txt 2>&1
+ls -la $OUT | tail -20
