@@ -66,6 +66,8 @@ def parse(argv=None):
     ap.add_argument("--global-batch", type=int, default=256,
                     help="strong scaling: graphs per step over ALL GPUs (BASELINE config 5: 256)")
     ap.add_argument("--pool", type=int, default=40, help="distinct batches resident in HBM per GPU")
+    ap.add_argument("--stress-nodes", type=int, default=0,
+                    help="force the FIRST graph of every batch to this many nodes (SURVEY D2 item 4: DD with its 5748-node graph)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed loop until this much is timed")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE config 3's secondary leg (hs stored bf16, X.W on bf16 MFMA); never the headline")
@@ -317,8 +319,12 @@ def main():
     else:
         B = args.batch
         # every rank draws its own graphs: rank r owns graph ids [r*pool*B, (r+1)*pool*B)
-        graphs = synth.make_graphs(args.workload, args.pool * B, start=rank * args.pool * B)
-        batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
+        if args.stress_nodes > 0:      # every batch carries one forced large graph
+            batches_cpu = [synth.make_batch(args.workload, B, start=(rank * args.pool + i) * B, force_first_n=args.stress_nodes)
+                           for i in range(args.pool)]
+        else:
+            graphs = synth.make_graphs(args.workload, args.pool * B, start=rank * args.pool * B)
+            batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
         gb = B * world
     batches = [b.to(dev) for b in batches_cpu]
     nb = len(batches)
@@ -666,6 +672,7 @@ def main():
             "config": {"workload": (f"{args.workload}-shape synthetic graphs (SURVEY §8(d) D2 cfg: n~N(75,30) clip[32,492], "
                                     f"mean degree ~37, F={F}, C={C})" if args.workload == "COLLAB" else
                                     f"{args.workload}-shape synthetic graphs (F={F}, C={C})") +
+                                   (f", first graph of every batch forced to {args.stress_nodes} nodes" if args.stress_nodes else "") +
                                    f", {per_gpu}, {nb} distinct resident batches per GPU",
                        "global_batch": gb, "avg_graphs_per_rank_per_step": Bavg, "avg_nodes_per_batch": avgN,
                        "avg_directed_edges_per_batch": avgE,

@@ -32,7 +32,12 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
       for (int j = 0; j < n; ++j) rank += keys[j] < my ? 1 : 0;
       if (rank < DGCNN_K) sel[rank] = tid;
     }
-  } else if (n <= SP_LDS_KEYS / 2) {
+  } else {
+    // (graphs of up to SP_LDS_KEYS / 2 nodes keep their packed keys in LDS; larger ones -- DD's 5748-node graph -- re-pack them
+    //  from the L2-resident key column in every pass: 4 + 1 scans instead of the 30 scans of a k-round selection, which took
+    //  88 us for that graph, or the ~78 barrier-separated passes of a 4096-key bitonic sort)
+    const bool in_lds = n <= SP_LDS_KEYS / 2;
+    auto key_at = [&](int t) { return in_lds ? keys[t] : dg_pack_key(x4[n0 + t], t); };
     // Only the first K of the order are needed: RADIX SELECT of the K-th key's 32-bit value (four passes over 8-bit
     // digits, an LDS histogram per pass), then the <= K + ties candidates at or below it are ranked among themselves.
     // ~10 barriers in all, against the ~55 barrier-separated passes of a bitonic sort of 1024 keys (the largest graph of
@@ -43,7 +48,7 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     unsigned int* hist = reinterpret_cast<unsigned int*>(cand + 256);                // [256]
     unsigned int& s_prefix = hist[256]; unsigned int& s_mask = hist[257];
     unsigned int& s_need = hist[258]; unsigned int& s_cnt = hist[259];
-    for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
+    if (in_lds) for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
     if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = (unsigned)m; s_cnt = 0u; }
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
@@ -51,7 +56,7 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
       __syncthreads();
       const unsigned int prefix = s_prefix, mask = s_mask, need = s_need;
       for (int t = tid; t < n; t += T) {
-        const unsigned int u = (unsigned int)(keys[t] >> 32);
+        const unsigned int u = (unsigned int)(key_at(t) >> 32);
         if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
       }
       __syncthreads();
@@ -75,7 +80,7 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     }
     const unsigned int ustar = s_prefix;                // value of the K-th key
     for (int t = tid; t < n; t += T) {
-      const unsigned long long k = keys[t];
+      const unsigned long long k = key_at(t);
       if ((unsigned int)(k >> 32) <= ustar) {
         const unsigned int pos = atomicAdd(&s_cnt, 1u);
         if (pos < 256u) cand[pos] = k;
@@ -90,35 +95,32 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
         for (int j = 0; j < cnt; ++j) rank += cand[j] < my ? 1 : 0;
         if (rank < DGCNN_K) sel[rank] = (int)(my & 0xffffffffull);
       }
-    } else {                     // more than 256 - K keys tie with the K-th one: full sort
+    } else if (n <= SP_LDS_KEYS) {      // more than 256 - K keys tie with the K-th one: full sort
       __syncthreads();
+      if (!in_lds) { for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t); __syncthreads(); }
       dg_block_bitonic<unsigned long long>(keys, n);
       if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
-    }
-  } else if (n <= SP_LDS_KEYS) {
-    for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
-    __syncthreads();
-    dg_block_bitonic<unsigned long long>(keys, n);
-    if (tid < m) sel[tid] = (int)(keys[tid] & 0xffffffffull);
-  } else {
-    unsigned long long prev = 0ull;
-    for (int r = 0; r < m; ++r) {
-      unsigned long long best = ~0ull;
-      for (int t = tid; t < n; t += T) {
-        const unsigned long long p = dg_pack_key(x4[n0 + t], t);
-        if ((r == 0 || p > prev) && p < best) best = p;
-      }
-      for (int o = 32; o > 0; o >>= 1) {       // workgroup min: wave shuffle then LDS
-        const unsigned long long other = __shfl_xor(best, o);
-        best = other < best ? other : best;
-      }
-      if ((tid & 63) == 0) red[tid >> 6] = best;
+    } else {                     // ... in a graph too large for the LDS sort: one scan per selected node
       __syncthreads();
-      unsigned long long b0 = red[0];
-      for (int w = 1; w < T / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
-      prev = b0;
-      if (tid == 0) sel[r] = (int)(b0 & 0xffffffffull);
-      __syncthreads();
+      unsigned long long prev = 0ull;
+      for (int r = 0; r < m; ++r) {
+        unsigned long long best = ~0ull;
+        for (int t = tid; t < n; t += T) {
+          const unsigned long long p = dg_pack_key(x4[n0 + t], t);
+          if ((r == 0 || p > prev) && p < best) best = p;
+        }
+        for (int o = 32; o > 0; o >>= 1) {       // workgroup min: wave shuffle then LDS
+          const unsigned long long other = __shfl_xor(best, o);
+          best = other < best ? other : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long b0 = red[0];
+        for (int w = 1; w < T / 64; ++w) b0 = red[w] < b0 ? red[w] : b0;
+        prev = b0;
+        if (tid == 0) sel[r] = (int)(b0 & 0xffffffffull);
+        __syncthreads();
+      }
     }
   }
   __syncthreads();

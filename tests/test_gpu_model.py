@@ -68,12 +68,13 @@ def test_golden_step_fixture_loss_grads_and_post_adam_parameters(golden_dir, nam
 
 
 WORKLOADS = [("MUTAG", 50, None), ("PROTEINS", 50, None), ("COLLAB", 50, None), ("COLLAB_REAL", 50, None),
-             ("IMDB", 50, None), ("DD", 50, None), ("DD", 8, 5748)]
+             ("IMDB", 50, None), ("DD", 50, None), ("DD", 8, 5748), ("DD", 50, 5748)]
 
 
 @pytest.mark.parametrize("name,bs,force", WORKLOADS, ids=[f"{w[0]}-{w[1]}-{w[2]}" for w in WORKLOADS])
 def test_workload_forward_and_backward(name, bs, force):
-    """BASELINE.json configs at their batch size (DD also with the forced 5748-node graph)."""
+    """BASELINE.json configs at their batch size (DD also with the forced 5748-node graph: SURVEY D2 item 4's stress batch,
+    at batch 8 and at the full batch of 50 -- the fp64 oracle's dense block of that graph is 264 MB)."""
     sh = synth.SHAPES[name]
     b = synth.make_batch(name, bs, start=1000, force_first_n=force)
     m = make_model(sh.num_features, sh.num_classes)
