@@ -457,11 +457,25 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                                max_edges, epoch, stream, nullptr, nullptr);
 }
 
+// form of a batch's backward: `dense` = the dense per-layer kernels (else CSR gather); `chain` = conv4 + conv3 as one
+// graph-chain launch (gcn_chain.hip: needs the bitmap the forward's preparation built and graphs of <= 256 nodes);
+// `plan` = the item table / graph schedule exists (batches above one graph per persistent workgroup)
+struct DgBwdForm { bool dense, chain, plan; };
+static DgBwdForm dg_backward_form(int N, int E, int B, int F, int flags, int max_nodes) {
+  DgBwdForm b{false, false, false};
+  if (flags & DGCNN_FLAG_FORCE_FUSED) return b;            // (the fused graph-per-workgroup forward never builds the bitmap)
+  const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
+  b.dense = f.dense; b.plan = f.plan;
+  b.chain = f.bitmap && !(flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) && max_nodes > 0 && max_nodes <= dg_chain_bwd_max_nodes() &&
+            (f.plan || !dg_chain_needs_schedule(B));
+  return b;
+}
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
                                   float loss_scale, int training, float* grads, float* metrics,
-                                  const DgAdam* adam, hipStream_t s, bool dense, const DgPrepRider* rider_b = nullptr,
+                                  const DgAdam* adam, hipStream_t s, const DgBwdForm& bf, const DgPrepRider* rider_b = nullptr,
                                   bool tail_done = false) {
+  const bool dense = bf.dense;
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -488,8 +502,15 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
     // dense block form (the forward of this batch took it: the bitmap is in the workspace); F > 32 keeps the gather
     // kernel for conv1's own backward (its operand is the raw [N,F] input)
     const DgDense G = dg_dense_view(ws, wl, N, B);
+    if (bf.chain) {
+      // conv4 + conv3 backward of every graph inside one workgroup: gas4 -> gas2 (gasB), partial {dW4, db3}, {dW3, db2}
+      DG_TRY(dg_launch_chain_bwd_a(N, B, G.graph_ptr, G.bits, dinv, gas4, params + pl.off[6], params + pl.off[4], x3, gp3, x2, gp2,
+                                   gasB, dg_ptr<float>(ws, wl.pa4), wl.P1, dg_ptr<float>(ws, wl.pb3), wl.P32,
+                                   bf.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s));
+    } else {
     DG_TRY(dg_launch_gcn_bwd1d(&G, dinv, gas4, params + pl.off[6], x3, gp3, gasA, dg_ptr<float>(ws, wl.pa4), wl.P1, s));
     DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasA, params + pl.off[4], x2, gp2, gasB, dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+    }
     if (F <= DG_AF_MAX_F) {
       DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasB, params + pl.off[2], x1, gp1, gasA, dg_ptr<float>(ws, wl.pb2), wl.P32, s,
                                   dg_cptr<float>(ws, wl.ax), F, dg_ptr<float>(ws, wl.pb1)));
@@ -499,12 +520,20 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                                  dg_ptr<float>(ws, wl.pb1), wl.P32, s));
     }
   } else {
+  const bool bwd1_hosts_rider = tail_done && !wg_rider && rider_b;      // (then conv4's backward launch carries prep phase B)
+  if (bf.chain && !bwd1_hosts_rider) {
+    const DgDense G = dg_dense_view(ws, wl, N, B);
+    DG_TRY(dg_launch_chain_bwd_a(N, B, G.graph_ptr, G.bits, dinv, gas4, params + pl.off[6], params + pl.off[4], x3, gp3, x2, gp2,
+                                 gasB, dg_ptr<float>(ws, wl.pa4), wl.P1, dg_ptr<float>(ws, wl.pb3), wl.P32,
+                                 bf.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s));
+  } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
                              dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+  }
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
   if (F <= DG_AF_MAX_F) {
     // ... carrying conv1's whole backward: dW1 = ga1^T . (A_hat x), from the ax slab the forward saved
@@ -534,7 +563,7 @@ int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
   if (!params || !x || !ws || !logp || !grads || N <= 0 || B <= 0) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, glogp, y, loss_scale, training ? 1 : 0,
-                                grads, metrics, nullptr, (hipStream_t)stream, dg_backward_dense(N, E, B, flags, max_nodes));
+                                grads, metrics, nullptr, (hipStream_t)stream, dg_backward_form(N, E, B, F, flags, max_nodes));
 }
 
 int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, const float* x, void* ws,
@@ -547,7 +576,7 @@ int dgcnn_model_backward_step(int N, int E, int B, int F, int C, float* params, 
   ad.params = params; ad.exp_avg = exp_avg; ad.exp_avg_sq = exp_avg_sq;
   ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.step = step;
   return dg_model_backward_impl(N, E, B, F, C, params, x, ws, logp, nullptr, y, loss_scale, training ? 1 : 0,
-                                grads, metrics, &ad, (hipStream_t)stream, dg_backward_dense(N, E, B, flags, max_nodes));
+                                grads, metrics, &ad, (hipStream_t)stream, dg_backward_form(N, E, B, F, flags, max_nodes));
 }
 
 // ---- pipelined training step ------------------------------------------------------------------------
@@ -633,7 +662,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   }
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
-                                dg_backward_dense(cur->N, cur->E, cur->B, flags, cur->max_nodes), rode ? rider : nullptr,
+                                dg_backward_form(cur->N, cur->E, cur->B, cur->F, flags, cur->max_nodes), rode ? rider : nullptr,
                                 tail_done != 0));
   if (next && rode && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
     DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,

@@ -899,6 +899,320 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                                 t.pooled, dbg, ext);
 }
 
+// =================================================================================================================
+// BACKWARD chain, conv4 and conv3 of a graph in one workgroup (replaces k_gcn_bwd1* and the layer-3 k_gcn_bwd32*):
+//   gh4[j]  = dinv[j] * sum_{i in N(j)+j} gas4[i]                       block product, ONE column (three bf16 parts as three
+//                                                                       columns of one B operand, as in the forward's conv4)
+//   gx3     = gh4 * W4 + gp3 ; ga3 = gx3 (1 - x3^2) ; gas3 = dinv ga3   -> LDS image (three bf16 parts), never to HBM
+//   dW4    += gh4 x3 ; db3 += ga3
+//   gh3[j]  = dinv[j] * sum_i gas3[i]                                   32-wide block product, evaluated in BOTH orientations
+//                                                                       from the same operand registers: lane = node (for
+//                                                                       gx2 and tanh') and lane = column (for dW3)
+//   dW3    += gh3^T x2                                                  fp32 MFMA, contraction over the tile's 16 nodes;
+//                                                                       node (step s, lane group kq) = 4 kq + s on both
+//                                                                       operands: exactly what the accumulator lanes hold
+//   gx2     = gh3 W3 + gp2 ; ga2 = gx2 (1 - x2^2) ; gas2 = dinv ga2     -> global (conv2's backward kernel consumes it)
+//   db2    += ga2
+// Same static schedule, prefetch and two-tiles-per-wave structure as the forward.  dW3 accumulates in 16 registers per wave
+// across all graphs of the workgroup; the three small vectors (dW4, db3, db2) accumulate in wave-private LDS slots (row sums
+// over the 16 node lanes on the DPP path, then one read-modify-write by the owning lanes: no other wave touches the slot).
+// The final fixed-order sum over the waves writes ONE partial row per workgroup in the layouts k_wgrad already reduces.
+// =================================================================================================================
+template <int WAVES, int MAXN>
+struct ChB {
+  static constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES, KW = MAXN / 32, PS = ROWS * 32, BUF = 6 * PS;
+  static constexpr int PB = (MAXN * KW + THREADS - 1) / THREADS;
+  static constexpr int OFF_WT = BUF;                     // W3^T in MFMA-operand order [2][8][64] fp32
+  static constexpr int OFF_W4 = OFF_WT + 4096;           // W4 [32]
+  static constexpr int OFF_DV = OFF_W4 + 128;            // two sets (graph parity): dinv [ROWS]
+  static constexpr int OFF_G4 = OFF_DV + 2 * 4 * ROWS;   // two sets: gas4 as three bf16 parts [3][ROWS]
+  static constexpr int OFF_BL = OFF_G4 + 2 * 6 * ROWS;   // bitmap rows
+  static constexpr int OFF_TAB = OFF_BL + 4 * KW * MAXN;
+  static constexpr int OFF_GT = OFF_TAB + 128;           // per wave: gh4 of its two tiles [2][16]
+  static constexpr int OFF_SL = OFF_GT + WAVES * 128;    // per wave: dW4 [32] | db3 [32] | db2 [32]
+  static constexpr int TOTAL = OFF_SL + WAVES * 384;
+};
+
+// sum over the 16 lanes of each row (lanes sharing kq): every lane of the row receives the total (fixed order)
+__device__ __forceinline__ float ch_row16_sum(float v) {
+  v += DG_DPP(v, 0xB1, 0xf);    // quad_perm:[1,0,3,2]
+  v += DG_DPP(v, 0x4E, 0xf);    // quad_perm:[2,3,0,1]
+  v += DG_DPP(v, 0x124, 0xf);   // row_ror:4
+  v += DG_DPP(v, 0x128, 0xf);   // row_ror:8
+  return v;
+}
+
+template <int WAVES, bool LOOP, int MAXN>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))
+k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
+              const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ gas4,
+              const float* __restrict__ W4, const float* __restrict__ W3, const float* __restrict__ x3,
+              const float* __restrict__ gp3, const float* __restrict__ x2, const float* __restrict__ gp2,
+              float* __restrict__ gas2, float* __restrict__ pa4, int P1, float* __restrict__ pb3, int P32) {
+  using C = ChB<WAVES, MAXN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  char* H = smem;
+  float* WTop = reinterpret_cast<float*>(smem + C::OFF_WT);
+  float* w4s = reinterpret_cast<float*>(smem + C::OFF_W4);
+  unsigned* bl = reinterpret_cast<unsigned*>(smem + C::OFF_BL);
+  uint2* tab = reinterpret_cast<uint2*>(smem + C::OFF_TAB);
+  float* g4t = reinterpret_cast<float*>(smem + C::OFF_GT) + wave * 32;
+  float* slot = reinterpret_cast<float*>(smem + C::OFF_SL) + wave * 96;
+  const int nbig = sched ? nbig_p[0] : 0, ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
+  auto entry_of = [&](int r) {
+    const int li = r * G + ((r & 1) ? G - 1 - w : w), lc = min(li, max(ns - 1, 0));
+    int2 e;
+    if (sched) e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + lc));
+    else { e.x = graph_ptr[lc]; e.y = graph_ptr[lc + 1] - e.x; }
+    return make_int2(e.x, (li < ns && e.y <= MAXN) ? e.y : 0);
+  };
+  int2 eC = entry_of(0), eN = LOOP ? entry_of(1) : make_int2(0, 0);
+  unsigned pbit[C::PB]; float pdv = 0.f, pg4 = 0.f;
+  auto prefetch = [&](int pn0, int pn) {
+    const int pS = 1 << dgd_class(max(pn, 1));
+    const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
+    const int last = max(pn * pS - 1, 0), lr = pn0 + min(tid, max(pn - 1, 0));
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
+    pdv = dinv[lr]; pg4 = gas4[lr];
+  };
+  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
+  prefetch(n0, n);
+  // ---- once per workgroup: W3^T in operand order, W4, nibble table, zeroed slots ---------------------------------------------
+  {   // table [kb][s][lane] = W3[o = kappa(s, lane >> 4)][k = 16 kb + (lane & 15)]   (A operand of gx = gh W3, transposed form)
+    for (int e = tid; e < 1024; e += C::THREADS) {
+      const int o = e >> 5, k = e & 31;                  // coalesced: element e = W3[o][k]
+      const int s_ = ((o >> 4) << 2) | (o & 3), l = (k & 15) | (((o >> 2) & 3) << 4);
+      WTop[(((k >> 4) * 8 + s_) << 6) + l] = W3[e];
+    }
+    if (tid < 32) w4s[tid] = W4[tid];
+    if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
+                                        ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+    for (int e = tid; e < WAVES * 96; e += C::THREADS) reinterpret_cast<float*>(smem + C::OFF_SL)[e] = 0.f;
+  }
+  __syncthreads();
+  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
+  const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;
+  const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
+  f32x4 accW[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  const float4 w4a = *reinterpret_cast<const float4*>(w4s + 4 * kq), w4b = *reinterpret_cast<const float4*>(w4s + 16 + 4 * kq);
+  int par = 0;
+  for (int r = 0; LOOP ? r * G < ns : r < 1; ++r) {
+    float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
+    unsigned short* g4p = reinterpret_cast<unsigned short*>(smem + C::OFF_G4) + par * 3 * C::ROWS;
+    const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
+    const int S = 1 << dgd_class(max(n, 1));
+    // ---- stage: bitmap rows, dinv, gas4 as three bf16 parts (zeros up to RU) ------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j)
+      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
+    if (tid < C::ROWS) {
+      dv[tid] = tid < n ? pdv : 0.f;
+      if (tid < RU) {
+        unsigned q0, q1, q2;
+        ch_split3(tid < n ? pg4 : 0.f, q0, q1, q2);
+        g4p[tid] = (unsigned short)q0; g4p[C::ROWS + tid] = (unsigned short)q1; g4p[2 * C::ROWS + tid] = (unsigned short)q2;
+      }
+    }
+    if (RU > 16 * T && tid < 192)      // rows 16T .. RU-1 of the gas3 image: written by no tile
+      *reinterpret_cast<uint4*>(H + (tid >> 5) * C::PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
+    dg_lds_barrier();
+    int n0N = 0, nN = 0;
+    if (LOOP) {
+      n0N = __builtin_amdgcn_readfirstlane(eN.x); nN = __builtin_amdgcn_readfirstlane(eN.y);
+      eN = entry_of(r + 2);
+      prefetch(n0N, nN);
+    }
+    const unsigned* blr[2] = {bl + min(mrow0, max(n - 1, 0)) * S, bl + min(mrow1, max(n - 1, 0)) * S};
+    const int mrow[2] = {mrow0, mrow1};
+    const bool rv[2] = {mrow0 < n, mrow1 < n};
+    const float dn[2] = {dv[mrow0], dv[mrow1]};
+    const bool live[2] = {wave < T, wave + WAVES < T};
+
+    // ======== conv4 backward + start of conv3's: per tile ========
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (live[ti]) {
+        const int m = mrow[ti];
+        const bool ok = rv[ti];
+        // operands of the epilogue that do not depend on the product: requested first
+        const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
+        const float4 xa = *reinterpret_cast<const float4*>(x3 + ro), xb = *reinterpret_cast<const float4*>(x3 + ro + 16);
+        const float4 ga_ = *reinterpret_cast<const float4*>(gp3 + ro), gb_ = *reinterpret_cast<const float4*>(gp3 + ro + 16);
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+        const unsigned short* hq = g4p + min(nl, 2) * C::ROWS + 4 * kq;
+#pragma unroll
+        for (int u = 0; u < C::KW; ++u) {
+          if (u < K32) {
+            uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
+            if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+            bf16x8 bop;
+            unsigned* bu = reinterpret_cast<unsigned*>(&bop);
+            bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(ok ? blr[ti][u] : 0u, kq, tab), bop, a4, 0, 0, 0);
+          }
+        }
+        // lane (j = nl, kq): part j of rows 4kq + r -> gh4 of those rows through the wave's LDS tile -> lane = node
+        {
+          float tot[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) tot[rr] = (a4[rr] + __shfl_xor(a4[rr], 1)) + __shfl_xor(a4[rr], 2);
+          if (nl == 0) {
+            const float4 dq = *reinterpret_cast<const float4*>(dv + 16 * (wave + WAVES * ti) + 4 * kq);
+            *reinterpret_cast<float4*>(g4t + 16 * ti + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
+          }
+        }
+        const float gh = g4t[16 * ti + nl];              // (same wave wrote it: program order + lgkmcnt)
+        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        const float gv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
+        const float wv[8] = {w4a.x, w4a.y, w4a.z, w4a.w, w4b.x, w4b.y, w4b.z, w4b.w};
+        float gas3[8], s4[8], s3[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float ga = ok ? fmaf(gh, wv[c], gv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+          gas3[c] = dn[ti] * ga;
+          s4[c] = ch_row16_sum(ok ? gh * xv[c] : 0.f);
+          s3[c] = ch_row16_sum(ga);
+        }
+        if (nl == 0) {             // this wave's slots: cols 4kq..4kq+3 and 16+4kq..
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int col = 16 * (c >> 2) + 4 * kq + (c & 3);
+            slot[col] += s4[c]; slot[32 + col] += s3[c];
+          }
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {   // gas3 -> the image (three bf16 parts, row-major, slot-swizzled)
+          unsigned sp[3][4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) ch_split3(gas3[4 * hb + rr], sp[0][rr], sp[1][rr], sp[2][rr]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2*>(H + (p * 2 + hb) * C::PS + m * 32 + wsl) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+        }
+      }
+    }
+    dg_lds_barrier();
+
+    // ======== conv3 backward: per tile ========
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (live[ti]) {
+        const int m = mrow[ti];
+        const bool ok = rv[ti];
+        const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
+        const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
+        const float4 ga_ = *reinterpret_cast<const float4*>(gp2 + ro), gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
+        // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
+        const int mt = 16 * (wave + WAVES * ti);
+        float xN[2][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int mm = mt + 4 * kq + s_;
+          const float* xr = x2 + (size_t)(n0 + min(mm, n - 1)) * 32 + nl;
+          const float v0 = xr[0], v1 = xr[16];
+          xN[0][s_] = mm < n ? v0 : 0.f; xN[1][s_] = mm < n ? v1 : 0.f;
+        }
+        f32x4 accT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accN[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const char* hp = H + rdoff;
+#pragma unroll
+        for (int u = 0; u < C::KW; ++u) {
+          if (u < K32) {
+            const bf16x8 bop = ch_bits_operand(ok ? blr[ti][u] : 0u, kq, tab);
+            bf16x8 a[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) {
+                accT[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop, accT[nb], 0, 0, 0);   // lane = node
+                accN[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bop, a[p][nb], accN[nb], 0, 0, 0);   // lane = column
+              }
+          }
+        }
+        // dW3 += gh^T x2 : A[o][node] from the lane = column product (rows 4kq + s), scaled by dinv of those rows
+        {
+          const float4 dq = *reinterpret_cast<const float4*>(dv + mt + 4 * kq);
+          const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb)
+                accW[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dd[s_] * accN[mb][s_], xN[nb][s_], accW[mb][nb], 0, 0, 0);
+        }
+        // gx2 = gh W3 (transposed form: A = W3^T table, B = gh in the lane = node layout)
+        f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+          const float gv_ = dn[ti] * accT[s_ >> 2][s_ & 3];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(WTop[(kb * 8 + s_) * 64 + lane], gv_, gx[kb], 0, 0, 0);
+        }
+        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        const float gpv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
+        float go[8], s2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float ga = ok ? (gx[c >> 2][c & 3] + gpv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+          go[c] = dn[ti] * ga;
+          s2[c] = ch_row16_sum(ga);
+        }
+        if (ok) {
+          float* dst = gas2 + (size_t)(n0 + m) * 32 + 4 * kq;
+          *reinterpret_cast<float4*>(dst) = make_float4(go[0], go[1], go[2], go[3]);
+          *reinterpret_cast<float4*>(dst + 16) = make_float4(go[4], go[5], go[6], go[7]);
+        }
+        if (nl == 0) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) slot[64 + 16 * (c >> 2) + 4 * kq + (c & 3)] += s2[c];
+        }
+      }
+    }
+    n0 = n0N; n = nN; par ^= 1;
+  }
+  // ---- this workgroup's partial rows: the waves' accumulators combined in a fixed order ---------------------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);             // [WAVES][1024] (the image is dead now)
+  {
+    float* my = red + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) my[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW[mb][nb][rr];
+  }
+  __syncthreads();
+  const float* slots = reinterpret_cast<const float*>(smem + C::OFF_SL);
+  if ((int)blockIdx.x < P32) {
+    float* dst = pb3 + (size_t)blockIdx.x * 1056;
+    for (int t = tid; t < 1056; t += C::THREADS) {
+      float a = 0.f;
+      if (t < 1024) { for (int wv_ = 0; wv_ < WAVES; ++wv_) a += red[wv_ * 1024 + t]; }
+      else { for (int wv_ = 0; wv_ < WAVES; ++wv_) a += slots[wv_ * 96 + 64 + (t - 1024)]; }       // db2
+      dst[t] = a;
+    }
+  }
+  if ((int)blockIdx.x < P1 && tid < 64) {
+    float a = 0.f;
+    for (int wv_ = 0; wv_ < WAVES; ++wv_) a += slots[wv_ * 96 + tid];                                  // dW4 | db3
+    pa4[(size_t)blockIdx.x * 64 + tid] = a;
+  }
+  // partial rows no workgroup owns (the reductions of k_wgrad run over P32 / P1 rows): zero
+  for (int row = (int)blockIdx.x + G; row < P32; row += G)
+    for (int t = tid; t < 1056; t += C::THREADS) pb3[(size_t)row * 1056 + t] = 0.f;
+  for (int row = (int)blockIdx.x + G; row < P1; row += G)
+    if (tid < 64) pa4[(size_t)row * 64 + tid] = 0.f;
+}
+
 // ---- host launcher ----------------------------------------------------------------------------------------------------
 // size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
 // workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
@@ -1000,6 +1314,44 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                             ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
   if (F <= 8) CH_LT(1, 4); else if (F <= 16) CH_LT(2, 4); else CH_LT(4, 8);
 #undef CH_LT
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+// ---- backward chain (conv4 + conv3) -------------------------------------------------------------------------------------
+#define CH_BWD_MAXN 256
+int dg_chain_bwd_max_nodes() { return CH_BWD_MAXN; }
+int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas4,
+                          const float* W4, const float* W3, const float* x3, const float* gp3, const float* x2, const float* gp2,
+                          float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s) {
+  if (N <= 0 || B <= 0 || !graph_ptr || !bits || !dinv || !gas4 || !W4 || !W3 || !x3 || !gp3 || !x2 || !gp2 || !gas2 || !pa4 || !pb3 ||
+      P1 <= 0 || P32 <= 0)
+    return DGCNN_EINVAL;
+  if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
+  using CB8 = ChB<8, CH_BWD_MAXN>;
+  using CB16 = ChB<16, CH_BWD_MAXN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_a<8, true, CH_BWD_MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize, CB8::TOTAL) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_a<16, false, CH_BWD_MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize, CB16::TOTAL) != hipSuccess)
+      return DGCNN_ELAUNCH;
+    attr_set = true;
+  }
+  static_assert(CB8::BUF >= 8 * 4096 && CB16::BUF >= 16 * 4096, "the final reduction aliases the image");
+  const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
+  const int* nbig = dmap ? dmap + DGD_NBIG + 1 : nullptr;      // graphs above 256 nodes come first in the schedule (none here: checked by the caller)
+  // every workgroup writes ONE partial row: the grid cannot exceed the rows k_wgrad reduces (P32 / P1 = node tiles of the
+  // batch, capped): batches of very small graphs (more graphs than tiles) take the looping form with fewer workgroups
+  int grid = B < 512 ? B : 512;
+  if (grid > P32) grid = P32;
+  if (grid > P1) grid = P1;
+  if (grid == B && B <= CH_ONESHOT_MAX_B) {
+    hipLaunchKernelGGL((k_chain_bwd_a<16, false, CH_BWD_MAXN>), dim3(B), dim3(1024), CB16::TOTAL, s, N, B, (const int*)nullptr, (const int*)nullptr,
+                       graph_ptr, bits, dinv, gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32);
+  } else {
+    hipLaunchKernelGGL((k_chain_bwd_a<8, true, CH_BWD_MAXN>), dim3(grid), dim3(512), CB8::TOTAL, s, N, B, sched, nbig, graph_ptr, bits, dinv,
+                       gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32);
+  }
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
