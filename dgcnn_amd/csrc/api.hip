@@ -466,8 +466,11 @@ static DgBwdForm dg_backward_form(int N, int E, int B, int F, int flags, int max
   if (flags & DGCNN_FLAG_FORCE_FUSED) return b;            // (the fused graph-per-workgroup forward never builds the bitmap)
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
   b.dense = f.dense; b.plan = f.plan;
-  b.chain = f.bitmap && !(flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) && max_nodes > 0 && max_nodes <= dg_chain_bwd_max_nodes() &&
-            (f.plan || !dg_chain_needs_schedule(B));
+  // the backward chain pays where the batch fills the chip (the dense form's regime: 2048 COLLAB graphs 62 -> 35 us for the two
+  // layers); at the reference's batch of 50 the largest graph's critical path makes it no faster than the two gather
+  // launches it replaces (10.6 vs 10.2 us) -- DGCNN_FLAG_CHAIN asks for it anyway (tests)
+  b.chain = f.bitmap && (f.dense || (flags & DGCNN_FLAG_CHAIN)) && !(flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) &&
+            max_nodes > 0 && max_nodes <= dg_chain_bwd_max_nodes() && (f.plan || !dg_chain_needs_schedule(B));
   return b;
 }
 static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float* params, const float* x,
