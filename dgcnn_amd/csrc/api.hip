@@ -514,7 +514,11 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
     DG_TRY(dg_launch_gcn_bwd1d(&G, dinv, gas4, params + pl.off[6], x3, gp3, gasA, dg_ptr<float>(ws, wl.pa4), wl.P1, s));
     DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasA, params + pl.off[4], x2, gp2, gasB, dg_ptr<float>(ws, wl.pb3), wl.P32, s));
     }
-    if (F <= DG_AF_MAX_F) {
+    if (F <= DG_AF_MAX_F && bf.chain) {
+      DG_TRY(dg_launch_chain_bwd_b(N, B, F, G.graph_ptr, G.bits, dinv, gasB, params + pl.off[2], x1, gp1, dg_cptr<float>(ws, wl.ax),
+                                   dg_ptr<float>(ws, wl.pb2), dg_ptr<float>(ws, wl.pb1), wl.P32,
+                                   bf.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s));
+    } else if (F <= DG_AF_MAX_F) {
       DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasB, params + pl.off[2], x1, gp1, gasA, dg_ptr<float>(ws, wl.pb2), wl.P32, s,
                                   dg_cptr<float>(ws, wl.ax), F, dg_ptr<float>(ws, wl.pb1)));
     } else {

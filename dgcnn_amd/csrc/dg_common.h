@@ -420,6 +420,9 @@ int dg_chain_bwd_max_nodes();
 int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas4,
                           const float* W4, const float* W3, const float* x3, const float* gp3, const float* x2, const float* gp2,
                           float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s);
+int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas2,
+                          const float* W2, const float* x1, const float* gp1, const float* ax, float* pb2, float* pb1, int P32,
+                          int32_t* dmap, hipStream_t s);
 int dg_chain_train_max_b();
 int dg_chain_train_max_nodes();
 int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,

@@ -1213,6 +1213,252 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
     if (tid < 64) pa4[(size_t)row * 64 + tid] = 0.f;
 }
 
+// =================================================================================================================
+// BACKWARD chain, second kernel: conv2's backward carrying conv1's whole weight gradient (aggregate-first conv1, F <= 32;
+// replaces the layer-2 k_gcn_bwd32*<AF>).  Input gas2 [N,32] (k_chain_bwd_a), per graph:
+//   gh2 = dinv * (Adj gas2)        block product in both orientations (as in k_chain_bwd_a)
+//   dW2 += gh2^T x1                lane = column operands, contraction over the tile's nodes
+//   gx1 = gh2 W2 + gp1             evaluated with gh2 (lane = node) as the A operand: the RESULT is lane = column, the layout
+//   ga1 = gx1 (1 - x1^2)           dW1's A operand needs -- conv1 has no further backward, so nothing is needed lane = node
+//   dW1 += ga1^T ax ; db1 += ga1   (ax = A_hat x saved by the forward)
+// Persistent registers: dW2 (16) + dW1 (8 per 16 raw features); db1 in the wave's LDS slot.
+// =================================================================================================================
+template <int WAVES, bool LOOP, int MAXN, int NBA>     // NBA = 16-column blocks of the raw features (F <= 16: 1, else 2)
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))
+k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
+              const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ gas2,
+              const float* __restrict__ W2, const float* __restrict__ x1, const float* __restrict__ gp1, const float* __restrict__ axg,
+              float* __restrict__ pb2, float* __restrict__ pb1, int P32) {
+  using C = ChB<WAVES, MAXN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  char* H = smem;
+  float* Wop = reinterpret_cast<float*>(smem + C::OFF_WT);       // B operand of gx = gh W2: [kb][s][lane] = W2[o = kappa(s, lane>>4)][16kb + (lane&15)]
+  unsigned* bl = reinterpret_cast<unsigned*>(smem + C::OFF_BL);
+  uint2* tab = reinterpret_cast<uint2*>(smem + C::OFF_TAB);
+  float* slot = reinterpret_cast<float*>(smem + C::OFF_SL) + wave * 96;
+  const int nbig = sched ? nbig_p[0] : 0, ns = B - nbig, G = (int)gridDim.x, w = (int)blockIdx.x;
+  auto entry_of = [&](int r) {
+    const int li = r * G + ((r & 1) ? G - 1 - w : w), lc = min(li, max(ns - 1, 0));
+    int2 e;
+    if (sched) e = *reinterpret_cast<const int2*>(sched + 2 * (nbig + lc));
+    else { e.x = graph_ptr[lc]; e.y = graph_ptr[lc + 1] - e.x; }
+    return make_int2(e.x, (li < ns && e.y <= MAXN) ? e.y : 0);
+  };
+  int2 eC = entry_of(0), eN = LOOP ? entry_of(1) : make_int2(0, 0);
+  unsigned pbit[C::PB]; float pdv = 0.f;
+  auto prefetch = [&](int pn0, int pn) {
+    const int pS = 1 << dgd_class(max(pn, 1));
+    const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
+    const int last = max(pn * pS - 1, 0);
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
+    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
+  };
+  int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
+  prefetch(n0, n);
+  {
+    for (int e = tid; e < 1024; e += C::THREADS) {
+      const int o = e >> 5, k = e & 31;
+      const int s_ = ((o >> 4) << 2) | (o & 3), l = (k & 15) | (((o >> 2) & 3) << 4);
+      Wop[(((k >> 4) * 8 + s_) << 6) + l] = W2[e];
+    }
+    if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
+                                        ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+    for (int e = tid; e < WAVES * 96; e += C::THREADS) reinterpret_cast<float*>(smem + C::OFF_SL)[e] = 0.f;
+  }
+  __syncthreads();
+  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
+  const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;
+  f32x4 accW[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  f32x4 accA[2][NBA];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb) accA[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int par = 0;
+  for (int r = 0; LOOP ? r * G < ns : r < 1; ++r) {
+    float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
+    const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
+    const int S = 1 << dgd_class(max(n, 1));
+    // ---- stage: bitmap rows, dinv, and the graph's gas2 rows as three bf16 parts (item = row k, 4-column slot q of 8) -------
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j)
+      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
+    if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;
+    for (int it0 = 0; it0 < RU * 8; it0 += 2 * C::THREADS) {        // two items per thread in flight
+      float4 v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int it = it0 + tid + C::THREADS * j, k = it >> 3, q = it & 7;
+        v[j] = *reinterpret_cast<const float4*>(gas2 + (size_t)(n0 + min(k, max(n - 1, 0))) * 32 + 4 * q);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int it = it0 + tid + C::THREADS * j, k = it >> 3, q = it & 7;
+        if (it < RU * 8) {
+          const bool okk = k < n;
+          const float f[4] = {okk ? v[j].x : 0.f, okk ? v[j].y : 0.f, okk ? v[j].z : 0.f, okk ? v[j].w : 0.f};
+          unsigned sp[3][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ch_split3(f[i], sp[0][i], sp[1][i], sp[2][i]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2*>(H + (p * 2 + (q >> 2)) * C::PS + k * 32 + 8 * ((q & 3) ^ ((k >> 2) & 3))) =
+                make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+        }
+      }
+    }
+    dg_lds_barrier();
+    int n0N = 0, nN = 0;
+    if (LOOP) {
+      n0N = __builtin_amdgcn_readfirstlane(eN.x); nN = __builtin_amdgcn_readfirstlane(eN.y);
+      eN = entry_of(r + 2);
+      prefetch(n0N, nN);
+    }
+    const unsigned* blr[2] = {bl + min(mrow0, max(n - 1, 0)) * S, bl + min(mrow1, max(n - 1, 0)) * S};
+    const bool rv[2] = {mrow0 < n, mrow1 < n};
+    const float dn[2] = {dv[mrow0], dv[mrow1]};
+    const bool live[2] = {wave < T, wave + WAVES < T};
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (live[ti]) {
+        const bool ok = rv[ti];
+        const int mt = 16 * (wave + WAVES * ti);
+        // operands in the lane = column layout: rows 4kq + s of columns 16nb + nl
+        float xN[2][4], gN[2][4], aN[NBA][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int mm = mt + 4 * kq + s_;
+          const bool okr = mm < n;
+          const size_t ro = (size_t)(n0 + min(mm, n - 1));
+          const float* xr = x1 + ro * 32 + nl;
+          const float* gr = gp1 + ro * 32 + nl;
+          const float x0 = xr[0], x1v = xr[16], g0 = gr[0], g1 = gr[16];
+          xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
+          gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NBA; ++nb) {
+            const int f = 16 * nb + nl;
+            const float av = axg[ro * Fa + min(f, Fa - 1)];
+            aN[nb][s_] = (okr && f < Fa) ? av : 0.f;
+          }
+        }
+        f32x4 accT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accN[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const char* hp = H + rdoff;
+#pragma unroll
+        for (int u = 0; u < C::KW; ++u) {
+          if (u < K32) {
+            const bf16x8 bop = ch_bits_operand(ok ? blr[ti][u] : 0u, kq, tab);
+            bf16x8 a[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) {
+                accT[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop, accT[nb], 0, 0, 0);
+                accN[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bop, a[p][nb], accN[nb], 0, 0, 0);
+              }
+          }
+        }
+        const float4 dq = *reinterpret_cast<const float4*>(dv + mt + 4 * kq);
+        const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+        // dW2 += gh^T x1
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              accW[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dd[s_] * accN[mb][s_], xN[nb][s_], accW[mb][nb], 0, 0, 0);
+        // gx1 (lane = column): D[node][k] = sum_o gh[node][o] W2[o][k], A = gh in the lane = node layout, B = W2 table
+        f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+          const float gv_ = dn[ti] * accT[s_ >> 2][s_ & 3];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_, Wop[(kb * 8 + s_) * 64 + lane], gx[kb], 0, 0, 0);
+        }
+        // ga1 (rows 4kq + s of column 16kb + nl), db1, dW1 += ga1^T ax
+        float gaN[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float sb = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) {
+            gaN[kb][s_] = (gx[kb][s_] + gN[kb][s_]) * (1.f - xN[kb][s_] * xN[kb][s_]);      // (rows >= n: gx = 0, gp = 0)
+            sb += gaN[kb][s_];
+          }
+          sb += __shfl_xor(sb, 16);
+          sb += __shfl_xor(sb, 32);
+          if (kq == 0) slot[16 * kb + nl] += sb;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBA; ++nb)
+              accA[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaN[mb][s_], aN[nb][s_], accA[mb][nb], 0, 0, 0);
+      }
+    }
+    dg_lds_barrier();                 // (the image is rewritten by the next graph's staging)
+    n0 = n0N; n = nN; par ^= 1;
+  }
+  // ---- partial rows ------------------------------------------------------------------------------------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);             // [WAVES][1024]
+  {
+    float* my = red + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) my[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW[mb][nb][rr];
+  }
+  __syncthreads();
+  const float* slots = reinterpret_cast<const float*>(smem + C::OFF_SL);
+  if ((int)blockIdx.x < P32) {
+    float* dst = pb2 + (size_t)blockIdx.x * 1056;
+    for (int t = tid; t < 1056; t += C::THREADS) {
+      float a = 0.f;
+      if (t < 1024) { for (int wv_ = 0; wv_ < WAVES; ++wv_) a += red[wv_ * 1024 + t]; }
+      else { for (int wv_ = 0; wv_ < WAVES; ++wv_) a += slots[wv_ * 96 + (t - 1024)]; }              // db1
+      dst[t] = a;
+    }
+  }
+  __syncthreads();
+  {
+    float* my = red + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) my[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accA[mb][nb][rr];
+  }
+  __syncthreads();
+  if ((int)blockIdx.x < P32) {
+    float* d1 = pb1 + (size_t)blockIdx.x * 32 * Fa;
+    for (int t = tid; t < 32 * Fa; t += C::THREADS) {
+      const int o = t / Fa, f = t - o * Fa;
+      float a = 0.f;
+      for (int wv_ = 0; wv_ < WAVES; ++wv_) a += red[wv_ * 1024 + o * 32 + f];
+      d1[t] = a;                                                                     // W1's own [32,Fa] layout
+    }
+  }
+  for (int row = (int)blockIdx.x + G; row < P32; row += G) {
+    for (int t = tid; t < 1056; t += C::THREADS) pb2[(size_t)row * 1056 + t] = 0.f;
+    for (int t = tid; t < 32 * Fa; t += C::THREADS) pb1[(size_t)row * 32 * Fa + t] = 0.f;
+  }
+}
+
 // ---- host launcher ----------------------------------------------------------------------------------------------------
 // size classes: graphs of <= 128 nodes (8 waves, one 16-row tile each, hs ping-pongs between two LDS images: 62 KB, two
 // workgroups per CU) and 129..512 nodes (16 waves x two tiles, one LDS image: 111 KB).  Each launch walks all B graphs
@@ -1352,6 +1598,38 @@ int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t
     hipLaunchKernelGGL((k_chain_bwd_a<8, true, CH_BWD_MAXN>), dim3(grid), dim3(512), CB8::TOTAL, s, N, B, sched, nbig, graph_ptr, bits, dinv,
                        gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32);
   }
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
+int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas2,
+                          const float* W2, const float* x1, const float* gp1, const float* ax, float* pb2, float* pb1, int P32,
+                          int32_t* dmap, hipStream_t s) {
+  if (N <= 0 || B <= 0 || Fa < 1 || Fa > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !gas2 || !W2 || !x1 || !gp1 || !ax || !pb2 ||
+      !pb1 || P32 <= 0)
+    return DGCNN_EINVAL;
+  if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
+  using CB8 = ChB<8, CH_BWD_MAXN>;
+  using CB16 = ChB<16, CH_BWD_MAXN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define CH_ATTRB(W, LP, NB, TOT) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_b<W, LP, CH_BWD_MAXN, NB>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, TOT) != hipSuccess)
+    if (CH_ATTRB(8, true, 1, CB8::TOTAL) || CH_ATTRB(8, true, 2, CB8::TOTAL) || CH_ATTRB(16, false, 1, CB16::TOTAL) ||
+        CH_ATTRB(16, false, 2, CB16::TOTAL))
+      return DGCNN_ELAUNCH;
+    attr_set = true;
+  }
+  const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
+  const int* nbig = dmap ? dmap + DGD_NBIG + 1 : nullptr;
+  int grid = B < 512 ? B : 512;
+  if (grid > P32) grid = P32;
+#define CH_LB(W, LP, NB, GRID, TOT, SCH, NBG) hipLaunchKernelGGL((k_chain_bwd_b<W, LP, CH_BWD_MAXN, NB>), dim3(GRID), dim3(64 * W), TOT, s, N, B, Fa, \
+    SCH, NBG, graph_ptr, bits, dinv, gas2, W2, x1, gp1, ax, pb2, pb1, P32)
+  const int* none = nullptr;
+  if (grid == B && B <= CH_ONESHOT_MAX_B) { if (Fa <= 16) CH_LB(16, false, 1, B, CB16::TOTAL, none, none); else CH_LB(16, false, 2, B, CB16::TOTAL, none, none); }
+  else { if (Fa <= 16) CH_LB(8, true, 1, grid, CB8::TOTAL, sched, nbig); else CH_LB(8, true, 2, grid, CB8::TOTAL, sched, nbig); }
+#undef CH_LB
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
