@@ -382,9 +382,10 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.gz5), dg_ptr<float>(ws, wl.gp1),
                                         dg_ptr<float>(ws, wl.gp2), dg_ptr<float>(ws, wl.gp3), dg_ptr<float>(ws, wl.gas4),
                                         dg_ptr<float>(ws, wl.gb4p), dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
-                                        dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
+                                        dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
+                                        wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
     g_prof_which = -1;
-    *tail_done = 1;
+    *tail_done = B <= wl.P1 ? 2 : 1;       // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too
     if (rider_a && rode) *rode = 1;
     return DGCNN_OK;
   }
@@ -477,7 +478,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                                   void* ws, const float* logp, const float* glogp, const int64_t* y,
                                   float loss_scale, int training, float* grads, float* metrics,
                                   const DgAdam* adam, hipStream_t s, const DgBwdForm& bf, const DgPrepRider* rider_b = nullptr,
-                                  bool tail_done = false) {
+                                  int tail_done = 0) {
   const bool dense = bf.dense;
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
@@ -528,7 +529,11 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
     }
   } else {
   const bool bwd1_hosts_rider = tail_done && !wg_rider && rider_b;      // (then conv4's backward launch carries prep phase B)
-  if (bf.chain && !bwd1_hosts_rider) {
+  if (tail_done == 2 && !bwd1_hosts_rider) {
+    // conv4's backward ran inside the one-launch training kernel: gas3 is in gasA, {dW4, db3} in pa4
+    DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
+                               dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+  } else if (bf.chain && !bwd1_hosts_rider) {
     const DgDense G = dg_dense_view(ws, wl, N, B);
     DG_TRY(dg_launch_chain_bwd_a(N, B, G.graph_ptr, G.bits, dinv, gas4, params + pl.off[6], params + pl.off[4], x3, gp3, x2, gp2,
                                  gasB, dg_ptr<float>(ws, wl.pa4), wl.P1, dg_ptr<float>(ws, wl.pb3), wl.P32,
@@ -670,7 +675,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
                                 dg_backward_form(cur->N, cur->E, cur->B, cur->F, flags, cur->max_nodes), rode ? rider : nullptr,
-                                tail_done != 0));
+                                tail_done));
   if (next && rode && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
     DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
                               reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));

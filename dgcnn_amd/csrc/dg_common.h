@@ -430,8 +430,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* x3, float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d,
                                  uint8_t* drop_mask, float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale,
                                  float* dlogit, float* gz1, float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4,
-                                 float* gb4p, float* lossv, float* ptail, int32_t* err, uint32_t epoch, hipStream_t s,
-                                 const struct DgPrepRider* rider = nullptr,
+                                 float* gb4p, float* lossv, float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1,
+                                 hipStream_t s, const struct DgPrepRider* rider = nullptr,
                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,

@@ -81,6 +81,8 @@ __device__ __forceinline__ bf16x8 ch_bits_operand(unsigned w, int kg, const uint
   return b;
 }
 
+__device__ __forceinline__ float ch_row16_sum(float v);
+
 template <int WAVES, int TPW, bool PING>
 __global__ void __launch_bounds__(64 * WAVES)
 k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits, const float* __restrict__ dinv,
@@ -858,9 +860,99 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 // chains on the same 1024 threads; the x1..x4 rows the chain just wrote are read back by the workgroup that wrote them.
 // Rider range (blocks >= B): phase A of the next batch's graph preparation, as on k_readout_tail.
 // =================================================================================================================
+// conv4's backward (+ the start of conv3's) for ONE graph of <= 256 nodes on 16 waves, one tile per wave -- the first half of
+// k_chain_bwd_a, appended to the one-launch training kernel of small batches (the separate k_gcn_bwd1 launch, 4.9 us at the
+// dispatch floor, goes away): gh4 = dinv (Adj gas4), gas3 = dinv (gh4 W4 + gp3)(1 - x3^2) -> global, {dW4, db3} -> this
+// graph's row of pa4.  `bl` (bitmap rows, stride S), `dv` (dinv) and `tab` are the chain forward's LDS images of this graph;
+// g4p [3][ROWS] bf16, g4t [16 waves][16] and slots [16 waves][64] are scratch.
+__device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned* bl, const float* dv, const uint2* tab,
+                                                   unsigned short* g4p, int ROWS, float* g4t_all, float* slots_all,
+                                                   const float* __restrict__ gas4, const float* __restrict__ W4,
+                                                   const float* __restrict__ x3, const float* __restrict__ gp3,
+                                                   float* __restrict__ gas3, float* __restrict__ pa4row) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
+  const int S = 1 << dgd_class(max(n, 1));
+  float* g4t = g4t_all + wave * 16;
+  float* slot = slots_all + wave * 64;
+  if (tid < RU) {
+    unsigned q0, q1, q2;
+    ch_split3(tid < n ? gas4[n0 + tid] : 0.f, q0, q1, q2);
+    g4p[tid] = (unsigned short)q0; g4p[ROWS + tid] = (unsigned short)q1; g4p[2 * ROWS + tid] = (unsigned short)q2;
+  }
+  if (lane < 64 && tid < 1024) slot[lane] = 0.f;
+  const int m = 16 * wave + nl;
+  const bool live = wave < T, ok = m < n;
+  float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa, ga_ = xa, gb_ = xa, w4a = xa, w4b = xa;
+  if (live) {       // operands of the epilogue, requested before the barrier
+    const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
+    xa = *reinterpret_cast<const float4*>(x3 + ro); xb = *reinterpret_cast<const float4*>(x3 + ro + 16);
+    ga_ = *reinterpret_cast<const float4*>(gp3 + ro); gb_ = *reinterpret_cast<const float4*>(gp3 + ro + 16);
+    w4a = *reinterpret_cast<const float4*>(W4 + 4 * kq); w4b = *reinterpret_cast<const float4*>(W4 + 16 + 4 * kq);
+  }
+  dg_lds_barrier();
+  if (live) {
+    const unsigned* blr = bl + min(m, n - 1) * S;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned short* hq = g4p + min(nl, 2) * ROWS + 4 * kq;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < K32) {
+        uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
+        if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+        bf16x8 bop;
+        unsigned* bu = reinterpret_cast<unsigned*>(&bop);
+        bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(ok ? blr[u] : 0u, kq, tab), bop, a4, 0, 0, 0);
+      }
+    }
+    float tot[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) tot[rr] = (a4[rr] + __shfl_xor(a4[rr], 1)) + __shfl_xor(a4[rr], 2);
+    if (nl == 0) {
+      const float4 dq = *reinterpret_cast<const float4*>(dv + 16 * wave + 4 * kq);
+      *reinterpret_cast<float4*>(g4t + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
+    }
+    const float gh = g4t[nl];
+    const float dn = dv[m];
+    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    const float gv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
+    const float wv[8] = {w4a.x, w4a.y, w4a.z, w4a.w, w4b.x, w4b.y, w4b.z, w4b.w};
+    float go[8], s4[8], s3[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float ga = ok ? fmaf(gh, wv[c], gv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+      go[c] = dn * ga;
+      s4[c] = ch_row16_sum(ok ? gh * xv[c] : 0.f);
+      s3[c] = ch_row16_sum(ga);
+    }
+    if (ok) {
+      float* dst = gas3 + (size_t)(n0 + m) * 32 + 4 * kq;
+      *reinterpret_cast<float4*>(dst) = make_float4(go[0], go[1], go[2], go[3]);
+      *reinterpret_cast<float4*>(dst + 16) = make_float4(go[4], go[5], go[6], go[7]);
+    }
+    if (nl == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = 16 * (c >> 2) + 4 * kq + (c & 3);
+        slot[col] = s4[c]; slot[32 + col] = s3[c];
+      }
+    }
+  }
+  dg_lds_barrier();
+  if (tid < 64) {
+    float a = 0.f;
+    for (int wv_ = 0; wv_ < 16; ++wv_) a += slots_all[wv_ * 64 + tid];          // fixed order (dead waves left zeros)
+    pa4row[tid] = a;
+  }
+}
+
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
 struct ChTail {
   unsigned int* err; unsigned int epoch;
+  const float* W4; float* gas3; float* pa4; int P1;      // conv4's backward rides along when pa4 != null (P1 >= B rows)
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
   const int64_t* y; float loss_scale; float *dlogit, *gz1g, *gz6g, *gz5g, *gp1, *gp2, *gp3, *gas4, *gb4p, *lossv, *ptail;
 };
@@ -897,6 +989,18 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   dg_tail_bwd_body<false, true>(B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
                                 t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
                                 t.pooled, dbg, ext);
+  if (t.pa4) {
+    __syncthreads();      // (vmcnt(0): this graph's gas4 and gp3 rows are written; the readout's LDS plan is dead)
+    using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
+    const int b = blockIdx.x;
+    const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
+    ch_conv4_bwd_graph(n0, n, reinterpret_cast<const unsigned*>(smem + C::OFF_BL), reinterpret_cast<const float*>(smem + C::OFF_DV),
+                       reinterpret_cast<const uint2*>(smem + C::OFF_TAB), reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
+                       reinterpret_cast<float*>(smem + 65536), reinterpret_cast<float*>(smem + 65536 + 1024), t.gas4, t.W4, x3, t.gp3,
+                       t.gas3, t.pa4 + (size_t)b * 64);
+    for (int row = b + B; row < t.P1; row += B)       // rows of pa4 no graph owns
+      if (threadIdx.x < 64) t.pa4[(size_t)row * 64 + threadIdx.x] = 0.f;
+  }
 }
 
 // =================================================================================================================
@@ -1533,8 +1637,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask,
                                  float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit, float* gz1,
                                  float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
-                                 float* ptail, int32_t* err, uint32_t epoch, hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start,
-                                 hipEvent_t ev_stop) {
+                                 float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1, hipStream_t s,
+                                 const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || !y)
     return DGCNN_EINVAL;
@@ -1543,6 +1647,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   ChTail t;
   t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
+  t.W4 = gw.W4; t.gas3 = gas3; t.pa4 = (pa4 && gas3 && P1 >= B) ? pa4 : nullptr; t.P1 = P1;
   t.C = C; t.w = dg_tail_w(params, pl); t.pooled = pooled; t.perm = perm; t.a5g = a5; t.a6g = a6; t.a1dg = a1d; t.maskg = drop_mask;
   t.logp = logp; t.training = training; t.seed = seed; t.y = y; t.loss_scale = loss_scale; t.dlogit = dlogit; t.gz1g = gz1;
   t.gz6g = gz6; t.gz5g = gz5; t.gp1 = gp1; t.gp2 = gp2; t.gp3 = gp3; t.gas4 = gas4; t.gb4p = gb4p; t.lossv = lossv; t.ptail = ptail;

@@ -307,8 +307,11 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     m3.train(); m3._seed_base, m3._fwd_count = 11, 0
     tr3 = Trainer(m3)
     tr3.train_step(b, b.y)
-    assert torch.equal(tr3.grads, gradB)
-    assert torch.equal(m3.flat_params, m2.flat_params)   # same Adam arithmetic, element for element
+    # (the one-launch training kernel evaluates conv4's backward as a block product on the matrix cores, the per-op route
+    #  as a CSR gather: the same sums in a different order -- equal within fp32 rounding, not bit for bit)
+    ga, gb = tr3.grads.double(), gradB.double()
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-9
+    np.testing.assert_allclose(m3.flat_params.cpu().numpy(), m2.flat_params.cpu().numpy(), rtol=1e-4, atol=2e-6)
     # and the loss agrees with the oracle on the kernel's own mask/perm
     mask = m2.last_workspace_view("drop_mask").cpu(); perm = m2.last_workspace_view("perm").cpu()
     _, loss_ref, _, _ = ref_dense.loss_and_grads_dense(sd, b_cpu.x, b_cpu.edge_index, b_cpu.batch, b_cpu.y,
