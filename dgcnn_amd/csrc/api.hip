@@ -228,8 +228,9 @@ static bool dg_use_dense(int N, int E, int B, int flags, int max_nodes) {
 // a node bound <= 512) and a raw feature width that admits the aggregate-first conv1; independent of the form the
 // BACKWARD takes (dense per-layer kernels for large batches, CSR gather for small ones: dg_use_dense).
 static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
-  if (flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16 | DGCNN_FLAG_AGG_SPARSE | DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED))
+  if (flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_AGG_SPARSE | DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED))
     return false;      // (each of these names another kernel family)
+  if ((flags & DGCNN_FLAG_BF16) && max_nodes > dg_chain_small_rows(B)) return false;      // (no bf16 form of the size-class kernel)
   if (F > DG_AF_MAX_F) return false;
   if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || E <= 0) return false;
   if (max_nodes <= 0 || max_nodes > DGD_MAXN) return false;
@@ -242,8 +243,11 @@ static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
 struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
 static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   DgForm f;
-  f.dense = dg_use_dense(N, E, B, flags, max_nodes);
   f.chain = dg_use_chain(N, E, B, F, flags, max_nodes);
+  // the bf16 leg changes the FORWARD's arithmetic only (hs in bf16, X.W on the bf16 matrix cores): with the chain forward
+  // taking it, the backward -- fp32 in either case -- follows the fp32 rule; without, the leg exists in the dense per-layer
+  // form only (dg_use_dense says yes whenever that form is admissible)
+  f.dense = dg_use_dense(N, E, B, (f.chain ? flags & ~DGCNN_FLAG_BF16 : flags), max_nodes);
   f.bitmap = f.dense || f.chain;
   f.plan = f.dense || (f.chain && dg_chain_needs_schedule(B));      // item table + graph schedule (one workgroup of phase B)
   f.edge_check = (f.bitmap && !f.dense) ? 1 : 0;       // chain forward over a gather backward: phase B keeps the per-edge check
@@ -265,7 +269,7 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
-  const bool chain_tail = f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+  const bool chain_tail = f.chain && !(flags & DGCNN_FLAG_BF16) && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
                           max_nodes <= dg_chain_train_max_nodes();
   return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0);
 }
@@ -331,7 +335,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   const bool chain = !fused && !fused_d && fm.chain;
   const bool bitmap = dense || chain;
   const int bf16 = (flags & DGCNN_FLAG_BF16) ? 1 : 0;
-  if (bf16 && !dense) return DGCNN_EUNSUPPORTED;          // the bf16 leg runs in the dense block form only
+  if (bf16 && !dense && !chain) return DGCNN_EUNSUPPORTED;          // the bf16 leg runs in the chain / dense block forms only
   const DgDense G = dg_dense_view(ws, wl, N, B);
   const bool af = F <= DG_AF_MAX_F;    // conv1 aggregate-first: prep leaves xs = dinv*x in hsA, no linear at all
   DgLinFirst lf; lf.x = x; lf.W = af ? nullptr : params + pl.off[0]; lf.hs = hsA; lf.F = F;
@@ -371,7 +375,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  if (chain && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+  if (chain && !bf16 && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
       max_nodes <= dg_chain_train_max_nodes()) {
     // small training batch: chain forward + readout forward + readout backward of every graph in ONE launch
     DG_TRY(dg_launch_chain_readout_tail(N, B, F, C, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
@@ -391,7 +395,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   if (chain) {
     DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
-                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, s,
+                               dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, bf16, s,
                                g_prof_which >= 0 ? g_prof_a : nullptr,
                                g_prof_which >= 0 ? g_prof_b : nullptr));
     g_prof_which = -1;
@@ -470,7 +474,7 @@ static DgBwdForm dg_backward_form(int N, int E, int B, int F, int flags, int max
   // the backward chain pays where the batch fills the chip (the dense form's regime: 2048 COLLAB graphs 62 -> 35 us for the two
   // layers); at the reference's batch of 50 the largest graph's critical path makes it no faster than the two gather
   // launches it replaces (10.6 vs 10.2 us) -- DGCNN_FLAG_CHAIN asks for it anyway (tests)
-  b.chain = f.bitmap && (f.dense || (flags & DGCNN_FLAG_CHAIN)) && !(flags & (DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16)) &&
+  b.chain = f.bitmap && (f.dense || (flags & DGCNN_FLAG_CHAIN)) && !(flags & DGCNN_FLAG_NO_CHAIN) &&
             max_nodes > 0 && max_nodes <= dg_chain_bwd_max_nodes() && (f.plan || !dg_chain_needs_schedule(B));
   return b;
 }

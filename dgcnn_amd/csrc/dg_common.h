@@ -435,7 +435,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
-                        float* x3, float* x4, int32_t* dmap, hipStream_t s, hipEvent_t ev_start = nullptr,
+                        float* x3, float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
 // graph-per-workgroup fused forward in the dense block form (gcn_dense.hip): conv1..conv4 + readout, one launch
 struct DgParams;

@@ -439,7 +439,16 @@ struct ChQ {
 
 // WAVES = 4: graphs of <= 128 nodes, four workgroups per CU; WAVES = 8: <= 256 nodes (one LDS image of 48 KB), two per CU
 // XI: xs items (row, 4-column slot) per thread; W1S: k-steps of conv1's weight table (4: F <= 16, 8: F <= 32)
-template <int WAVES, int XI, int W1S, bool LOOP, int MAXN = 32 * WAVES>      // LOOP = false: exactly one graph per workgroup (grid = B), nothing is prefetched
+// BF (the bf16 leg, BASELINE config 3): the pre-scaled linear outputs hs_2, hs_3 are kept as ONE bf16 part (round to nearest
+// even: what "hs stored in bf16" means when hs never leaves the CU) and X.W^T runs on v_mfma_f32_16x16x32_bf16 with both
+// operands rounded to bf16 -- one matrix instruction per 16 output columns instead of eight fp32 ones; conv1's raw
+// features, its own linear step, the 32 -> 1 step and every sum stay fp32.
+__device__ __forceinline__ unsigned ch_f2bf(float f) {      // round to nearest even (finite inputs)
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+template <int WAVES, int XI, int W1S, bool LOOP, int MAXN = 32 * WAVES, bool BF = false>      // LOOP = false: exactly one graph per workgroup (grid = B), nothing is prefetched
 __device__ __forceinline__ void
 ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
               const unsigned* __restrict__ bits,
@@ -517,7 +526,14 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #pragma unroll
     for (int j = 0; j < C::WJ; ++j) {
       const int e = tid + C::THREADS * j;
+      if (BF) {     // bf16 A operands of X.W^T: [ob][lane][8]: W[16 ob + (lane & 15)][k], k = 4kq + j (j < 4), 16 + 4kq + j - 4
+        const int o = e >> 5, k = e & 31;
+        const int d = ((((o >> 4) << 6) + (o & 15) + (((k >> 2) & 3) << 4)) << 3) + (k & 3) + ((k >> 4) << 2);
+        reinterpret_cast<unsigned short*>(W2op)[d] = (unsigned short)ch_f2bf(w2[j]);
+        reinterpret_cast<unsigned short*>(W3op)[d] = (unsigned short)ch_f2bf(w3[j]);
+      } else {
       W2op[slot_of(e >> 5, e & 31, 8)] = w2[j]; W3op[slot_of(e >> 5, e & 31, 8)] = w3[j];
+      }
       if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F, W1S)] = w1[j]; }
     }
     if (tid < 128) bt[tid] = bv;
@@ -600,8 +616,8 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 
     // block products of this wave's tiles with the image: every HS^T operand read once, used by both tiles; the reads of
     // word u+1 are issued before the matrix instructions of word u
-    auto product = [&](auto nbc, const char* Hc, f32x4 (&acc)[2][2]) {
-      constexpr int NBP = decltype(nbc)::value;
+    auto product = [&](auto nbc, auto pc, const char* Hc, f32x4 (&acc)[2][2]) {
+      constexpr int NBP = decltype(nbc)::value, NP = decltype(pc)::value;       // planes, bf16 parts of the image
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) { acc[ti][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       const char* hp = Hc + rdoff;
@@ -610,18 +626,18 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
         if (u < K32) {
           const bf16x8 bop0 = ch_bits_operand(rv0 ? bl0[u] : 0u, kq, tab);
           const bf16x8 bop1 = ch_bits_operand(rv1 ? bl1[u] : 0u, kq, tab);
-          bf16x8 a[3][NBP];
+          bf16x8 a[NP][NBP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int nb = 0; nb < NBP; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * C::PS + u * 1024);
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int nb = 0; nb < NBP; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop0, acc[0][nb], 0, 0, 0);
           if (live1) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
               for (int nb = 0; nb < NBP; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop1, acc[1][nb], 0, 0, 0);
           }
@@ -640,6 +656,27 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
           *reinterpret_cast<float4*>(dst) = make_float4(v[ti][0][0], v[ti][0][1], v[ti][0][2], v[ti][0][3]);
           *reinterpret_cast<float4*>(dst + 16) = make_float4(v[ti][1][0], v[ti][1][1], v[ti][1][2], v[ti][1][3]);
         }
+      if (BF) {      // bf16 leg: ONE matrix instruction per 16 output columns, both operands rounded to bf16
+        const uint4* wb = reinterpret_cast<const uint4*>(Wop);
+        bf16x8 wa[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) { const uint4 q = wb[ob * 64 + lane]; wa[ob] = __builtin_bit_cast(bf16x8, q); }
+#pragma unroll
+        for (int ti = T0; ti < NT; ++ti) {
+          uint4 xq;
+          xq.x = ch_f2bf(v[ti][0][0]) | (ch_f2bf(v[ti][0][1]) << 16); xq.y = ch_f2bf(v[ti][0][2]) | (ch_f2bf(v[ti][0][3]) << 16);
+          xq.z = ch_f2bf(v[ti][1][0]) | (ch_f2bf(v[ti][1][1]) << 16); xq.w = ch_f2bf(v[ti][1][2]) | (ch_f2bf(v[ti][1][3]) << 16);
+          const bf16x8 xb = __builtin_bit_cast(bf16x8, xq);
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ob], xb, d, 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) hs[ti][ob][rr] = dn[ti] * d[rr];
+          }
+        }
+        return;
+      }
       float wv[2][8];
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
@@ -672,6 +709,13 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
           for (int rr = 0; rr < 4; ++rr) hs[ti][ob][rr] = dn[ti] * (NH == 2 ? d2[ti][ob][0][rr] + d2[ti][ob][NH - 1][rr] : d2[ti][ob][0][rr]);
     };
     auto write_hs = [&](char* Hn, int ti, const f32x4 (&hs)[2]) {
+      if (BF) {      // one bf16 part, round to nearest even
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+          *reinterpret_cast<uint2*>(Hn + ob * C::PS + mrow[ti] * 32 + wsl) =
+              make_uint2(ch_f2bf(hs[ob][0]) | (ch_f2bf(hs[ob][1]) << 16), ch_f2bf(hs[ob][2]) | (ch_f2bf(hs[ob][3]) << 16));
+        return;
+      }
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob) {
         unsigned sp[3][4];
@@ -698,7 +742,8 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     // ---- conv1 (aggregate-first): ax = dn (Adj xs) saved, x1 = tanh(ax W1^T + b1), hs2 = dn (x1 W2^T) ----------------------
     if (live0) {
       f32x4 acc[2][2];
-      if (NBF == 2) product(I2{}, H, acc); else product(I1{}, H, acc);
+      using I3 = std::integral_constant<int, 3>;
+      if (NBF == 2) product(I2{}, I3{}, H, acc); else product(I1{}, I3{}, H, acc);
       auto conv1_tail = [&](auto ntc, auto t0c) {
         constexpr int T0 = decltype(t0c)::value, NT = T0 + decltype(ntc)::value;
         const float4 b0 = bias4(0, 0), b1v = bias4(0, 1);
@@ -748,7 +793,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     // ---- conv2 -----------------------------------------------------------------------------------------------------------
     if (live0) {
       f32x4 acc[2][2], v[2][2];
-      product(I2{}, H + pong, acc);
+      product(I2{}, std::integral_constant<int, BF ? 1 : 3>{}, H + pong, acc);
       using I0 = std::integral_constant<int, 0>;
       if (CH_LOCKSTEP && live1) { act32(I2{}, I0{}, 1, acc, v); rows_and_linear(I2{}, I0{}, v, x2, W3op, hsv); }
       else {
@@ -766,7 +811,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     if (live0) {
       const float4 w0 = bias4(3, 0), w1 = bias4(3, 1);
       f32x4 acc[2][2], v[2][2];
-      product(I2{}, H, acc);
+      product(I2{}, std::integral_constant<int, BF ? 1 : 3>{}, H, acc);
       auto conv3_tail = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;
         act32(ntc, std::integral_constant<int, 0>{}, 2, acc, v);
@@ -845,13 +890,13 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #endif
 }
 
-template <int WAVES, int XI, int W1S, bool LOOP>
+template <int WAVES, int XI, int W1S, bool LOOP, bool BF = false>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 registers
 k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
               const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw,
               float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
               unsigned long long* __restrict__ dbg) {
-  ch_chain_body<WAVES, XI, W1S, LOOP>(N, B, F, sched, nbig_p, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, dbg);
+  ch_chain_body<WAVES, XI, W1S, LOOP, 32 * WAVES, BF>(N, B, F, sched, nbig_p, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, dbg);
 }
 
 // =================================================================================================================
@@ -1586,7 +1631,7 @@ int dg_chain_needs_schedule(int B) { return B > CH_GRID_Q ? 1 : 0; }
 
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const DgParams* pl, float* ax, float* x1, float* x2, float* x3,
-                        float* x4, int32_t* dmap, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   // dmap == null: no schedule was built (dg_chain_needs_schedule(B) == 0): one graph per workgroup straight from graph_ptr
   if (N <= 0 || B <= 0 || F < 1 || F > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !xs) return DGCNN_EINVAL;
   if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
@@ -1596,7 +1641,9 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   using CL = ChCfg<16, 2, false>;
   static bool attr_set = false;
   if (!attr_set) {
-#define CH_ATTR(W, XI, WS, LP) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP>), \
+#define CH_ATTR(W, XI, WS, LP) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP, false>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess || \
+                                hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP, true>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess)
     if (CH_ATTR(CH_QW, 1, 4, true) || CH_ATTR(CH_QW, 2, 4, true) || CH_ATTR(CH_QW, 4, 8, true) ||
         CH_ATTR(16, 1, 4, false) || CH_ATTR(16, 2, 4, false) || CH_ATTR(16, 4, 8, false) ||
@@ -1608,8 +1655,9 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
   const int* nbig = dmap ? dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0) : nullptr;      // graphs above the size class = first entry of the class
   // XI = xs items per thread: rows x 4-column slots with data / threads = 2^lg / 2 (at least 1)
-#define CH_LQ(W, XI, WS, LP, GRID, SCH) hipExtLaunchKernelGGL((k_chain_fwd_q<W, XI, WS, LP>), dim3(GRID), dim3(64 * W), ChQ<W, WS>::TOTAL, s, \
+#define CH_LQ1(W, XI, WS, LP, BFV, GRID, SCH) hipExtLaunchKernelGGL((k_chain_fwd_q<W, XI, WS, LP, BFV>), dim3(GRID), dim3(64 * W), ChQ<W, WS>::TOTAL, s, \
     ev_start, ev_stop, 0, N, B, F, SCH, nbig, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, dg_debug_buffer())
+#define CH_LQ(W, XI, WS, LP, GRID, SCH) do { if (bf16) CH_LQ1(W, XI, WS, LP, true, GRID, SCH); else CH_LQ1(W, XI, WS, LP, false, GRID, SCH); } while (0)
   if (B <= CH_ONESHOT_MAX_B) {           // one 16-wave workgroup per graph, straight from graph_ptr (graphs of <= 512 nodes)
     const int* none = nullptr;
     if (F <= 8) CH_LQ(16, 1, 4, false, B, none); else if (F <= 16) CH_LQ(16, 2, 4, false, B, none); else CH_LQ(16, 4, 8, false, B, none);
@@ -1619,7 +1667,9 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   const int grid = B < CH_GRID_Q ? B : CH_GRID_Q;
   if (F <= 8) CH_LQ(CH_QW, 1, 4, true, grid, sched); else if (F <= 16) CH_LQ(CH_QW, 2, 4, true, grid, sched); else CH_LQ(CH_QW, 4, 8, true, grid, sched);
 #undef CH_LQ
+#undef CH_LQ1
   DG_CHECK_LAUNCH();
+  if (bf16 && (max_nodes <= 0 || max_nodes > CH_SMALL_ROWS)) return DGCNN_EUNSUPPORTED;      // (the size-class kernel has no bf16 form)
   if (max_nodes <= 0 || max_nodes > CH_SMALL_ROWS) {
     hipLaunchKernelGGL((k_chain_fwd<16, 2, false>), dim3(B), dim3(CL::THREADS), CL::TOTAL, s, N, F, graph_ptr, bits, dinv, xs, gw,
                        ax, x1, x2, x3, x4, CH_SMALL_ROWS, sched, nbig);
