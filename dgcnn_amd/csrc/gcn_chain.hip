@@ -552,17 +552,22 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     unsigned short* h4p = reinterpret_cast<unsigned short*>(smem + C::OFF_H4) + par * 3 * C::ROWS;
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
+    // (a per-iteration copy of the thread index the compiler cannot see through: otherwise every address piece of the staging
+    //  below is loop-invariant, gets hoisted out of the graph walk and SPILLED -- and each reload is a scratch load followed by
+    //  s_waitcnt vmcnt(0), which also waits for the next graph's prefetch: 7 of them made conv4's 3 MFMAs take 5.7 k cycles)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
     // graphs of <= ROWS/2 nodes keep TWO images, rows [0, ROWS/2) and [ROWS/2, ROWS) of every plane, and alternate between
     // them: a layer's output image is not the one still being read, so the barrier in front of its stores is not needed
     const int pong = (2 * n <= C::ROWS) ? (C::ROWS / 2) * 32 : 0;
     // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
-      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
-    if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;
+      if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
+    if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-      const int it = tid + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
+      const int it = tl + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
       if (k < n) {
         unsigned sp[3][4];
 #pragma unroll
@@ -576,7 +581,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     }
     {   // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
       const int sh = NBF + 1;                              // 4 * NBF slots per row
-      for (int it = tid; it < (RU << sh); it += C::THREADS) {
+      for (int it = tl; it < (RU << sh); it += C::THREADS) {
         const int k = it >> sh, qq = it & ((1 << sh) - 1);
         if (!(k < n && qq < (1 << lg))) {
           const int nb = qq >> 2, sl = qq & 3;
@@ -587,13 +592,13 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
       }
     }
     if (RU > 16 * T) {   // rows 16T .. RU-1 (sixteen) of the planes conv1 does not use, and of h4s: written by no tile
-      if (tid < 192) {
-        const int piece = tid & 1, row = 16 * T + ((tid >> 1) & 15), pp = tid >> 5;
+      if (tl < 192) {
+        const int piece = tl & 1, row = 16 * T + ((tl >> 1) & 15), pp = tl >> 5;
         if ((pp & 1) >= NBF) *reinterpret_cast<uint4*>(H + pp * C::PS + row * 32 + 16 * piece) = make_uint4(0u, 0u, 0u, 0u);
       }
-      if (tid < 48) h4p[(tid >> 4) * C::ROWS + 16 * T + (tid & 15)] = 0;
-      if (pong && tid < 192)
-        *reinterpret_cast<uint4*>(H + pong + (tid >> 5) * C::PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
+      if (tl < 48) h4p[(tl >> 4) * C::ROWS + 16 * T + (tl & 15)] = 0;
+      if (pong && tl < 192)
+        *reinterpret_cast<uint4*>(H + pong + (tl >> 5) * C::PS + (16 * T + ((tl >> 1) & 15)) * 32 + 16 * (tl & 1)) = make_uint4(0u, 0u, 0u, 0u);
     }
     CH_T(1);                                              // 1: wait for the prefetched data + staging stores
     dg_lds_barrier();
@@ -868,9 +873,11 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) { s1[ti][rr] = __shfl_xor(a4[ti][rr], 1); s2[ti][rr] = __shfl_xor(a4[ti][rr], 2); }
       if (nl == 0) {
+        int kqv = kq;
+        asm volatile("" : "+v"(kqv));        // (see the staging: nothing below may be hoisted out of the graph walk)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-          const int mm = 16 * (wave + WAVES * ti) + 4 * kq;
+          const int mm = 16 * (wave + WAVES * ti) + 4 * kqv;
           const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
           const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
@@ -1154,20 +1161,22 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
     unsigned short* g4p = reinterpret_cast<unsigned short*>(smem + C::OFF_G4) + par * 3 * C::ROWS;
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
+    int tl = tid;
+    asm volatile("" : "+v"(tl));      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
     // ---- stage: bitmap rows, dinv, gas4 as three bf16 parts (zeros up to RU) ------------------------------------------------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
-      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
-    if (tid < C::ROWS) {
-      dv[tid] = tid < n ? pdv : 0.f;
-      if (tid < RU) {
+      if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
+    if (tl < C::ROWS) {
+      dv[tl] = tl < n ? pdv : 0.f;
+      if (tl < RU) {
         unsigned q0, q1, q2;
-        ch_split3(tid < n ? pg4 : 0.f, q0, q1, q2);
-        g4p[tid] = (unsigned short)q0; g4p[C::ROWS + tid] = (unsigned short)q1; g4p[2 * C::ROWS + tid] = (unsigned short)q2;
+        ch_split3(tl < n ? pg4 : 0.f, q0, q1, q2);
+        g4p[tl] = (unsigned short)q0; g4p[C::ROWS + tl] = (unsigned short)q1; g4p[2 * C::ROWS + tl] = (unsigned short)q2;
       }
     }
-    if (RU > 16 * T && tid < 192)      // rows 16T .. RU-1 of the gas3 image: written by no tile
-      *reinterpret_cast<uint4*>(H + (tid >> 5) * C::PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
+    if (RU > 16 * T && tl < 192)      // rows 16T .. RU-1 of the gas3 image: written by no tile
+      *reinterpret_cast<uint4*>(H + (tl >> 5) * C::PS + (16 * T + ((tl >> 1) & 15)) * 32 + 16 * (tl & 1)) = make_uint4(0u, 0u, 0u, 0u);
     dg_lds_barrier();
     int n0N = 0, nN = 0;
     if (LOOP) {
@@ -1432,21 +1441,23 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
     float* dv = reinterpret_cast<float*>(smem + C::OFF_DV) + par * C::ROWS;
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
+    int tl = tid;
+    asm volatile("" : "+v"(tl));      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
     // ---- stage: bitmap rows, dinv, and the graph's gas2 rows as three bf16 parts (item = row k, 4-column slot q of 8) -------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
-      if (tid + C::THREADS * j < n * S) bl[tid + C::THREADS * j] = pbit[j];
-    if (tid < C::ROWS) dv[tid] = tid < n ? pdv : 0.f;
+      if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
+    if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
     for (int it0 = 0; it0 < RU * 8; it0 += 2 * C::THREADS) {        // two items per thread in flight
       float4 v[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int it = it0 + tid + C::THREADS * j, k = it >> 3, q = it & 7;
+        const int it = it0 + tl + C::THREADS * j, k = it >> 3, q = it & 7;
         v[j] = *reinterpret_cast<const float4*>(gas2 + (size_t)(n0 + min(k, max(n - 1, 0))) * 32 + 4 * q);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int it = it0 + tid + C::THREADS * j, k = it >> 3, q = it & 7;
+        const int it = it0 + tl + C::THREADS * j, k = it >> 3, q = it & 7;
         if (it < RU * 8) {
           const bool okk = k < n;
           const float f[4] = {okk ? v[j].x : 0.f, okk ? v[j].y : 0.f, okk ? v[j].z : 0.f, okk ? v[j].w : 0.f};
