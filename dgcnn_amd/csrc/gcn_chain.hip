@@ -565,6 +565,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     for (int j = 0; j < C::PB; ++j)
       if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
     if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
+    CH_T(14);
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
       const int it = tl + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
@@ -579,6 +580,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
               make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
       }
     }
+    CH_T(15);
     {   // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
       const int sh = NBF + 1;                              // 4 * NBF slots per row
       for (int it = tl; it < (RU << sh); it += C::THREADS) {

@@ -219,3 +219,30 @@ def test_host_side_of_the_library_under_address_sanitizer():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_host_check.py"), lib], capture_output=True, text=True,
                        env=env, timeout=300)
     assert "ASAN_HOST_OK" in r.stdout and "AddressSanitizer" not in r.stderr, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
+    """dgcnn_forward_form (which kernel families a batch takes): no GPU involved.  The reference's batch of 50 COLLAB-shaped
+    graphs takes the one-launch chain + readout training kernel over a gather backward; 2048 graphs the persistent chain
+    forward over the dense/chain backward; every opt-out flag and every missing precondition falls back."""
+    L = built_lib
+    CU, DENSE, CHAIN, SPARSE, NOCHAIN, BF16, TILED = (_lib.FLAG_COALESCED_UNDIRECTED, _lib.FLAG_AGG_DENSE, _lib.FLAG_CHAIN,
+                                                      _lib.FLAG_AGG_SPARSE, _lib.FLAG_NO_CHAIN, _lib.FLAG_BF16, _lib.FLAG_FORCE_TILED)
+    f = L.dgcnn_forward_form
+    N50, E50 = 3800, 140000
+    assert f(N50, E50, 50, 1, CU, 180) == 2 | 4                    # chain forward + one-launch training kernel
+    assert f(N50, E50, 50, 1, CU, 300) == 0                        # a graph above 256 nodes in a small batch: gather kernels
+    assert f(N50, E50, 50, 1, CU | CHAIN, 300) == 2                # ... unless asked for (no one-launch kernel above 256 nodes)
+    assert f(N50, E50, 50, 1, 0, 180) == 0                         # no coalesced + undirected promise: no bitmap
+    assert f(N50, E50, 50, 1, CU, 0) == 0                          # no node bound
+    assert f(N50, E50, 50, 90, CU, 180) == 0                       # F > 32: linear-first conv1, per-layer kernels
+    assert f(N50, E50, 50, 1, CU | NOCHAIN, 180) == 0
+    assert f(N50, E50, 50, 1, CU | SPARSE, 180) == 0
+    assert f(N50, E50, 50, 1, CU | TILED, 180) == 0
+    assert f(N50, E50, 50, 1, CU | DENSE, 180) == 1 | 2            # dense backward forced: chain forward, separate readout launches
+    assert f(N50, E50, 50, 1, CU | BF16, 180) == 2                 # bf16 leg: chain forward (bf16 image), fp32 backward rule
+    N2k, E2k = 153000, 5700000
+    assert f(N2k, E2k, 2048, 1, CU, 250) == 1 | 2
+    assert f(N2k, E2k, 2048, 1, CU, 600) == 0                      # above the dense bound of 512 nodes
+    assert f(N2k, E2k, 2048, 1, CU | NOCHAIN, 250) == 1
+    assert f(0, 0, 1, 1, 0, 0) < 0 and f(10, 10, 1, 0, 0, 0) < 0   # bad sizes: error code

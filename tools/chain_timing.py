@@ -32,6 +32,8 @@ ng = d[:, 11].sum()
 for k, n in enumerate(names):
     print(f"  {n:20s} per WG {d[:,k].mean():9.0f}  per graph {d[:,k].sum()/ng:8.0f}  share {100*d[:,k].sum()/tot.sum():5.1f} %")
 
+for k, n in ((14, "  stage: bitmap+dv"), (15, "  stage: x split")):
+    print(f"  {n:20s} per WG {d[:,k].mean():9.0f}  per graph {d[:,k].sum()/ng:8.0f}")
 if d[:, 12].max() > 0:
     t0 = d[:, 12].min()
     st, en = (d[:, 12] - t0) / 100.0, (d[:, 13] - t0) / 100.0      # 100 MHz constant clock -> us
