@@ -445,11 +445,22 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
     if (rider_a && rode) *rode = 1;
     return DGCNN_OK;
   }
-  // SortPooling + the whole dense tail: one launch, one workgroup per graph
+  // SortPooling + the whole dense tail: one launch, one workgroup per graph -- up to conv6's output when the batch is large
+  // enough for classifier_1 / classifier_2 to run as GEMMs over graphs (classifier.hip: with their backward when this is a
+  // training step with labels; *tail_done = 4 then tells the backward that gz6 already holds conv6's output gradient)
+  const bool batched_head = dg_classifier_batched(B);
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
                                dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
-                               dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s, rider_a));
+                               dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s, rider_a, !batched_head));
+  if (batched_head) {
+    const bool with_bwd = tt && tail_done;
+    DG_TRY(dg_launch_classifier(B, C, params, &pl, dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
+                                dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, with_bwd ? tt->y : nullptr,
+                                with_bwd ? tt->loss_scale : 0.f, dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1),
+                                dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail), s));
+    if (with_bwd) *tail_done = 4;
+  }
   if (rider_a && rode) *rode = 1;
   return DGCNN_OK;
 }
@@ -484,6 +495,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                                   const DgAdam* adam, hipStream_t s, const DgBwdForm& bf, const DgPrepRider* rider_b = nullptr,
                                   int tail_done = 0) {
   const bool dense = bf.dense;
+  const bool head_done = (tail_done & 4) != 0;      // the batched classifier ran its backward inside the forward half of the step
+  tail_done &= 3;
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -505,7 +518,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.dlogit), dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6),
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
-                            dg_cptr<float>(ws, wl.pooled), s, rider_b));
+                            dg_cptr<float>(ws, wl.pooled), s, rider_b, !head_done));
   if (dense) {
     // dense block form (the forward of this batch took it: the bitmap is in the workspace); F > 32 keeps the gather
     // kernel for conv1's own backward (its operand is the raw [N,F] input)

@@ -1,0 +1,285 @@
+// classifier.hip -- classifier_1 / classifier_2 (reference model.py:21-23, 41-45: Linear(352,128) + ReLU + Dropout(0.5),
+// Linear(128,C), log_softmax) and their backward for LARGE batches, 16 graphs per workgroup.
+//
+// Why a second form: the readout kernels (tail.hip) give every graph its own workgroup -- right at the reference's batch
+// of 50, where a step is one latency chain per graph.  With thousands of graphs per launch every one of those workgroups
+// streams classifier_1's 180 KB through its CU's vector-memory path, forward and again backward: 2048 graphs x 360 KB =
+// 0.74 GB of L2 -> CU traffic for 0.37 GFLOP, 5.9 k + 5.6 k of the ~20 k cycles a graph spends in each readout kernel
+// (phase clocks, 2048 COLLAB graphs).  Across graphs the two layers are plain GEMMs, [B,352].[352,128] and back
+// [B,128].[128,352]: here a workgroup takes 16 graphs, reads the weights ONCE for all of them (2 x 180 KB per 16 graphs)
+// and runs both products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, M = the 16 graphs).  The readout kernels
+// then stop at conv6's output (k_readout_fwd<BIG, HEAD = false>) and start at its gradient (k_tail_bwd<BIG, HEAD = false>).
+//
+// Same arithmetic as the per-graph form up to fp32 summation order (a dot product's terms are added in matrix-core order);
+// the dropout mask is the same function of (seed, graph, unit), the loss / accuracy bookkeeping and classifier_2's
+// per-graph weight-gradient partials have the same layout -- k_wgrad does not know which form ran.
+#include "dg_common.h"
+#include "dg_readout.h"
+
+#define CL_GB 16                       // graphs per workgroup (the M of the matrix instruction)
+#define CL_THREADS 512                 // 8 waves: one 16-unit column tile of classifier_1 each
+#define CL_FS (DGCNN_FLAT + 4)         // row strides of the LDS tiles: 16-byte reads of 16 rows fall on distinct banks
+#define CL_HS (DGCNN_HID1 + 4)
+
+// MODE 0: forward only (inference, and training steps whose backward starts from an upstream gradient);
+// MODE 1: forward + backward from labels (NLL mean, train.py:40-45).
+template <int MODE>
+__global__ void __launch_bounds__(CL_THREADS)
+k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __restrict__ a1dg, uint8_t* __restrict__ maskg,
+             float* __restrict__ logp, int training, uint64_t seed, const int64_t* __restrict__ y, float loss_scale,
+             float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g, float* __restrict__ lossv,
+             float* __restrict__ ptail, unsigned long long* dbg) {
+#define CL_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + (k)] = clock64(); } while (0)      // (slots 0..15 belong to the readout kernels)
+  CL_MARK(0);
+  if (dbg && threadIdx.x == 0) atomicMin(&dbg[41], wall_clock64());
+  __shared__ __attribute__((aligned(16))) float fl[CL_GB * CL_FS];       // conv6 outputs of the 16 graphs (ReLU mask of the way back)
+  __shared__ __attribute__((aligned(16))) float a1s[CL_GB * CL_HS];      // classifier_1 outputs after ReLU / dropout
+  __shared__ __attribute__((aligned(16))) float gz1s[CL_GB * CL_HS];     // gradient wrt classifier_1's pre-activation
+  __shared__ float lg[CL_GB * DGCNN_MAX_C];                              // logits, then log-probabilities
+  __shared__ float dl[CL_GB * DGCNN_MAX_C];                              // gradient wrt the logits
+  // every small operand is brought into LDS by the kernel's first loads: a workgroup is ONE latency chain (128 workgroups on
+  // 128 CUs at 2048 graphs, nothing else on the CU to hide a round trip), and with a cold global load in front of every
+  // phase the first version spent 25 us here -- a dozen dependent round trips -- for 3 us of matrix instructions
+  __shared__ float w2s[DGCNN_MAX_C * DGCNN_HID1];                        // classifier_2's weights
+  __shared__ float b1s[DGCNN_HID1], b2s[DGCNN_MAX_C];
+  __shared__ int ys[CL_GB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, kq = lane >> 4;
+  const int b0 = blockIdx.x * CL_GB, nb = min(CL_GB, B - b0);
+  // (workgroups walk the shared weights from different starting tiles: all of them asking one L2 channel for the same
+  //  line at the same moment is the slow way to read 180 KB)
+  // (consecutive workgroups land on different XCDs, each with its own L2: the ones that share an L2 are blockIdx.x >> 3 apart)
+  const int xr = (int)blockIdx.x >> 3;
+  const int ut = (wv + xr) & 7;                                          // this wave's 16-unit tile of classifier_1
+
+  // classifier_1's rows of this wave's 16 units: requested first (22 x 16 bytes per lane, the forward's whole share of the
+  // 180 KB), they land while the graphs' rows are staged.  Lane (unit nl, kq) holds columns 16j + 4kq .. + 3 of its row:
+  // element s of the four is the k-slot of matrix step 4j + s -- the A operand below is read with the same assignment
+  float4 wq[22];
+  {
+    const float* wr = w.Wf1 + (size_t)(16 * ut + nl) * DGCNN_FLAT + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) wq[j] = *reinterpret_cast<const float4*>(wr + 16 * j);
+#if defined(CL_EXP) && CL_EXP == 1
+#pragma unroll
+    for (int j = 0; j < 22; ++j) wq[j] = make_float4(0.01f * j, 0.02f, 0.03f, 0.04f * kq);
+#endif
+  }
+  {   // EVERY load of the set-up is in flight before the first LDS store: a load followed by its own LDS store is a round
+      // trip of its own (loads complete in order), and the first version paid four of them in a row here
+    constexpr int NQ = CL_GB * (DGCNN_FLAT / 4), NI = (NQ + CL_THREADS - 1) / CL_THREADS;
+    constexpr int NW2 = DGCNN_MAX_C * DGCNN_HID1 / CL_THREADS;
+    float w2r[NW2];
+#pragma unroll
+    for (int i = 0; i < NW2; ++i) w2r[i] = (tid + CL_THREADS * i < C * DGCNN_HID1) ? w.Wf2[tid + CL_THREADS * i] : 0.f;
+    float smallv = 0.f;
+    int yv = 0;
+    if (tid < DGCNN_HID1) smallv = w.bf1[tid];
+    else if (tid < DGCNN_HID1 + C) smallv = w.bf2[tid - DGCNN_HID1];
+    else if (MODE == 1 && tid >= 256 && tid < 256 + nb) yv = (int)y[b0 + tid - 256];
+    float4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {      // the 16 graphs' conv6 outputs
+      const int t = tid + CL_THREADS * i, g = t / (DGCNN_FLAT / 4), q = t - g * (DGCNN_FLAT / 4);
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if defined(CL_EXP) && CL_EXP == 2
+      if (t < NQ && g < nb) v[i] = make_float4(0.1f * g, 0.2f, 0.3f * q, 0.4f);
+#else
+      if (t < NQ && g < nb) v[i] = *reinterpret_cast<const float4*>(a6g + (size_t)(b0 + g) * DGCNN_FLAT + 4 * q);
+#endif
+    }
+#pragma unroll
+    for (int i = 0; i < NW2; ++i) if (tid + CL_THREADS * i < C * DGCNN_HID1) w2s[tid + CL_THREADS * i] = w2r[i];
+    if (tid < DGCNN_HID1) b1s[tid] = smallv;
+    else if (tid < DGCNN_HID1 + C) b2s[tid - DGCNN_HID1] = smallv;
+    else if (MODE == 1 && tid >= 256 && tid < 256 + CL_GB) ys[tid - 256] = yv;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = tid + CL_THREADS * i, g = t / (DGCNN_FLAT / 4), q = t - g * (DGCNN_FLAT / 4);
+      if (t < NQ) *reinterpret_cast<float4*>(fl + g * CL_FS + 4 * q) = v[i];
+    }
+  }
+  __syncthreads();
+  CL_MARK(1);
+  // ---- classifier_1: z[g][u] = sum_k flat[g][k] W1[u][k]; ReLU; Dropout(0.5) -------------------------------------------
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = fl + nl * CL_FS + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(ar + 16 * j);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wq[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wq[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wq[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wq[j].w, acc, 0, 0, 0);
+    }
+    const int u = 16 * ut + nl;                      // this lane: unit u of graphs 4kq .. 4kq + 3
+    const float bu = b1s[u];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int g = 4 * kq + r;
+      float av = fmaxf(acc[r] + bu, 0.f);
+      uint8_t keep = 1;
+      if (training) {
+        keep = dg_keep(seed, (uint64_t)(b0 + g) * DGCNN_HID1 + u) ? 1 : 0;
+        av = keep ? av * 2.0f : 0.f;                 // p = 0.5 -> scale 1/(1-p) = 2
+      }
+      a1s[g * CL_HS + u] = av;
+      if (g < nb) { a1dg[(size_t)(b0 + g) * DGCNN_HID1 + u] = av; maskg[(size_t)(b0 + g) * DGCNN_HID1 + u] = keep; }
+    }
+  }
+  // the way back through classifier_1 reads the same 180 KB by columns: this wave's (up to three) column tiles are requested
+  // NOW, into the registers the forward's rows just left, and land while classifier_2 / log_softmax / their backward run.
+  // Lane (m = nl, kq) of tile t holds W1[16i + 4kq + s][16t + nl], the k-slot of matrix step 4i + s (64-byte row segments)
+  float bw[3][MODE == 1 ? 32 : 1];
+  int bt[3];
+  if (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int tt = wv + 8 * q;
+      bt[q] = tt < 22 ? (tt + 3 * xr) % 22 : -1;
+      const float* wc = w.Wf1 + (size_t)(4 * kq) * DGCNN_FLAT + 16 * max(bt[q], 0) + nl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bw[q][4 * i + s] = wc[(size_t)(16 * i + s) * DGCNN_FLAT];
+    }
+  }
+  CL_MARK(2);
+  dg_lds_barrier();
+  CL_MARK(3);
+  // ---- classifier_2: 128 -> C, eight lanes per (graph, class), fixed xor butterfly ---------------------------------------
+  {
+    const int p8 = tid & 7;
+    for (int o = tid >> 3; o < CL_GB * C; o += CL_THREADS / 8) {
+      const int g = o / C, c = o - g * C;
+      const float* wr = w2s + c * DGCNN_HID1 + p8;
+      const float* ar = a1s + g * CL_HS + p8;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) { s0 = fmaf(wr[8 * i], ar[8 * i], s0); s1 = fmaf(wr[8 * i + 8], ar[8 * i + 8], s1); }
+      float tot = s0 + s1;
+      tot += __shfl_xor(tot, 1);
+      tot += __shfl_xor(tot, 2);
+      tot += __shfl_xor(tot, 4);
+      if (p8 == 0) lg[g * DGCNN_MAX_C + c] = tot + b2s[c];
+    }
+  }
+  dg_lds_barrier();
+  CL_MARK(4);
+  // ---- log_softmax over C, loss / accuracy bookkeeping, d(loss)/d(logits): a graph per half wave (C <= 32: one round for
+  //      the 16 graphs) or per wave (two rounds) ------------------------------------------------------------------------
+  {
+    const bool halves = C <= 32;
+    const int hb = halves ? (lane & 32) : 0, cl = lane - hb;            // first lane of this graph's lanes, class of this lane
+    for (int g = halves ? 2 * wv + (lane >> 5) : wv; g < CL_GB; g += CL_THREADS / 64) {
+      const float v = cl < C ? lg[g * DGCNN_MAX_C + cl] : -INFINITY;
+      float mx = v;
+      for (int o = halves ? 16 : 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = cl < C ? expf(v - mx) : 0.f;
+      for (int o = halves ? 16 : 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+      const float lp = cl < C ? (v - mx) - logf(e) : -INFINITY;
+      if (g < nb && cl < C) logp[(size_t)(b0 + g) * C + cl] = lp;
+      if (MODE == 1) {
+        const int b = b0 + g;
+        const float sc = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;
+        const int yraw = ys[g];
+        // a label outside [0, C) (the reference's NLLLoss raises for it): clamped for memory safety, the graph's loss is NaN
+        // and sticks in the metrics accumulator until Trainer.read_metrics raises
+        const bool ybad = (unsigned)yraw >= (unsigned)C;
+        const int yb = ybad ? 0 : yraw;
+        float m2 = lp;
+        for (int o = halves ? 16 : 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
+        unsigned long long ball = __ballot(cl < C && lp == m2);
+        if (halves) ball = (ball >> hb) & 0xffffffffull;
+        const int am = __ffsll((long long)ball) - 1;       // first max index, like torch.argmax (train.py:44)
+        const float lpy = __shfl(lp, hb + yb);
+        if (g < nb && cl == 0) { lossv[2 * b] = ybad ? __builtin_nanf("") : -lpy * sc; lossv[2 * b + 1] = (am == yb) ? 1.f : 0.f; }
+        // d(loss)/d(logit c) = g_c - softmax_c * sum(g), the upstream gradient g being -sc at the label
+        const float gl = (cl == yb) ? -sc : 0.f;
+        const float d = (cl < C && g < nb) ? gl + expf(lp) * sc : 0.f;
+        if (cl < C) {
+          dl[g * DGCNN_MAX_C + cl] = d;
+          if (g < nb) dlogit[(size_t)b * C + cl] = d;
+        }
+        if (halves) break;
+      } else if (halves) break;
+    }
+  }
+  if (MODE == 0) return;
+  dg_lds_barrier();
+  CL_MARK(5);
+  // ---- back through classifier_2, dropout, ReLU: gz1[g][j]; per-graph partials of classifier_2's weight gradient --------
+  {
+    const int j = tid & (DGCNN_HID1 - 1), g0 = tid >> 7;                 // 4 graphs per pass, 4 passes, all in flight
+    float ga[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      const float wc = w2s[c * DGCNN_HID1 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ga[i] = fmaf(dl[(g0 + 4 * i) * DGCNN_MAX_C + c], wc, ga[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = g0 + 4 * i;
+      const float a = a1s[g * CL_HS + j];
+      const float gz = (a != 0.f) ? (training ? ga[i] * 2.0f : ga[i]) : 0.f;
+      gz1s[g * CL_HS + j] = gz;
+      if (g < nb) gz1g[(size_t)(b0 + g) * DGCNN_HID1 + j] = gz;
+    }
+  }
+  for (int t = tid; t < C * DGCNN_HID1 + C; t += CL_THREADS) {           // element t of every graph's partial: 16 stores in flight
+    const bool wpart = t < C * DGCNN_HID1;
+    const int c = wpart ? t >> 7 : t - C * DGCNN_HID1, j = t & (DGCNN_HID1 - 1);
+    float* pt = ptail + (size_t)b0 * DG_PTAIL(C) + DG_PT_WF2 + t;
+#pragma unroll
+    for (int g = 0; g < CL_GB; ++g)
+      if (g < nb) pt[(size_t)g * DG_PTAIL(C)] = wpart ? dl[g * DGCNN_MAX_C + c] * a1s[g * CL_HS + j] : dl[g * DGCNN_MAX_C + c];
+  }
+  dg_lds_barrier();
+  CL_MARK(6);
+  // ---- back through classifier_1: gflat[g][m] = sum_j gz1[g][j] W1[j][m], and the ReLU after conv6 ----------------------
+  {
+    float4 az[8];
+    const float* ar = gz1s + nl * CL_HS + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) az[i] = *reinterpret_cast<const float4*>(ar + 16 * i);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (bt[q] >= 0) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].x, bw[q][4 * i + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].y, bw[q][4 * i + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].z, bw[q][4 * i + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].w, bw[q][4 * i + 3], acc, 0, 0, 0);
+        }
+        const int m = 16 * bt[q] + nl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int g = 4 * kq + r;
+          if (g < nb) gz6g[(size_t)(b0 + g) * DGCNN_FLAT + m] = fl[g * CL_FS + m] > 0.f ? acc[r] : 0.f;
+        }
+      }
+    }
+  }
+  CL_MARK(7);
+  if (dbg && threadIdx.x == 0) { atomicMax(&dbg[40], wall_clock64()); if (blockIdx.x == 0) dbg[42] = wall_clock64(); }
+#undef CL_MARK
+}
+
+// graphs per launch from which the readout pair splits the classifier off (tail.hip's two-workgroups-per-CU forms start at
+// the same size)
+int dg_launch_classifier(int B, int C, const float* params, const DgParams* pl, const float* a6, float* a1d, uint8_t* drop_mask,
+                         float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit,
+                         float* gz1, float* gz6, float* lossv, float* ptail, hipStream_t s) {
+  if (B <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  const int grid = (B + CL_GB - 1) / CL_GB;
+  if (y)
+    hipLaunchKernelGGL(k_classifier<1>, dim3(grid), dim3(CL_THREADS), 0, s, B, C, dg_tail_w(params, pl), a6, a1d, drop_mask, logp,
+                       training, seed, y, loss_scale, dlogit, gz1, gz6, lossv, ptail, dg_debug_buffer());
+  else
+    hipLaunchKernelGGL(k_classifier<0>, dim3(grid), dim3(CL_THREADS), 0, s, B, C, dg_tail_w(params, pl), a6, a1d, drop_mask, logp,
+                       training, seed, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, dg_debug_buffer());
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}

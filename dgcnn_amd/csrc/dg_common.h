@@ -498,7 +498,12 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
-                          int training, uint64_t seed, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+                          int training, uint64_t seed, hipStream_t s, const struct DgPrepRider* rider = nullptr, bool head = true);
+// classifier_1 / classifier_2 batched over graphs (classifier.hip); y != nullptr: with the backward from labels
+int dg_launch_classifier(int B, int C, const float* params, const DgParams* pl, const float* a6, float* a1d, uint8_t* drop_mask,
+                         float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit,
+                         float* gz1, float* gz6, float* lossv, float* ptail, hipStream_t s);
+bool dg_classifier_batched(int B);
 int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const float* params, const DgParams* pl,
                         const float* x, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const int32_t* graph_ptr, const int32_t* graph_eptr, float* ax, float* x1, float* x2, float* x3,
@@ -515,7 +520,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
-                       const float* pooled, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+                       const float* pooled, hipStream_t s, const struct DgPrepRider* rider = nullptr, bool head = true);
 struct DgAdam {          // optional optimizer step fused into the weight-gradient kernel
   float *params, *exp_avg, *exp_avg_sq;
   float lr, beta1, beta2, eps;

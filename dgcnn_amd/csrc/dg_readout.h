@@ -189,7 +189,9 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
 // over the sort or over conv5/conv6 -- the conv weights are loaded after the sort and classifier_1's rows at their
 // use (every weight is L2-resident when thousands of workgroups read the same 209 KB; the early prefetch only bought
 // 7 spilled registers = 58 MB of scratch traffic per launch at 2048 graphs).  Same arithmetic order: bit-identical.
-template <bool BIG = false>
+// HEAD = false (large batches): stops at conv6's output; classifier_1/2 and log_softmax run batched over graphs
+// (classifier.hip) instead of once per graph.
+template <bool BIG = false, bool HEAD = true>
 __device__ __forceinline__ void dg_readout_fwd_body(
     const RdSmem& M, int b, int n0, int n, int C, const TailW& w, const float* keys, int key_n0,
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ x3,
@@ -324,6 +326,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
       a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
     }
   }
+  if (!HEAD) return;
   dg_lds_barrier();
   RD_MARK(11);
   // classifier_1: 352 -> 128, ReLU, Dropout(0.5).  16 waves x 8 rows; the weights were prefetched before conv5;

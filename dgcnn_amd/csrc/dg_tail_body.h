@@ -15,9 +15,11 @@
 // body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
 // training kernel k_readout_tail (forward readout + this, one launch)
 struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb; };      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
-template <bool BIG, bool MERGED = false>
+// HEAD = false (large batches): classifier_2 / classifier_1's backward ran batched over graphs (classifier.hip) and left
+// the gradient of conv6's output in gz6g -- steps 1-3 are skipped.
+template <bool BIG, bool MERGED = false, bool HEAD = true>
 __device__ __forceinline__ void dg_tail_bwd_body(
-    int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+    int b, int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
     const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
     const float* __restrict__ a6g, const float* __restrict__ a1dg, const float* __restrict__ logp,
     const float* __restrict__ glogp, const int64_t* __restrict__ y, float loss_scale, int training,
@@ -47,7 +49,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   __shared__ float ga4s[DGCNN_K];
   __shared__ int selS[DGCNN_K];
   __shared__ float x4S[DGCNN_K], dvS[DGCNN_K];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
@@ -55,10 +57,10 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   DgStage<NW5, RD_THREADS> st5;
   DgStage<NW6, RD_THREADS> st6;
   DgStage<KCAT, RD_THREADS> stp;
-  if (!MERGED) { st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)blockIdx.x * KCAT, tid); }
+  if (!MERGED) { st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)b * KCAT, tid); }
   float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
   int yb_ = 0;
-  if (wv == 0) {
+  if (HEAD && wv == 0) {
     if (MERGED) lp_ = lane < C ? ext.lg[lane] : -INFINITY;
     else lp_ = lane < C ? logp[(size_t)b * C + lane] : -INFINITY;
     if (glogp) g_ = lane < C ? glogp[(size_t)b * C + lane] : 0.f;
@@ -66,7 +68,8 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   }
   // operands of the later steps that live in global memory: loaded NOW (their round trips overlap steps 1-2)
   float a6_ = 0.f, a5a_ = 0.f, a5b_ = 0.f;
-  if (tid < DGCNN_FLAT) a6_ = MERGED ? ext.flat[tid] : a6g[(size_t)b * DGCNN_FLAT + tid];          // step 3: ReLU mask of conv6
+  if (tid < DGCNN_FLAT)                                                                // step 3: ReLU mask of conv6
+    a6_ = !HEAD ? gz6g[(size_t)b * DGCNN_FLAT + tid] : MERGED ? ext.flat[tid] : a6g[(size_t)b * DGCNN_FLAT + tid];      // (HEAD = false: the finished gradient)
   if (tid < DGCNN_C5 * DGCNN_T5) {                                                     // step 5: MaxPool argmax
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
@@ -81,7 +84,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
 #pragma unroll
   for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
-  if (tid < DGCNN_HID1) {
+  if (HEAD && tid < DGCNN_HID1) {
     a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
 #pragma unroll
     for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
@@ -92,7 +95,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // 704 threads = 8 row groups (16 rows each) x 88 column quads: 16 x 16-byte loads per thread (one quarter of the
   // vector-memory instructions a dword-per-lane mapping needs for the same 180 KB)
   float4 wpre[BIG ? 1 : 16];
-  if (!BIG && tid < 2 * DGCNN_FLAT) {
+  if (HEAD && !BIG && tid < 2 * DGCNN_FLAT) {
     const int rg = tid / 88, mq = tid - rg * 88;
     const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
 #pragma unroll
@@ -106,6 +109,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
   if (tid < DGCNN_K) ga4s[tid] = 0.f;
 
+  if (HEAD) {
   // 1. d(loss)/d(logits) from the upstream gradient wrt log-probs (or from labels: NLL mean)
   if (wv == 0) {
     const float lp = lp_;
@@ -129,12 +133,13 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     const float d = lane < C ? g - expf(lp) * sg : 0.f;
     if (lane < C) { dl[lane] = d; dlogit[(size_t)b * C + lane] = d; }
   }
+  }
   dg_lds_barrier();
   TB_MARK(1);
   float x4n_ = 0.f, dvn_ = 0.f;             // conv4 output / dst scale of the selected nodes (wave 1; used in step 6)
   if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
   // 2. through classifier_2, dropout, ReLU
-  if (tid < DGCNN_HID1) {
+  if (HEAD && tid < DGCNN_HID1) {
     float ga = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) if (c < C) ga = fmaf(dl[c], wf2_[c], ga);
@@ -145,18 +150,20 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     a1ds[tid] = a;
     gz1g[(size_t)b * DGCNN_HID1 + tid] = gz;
   }
-  dg_lds_barrier();
+  if (HEAD) dg_lds_barrier();
   // per-graph partial of classifier_2's weight gradient: dl[c] * a1d[j]  (and bias = dl[c])
   float* pt = ptail + (size_t)b * DG_PTAIL(C);
-  for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
-    const int c = t / DGCNN_HID1, j = t - c * DGCNN_HID1;
-    pt[DG_PT_WF2 + t] = dl[c] * a1ds[j];
+  if (HEAD) {
+    for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
+      const int c = t / DGCNN_HID1, j = t - c * DGCNN_HID1;
+      pt[DG_PT_WF2 + t] = dl[c] * a1ds[j];
+    }
+    if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
   }
-  if (tid < C) pt[DG_PT_WF2 + C * DGCNN_HID1 + tid] = dl[tid];
   TB_MARK(2);
   // 3. through classifier_1: 352 outputs x 128 terms, split in two halves of 64 terms (704 threads); the
   //    weights were prefetched into registers at kernel start
-  if (tid < 2 * DGCNN_FLAT) {
+  if (HEAD && tid < 2 * DGCNN_FLAT) {
     const int rg = tid / 88, mq = tid - rg * 88;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (BIG) {
@@ -183,14 +190,15 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     }
     *reinterpret_cast<float4*>(&gfh[rg][4 * mq]) = g;
   }
-  __syncthreads();
-  if (tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
+  if (HEAD) __syncthreads();
+  if (HEAD && tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
     const float gf = ((gfh[0][tid] + gfh[1][tid]) + (gfh[2][tid] + gfh[3][tid])) +
                      ((gfh[4][tid] + gfh[5][tid]) + (gfh[6][tid] + gfh[7][tid]));
     const float g6 = a6_ > 0.f ? gf : 0.f;
     gz6s[tid] = g6;
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
+  if (!HEAD && tid < DGCNN_FLAT) gz6s[tid] = a6_;
   __syncthreads();
   TB_MARK(3);
   // 4. conv6 data gradient on the matrix cores: gp5[c][u] = sum_{oc,d} W6[oc][c][d] gz6[oc][u-d]

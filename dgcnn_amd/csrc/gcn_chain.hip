@@ -1040,7 +1040,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                         t.training, t.seed, dbg);
   }
   __syncthreads();
-  dg_tail_bwd_body<false, true>(B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
+  dg_tail_bwd_body<false, true>((int)blockIdx.x, B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
                                 t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
                                 t.pooled, dbg, ext);
   if (t.pa4) {

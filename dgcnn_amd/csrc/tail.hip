@@ -86,16 +86,31 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 // LDS plan (bytes): region A 32 KiB = sort keys, afterwards reused for the pooled rows (11640),
 // conv5 weights (6208) and conv6 weights (10240); small activations after it.
 // ---------------------------------------------------------------------------------------------
+// Which blocks of a launch are the RIDER (the next batch's graph preparation, dg_prep.h) and which are graph workgroups.
+// Small batches: graphs first, rider blocks behind them (they fill the CUs the graphs leave idle).  Large batches (BIG):
+// INTERLEAVED at the ratio nblk : B -- the rider is an HBM stream (16 bytes of int64 edge_index per edge: 160 MB at 2048
+// COLLAB graphs, ~30 us at full bandwidth) and the graph workgroups are latency chains that use almost none; dispatched one
+// behind the other they cost the sum (2048 graphs: 30 us of graph workgroups, then 30 us of rider blocks, in each of the
+// two readout launches), dispatched mixed they share the machine.  Results do not depend on the mapping.
+struct DgRole { bool rider; int idx; };
+__device__ __forceinline__ DgRole dg_block_role(int i, int B, int nblk, bool interleave) {
+  if (!interleave || nblk <= 0) return DgRole{i >= B, i >= B ? i - B : i};
+  const long long T = (long long)B + nblk;
+  const int r0 = (int)(((long long)i * nblk) / T), r1 = (int)(((long long)(i + 1) * nblk) / T);      // riders among blocks [0, i), [0, i]
+  return DgRole{r1 > r0, r1 > r0 ? r0 : i - r0};
+}
+
 // BIG (many graphs): registers capped at 64 so that two workgroups share a CU and hide each other's latency chain
-template <bool BIG>
+template <bool BIG, bool HEAD = true>
 __global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
 k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __restrict__ x1,
               const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
               float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g, float* __restrict__ a6g,
               float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
               uint64_t seed, unsigned long long* dbg, int B, DgPrepRider rd) {
-  if ((int)blockIdx.x >= B) {    // rider range: phase A of the NEXT batch's graph preparation (dg_prep.h)
-    dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
+  const DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk, false);
+  if (role.rider) {    // rider blocks: phase A of the NEXT batch's graph preparation (dg_prep.h)
+    dg_prep_fast_a_body(role.idx * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
                         rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
     return;
   }
@@ -103,21 +118,30 @@ k_readout_fwd(int C, TailW w, const int* __restrict__ graph_ptr, const float* __
   __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
   __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];
   const RdSmem M = dg_rd_carve(region0, small);
-  const int b = blockIdx.x;
+  const int b = role.idx;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
-  dg_readout_fwd_body<BIG>(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
-                           training, seed, dbg);
+#ifdef RD_TIMING      // measurement builds: wall-clock start / end of every workgroup (tools/wg_spans.py)
+  if (dbg && threadIdx.x == 0) dbg[1024 + 4 * b] = wall_clock64();
+#endif
+  dg_readout_fwd_body<BIG, HEAD>(M, b, n0, n, C, w, x4, n0, x1, x2, x3, x4, pooled, perm, a5g, a6g, a1dg, maskg, logp,
+                                 training, seed, dbg);
+#ifdef RD_TIMING
+  if (dbg && threadIdx.x == 0) dbg[1024 + 4 * b + 1] = wall_clock64();
+#endif
 }
 
 int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                           const float* x1, const float* x2, const float* x3, const float* x4, float* pooled,
                           int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp,
-                          int training, uint64_t seed, hipStream_t s, const DgPrepRider* rider) {
+                          int training, uint64_t seed, hipStream_t s, const DgPrepRider* rider, bool head) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static const bool nobig = dg_knob("DG_NO_BIG_READOUT");      // A/B switch (DG_DEBUG_KNOBS builds only)
-  if (B >= DG_TAIL_BIG_MIN_B && !nobig)
+  if (!head)       // conv6's output only: the classifier runs batched over graphs (classifier.hip)
+    hipLaunchKernelGGL((k_readout_fwd<true, false>), dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
+                       x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
+  else if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_readout_fwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr,
                        x1, x2, x3, x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dg_debug_buffer(), B, rd);
   else
@@ -129,7 +153,7 @@ int dg_launch_readout_fwd(int N, int B, int C, const float* params, const DgPara
 
 #include "dg_tail_body.h"
 
-template <bool BIG>
+template <bool BIG, bool HEAD = true>
 __global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 8 : 4)))
 k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
            const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
@@ -139,16 +163,24 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
            float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
-  if ((int)blockIdx.x >= B) {    // rider range: phase B of the NEXT batch's graph preparation (phase A rode on the
-                                 // readout launch of this step's forward, complete by now)
-    dg_prep_fast_b_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
+  const DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk, false);
+  if (role.rider) {    // rider blocks: phase B of the NEXT batch's graph preparation (phase A rode on the
+                       // readout launch of this step's forward, complete by now)
+    dg_prep_fast_b_body(role.idx * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
                         rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
                         rd.dmap, rd.edge_check != 0);
-    if (rd.dmap && (int)blockIdx.x == B) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
+    if (rd.dmap && role.idx == 0) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
     return;
   }
-  dg_tail_bwd_body<BIG>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, glogp, y, loss_scale, training, dlogit, gz1g,
-                        gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+#ifdef RD_TIMING
+  if (dbg && threadIdx.x == 0) dbg[1024 + 4 * role.idx + 2] = wall_clock64();
+#endif
+  dg_tail_bwd_body<BIG, false, HEAD>(role.idx, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, glogp, y, loss_scale, training,
+                                     dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+#ifdef RD_TIMING
+  __syncthreads();
+  if (dbg && threadIdx.x == 0) dbg[1024 + 4 * role.idx + 3] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -191,7 +223,7 @@ k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* _
                         dbg);
   }
   __syncthreads();        // (full barrier, vmcnt(0): this graph's activations / perm are written)
-  dg_tail_bwd_body<false, true>(B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training,
+  dg_tail_bwd_body<false, true>((int)blockIdx.x, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training,
                                 dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg, ext);
 }
 
@@ -211,19 +243,28 @@ int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgPar
   return DGCNN_OK;
 }
 int dg_readout_tail_max_b() { return DG_TAIL_BIG_MIN_B - 1; }
+// batches from which classifier_1 / classifier_2 leave the per-graph readout kernels for the batched form (classifier.hip)
+bool dg_classifier_batched(int B) {
+  static const bool off = dg_knob("DG_NO_BATCHED_CLASSIFIER");      // A/B switch (DG_DEBUG_KNOBS builds only)
+  return B >= DG_TAIL_BIG_MIN_B && !off;
+}
 
 int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                        const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
-                       const float* pooled, hipStream_t s, const DgPrepRider* rider) {
+                       const float* pooled, hipStream_t s, const DgPrepRider* rider, bool head) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static const bool nobig = dg_knob("DG_NO_BIG_TAIL");      // A/B switch (DG_DEBUG_KNOBS builds only)
-  if (B >= DG_TAIL_BIG_MIN_B && !nobig)
+  if (!head)       // the classifier's backward ran batched over graphs: gz6 holds the gradient of conv6's output
+    hipLaunchKernelGGL((k_tail_bwd<true, false>), dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+                       perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+  else if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
                        gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
