@@ -674,6 +674,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
       rd.edge_check = nf.edge_check;
     }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
+    rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);
     rider = &rd;
   }
   int rode = 0, tail_done = 0;

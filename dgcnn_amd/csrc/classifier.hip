@@ -20,6 +20,7 @@
 #define CL_THREADS 512                 // 8 waves: one 16-unit column tile of classifier_1 each
 #define CL_FS (DGCNN_FLAT + 4)         // row strides of the LDS tiles: 16-byte reads of 16 rows fall on distinct banks
 #define CL_HS (DGCNN_HID1 + 4)
+#define CL_WS (DGCNN_FLAT / 2 + 4)     // row stride of a staged half of classifier_1's weights
 
 // MODE 0: forward only (inference, and training steps whose backward starts from an upstream gradient);
 // MODE 1: forward + backward from labels (NLL mean, train.py:40-45).
@@ -40,7 +41,12 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
   // every small operand is brought into LDS by the kernel's first loads: a workgroup is ONE latency chain (128 workgroups on
   // 128 CUs at 2048 graphs, nothing else on the CU to hide a round trip), and with a cold global load in front of every
   // phase the first version spent 25 us here -- a dozen dependent round trips -- for 3 us of matrix instructions
-  __shared__ float w2s[DGCNN_MAX_C * DGCNN_HID1];                        // classifier_2's weights
+  // classifier_1's weights pass through LDS in two halves of 176 columns ([128 units][176 + 4]): straight from global into the
+  // B operand, lane (unit nl, kq) reads 16 bytes of ITS unit's row and the 16 lanes of a quad touch 16 different cache lines
+  // -- 11.5 k tag lookups for the 180 KB, 7 us of the first version's 23.  Staged, a row's 704 bytes are read by 44
+  // consecutive lanes.  classifier_2's weights take the buffer over once the forward product is done.
+  __shared__ __attribute__((aligned(16))) float wc[DGCNN_HID1 * CL_WS];
+  float* w2s = wc;
   __shared__ float b1s[DGCNN_HID1], b2s[DGCNN_MAX_C];
   __shared__ int ys[CL_GB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, kq = lane >> 4;
@@ -51,26 +57,27 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
   const int xr = (int)blockIdx.x >> 3;
   const int ut = (wv + xr) & 7;                                          // this wave's 16-unit tile of classifier_1
 
-  // classifier_1's rows of this wave's 16 units: requested first (22 x 16 bytes per lane, the forward's whole share of the
-  // 180 KB), they land while the graphs' rows are staged.  Lane (unit nl, kq) holds columns 16j + 4kq .. + 3 of its row:
-  // element s of the four is the k-slot of matrix step 4j + s -- the A operand below is read with the same assignment
-  float4 wq[22];
-  {
-    const float* wr = w.Wf1 + (size_t)(16 * ut + nl) * DGCNN_FLAT + 4 * kq;
-#pragma unroll
-    for (int j = 0; j < 22; ++j) wq[j] = *reinterpret_cast<const float4*>(wr + 16 * j);
-#if defined(CL_EXP) && CL_EXP == 1
-#pragma unroll
-    for (int j = 0; j < 22; ++j) wq[j] = make_float4(0.01f * j, 0.02f, 0.03f, 0.04f * kq);
-#endif
+  constexpr int NQ = CL_GB * (DGCNN_FLAT / 4), NI = (NQ + CL_THREADS - 1) / CL_THREADS;      // 16-byte pieces of the graphs' rows
+  constexpr int HQ = DGCNN_FLAT / 8;                                                           // 16-byte pieces per unit row and half (44)
+  constexpr int NH = DGCNN_HID1 * HQ / CL_THREADS;                                             // ... per thread and half (11)
+  static_assert(DGCNN_HID1 * HQ % CL_THREADS == 0, "a half of classifier_1 is a whole number of pieces per thread");
+  constexpr int NW2 = DGCNN_MAX_C * DGCNN_HID1 / CL_THREADS;
+  f32x4 wh[NH], wh1[NH];       // (a native vector type: an array of HIP's float4 structs written in two places stayed in scratch)
+  // (macros, not lambdas: captured by reference the register array stayed an alloca -- 192 bytes of scratch per lane)
+#define CL_LOAD_HALF(h, wh)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                                   \
+    const int idx = tid + CL_THREADS * i, u = idx / HQ, q = idx - u * HQ;                                            \
+    wh[i] = *reinterpret_cast<const f32x4*>(w.Wf1 + (size_t)u * DGCNN_FLAT + (DGCNN_FLAT / 2) * (h) + 4 * q);      \
+  }
+#define CL_STORE_HALF(wh)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                                   \
+    const int idx = tid + CL_THREADS * i, u = idx / HQ, q = idx - u * HQ;                                            \
+    *reinterpret_cast<f32x4*>(wc + u * CL_WS + 4 * q) = wh[i];                                                       \
   }
   {   // EVERY load of the set-up is in flight before the first LDS store: a load followed by its own LDS store is a round
-      // trip of its own (loads complete in order), and the first version paid four of them in a row here
-    constexpr int NQ = CL_GB * (DGCNN_FLAT / 4), NI = (NQ + CL_THREADS - 1) / CL_THREADS;
-    constexpr int NW2 = DGCNN_MAX_C * DGCNN_HID1 / CL_THREADS;
-    float w2r[NW2];
-#pragma unroll
-    for (int i = 0; i < NW2; ++i) w2r[i] = (tid + CL_THREADS * i < C * DGCNN_HID1) ? w.Wf2[tid + CL_THREADS * i] : 0.f;
+      // trip of its own (loads complete in order)
+    CL_LOAD_HALF(0, wh)
+    CL_LOAD_HALF(1, wh1)                             // (both halves requested at once: one cold round trip, not two)
     float smallv = 0.f;
     int yv = 0;
     if (tid < DGCNN_HID1) smallv = w.bf1[tid];
@@ -81,14 +88,8 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
     for (int i = 0; i < NI; ++i) {      // the 16 graphs' conv6 outputs
       const int t = tid + CL_THREADS * i, g = t / (DGCNN_FLAT / 4), q = t - g * (DGCNN_FLAT / 4);
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#if defined(CL_EXP) && CL_EXP == 2
-      if (t < NQ && g < nb) v[i] = make_float4(0.1f * g, 0.2f, 0.3f * q, 0.4f);
-#else
       if (t < NQ && g < nb) v[i] = *reinterpret_cast<const float4*>(a6g + (size_t)(b0 + g) * DGCNN_FLAT + 4 * q);
-#endif
     }
-#pragma unroll
-    for (int i = 0; i < NW2; ++i) if (tid + CL_THREADS * i < C * DGCNN_HID1) w2s[tid + CL_THREADS * i] = w2r[i];
     if (tid < DGCNN_HID1) b1s[tid] = smallv;
     else if (tid < DGCNN_HID1 + C) b2s[tid - DGCNN_HID1] = smallv;
     else if (MODE == 1 && tid >= 256 && tid < 256 + CL_GB) ys[tid - 256] = yv;
@@ -97,21 +98,35 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
       const int t = tid + CL_THREADS * i, g = t / (DGCNN_FLAT / 4), q = t - g * (DGCNN_FLAT / 4);
       if (t < NQ) *reinterpret_cast<float4*>(fl + g * CL_FS + 4 * q) = v[i];
     }
+    CL_STORE_HALF(wh)
   }
   __syncthreads();
   CL_MARK(1);
   // ---- classifier_1: z[g][u] = sum_k flat[g][k] W1[u][k]; ReLU; Dropout(0.5) -------------------------------------------
+  // lane (nl, kq): A = flat[graph nl][16j + 4kq + s], B = W1[unit 16 ut + nl][same k] for matrix step 4j + s of a half
+  float w2r[NW2];
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* ar = fl + nl * CL_FS + 4 * kq;
+    auto half_product = [&](int h) __attribute__((always_inline)) {
+      const float* ar = fl + nl * CL_FS + (DGCNN_FLAT / 2) * h + 4 * kq;
+      const float* br = wc + (16 * ut + nl) * CL_WS + 4 * kq;
 #pragma unroll
-    for (int j = 0; j < 22; ++j) {
-      const float4 a = *reinterpret_cast<const float4*>(ar + 16 * j);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wq[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wq[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wq[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wq[j].w, acc, 0, 0, 0);
-    }
+      for (int j = 0; j < 11; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(ar + 16 * j);
+        const float4 bq = *reinterpret_cast<const float4*>(br + 16 * j);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NW2; ++i) w2r[i] = (tid + CL_THREADS * i < C * DGCNN_HID1) ? w.Wf2[tid + CL_THREADS * i] : 0.f;
+    half_product(0);
+    dg_lds_barrier();                                // every wave has read the first half
+    CL_STORE_HALF(wh1)
+    dg_lds_barrier();
+    half_product(1);
     const int u = 16 * ut + nl;                      // this lane: unit u of graphs 4kq .. 4kq + 3
     const float bu = b1s[u];
 #pragma unroll
@@ -145,6 +160,9 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
     }
   }
   CL_MARK(2);
+  dg_lds_barrier();                                  // every wave has read the second half: classifier_2's weights move in
+#pragma unroll
+  for (int i = 0; i < NW2; ++i) if (tid + CL_THREADS * i < C * DGCNN_HID1) w2s[tid + CL_THREADS * i] = w2r[i];
   dg_lds_barrier();
   CL_MARK(3);
   // ---- classifier_2: 128 -> C, eight lanes per (graph, class), fixed xor butterfly ---------------------------------------
@@ -265,6 +283,8 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
   CL_MARK(7);
   if (dbg && threadIdx.x == 0) { atomicMax(&dbg[40], wall_clock64()); if (blockIdx.x == 0) dbg[42] = wall_clock64(); }
 #undef CL_MARK
+#undef CL_LOAD_HALF
+#undef CL_STORE_HALF
 }
 
 // graphs per launch from which the readout pair splits the classifier off (tail.hip's two-workgroups-per-CU forms start at

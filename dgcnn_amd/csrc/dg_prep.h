@@ -14,7 +14,8 @@ struct DgPrepRider {
   const float* x; float* xs; int F;      // aggregate-first conv1: xs[i] = dinv[i]*x[i] ([N,F]); x == nullptr: none
   unsigned int* err;
   unsigned int epoch;
-  int nblk;        // rider workgroups appended to the host kernel's grid (0 = none)
+  int nblk;        // rider workgroups appended to the host kernel's grid (0 = none): phase A
+  int nblk_b;      // ... phase B (fewer when it has no per-edge work: 8 threads per node, not one per edge)
   unsigned int* bits; int* dmap;   // dense per-graph block structures (dg_dense.h); bits == nullptr: not built
   int edge_check;  // 1: the reverse-edge check stays the per-edge binary search of phase B although the bitmap is built
                    // (small batches that take only the chain forward from it: no third launch for the bitmap's symmetry check)
@@ -22,6 +23,15 @@ struct DgPrepRider {
 static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {      // threads of phase A / phase B
   int work = E > N + 1 ? E : N + 1;
   if (dense && 8LL * N < 0x7fffffffLL && 8 * N > work) work = 8 * N;                  // bitmap: 8 lanes per row
+  return B + 1 > work ? B + 1 : work;
+}
+
+// phase B has per-edge work only when it checks the reverse edges itself (no bitmap, or `edge_check`); otherwise its threads
+// beyond 8 per node would start and return -- 8.8 k empty 1024-thread blocks at 2048 COLLAB graphs, a third of the launch
+static inline int dg_prep_fast_work_b(int E, int N, int B, bool dense, bool edge_check) {
+  int work = N + 1;
+  if (!dense || edge_check) work = E > work ? E : work;
+  if (dense && 8LL * N < 0x7fffffffLL && 8 * N > work) work = 8 * N;
   return B + 1 > work ? B + 1 : work;
 }
 
@@ -234,14 +244,22 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
     const int row = t >> 3, l8 = t & 7;
     if (8LL * N < 0x7fffffffLL) {
       // (all 8 lanes of a row take the same branches: the shuffles below are executed by whole groups)
+      // TWO dependent round trips per row, not four: the row's graph id and its CSR bounds are requested together (on a
+      // clamped row, unconditionally), then the graph's bounds and the first 64 neighbours together -- the neighbour loads
+      // need only the CSR bounds, their graph-relative ids are formed when both have landed.  (batch -> graph_ptr -> `ok` ->
+      // rowptr -> colidx, each gated on the one before, made this a latency chain: 37 us at 2048 COLLAB graphs for 40 MB)
       const bool live = row < N;
-      const int g = live ? (int)batch[row] : -1;
-      int n0 = 0, ng = 0;
-      if ((unsigned)g < (unsigned)B) { n0 = graph_ptr[g]; ng = graph_ptr[g + 1] - n0; }
+      const int rowc = live ? row : 0;
+      const int gload = N > 0 ? (int)batch[rowc] : -1;
+      const int rs0 = N > 0 ? rowptr[rowc] : 0, re0 = N > 0 ? rowptr[rowc + 1] : 0;
+      const int g = live ? gload : -1;
+      const int gc = (unsigned)g < (unsigned)B ? g : 0;
+      int n0 = B > 0 ? graph_ptr[gc] : 0, ng = B > 0 ? graph_ptr[gc + 1] - n0 : 0;
+      if ((unsigned)g >= (unsigned)B) { n0 = 0; ng = 0; }
       const int sj = row - n0;
       const bool ok = live && (unsigned)g < (unsigned)B && sj >= 0 && sj < ng && ng <= DGD_MAXN;
       const int S = ok ? 1 << dgd_class(ng) : 0;
-      const int rs = ok ? rowptr[row] : 0, re = ok ? rowptr[row + 1] : 0;
+      const int rs = live ? rs0 : 0, re = live ? re0 : 0;      // (a row whose graph is not `ok` is walked too: it stores nothing, flags nothing)
       bool bad = false;
       auto build = [&](auto tag) {
         constexpr int W = decltype(tag)::value;           // words kept per lane (>= S)
@@ -276,7 +294,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       // (rows of one wave may belong to graphs of different classes: every group of 8 aligned lanes runs the variant its
       //  own graph needs, and the shuffles stay inside the group)
       if (S <= 4) build(std::integral_constant<int, 4>{}); else build(std::integral_constant<int, 16>{});
-      if (bad) { err[1] = epoch; err[3] = ~epoch; }
+      if (bad && ok) { err[1] = epoch; err[3] = ~epoch; }
     }
     if (t < B && graph_ptr[t + 1] - graph_ptr[t] > DGD_MAXN) { err[1] = epoch; err[3] = ~epoch; }      // max_nodes promise (<= 512) broken
   }

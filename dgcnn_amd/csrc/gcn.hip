@@ -565,7 +565,7 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rd.nblk), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
+  hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rd.nblk_b), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
                      pa4, P1, rd);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

@@ -229,7 +229,8 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch, bits);
     DG_CHECK_LAUNCH();
     const bool scale = lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
-    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr, colidx,
+    const int work_b = dg_prep_fast_work_b(E, N, B, bits != nullptr, edge_check);
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr, colidx,
                        graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
                        scale ? lf->hs : nullptr, batch, bits, dmap, edge_check);
     if (scale && lin_done) *lin_done = 1;

@@ -163,7 +163,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
            float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
-  const DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk, false);
+  const DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk_b, false);
   if (role.rider) {    // rider blocks: phase B of the NEXT batch's graph preparation (phase A rode on the
                        // readout launch of this step's forward, complete by now)
     dg_prep_fast_b_body(role.idx * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
@@ -261,15 +261,15 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   if (rider) rd = *rider;
   static const bool nobig = dg_knob("DG_NO_BIG_TAIL");      // A/B switch (DG_DEBUG_KNOBS builds only)
   if (!head)       // the classifier's backward ran batched over graphs: gz6 holds the gradient of conv6's output
-    hipLaunchKernelGGL((k_tail_bwd<true, false>), dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+    hipLaunchKernelGGL((k_tail_bwd<true, false>), dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
                        gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
   else if (B >= DG_TAIL_BIG_MIN_B && !nobig)
-    hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+    hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
                        gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
   else
-    hipLaunchKernelGGL(k_tail_bwd<false>, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
+    hipLaunchKernelGGL(k_tail_bwd<false>, dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
                        gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
   DG_CHECK_LAUNCH();
@@ -584,14 +584,14 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
                      : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 64) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
       hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
     }
-    if (rider && rider->nblk > 0)       // (diagnostic mode: the rider as a launch of its own)
-      hipLaunchKernelGGL(k_wgrad, dim3(4 * rider->nblk), dim3(256), 0, s, A, *rider, 0);
+    if (rider && rider->nblk_b > 0)       // (diagnostic mode: the rider as a launch of its own)
+      hipLaunchKernelGGL(k_wgrad, dim3(4 * rider->nblk_b), dim3(256), 0, s, A, *rider, 0);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  hipLaunchKernelGGL(k_wgrad, dim3(nb + 4 * rd.nblk), dim3(256), 0, s, A, rd, nb);      // (nblk counts 1024-thread blocks)
+  hipLaunchKernelGGL(k_wgrad, dim3(nb + 4 * rd.nblk_b), dim3(256), 0, s, A, rd, nb);      // (nblk_b counts 1024-thread blocks)
   DG_CHECK_LAUNCH();
   (void)N;
   return DGCNN_OK;
