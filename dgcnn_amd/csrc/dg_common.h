@@ -98,6 +98,7 @@ static inline int dg_wg_two_stage_b() {
 #ifndef DG_WG_ROWS_PER_CHUNK
 #define DG_WG_ROWS_PER_CHUNK 32
 #endif
+#define DG_WG_T1_EXTRA (DGCNN_HID1 + 2 + 1 + 5)      // per chunk, behind the tail partials: classifier_1's bias gradient, {loss, #correct}, db4
 #ifndef DG_WG_FC1_KCHUNK
 #define DG_WG_FC1_KCHUNK 128
 #endif
@@ -170,7 +171,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   R(ptail, 4 * b * (int64_t)DG_PTAIL(C));
   R(ax, F <= DG_AF_MAX_F ? 4 * n * F : 0);      // aggregated raw input (aggregate-first conv1), saved for dW1
   // large batches only: stage-1 buffers of the two-stage weight-gradient reduction (tail.hip, dg_launch_wgrad)
-  R(wg_t1, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * DG_PTAIL(C) : 0);
+  R(wg_t1, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_ROWS_PER_CHUNK) * (DG_PTAIL(C) + DG_WG_T1_EXTRA) : 0);
   R(wg_t2, B > dg_wg_two_stage_b() ? 4 * (int64_t)dg_cdiv(B, DG_WG_FC1_KCHUNK) * DGCNN_HID1 * DGCNN_FLAT : 0);
   // dense per-graph block structures (dg_prep.h): adjacency bitmap (five stride classes) + work-item map
   R(adjbits, 4 * 31 * n);

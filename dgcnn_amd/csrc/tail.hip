@@ -410,6 +410,25 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     }
     return;
   }
+  if (sg.type == WG_REDUCE_CHUNK && sg.R == 32) {
+    // stage 1 of the large-batch form: output i = (chunk, column) sums 32 consecutive rows; all 32 loads of a lane in flight
+    // (the generic path below issues them 16 at a time); same order of additions: (t[u] + t[u+16]) first, then the tree
+    const int i = ((int)blockIdx.x - sg.block0) * 256 + (int)threadIdx.x;
+    if (i < sg.count) {
+      const int ch = i / sg.stride, col = i - ch * sg.stride;
+      const float* sp = sg.src + (size_t)ch * 32 * sg.stride + col;
+      const int nrow = min(32, sg.aux - ch * 32);
+      float a[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a[u] = u < nrow ? sp[(size_t)u * sg.stride] : 0.f;
+#pragma unroll
+      for (int st = 16; st >= 1; st >>= 1)
+#pragma unroll
+        for (int u = 0; u < st; ++u) a[u] += a[u + st];
+      sg.out[i] = a[0];
+    }
+    return;
+  }
   if (sg.type == WG_REDUCE_COL) {
     // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS (every load instruction reads 256 contiguous bytes
     // of one partial row), rows dealt round-robin to the 4 waves, up to 64 loads in flight per lane, then a
@@ -518,6 +537,15 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     g.type = type; g.count = tiles; g.lpo = 64; g.R = B; g.block0 = nb; g.stride = 0; g.src = nullptr; g.out = out;
     nb += dg_cdiv(tiles, 4);
   };
+  // large batches: per-graph vectors are first summed per chunk of DG_WG_ROWS_PER_CHUNK graphs (stage 1, below); the three
+  // short per-graph sums -- classifier_1's bias gradient, the metrics, db4 -- go through it too: as 64-lane sums over 2048
+  // graphs they were the longest segments of the final launch (15 / 13 / 7.5 us at 2048 graphs, each alone)
+  const bool big1 = (which & 1) && B > dg_wg_two_stage_b();
+  const int nch_ = dg_cdiv(B, DG_WG_ROWS_PER_CHUNK);
+  float* t1_ = const_cast<float*>(dg_cptr<float>(ws, wl->wg_t1));
+  float* t3_ = t1_ + (size_t)nch_ * DG_PTAIL(C);            // [nch][128]
+  float* t4_ = t3_ + (size_t)nch_ * DGCNN_HID1;             // [nch][2]
+  float* t5_ = t4_ + (size_t)nch_ * 2;                      // [nch]
   // segments with the longest dependent latency first: their workgroups are dispatched first
   if (which & 2) {
     const float* pb1 = dg_cptr<float>(ws, wl->pb1);
@@ -531,7 +559,8 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     add_col(32 * F, wl->P32, grads + pl->off[0], pb1, 32 * F);                      // dW1
     add_col(32, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);                     // db1 (from layer-2 backward)
     add_col(32, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);                     // db2 (from layer-3 backward)
-    add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
+    if (big1) add(WG_SUMB, 1, 64, nch_, grads + pl->off[7], t5_, 0);                // db4 (chunk partials of stage 1)
+    else add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
   }
   if (which & 1) {
     const bool small = B <= dg_wg_two_stage_b();
@@ -555,7 +584,19 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       g1.type = WG_REDUCE_CHUNK; g1.count = nch * st; g1.lpo = 1; g1.R = DG_WG_ROWS_PER_CHUNK; g1.block0 = nb1;
       g1.stride = st; g1.aux = B; g1.src = pt; g1.out = t1;
       nb1 += dg_cdiv(g1.count, 256);
-      S.nseg = 2;
+      auto chunked = [&](int k, const float* src, int width, float* out) {
+        WgSeg& g = S.seg[k];
+        g.type = WG_REDUCE_CHUNK; g.count = nch * width; g.lpo = 1; g.R = DG_WG_ROWS_PER_CHUNK; g.block0 = nb1;
+        g.stride = width; g.aux = B; g.src = src; g.out = out;
+        nb1 += dg_cdiv(g.count, 256);
+      };
+      chunked(2, A.gz1, DGCNN_HID1, t3_);
+      chunked(3, dg_cptr<float>(ws, wl->lossv), 2, t4_);
+      chunked(4, dg_cptr<float>(ws, wl->gb4p), 1, t5_);
+      S.nseg = 5;
+      static const bool s1a = dg_knob("DG_WG_S1_ONLY_MFMA"), s1b = dg_knob("DG_WG_S1_ONLY_REDUCE");      // (timing A/B, debug builds)
+      if (s1a) { nb1 = g1.block0; S.nseg = 1; }
+      if (s1b) { S.seg[0] = S.seg[1]; S.seg[0].block0 = 0; nb1 -= g1.block0; S.nseg = 1; }
       hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
       DG_CHECK_LAUNCH();
       pt = t1; Rt = nch;
@@ -570,8 +611,12 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     add_col(DGCNN_C6, Rt, grads + pl->off[11], pt + DG_PT_B6, st);
     add_col(C * DGCNN_HID1, Rt, grads + pl->off[14], pt + DG_PT_WF2, st);
     add_col(C, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
-    add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
-    if (metrics) add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);   // train.py:44-45 bookkeeping
+    if (big1) add_col(DGCNN_HID1, nch_, grads + pl->off[13], t3_, DGCNN_HID1);
+    else add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
+    if (metrics) {                                                                        // train.py:44-45 bookkeeping
+      if (big1) add(WG_METRIC, 2, 64, nch_, metrics, t4_, 2);
+      else add(WG_METRIC, 2, 64, B, metrics, dg_cptr<float>(ws, wl->lossv), 2);
+    }
   }
   A.nseg = ns;
   if (nb == 0) return DGCNN_OK;
