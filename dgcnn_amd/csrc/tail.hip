@@ -86,12 +86,11 @@ int dg_launch_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t
 // LDS plan (bytes): region A 32 KiB = sort keys, afterwards reused for the pooled rows (11640),
 // conv5 weights (6208) and conv6 weights (10240); small activations after it.
 // ---------------------------------------------------------------------------------------------
-// Which blocks of a launch are the RIDER (the next batch's graph preparation, dg_prep.h) and which are graph workgroups.
-// Small batches: graphs first, rider blocks behind them (they fill the CUs the graphs leave idle).  Large batches (BIG):
-// INTERLEAVED at the ratio nblk : B -- the rider is an HBM stream (16 bytes of int64 edge_index per edge: 160 MB at 2048
-// COLLAB graphs, ~30 us at full bandwidth) and the graph workgroups are latency chains that use almost none; dispatched one
-// behind the other they cost the sum (2048 graphs: 30 us of graph workgroups, then 30 us of rider blocks, in each of the
-// two readout launches), dispatched mixed they share the machine.  Results do not depend on the mapping.
+// Which blocks of a launch are the RIDER (the next batch's graph preparation, dg_prep.h) and which are graph workgroups:
+// graphs first, rider blocks behind them.  `interleave` mixes them at the ratio nblk : B -- measured at 2048 COLLAB graphs it
+// is SLOWER for both readout launches (k_readout_fwd 59.5 -> 72 us with phase A's 160 MB edge stream between the graph
+// workgroups, k_tail_bwd 51 -> 56 us with phase B): the graph workgroups are chains of dependent loads whose latency grows
+// under a saturated memory system.  Kept as a switch for measurement; no launch uses it.
 struct DgRole { bool rider; int idx; };
 __device__ __forceinline__ DgRole dg_block_role(int i, int B, int nblk, bool interleave) {
   if (!interleave || nblk <= 0) return DgRole{i >= B, i >= B ? i - B : i};
@@ -163,7 +162,13 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
            float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
-  const DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk_b, false);
+  DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk_b, false);
+  // the rider block that also plans the next dense batch (dg_prep_dense_plan: ONE workgroup, ~8 us at 2048 graphs) trades
+  // places with graph 0: dispatched first it runs beside the graph workgroups, dispatched last it was the launch's tail
+  if (rd.nblk_b > 0 && rd.dmap) {
+    if (blockIdx.x == 0) role = DgRole{true, 0};
+    else if ((int)blockIdx.x == B) role = DgRole{false, 0};
+  }
   if (role.rider) {    // rider blocks: phase B of the NEXT batch's graph preparation (phase A rode on the
                        // readout launch of this step's forward, complete by now)
     dg_prep_fast_b_body(role.idx * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
