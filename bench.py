@@ -569,7 +569,9 @@ def main():
             else:
                 extra["pmc_note"] = why
         trace_small = dict(LIVE_TRACE_US)
-        if traffic is None:
+        # (the committed counters are of the default workload in fp32: no other shape borrows them)
+        default_cfg = args.workload == "COLLAB" and args.dtype == "f32" and not args.stress_nodes
+        if traffic is None and default_cfg:
             kname, traffic, src = committed_pmc_traffic(int(Bavg))
             traffic_src = None if traffic is None else f"committed {src}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes"
         chain = chain_small > 0.5
@@ -633,7 +635,7 @@ def main():
                 else:
                     extra["pmc_note_large_batch"] = why_l
             trace_large = LIVE_TRACE_US.get(kn2) if kn2 else None
-            if tr2_ is None:
+            if tr2_ is None and default_cfg:
                 kn2, tr2_, src2c = committed_pmc_traffic(LB)
                 src2 = None if tr2_ is None else f"committed {src2c}, kernel {kn2}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch"
             roofline_large = {"bound": "hbm", "batch": LB,
