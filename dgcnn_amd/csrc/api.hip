@@ -297,6 +297,19 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
 // *rode = 1 when it was attached).  tt != null (training step with labels): the readout forward and the readout
 // backward run as ONE launch when the batch allows it; *tail_done = 1 then tells the backward to skip its first launch.
 struct DgTrainTail { const int64_t* y; float loss_scale; };
+// Pipelined large-batch step: the point of the step's launch sequence at which the side stream's graph preparation of the NEXT
+// batch is forked (an event recorded on the caller's stream right behind launch `at`; dgcnn_pipeline_train_step sets and
+// clears the request around its forward / backward calls).  Points: 1 chain forward, 2 readout forward, 3 classifier,
+// 4 readout backward, 5 GCN backward a, 6 GCN backward b.
+struct DgForkRequest { hipEvent_t ev; int at; bool done; };
+static thread_local DgForkRequest g_fork{nullptr, 0, false};
+static inline int dg_fork_point(int k, hipStream_t s) {
+  if (g_fork.ev && !g_fork.done && g_fork.at == k) {
+    if (hipEventRecord(g_fork.ev, s) != hipSuccess) return DGCNN_ELAUNCH;
+    g_fork.done = true;
+  }
+  return DGCNN_OK;
+}
 static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float* params,
                                  const float* x, const int64_t* edge_index, const int64_t* batch,
                                  void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
@@ -449,10 +462,12 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   // enough for classifier_1 / classifier_2 to run as GEMMs over graphs (classifier.hip: with their backward when this is a
   // training step with labels; *tail_done = 4 then tells the backward that gz6 already holds conv6's output gradient)
   const bool batched_head = dg_classifier_batched(B);
+  DG_TRY(dg_fork_point(1, s));
   DG_TRY(dg_launch_readout_fwd(N, B, C, params, &pl, dg_ptr<int32_t>(ws, wl.graph_ptr), x1, x2, x3, x4,
                                dg_ptr<float>(ws, wl.pooled), dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5),
                                dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
                                dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed, s, rider_a, !batched_head));
+  DG_TRY(dg_fork_point(2, s));
   if (batched_head) {
     const bool with_bwd = tt && tail_done;
     DG_TRY(dg_launch_classifier(B, C, params, &pl, dg_ptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.a1d),
@@ -461,6 +476,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                 dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail), s));
     if (with_bwd) *tail_done = 4;
   }
+  DG_TRY(dg_fork_point(3, s));
   if (rider_a && rode) *rode = 1;
   return DGCNN_OK;
 }
@@ -519,6 +535,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
                             dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
                             dg_cptr<float>(ws, wl.pooled), s, rider_b, !head_done));
+  DG_TRY(dg_fork_point(4, s));
   if (dense) {
     // dense block form (the forward of this batch took it: the bitmap is in the workspace); F > 32 keeps the gather
     // kernel for conv1's own backward (its operand is the raw [N,F] input)
@@ -532,6 +549,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
     DG_TRY(dg_launch_gcn_bwd1d(&G, dinv, gas4, params + pl.off[6], x3, gp3, gasA, dg_ptr<float>(ws, wl.pa4), wl.P1, s));
     DG_TRY(dg_launch_gcn_bwd32d(&G, dinv, gasA, params + pl.off[4], x2, gp2, gasB, dg_ptr<float>(ws, wl.pb3), wl.P32, s));
     }
+    DG_TRY(dg_fork_point(5, s));
     if (F <= DG_AF_MAX_F && bf.chain) {
       DG_TRY(dg_launch_chain_bwd_b(N, B, F, G.graph_ptr, G.bits, dinv, gasB, params + pl.off[2], x1, gp1, dg_cptr<float>(ws, wl.ax),
                                    dg_ptr<float>(ws, wl.pb2), dg_ptr<float>(ws, wl.pb1), wl.P32,
@@ -577,6 +595,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                                dg_ptr<float>(ws, wl.pb1), wl.P32, s));
   }
   }
+  DG_TRY(dg_fork_point(6, s));
   // every weight gradient (tail + GCN partial reductions) in ONE launch, fixed-order reductions, optional Adam.
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
@@ -616,7 +635,23 @@ struct DgPipeline {
   const void* prep_ws = nullptr;         // workspace holding a prepared-but-not-yet-consumed graph structure
   int pN = 0, pE = 0, pB = 0, pflags = 0, pmaxn = 0;
   uint32_t pepoch = 0;
+  // large batches: the next batch's graph preparation runs as launches of its own on a SIDE stream, forked from the caller's
+  // stream at the start of the step and joined at its end (created at the first such step, destroyed with the pipeline)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
+// Above this many graphs per step the next batch's preparation leaves the rider slots of the step's launches for the side
+// stream.  Why: at 2048 COLLAB graphs every launch of the step fills the chip, so rider blocks are ADDED time (k_readout_fwd
+// 34 -> 59 us with phase A behind its graph workgroups, k_tail_bwd 35 -> 53 us with phase B), while most launches of the step
+// are latency chains that leave the memory system idle (k_chain_fwd_q moves 66 MB in 43 us): the preparation's 79 us of
+// launches (phase A is an HBM stream of the int64 edge list) overlap with the step's ~230 us instead.  At the reference's
+// batch of 50 the riders fill CUs the graph workgroups leave empty and cost nothing: kept there.
+#ifndef DG_SIDE_PREP_MIN_B
+#define DG_SIDE_PREP_MIN_B 257
+#endif
+#ifndef DG_SIDE_FORK_AT
+#define DG_SIDE_FORK_AT 4           // fork behind the readout backward (dg_fork_point)
+#endif
 
 int dgcnn_pipeline_create(void** handle) {
   if (!handle) return DGCNN_EINVAL;
@@ -626,7 +661,11 @@ int dgcnn_pipeline_create(void** handle) {
 
 int dgcnn_pipeline_destroy(void* handle) {
   if (!handle) return DGCNN_EINVAL;
-  delete static_cast<DgPipeline*>(handle);
+  DgPipeline* h = static_cast<DgPipeline*>(handle);
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  delete h;
   return DGCNN_OK;
 }
 
@@ -655,9 +694,21 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   }
   h->prep_ws = nullptr;
 
+  static const bool no_side = dg_knob("DG_NO_SIDE_PREP");      // A/B switch (DG_DEBUG_KNOBS builds only)
+  bool side_prep = next && cur->B >= DG_SIDE_PREP_MIN_B && !no_side;
+  if (side_prep && !h->side) {
+    int prio_least = 0, prio_greatest = 0;      // the LOWEST priority: the step's own launches take the CUs first
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      side_prep = false;                                         // (no side stream to be had: riders / in-stream as before)
+    }
+  }
   DgPrepRider rd{};
   const DgPrepRider* rider = nullptr;
-  if (next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
+  if (!side_prep && next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
     DgWs nl;
     DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
     rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
@@ -680,6 +731,15 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   int rode = 0, tail_done = 0;
   DgTrainTail tt;
   tt.y = cur->y; tt.loss_scale = cur->loss_scale;
+  g_fork = DgForkRequest{nullptr, 0, false};      // (a request left behind by a step that returned an error half way)
+  if (side_prep) {
+    int at = DG_SIDE_FORK_AT;
+#ifdef DG_DEBUG_KNOBS
+    if (const char* e = getenv("DG_FORK_AT")) at = atoi(e);
+#endif
+    g_fork = DgForkRequest{h->ev_fork, at, false};
+    if (at == 0) { if (hipEventRecord(h->ev_fork, s) != hipSuccess) return DGCNN_ELAUNCH; g_fork.done = true; }
+  }
   DG_TRY(dg_model_forward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->edge_index, cur->batch,
                                cur->ws, cur->logp, cur->training, cur->seed, flags, cur->max_nodes, cur->max_edges,
                                epoch, stream, rider, &rode, &tt, &tail_done));
@@ -699,7 +759,20 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
                               reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));
   if (next) {
     // no rider possible (general edge list, or this step took the graph-per-workgroup forward): prepare in-stream now
-    if (!rode)
+    if (side_prep) {
+      if (!g_fork.done && hipEventRecord(h->ev_fork, s) != hipSuccess) return DGCNN_ELAUNCH;      // (a route without that launch)
+      g_fork = DgForkRequest{nullptr, 0, false};
+      // The preparation runs beside the GCN backward chain kernels -- LDS / matrix-core latency chains that move little memory
+      // -- and the weight-gradient launches.  Fork point swept at 2048 COLLAB graphs (step, us; riders instead: 289.8):
+      // start of the step 287.2, behind the chain forward 291.7, readout forward 298.8, classifier 313.2, READOUT BACKWARD
+      // 277.7, GCN backward a 295.0, b 308.9 -- beside the readout kernels, whose graph workgroups are chains of dependent
+      // loads, the preparation's HBM stream stretches them by more than it saves.  Join: whatever the caller enqueues next
+      // sees the prepared structure.  (next->ws was last read by the previous step, which precedes the fork.)
+      if (hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return DGCNN_ELAUNCH;
+      DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
+                                 next->ws, next->flags, next->max_nodes, next->epoch, (dgcnn_stream_t)h->side));
+      if (hipEventRecord(h->ev_join, h->side) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess) return DGCNN_ELAUNCH;
+    } else if (!rode)
       DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
                                  next->ws, next->flags, next->max_nodes, next->epoch, stream));
     h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;

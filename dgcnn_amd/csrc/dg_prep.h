@@ -224,6 +224,10 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
 }
 // Kernel-B body: dinv per node, graph_eptr, and (per edge (s,d)) the reverse edge (d,s) must be in row d --
 // binary search inside that row only (<= log2(deg) steps).  Needs kernel A's outputs complete.
+// THREADS: threads per block of the hosting launch (sizes the LDS row buffers: 8 bytes per thread -- 2 KB in the 256-thread
+// launches; as a fixed 8 KB it kept the GCN backward chain kernels' workgroups, which need 2 x 70 KB of a CU's 160 KB, from being
+// placed beside a few blocks of the preparation running on the pipeline's side stream)
+template <int THREADS = 1024>
 __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __restrict__ ei, int E, int N, int B,
                                                     const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                     const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
@@ -298,7 +302,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       // per neighbour.  The 8 lanes are in one wave and LDS operations of a wave execute in order: no barrier, only the
       // counter wait.  (2048 COLLAB graphs, phase B riding on k_tail_bwd: that launch 57 -> 51 us.)
       auto build_lds = [&]() {
-        __shared__ unsigned int rowbuf[(1024 / 8) * 16];
+        __shared__ unsigned int rowbuf[(THREADS / 8) * 16];
         unsigned int* rb = rowbuf + (threadIdx.x >> 3) * 16;
         rb[l8] = 0u; rb[l8 + 8] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -187,7 +187,7 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
               float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int F,
               const float* __restrict__ x, float* __restrict__ xs, const int64_t* __restrict__ batch,
               unsigned int* __restrict__ bits, int* __restrict__ dmap, int edge_check) {
-  dg_prep_fast_b_body(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
+  dg_prep_fast_b_body<256>(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
                       err, epoch, x, xs, F, batch, bits, dmap, edge_check != 0);
   if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 256, B, graph_ptr, dmap);
 }

@@ -319,12 +319,14 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     assert abs(lsum - float(loss_ref)) < 1e-5
 
 
-def test_pipelined_step_gives_identical_training():
-    """dgcnn_pipeline_train_step (one call per step; graph prep of batch i+1 on the library's side stream during
-    step i) must not change a single bit, whether or not the promised next batch actually comes next."""
+@pytest.mark.parametrize("name,total,bs", [("COLLAB", 60, 12), ("MUTAG", 1500, 300)], ids=["riders", "side_stream"])
+def test_pipelined_step_gives_identical_training(name, total, bs):
+    """dgcnn_pipeline_train_step (one call per step; graph prep of batch i+1 during step i -- as rider workgroups of the
+    step's launches at the reference's batch sizes, as launches on the library's side stream above 256 graphs per step)
+    must not change a single bit, whether or not the promised next batch actually comes next."""
     from dgcnn_amd.train import Trainer
-    sh = synth.SHAPES["COLLAB"]
-    batches = [b.to("cuda") for b in synth.make_batches("COLLAB", 60, 12, start=4000)]
+    sh = synth.SHAPES[name]
+    batches = [b.to("cuda") for b in synth.make_batches(name, total, bs, start=4000)]
     outs = []
     for mode in ("plain", "pipelined", "pipelined_no_lookahead", "broken_promise", "interleaved_eval"):
         m = make_model(sh.num_features, sh.num_classes)
