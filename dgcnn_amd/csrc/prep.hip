@@ -181,15 +181,17 @@ k_prep_fast_a(const int64_t* __restrict__ ei, int E, int N, const int64_t* __res
 // Kernel B: dinv per node, and (per edge (s,d)) the reverse edge (d,s) must be in row d -- binary
 // search inside that row only (<= log2(deg) steps).  Pure verification + dinv; no atomics.  With x given it also
 // writes the pre-scaled raw features xs = dinv*x [N,F] for the aggregate-first conv1 (F <= DG_AF_MAX_F).
-__global__ void __launch_bounds__(256)
+// 1024 threads per block: block 0 also plans a dense batch (dg_prep_dense_plan, ONE workgroup -- 8 us with 1024 threads at 2048
+// graphs, ~30 us with 256, which made this launch 38 us long for 10 us of parallel work)
+__global__ void __launch_bounds__(1024)
 k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __restrict__ rowptr,
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
               float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int F,
               const float* __restrict__ x, float* __restrict__ xs, const int64_t* __restrict__ batch,
               unsigned int* __restrict__ bits, int* __restrict__ dmap, int edge_check) {
-  dg_prep_fast_b_body<256>(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
+  dg_prep_fast_b_body<1024>(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
                       err, epoch, x, xs, F, batch, bits, dmap, edge_check != 0);
-  if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 256, B, graph_ptr, dmap);
+  if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 1024, B, graph_ptr, dmap);
 }
 
 __global__ void __launch_bounds__(256)
@@ -230,7 +232,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     DG_CHECK_LAUNCH();
     const bool scale = lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
     const int work_b = dg_prep_fast_work_b(E, N, B, bits != nullptr, edge_check);
-    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 256)), dim3(256), 0, s, edge_index, E, N, B, rowptr, colidx,
+    hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 1024)), dim3(1024), 0, s, edge_index, E, N, B, rowptr, colidx,
                        graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
                        scale ? lf->hs : nullptr, batch, bits, dmap, edge_check);
     if (scale && lin_done) *lin_done = 1;
