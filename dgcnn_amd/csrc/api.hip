@@ -83,6 +83,11 @@ int64_t dgcnn_workspace_offset(const char* name, int N, int E, int B, int F, int
   return -1;
 }
 
+// DGCNN_FLAG_COALESCED_UNDIRECTED promises a symmetric edge list: its CSR by source equals its CSR by target, so the
+// model-level preparation writes ONE copy and the backward's gather kernels read it (the flag must be the same in the calls of
+// one batch: prepare / forward / backward -- include/dgcnn_hip.h).
+static inline bool dg_csr_symmetric(int flags, int E) { return (flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && E > 0; }
+
 int dgcnn_graph_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                      int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                      float* dinv, int32_t* graph_ptr, int32_t* scratch, int32_t* err_flag, int flags,
@@ -284,8 +289,10 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
   DgLinFirst lf; lf.x = x; lf.W = nullptr; lf.hs = dg_ptr<float>(ws, wl.hsA); lf.F = F;
   const DgForm fm = dg_form(N, E, B, F, flags, max_nodes);
   const bool dense = fm.bitmap;
+  const bool sym = dg_csr_symmetric(flags, E);      // (then the backward reads the CSR by target: no second copy is written)
   return dg_launch_prep(edge_index, E, batch, N, B, dg_ptr<int32_t>(ws, wl.rowptr), dg_ptr<int32_t>(ws, wl.colidx),
-                        dg_ptr<int32_t>(ws, wl.rowptr_t), dg_ptr<int32_t>(ws, wl.colidx_t), dg_ptr<float>(ws, wl.dinv),
+                        sym ? nullptr : dg_ptr<int32_t>(ws, wl.rowptr_t), sym ? nullptr : dg_ptr<int32_t>(ws, wl.colidx_t),
+                        dg_ptr<float>(ws, wl.dinv),
                         dg_ptr<int32_t>(ws, wl.graph_ptr), dg_ptr<int32_t>(ws, wl.graph_eptr),
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out), dg_ptr<int32_t>(ws, wl.err),
                         flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr,
@@ -356,8 +363,9 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   int lin_done = 0;
   // graph structure, once per batch (the reference recomputes the normalisation in all 4 layers)
   if (!(flags & DGCNN_FLAG_PREPARED))
-  DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx, dg_ptr<int32_t>(ws, wl.rowptr_t),
-                        dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
+  DG_TRY(dg_launch_prep(edge_index, E, batch, N, B, rowptr, colidx,
+                        dg_csr_symmetric(flags, E) ? nullptr : dg_ptr<int32_t>(ws, wl.rowptr_t),
+                        dg_csr_symmetric(flags, E) ? nullptr : dg_ptr<int32_t>(ws, wl.colidx_t), dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
                         bitmap ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr,
@@ -492,9 +500,9 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 // form of a batch's backward: `dense` = the dense per-layer kernels (else CSR gather); `chain` = conv4 + conv3 as one
 // graph-chain launch (gcn_chain.hip: needs the bitmap the forward's preparation built and graphs of <= 256 nodes);
 // `plan` = the item table / graph schedule exists (batches above one graph per persistent workgroup)
-struct DgBwdForm { bool dense, chain, plan; };
+struct DgBwdForm { bool dense, chain, plan, sym; };
 static DgBwdForm dg_backward_form(int N, int E, int B, int F, int flags, int max_nodes) {
-  DgBwdForm b{false, false, false};
+  DgBwdForm b{false, false, false, dg_csr_symmetric(flags, E)};
   if (flags & DGCNN_FLAG_FORCE_FUSED) return b;            // (the fused graph-per-workgroup forward never builds the bitmap)
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
   b.dense = f.dense; b.plan = f.plan;
@@ -516,8 +524,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
-  const int32_t* rowptr_t = dg_cptr<int32_t>(ws, wl.rowptr_t);
-  const int32_t* colidx_t = dg_cptr<int32_t>(ws, wl.colidx_t);
+  const int32_t* rowptr_t = dg_cptr<int32_t>(ws, bf.sym ? wl.rowptr : wl.rowptr_t);
+  const int32_t* colidx_t = dg_cptr<int32_t>(ws, bf.sym ? wl.colidx : wl.colidx_t);
   const float* dinv = dg_cptr<float>(ws, wl.dinv);
   float *gasA = dg_ptr<float>(ws, wl.gasA), *gasB = dg_ptr<float>(ws, wl.gasB), *gas4 = dg_ptr<float>(ws, wl.gas4);
   float *gp1 = dg_ptr<float>(ws, wl.gp1), *gp2 = dg_ptr<float>(ws, wl.gp2), *gp3 = dg_ptr<float>(ws, wl.gp3);
@@ -713,7 +721,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
     rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
     rd.rowptr = dg_ptr<int32_t>(next->ws, nl.rowptr); rd.colidx = dg_ptr<int32_t>(next->ws, nl.colidx);
-    rd.rowptr_t = dg_ptr<int32_t>(next->ws, nl.rowptr_t); rd.colidx_t = dg_ptr<int32_t>(next->ws, nl.colidx_t);
+    rd.rowptr_t = nullptr; rd.colidx_t = nullptr;      // (riders exist for undirected edge lists only: dg_csr_symmetric)
     rd.graph_ptr = dg_ptr<int32_t>(next->ws, nl.graph_ptr); rd.graph_eptr = dg_ptr<int32_t>(next->ws, nl.graph_eptr);
     rd.dinv = dg_ptr<float>(next->ws, nl.dinv); rd.err = dg_ptr<unsigned int>(next->ws, nl.err);
     const bool naf = next->F <= DG_AF_MAX_F;

@@ -206,12 +206,14 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
     const int dc = (uint64_t)d < (uint64_t)N ? (int)d : 0;
     const int sc = s < 0 ? 0 : (s >= N ? N - 1 : (int)s);
     const int pc = ps < 0 ? -1 : (ps >= N ? N - 1 : (int)ps);
+    // (an undirected edge list's CSR by source IS its CSR by target: the model-level callers pass null for the second copy
+    //  and their backward reads the first -- 8 of phase A's 24 bytes per edge; dgcnn_graph_prep still fills both)
     colidx[t] = dc;
-    colidx_t[t] = dc;
+    if (colidx_t) colidx_t[t] = dc;
     if (pc < sc || t == 0)
-      for (int k = pc + 1; k <= sc; ++k) { rowptr[k] = t; rowptr_t[k] = t; }
+      for (int k = pc + 1; k <= sc; ++k) { rowptr[k] = t; if (rowptr_t) rowptr_t[k] = t; }
     if (t == E - 1)
-      for (int k = sc + 1; k <= N; ++k) { rowptr[k] = E; rowptr_t[k] = E; }
+      for (int k = sc + 1; k <= N; ++k) { rowptr[k] = E; if (rowptr_t) rowptr_t[k] = E; }
   }
   if (t <= B) {
     int lo = 0, hi = N;

@@ -265,7 +265,8 @@ int dgcnn_fused_fits(int max_nodes, int max_edges, int F);   /* 1 if such a batc
  *   metrics: optional (label mode only) 2-float device accumulator: metrics[0] += sum_b loss_b,
  *           metrics[1] += #correct -- replaces the two `.item()` syncs per batch of train.py:44-45
  *   flags, max_nodes: the values the matching dgcnn_model_forward was given (they select the aggregation form,
- *           whose structures the forward left in the workspace)
+ *           whose structures the forward left in the workspace; with DGCNN_FLAG_COALESCED_UNDIRECTED the preparation
+ *           keeps ONE CSR -- an undirected edge list's CSR by source is its CSR by target -- and the backward reads it)
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_backward(int N, int E, int B, int F, int C, const float* params,
                          const float* x, void* ws, const float* logp,
