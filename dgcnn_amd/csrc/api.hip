@@ -648,14 +648,16 @@ struct DgPipeline {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
-// Above this many graphs per step the next batch's preparation leaves the rider slots of the step's launches for the side
+// From this many graphs per step on the next batch's preparation leaves the rider slots of the step's launches for the side
 // stream.  Why: at 2048 COLLAB graphs every launch of the step fills the chip, so rider blocks are ADDED time (k_readout_fwd
 // 34 -> 59 us with phase A behind its graph workgroups, k_tail_bwd 35 -> 53 us with phase B), while most launches of the step
 // are latency chains that leave the memory system idle (k_chain_fwd_q moves 66 MB in 43 us): the preparation's 79 us of
 // launches (phase A is an HBM stream of the int64 edge list) overlap with the step's ~230 us instead.  At the reference's
 // batch of 50 the riders fill CUs the graph workgroups leave empty and cost nothing: kept there.
+// Measured crossover (COLLAB graphs per step, side stream vs riders, us): 384: 118.9 vs 117.3, 512: 124.4 vs 124.4, 768: 149.1 vs
+// 156.0, 1024: 172.2 vs 184.5, 2048: 272.1 vs 286.8.
 #ifndef DG_SIDE_PREP_MIN_B
-#define DG_SIDE_PREP_MIN_B 257
+#define DG_SIDE_PREP_MIN_B 512
 #endif
 #ifndef DG_SIDE_FORK_AT
 #define DG_SIDE_FORK_AT 4           // fork behind the readout backward (dg_fork_point)

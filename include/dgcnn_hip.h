@@ -352,8 +352,8 @@ typedef struct dgcnn_step_args {
  * step (optimizer fields ignored). */
 int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream);
 
-/* The pipeline object is the ONE place where this library owns device-side resources: from the first training step of more
- * than 256 graphs on, a side stream (lowest priority, non-blocking) and two events.  The next batch's graph preparation then
+/* The pipeline object is the ONE place where this library owns device-side resources: from the first training step of 512
+ * graphs or more on, a side stream (lowest priority, non-blocking) and two events.  The next batch's graph preparation then
  * runs on that stream, forked from `stream` inside the step and joined to it before the call's last launch completes its
  * dependencies: everything the caller enqueues on `stream` afterwards sees the prepared structure, and nothing enqueued
  * before the call can be overtaken.  Smaller steps carry the preparation as spare workgroups of their own launches.

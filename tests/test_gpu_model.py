@@ -319,10 +319,10 @@ def test_fused_train_step_equals_dropin_route_and_oracle_loss():
     assert abs(lsum - float(loss_ref)) < 1e-5
 
 
-@pytest.mark.parametrize("name,total,bs", [("COLLAB", 60, 12), ("MUTAG", 1500, 300)], ids=["riders", "side_stream"])
+@pytest.mark.parametrize("name,total,bs", [("COLLAB", 60, 12), ("MUTAG", 2400, 600)], ids=["riders", "side_stream"])
 def test_pipelined_step_gives_identical_training(name, total, bs):
     """dgcnn_pipeline_train_step (one call per step; graph prep of batch i+1 during step i -- as rider workgroups of the
-    step's launches at the reference's batch sizes, as launches on the library's side stream above 256 graphs per step)
+    step's launches at the reference's batch sizes, as launches on the library's side stream from 512 graphs per step)
     must not change a single bit, whether or not the promised next batch actually comes next."""
     from dgcnn_amd.train import Trainer
     sh = synth.SHAPES[name]
