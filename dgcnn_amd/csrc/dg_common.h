@@ -420,10 +420,10 @@ int dg_chain_needs_schedule(int B);
 int dg_chain_bwd_max_nodes();
 int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas4,
                           const float* W4, const float* W3, const float* x3, const float* gp3, const float* x2, const float* gp2,
-                          float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s);
+                          float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s, const int32_t* gpsel = nullptr);
 int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas2,
                           const float* W2, const float* x1, const float* gp1, const float* ax, float* pb2, float* pb1, int P32,
-                          int32_t* dmap, hipStream_t s);
+                          int32_t* dmap, hipStream_t s, const int32_t* gpsel = nullptr);
 int dg_chain_train_max_b();
 int dg_chain_train_max_nodes();
 int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
@@ -521,7 +521,8 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
-                       const float* pooled, hipStream_t s, const struct DgPrepRider* rider = nullptr, bool head = true);
+                       const float* pooled, hipStream_t s, const struct DgPrepRider* rider = nullptr, bool head = true,
+                       int32_t* gpsel = nullptr);
 struct DgAdam {          // optional optimizer step fused into the weight-gradient kernel
   float *params, *exp_avg, *exp_avg_sq;
   float lr, beta1, beta2, eps;

@@ -26,7 +26,8 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
     float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
     float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{}) {
+    float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{},
+    int* __restrict__ gpsel = nullptr) {
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
   // MERGED (k_readout_tail): conv5 / conv6 weights, the pooled rows and the log-probabilities are still in the forward
@@ -103,8 +104,15 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   }
   if (!MERGED) { st5.store(W5s_own, tid); st6.store(W6s_own, tid); stp.store(sps_own, tid); }     // (waits only for the small loads above)
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
-  for (int t = tid; t < n * 32; t += RD_THREADS) {
-    gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
+  // gpsel (large batches whose GCN backward is the chain kernels): instead of the zero rows -- 3 x 128 B per node, 57 MB of the
+  // launch's 150 MB of HBM writes at 2048 COLLAB graphs -- one flag word per node; the rows of the <= 30 selected nodes are
+  // written by the scatter below, the consumers skip the others
+  if (gpsel) {
+    for (int t = tid; t < n; t += RD_THREADS) gpsel[n0 + t] = 0;
+  } else {
+    for (int t = tid; t < n * 32; t += RD_THREADS) {
+      gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
+    }
   }
   for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
   if (tid < DGCNN_K) ga4s[tid] = 0.f;
@@ -282,6 +290,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
         [&](int sl, int c, float v) {
           if (sl < msel && c < DGCNN_CAT) {
             const int node = selS[sl];
+            if (gpsel && c == 0) gpsel[node] = 1;      // (behind several barriers of this workgroup: after the clearing store)
             if (c < 32) gp1[(size_t)node * 32 + c] = v;
             else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;
             else if (c < 96) gp3[(size_t)node * 32 + c - 64] = v;

@@ -1106,7 +1106,8 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
               const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ gas4,
               const float* __restrict__ W4, const float* __restrict__ W3, const float* __restrict__ x3,
               const float* __restrict__ gp3, const float* __restrict__ x2, const float* __restrict__ gp2,
-              float* __restrict__ gas2, float* __restrict__ pa4, int P1, float* __restrict__ pb3, int P32) {
+              float* __restrict__ gas2, float* __restrict__ pa4, int P1, float* __restrict__ pb3, int P32,
+              const int* __restrict__ gpsel) {
   using C = ChB<WAVES, MAXN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1201,7 +1202,12 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         // operands of the epilogue that do not depend on the product: requested first
         const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
         const float4 xa = *reinterpret_cast<const float4*>(x3 + ro), xb = *reinterpret_cast<const float4*>(x3 + ro + 16);
-        const float4 ga_ = *reinterpret_cast<const float4*>(gp3 + ro), gb_ = *reinterpret_cast<const float4*>(gp3 + ro + 16);
+        // (gpsel: the readout backward of a large batch writes the SortPooling-gradient rows of the SELECTED nodes only and
+        //  a per-node flag -- no 57 MB of zero rows written there and read back here; a row without the flag is garbage)
+        float4 ga_ = make_float4(0.f, 0.f, 0.f, 0.f), gb_ = ga_;
+        if (!gpsel || gpsel[n0 + min(m, n - 1)] != 0) {
+          ga_ = *reinterpret_cast<const float4*>(gp3 + ro); gb_ = *reinterpret_cast<const float4*>(gp3 + ro + 16);
+        }
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
         const unsigned short* hq = g4p + min(nl, 2) * C::ROWS + 4 * kq;
 #pragma unroll
@@ -1265,7 +1271,10 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         const bool ok = rv[ti];
         const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
         const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
-        const float4 ga_ = *reinterpret_cast<const float4*>(gp2 + ro), gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
+        float4 ga_ = make_float4(0.f, 0.f, 0.f, 0.f), gb_ = ga_;
+        if (!gpsel || gpsel[n0 + min(m, n - 1)] != 0) {
+          ga_ = *reinterpret_cast<const float4*>(gp2 + ro); gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
+        }
         // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
         const int mt = 16 * (wave + WAVES * ti);
         float xN[2][4];
@@ -1388,7 +1397,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __restrict__ nbig_p, const int* __restrict__ graph_ptr,
               const unsigned* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ gas2,
               const float* __restrict__ W2, const float* __restrict__ x1, const float* __restrict__ gp1, const float* __restrict__ axg,
-              float* __restrict__ pb2, float* __restrict__ pb1, int P32) {
+              float* __restrict__ pb2, float* __restrict__ pb1, int P32, const int* __restrict__ gpsel) {
   using C = ChB<WAVES, MAXN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1498,7 +1507,9 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
           const size_t ro = (size_t)(n0 + min(mm, n - 1));
           const float* xr = x1 + ro * 32 + nl;
           const float* gr = gp1 + ro * 32 + nl;
-          const float x0 = xr[0], x1v = xr[16], g0 = gr[0], g1 = gr[16];
+          float g0 = 0.f, g1 = 0.f;
+          if (!gpsel || gpsel[ro] != 0) { g0 = gr[0]; g1 = gr[16]; }
+          const float x0 = xr[0], x1v = xr[16];
           xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
           gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
 #pragma unroll
@@ -1737,7 +1748,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
 int dg_chain_bwd_max_nodes() { return CH_BWD_MAXN; }
 int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas4,
                           const float* W4, const float* W3, const float* x3, const float* gp3, const float* x2, const float* gp2,
-                          float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s) {
+                          float* gas2, float* pa4, int P1, float* pb3, int P32, int32_t* dmap, hipStream_t s, const int32_t* gpsel) {
   if (N <= 0 || B <= 0 || !graph_ptr || !bits || !dinv || !gas4 || !W4 || !W3 || !x3 || !gp3 || !x2 || !gp2 || !gas2 || !pa4 || !pb3 ||
       P1 <= 0 || P32 <= 0)
     return DGCNN_EINVAL;
@@ -1761,10 +1772,10 @@ int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t
   if (grid > P1) grid = P1;
   if (grid == B && B <= CH_ONESHOT_MAX_B) {
     hipLaunchKernelGGL((k_chain_bwd_a<16, false, CH_BWD_MAXN>), dim3(B), dim3(1024), CB16::TOTAL, s, N, B, (const int*)nullptr, (const int*)nullptr,
-                       graph_ptr, bits, dinv, gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32);
+                       graph_ptr, bits, dinv, gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32, gpsel);
   } else {
     hipLaunchKernelGGL((k_chain_bwd_a<8, true, CH_BWD_MAXN>), dim3(grid), dim3(512), CB8::TOTAL, s, N, B, sched, nbig, graph_ptr, bits, dinv,
-                       gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32);
+                       gas4, W4, W3, x3, gp3, x2, gp2, gas2, pa4, P1, pb3, P32, gpsel);
   }
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
@@ -1772,7 +1783,7 @@ int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t
 
 int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv, const float* gas2,
                           const float* W2, const float* x1, const float* gp1, const float* ax, float* pb2, float* pb1, int P32,
-                          int32_t* dmap, hipStream_t s) {
+                          int32_t* dmap, hipStream_t s, const int32_t* gpsel) {
   if (N <= 0 || B <= 0 || Fa < 1 || Fa > DG_AF_MAX_F || !graph_ptr || !bits || !dinv || !gas2 || !W2 || !x1 || !gp1 || !ax || !pb2 ||
       !pb1 || P32 <= 0)
     return DGCNN_EINVAL;
@@ -1793,7 +1804,7 @@ int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const 
   int grid = B < 512 ? B : 512;
   if (grid > P32) grid = P32;
 #define CH_LB(W, LP, NB, GRID, TOT, SCH, NBG) hipLaunchKernelGGL((k_chain_bwd_b<W, LP, CH_BWD_MAXN, NB>), dim3(GRID), dim3(64 * W), TOT, s, N, B, Fa, \
-    SCH, NBG, graph_ptr, bits, dinv, gas2, W2, x1, gp1, ax, pb2, pb1, P32)
+    SCH, NBG, graph_ptr, bits, dinv, gas2, W2, x1, gp1, ax, pb2, pb1, P32, gpsel)
   const int* none = nullptr;
   if (grid == B && B <= CH_ONESHOT_MAX_B) { if (Fa <= 16) CH_LB(16, false, 1, B, CB16::TOTAL, none, none); else CH_LB(16, false, 2, B, CB16::TOTAL, none, none); }
   else { if (Fa <= 16) CH_LB(8, true, 1, grid, CB8::TOTAL, sched, nbig); else CH_LB(8, true, 2, grid, CB8::TOTAL, sched, nbig); }

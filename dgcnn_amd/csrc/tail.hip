@@ -161,7 +161,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
            float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g,
            float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
            float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
-           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd) {
+           float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, DgPrepRider rd, int* gpsel) {
   DgRole role = dg_block_role((int)blockIdx.x, B, rd.nblk_b, false);
   // the rider block that also plans the next dense batch (dg_prep_dense_plan: ONE workgroup, ~8 us at 2048 graphs) trades
   // places with graph 0: dispatched first it runs beside the graph workgroups, dispatched last it was the launch's tail
@@ -181,7 +181,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
   if (dbg && threadIdx.x == 0) dbg[1024 + 4 * role.idx + 2] = wall_clock64();
 #endif
   dg_tail_bwd_body<BIG, false, HEAD>(role.idx, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, glogp, y, loss_scale, training,
-                                     dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg);
+                                     dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg, TbExt{}, gpsel);
 #ifdef RD_TIMING
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[1024 + 4 * role.idx + 3] = wall_clock64();
@@ -259,7 +259,7 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        const float* a1d, const float* logp, const float* glogp, const int64_t* y,
                        float loss_scale, int training, float* dlogit, float* gz1, float* gz6, float* gz5,
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
-                       const float* pooled, hipStream_t s, const DgPrepRider* rider, bool head) {
+                       const float* pooled, hipStream_t s, const DgPrepRider* rider, bool head, int32_t* gpsel) {
   if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
   if ((glogp == nullptr) == (y == nullptr)) return DGCNN_EINVAL;
   DgPrepRider rd{};
@@ -268,15 +268,15 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   if (!head)       // the classifier's backward ran batched over graphs: gz6 holds the gradient of conv6's output
     hipLaunchKernelGGL((k_tail_bwd<true, false>), dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
-                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd, gpsel);
   else if (B >= DG_TAIL_BIG_MIN_B && !nobig)
     hipLaunchKernelGGL(k_tail_bwd<true>, dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
-                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd, gpsel);
   else
     hipLaunchKernelGGL(k_tail_bwd<false>, dim3(B + rd.nblk_b), dim3(RD_THREADS), 0, s, B, C, dg_tail_w(params, pl), graph_ptr,
                        perm, dinv, x4, a5, a6, a1d, logp, glogp, y, loss_scale, training, dlogit, gz1, gz6, gz5, gp1, gp2,
-                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd);
+                       gp3, gas4, gb4p, lossv, ptail, pooled, dg_debug_buffer(), rd, gpsel);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }

@@ -40,15 +40,27 @@ def test_batched_classifier_forward_and_dropin_backward_vs_oracle(name, bs, C):
     check_backward_parity(m, b, sd)
 
 
-@pytest.mark.parametrize("name,bs,C", CASES, ids=[f"{c[0]}-{c[1]}-C{c[2]}" for c in CASES])
-def test_batched_classifier_training_step_vs_oracle(name, bs, C):
+STEP_CASES = [c + (False,) for c in CASES] + [("MUTAG", 300, 2, True), ("PROTEINS", 263, 2, True), ("COLLAB", 270, 3, True)]
+
+
+@pytest.mark.parametrize("name,bs,C,chain", STEP_CASES, ids=[f"{c[0]}-{c[1]}-C{c[2]}{'-chain' if c[3] else ''}" for c in STEP_CASES])
+def test_batched_classifier_training_step_vs_oracle(name, bs, C, chain):
     """the fused training step (labels in the kernel): batched classifier forward + backward, readout backward from its
-    gz6 -- loss, accuracy and every gradient against the fp64 oracle on the kernel's own dropout mask and permutation"""
+    gz6 -- loss, accuracy and every gradient against the fp64 oracle on the kernel's own dropout mask and permutation.
+    `chain`: the dense graph-chain kernels forced (the library takes them from ~28 k nodes on), whose large-batch backward
+    reads SPARSE SortPooling-gradient slabs (rows of the selected nodes + a flag per node)"""
     from dgcnn_amd.train import Trainer
     b_cpu = _batch(name, bs, C)
+    if chain:
+        start = 300
+        while b_cpu.max_nodes > 256:      # (the chain backward admits graphs of up to 256 nodes)
+            start += bs
+            b_cpu = synth.make_batch(name, bs, start=start)
     b = b_cpu.to("cuda")
     m = make_model(synth.SHAPES[name].num_features, C)
     sd = cpu_state_dict(m)
+    if chain:
+        m.agg_mode, m.use_chain = "dense", True
     m.train(); m._seed_base, m._fwd_count = 7, 0
     tr = Trainer(m)
     tr.reset_metrics()
