@@ -106,7 +106,8 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
   // lane (nl, kq): A = flat[graph nl][16j + 4kq + s], B = W1[unit 16 ut + nl][same k] for matrix step 4j + s of a half
   float w2r[NW2];
   {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // TWO accumulators (the x/z and the y/w k-slots): a chain of 88 dependent matrix instructions ran at half the pipe's rate
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     auto half_product = [&](int h) __attribute__((always_inline)) {
       const float* ar = fl + nl * CL_FS + (DGCNN_FLAT / 2) * h + 4 * kq;
       const float* br = wc + (16 * ut + nl) * CL_WS + 4 * kq;
@@ -115,9 +116,9 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
         const float4 a = *reinterpret_cast<const float4*>(ar + 16 * j);
         const float4 bq = *reinterpret_cast<const float4*>(br + 16 * j);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc2, 0, 0, 0);
       }
     };
 #pragma unroll
@@ -127,6 +128,7 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
     CL_STORE_HALF(wh1)
     dg_lds_barrier();
     half_product(1);
+    acc += acc2;
     const int u = 16 * ut + nl;                      // this lane: unit u of graphs 4kq .. 4kq + 3
     const float bu = b1s[u];
 #pragma unroll
@@ -260,22 +262,27 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
     const float* ar = gz1s + nl * CL_HS + 4 * kq;
 #pragma unroll
     for (int i = 0; i < 8; ++i) az[i] = *reinterpret_cast<const float4*>(ar + 16 * i);
+    // the wave's (up to) three column tiles advance together: three independent chains of 32 matrix instructions
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].x, bw[q][4 * i + 0], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].y, bw[q][4 * i + 1], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].z, bw[q][4 * i + 2], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].w, bw[q][4 * i + 3], acc[q], 0, 0, 0);
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       if (bt[q] >= 0) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].x, bw[q][4 * i + 0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].y, bw[q][4 * i + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].z, bw[q][4 * i + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(az[i].w, bw[q][4 * i + 3], acc, 0, 0, 0);
-        }
         const int m = 16 * bt[q] + nl;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int g = 4 * kq + r;
-          if (g < nb) gz6g[(size_t)(b0 + g) * DGCNN_FLAT + m] = fl[g * CL_FS + m] > 0.f ? acc[r] : 0.f;
+          if (g < nb) gz6g[(size_t)(b0 + g) * DGCNN_FLAT + m] = fl[g * CL_FS + m] > 0.f ? acc[q][r] : 0.f;
         }
       }
     }
