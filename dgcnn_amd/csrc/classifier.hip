@@ -30,9 +30,17 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
              float* __restrict__ logp, int training, uint64_t seed, const int64_t* __restrict__ y, float loss_scale,
              float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g, float* __restrict__ lossv,
              float* __restrict__ ptail, unsigned long long* dbg) {
-#define CL_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + (k)] = clock64(); } while (0)      // (slots 0..15 belong to the readout kernels)
+  // phase stamps: measurement builds only (-DCL_TIMING, tools/phase_classifier.py) -- they use slots 32..42 of the debug
+  // buffer, beyond the 16 words dgcnn_debug_phase_clocks promises to touch
+#ifdef CL_TIMING
+#define CL_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[32 + (k)] = clock64(); } while (0)
+#else
+#define CL_MARK(k) do { } while (0)
+#endif
   CL_MARK(0);
+#ifdef CL_TIMING
   if (dbg && threadIdx.x == 0) atomicMin(&dbg[41], wall_clock64());
+#endif
   __shared__ __attribute__((aligned(16))) float fl[CL_GB * CL_FS];       // conv6 outputs of the 16 graphs (ReLU mask of the way back)
   __shared__ __attribute__((aligned(16))) float a1s[CL_GB * CL_HS];      // classifier_1 outputs after ReLU / dropout
   __shared__ __attribute__((aligned(16))) float gz1s[CL_GB * CL_HS];     // gradient wrt classifier_1's pre-activation
@@ -288,7 +296,10 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
     }
   }
   CL_MARK(7);
+#ifdef CL_TIMING
   if (dbg && threadIdx.x == 0) { atomicMax(&dbg[40], wall_clock64()); if (blockIdx.x == 0) dbg[42] = wall_clock64(); }
+#endif
+  (void)dbg;
 #undef CL_MARK
 #undef CL_LOAD_HALF
 #undef CL_STORE_HALF

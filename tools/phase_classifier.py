@@ -1,4 +1,5 @@
-"""GPU-box helper: clock64() phase deltas of workgroup 0 / thread 0 of k_classifier (large batches)."""
+"""GPU-box helper (CL_TIMING build): clock64() phase deltas of workgroup 0 / thread 0 of k_classifier (large batches).
+   bash tools/build_variant.sh cltiming "-DCL_TIMING"; DGCNN_HIP_LIB=$PWD/dgcnn_amd/variants/lib_cltiming.so python tools/phase_classifier.py 2048"""
 import sys, torch
 sys.path.insert(0, ".")
 from dgcnn_amd import _lib, synth
