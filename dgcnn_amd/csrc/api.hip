@@ -539,7 +539,15 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // instead of 3 x 128 B of zeros for every other node (2048 COLLAB graphs: 57 MB less written by k_tail_bwd, 35 MB less read)
   int32_t* gpsel = (head_done && dense && bf.chain && F <= DG_AF_MAX_F) ? dg_ptr<int32_t>(ws, wl.h4s) : nullptr;
   const bool wg_rider = tail_done && rider_b && !dense && dg_wgrad_takes_rider(B);
-  if (!tail_done)
+  // large batches (two-stage weight gradients) behind the batched classifier, nothing riding: the walking form of the readout
+  // backward -- one conv5 / conv6 partial row per workgroup of DG_TAIL_WALK graphs
+  const bool walk = head_done && !rider_b && B > dg_wg_two_stage_b();
+  if (walk)
+    DG_TRY(dg_launch_tail_bwd_walk(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm), dinv, x4,
+                                   dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6), dg_ptr<float>(ws, wl.gz6),
+                                   dg_ptr<float>(ws, wl.gz5), gp1, gp2, gp3, gas4, dg_ptr<float>(ws, wl.gb4p),
+                                   dg_ptr<float>(ws, wl.ptail), dg_cptr<float>(ws, wl.pooled), s, gpsel));
+  else if (!tail_done)
   DG_TRY(dg_launch_tail_bwd(N, B, C, params, &pl, dg_cptr<int32_t>(ws, wl.graph_ptr), dg_cptr<int32_t>(ws, wl.perm),
                             dinv, x4, dg_cptr<float>(ws, wl.a5), dg_cptr<float>(ws, wl.a6),
                             dg_cptr<float>(ws, wl.a1d), logp, glogp, y, loss_scale, training,
@@ -612,7 +620,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
   DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s,
-                         wg_rider ? rider_b : nullptr));
+                         wg_rider ? rider_b : nullptr, walk ? dg_tail_walk_rows(B) : 0));
   return DGCNN_OK;
 }
 

@@ -523,13 +523,20 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
                        float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv, float* ptail,
                        const float* pooled, hipStream_t s, const struct DgPrepRider* rider = nullptr, bool head = true,
                        int32_t* gpsel = nullptr);
+// large batches behind the batched classifier: a workgroup walks several graphs, ONE partial row per workgroup (tail.hip)
+int dg_launch_tail_bwd_walk(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                            const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
+                            float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* ptail,
+                            const float* pooled, hipStream_t s, int32_t* gpsel = nullptr);
+int dg_tail_walk_rows(int B);
 struct DgAdam {          // optional optimizer step fused into the weight-gradient kernel
   float *params, *exp_avg, *exp_avg_sq;
   float lr, beta1, beta2, eps;
   int64_t step;
 };
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const struct DgPrepRider* rider = nullptr,
+                    int tail_rows = 0);
 int dg_wgrad_takes_rider(int B);
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
     float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
     float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{},
-    int* __restrict__ gpsel = nullptr) {
+    int* __restrict__ gpsel = nullptr, float* pacc = nullptr, bool pacc_first = true, int tid_in = -1) {
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
   // MERGED (k_readout_tail): conv5 / conv6 weights, the pooled rows and the log-probabilities are still in the forward
@@ -50,7 +50,9 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   __shared__ float ga4s[DGCNN_K];
   __shared__ int selS[DGCNN_K];
   __shared__ float x4S[DGCNN_K], dvS[DGCNN_K];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // (tid_in: a walking caller hands in an OPAQUE per-iteration copy of the thread index, so that nothing derived from it is
+  //  loop-invariant for the compiler to hoist out of the walk and spill)
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
@@ -161,6 +163,13 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   if (HEAD) dg_lds_barrier();
   // per-graph partial of classifier_2's weight gradient: dl[c] * a1d[j]  (and bias = dl[c])
   float* pt = ptail + (size_t)b * DG_PTAIL(C);
+  // pacc (large batches, a workgroup walks several graphs): the conv5 / conv6 weight-gradient partials are ACCUMULATED in an LDS
+  // row of the workgroup instead of stored per graph (every element is owned by the same lane for every graph: no race, and
+  // the graphs are added in their order)
+  auto put = [&](int idx, float v) {
+    if (pacc) pacc[idx] = pacc_first ? v : pacc[idx] + v;
+    else pt[idx] = v;
+  };
   if (HEAD) {
     for (int t = tid; t < C * DGCNN_HID1; t += RD_THREADS) {
       const int c = t / DGCNN_HID1, j = t - c * DGCNN_HID1;
@@ -256,27 +265,27 @@ __device__ __forceinline__ void dg_tail_bwd_body(
           mt * 16, nt * 16, 12, lane,
           [&](int oc, int t) { return t < DGCNN_T6 ? gz6s[oc * DGCNN_T6 + t] : 0.f; },
           [&](int t, int n) { return t < DGCNN_T6 ? p5s[(n / DGCNN_KW6) * DGCNN_T5 + t + (n % DGCNN_KW6)] : 0.f; },
-          [&](int oc, int n, float v) { pt[DG_PT_W6 + oc * (DGCNN_C5 * DGCNN_KW6) + n] = v; });
+          [&](int oc, int n, float v) { put(DG_PT_W6 + oc * (DGCNN_C5 * DGCNN_KW6) + n, v); });
     } else {
       const int nt = job - 10;
       dg_mfma_tile16(
           0, nt * 16, 32, lane,
           [&](int o, int sl) { return sl < DGCNN_K ? gz5s[o * DGCNN_K + sl] : 0.f; },
           [&](int sl, int m) { return (sl < DGCNN_K && m < DGCNN_CAT) ? sps[sl * DGCNN_CAT + m] : 0.f; },
-          [&](int o, int m, float v) { if (m < DGCNN_CAT) pt[DG_PT_W5 + o * DGCNN_CAT + m] = v; });
+          [&](int o, int m, float v) { if (m < DGCNN_CAT) put(DG_PT_W5 + o * DGCNN_CAT + m, v); });
     }
   }
   if (tid < DGCNN_C6) {
     float acc = 0.f;
 #pragma unroll
     for (int tt = 0; tt < DGCNN_T6; ++tt) acc += gz6s[tid * DGCNN_T6 + tt];
-    pt[DG_PT_B6 + tid] = acc;
+    put(DG_PT_B6 + tid, acc);
   }
   if (tid >= 512 && tid < 512 + DGCNN_C5) {
     const int o = tid - 512;
     float acc = 0.f;
     for (int sl = 0; sl < DGCNN_K; ++sl) acc += gz5s[o * DGCNN_K + sl];
-    pt[DG_PT_B5 + o] = acc;
+    put(DG_PT_B5 + o, acc);
   }
   TB_MARK(6);
   // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes

@@ -188,6 +188,37 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
 #endif
 }
 
+// Large batches behind the batched classifier: a workgroup WALKS `per` consecutive graphs and keeps the conv5 / conv6
+// weight-gradient partials of all of them in ONE LDS row, stored once at the end -- B / per partial rows instead of B (at 2048
+// graphs the per-graph rows were 37 MB written here and read back by k_wgrad), and B / per workgroup launches.  (A first
+// persistent form of this kernel spilled 100 registers at the 64-register budget of two workgroups per CU: every address
+// piece of the body is loop-invariant and was hoisted out of the walk.  The per-iteration opaque graph index below keeps
+// the body's arithmetic inside the iteration -- the fix found on the chain kernels.)
+#ifndef DG_TAIL_WALK
+#define DG_TAIL_WALK 4
+#endif
+__global__ void __launch_bounds__(RD_THREADS) __attribute__((amdgpu_waves_per_eu(8)))
+k_tail_bwd_walk(int B, int per, int C, TailW w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
+                const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
+                const float* __restrict__ a6g, float* __restrict__ gz6g, float* __restrict__ gz5g, float* __restrict__ gp1,
+                float* __restrict__ gp2, float* __restrict__ gp3, float* __restrict__ gas4, float* __restrict__ gb4p,
+                float* __restrict__ ptail, const float* __restrict__ pooled, int* gpsel) {
+  __shared__ float pacc[DG_PT_WF2];
+  const int b0 = (int)blockIdx.x * per;
+  for (int it = 0; it < per; ++it) {
+    int b = b0 + it, tl = (int)threadIdx.x;
+    asm volatile("" : "+s"(b));
+    asm volatile("" : "+v"(tl));
+    if (b >= B) break;
+    dg_tail_bwd_body<true, false, false>(b, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
+                                         nullptr, nullptr, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, nullptr, ptail, pooled, nullptr,
+                                         TbExt{}, gpsel, pacc, it == 0, tl);
+    __syncthreads();
+  }
+  float* row = ptail + (size_t)blockIdx.x * DG_PTAIL(C);
+  for (int t = threadIdx.x; t < DG_PT_WF2; t += RD_THREADS) row[t] = pacc[t];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Training steps with labels: readout forward and readout backward of a graph need nothing of any other graph (the
 // NLL-mean scale 1/B is a constant), so ONE launch runs both per graph -- one dispatch and one cold-read chain fewer
@@ -281,6 +312,18 @@ int dg_launch_tail_bwd(int N, int B, int C, const float* params, const DgParams*
   return DGCNN_OK;
 }
 
+int dg_tail_walk_rows(int B) { return dg_cdiv(B, DG_TAIL_WALK); }
+int dg_launch_tail_bwd_walk(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
+                            const int32_t* perm, const float* dinv, const float* x4, const float* a5, const float* a6,
+                            float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* ptail,
+                            const float* pooled, hipStream_t s, int32_t* gpsel) {
+  if (B <= 0 || N <= 0 || C < 1 || C > DGCNN_MAX_C) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_tail_bwd_walk, dim3(dg_tail_walk_rows(B)), dim3(RD_THREADS), 0, s, B, DG_TAIL_WALK, C, dg_tail_w(params, pl),
+                     graph_ptr, perm, dinv, x4, a5, a6, gz6, gz5, gp1, gp2, gp3, gas4, gb4p, ptail, pooled, gpsel);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradients: ONE launch whose workgroups are partitioned into segments (WgSeg), one per parameter tensor.
 //   WG_REDUCE_COL       out[c] = sum of R partial rows (per-workgroup partials of the GCN backward kernels, per-graph
@@ -301,6 +344,7 @@ struct WgSeg {
   int block0;        // first block of this segment
   int stride;        // WG_REDUCE_COL: floats between partial rows ; WG_METRIC: 2 ; *_CHUNK: row width
   int aux;           // *_CHUNK: total number of rows (graphs) being reduced, R = rows per chunk
+  int width;         // WG_REDUCE_CHUNK: columns summed per row (a window of `width` columns of rows `stride` floats apart)
   const float* src;  // partial rows / per-graph values being summed
   float* out;
 };
@@ -317,7 +361,7 @@ struct WgArgs {
 __device__ __forceinline__ float dg_wg_term(const WgArgs& A, const WgSeg& sg, int i, int r) {
   switch (sg.type) {
     case WG_REDUCE_CHUNK: {   // output i = chunk * width + column: partial sum of rows [chunk*R, chunk*R + R)
-      const int ch = i / sg.stride, col = i - ch * sg.stride, row = ch * sg.R + r;
+      const int ch = i / sg.width, col = i - ch * sg.width, row = ch * sg.R + r;
       return row < sg.aux ? sg.src[(size_t)row * sg.stride + col] : 0.f; }
     case WG_SUMB:   return sg.src[r];
     case WG_METRIC: return sg.src[(size_t)r * 2 + i];
@@ -420,7 +464,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     // (the generic path below issues them 16 at a time); same order of additions: (t[u] + t[u+16]) first, then the tree
     const int i = ((int)blockIdx.x - sg.block0) * 256 + (int)threadIdx.x;
     if (i < sg.count) {
-      const int ch = i / sg.stride, col = i - ch * sg.stride;
+      const int ch = i / sg.width, col = i - ch * sg.width;
       const float* sp = sg.src + (size_t)ch * 32 * sg.stride + col;
       const int nrow = min(32, sg.aux - ch * 32);
       float a[32];
@@ -513,7 +557,8 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
 // backward kernels).  The two halves can run on different streams.
 int dg_wgrad_takes_rider(int B) { return B <= dg_wg_two_stage_b() ? 1 : 0; }      // single-launch form only
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const DgPrepRider* rider) {
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const DgPrepRider* rider, int tail_rows) {
+  // tail_rows: rows of `ptail` that hold conv5 / conv6 partials (k_tail_bwd_walk: one per workgroup); 0 = one per graph
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
@@ -572,6 +617,9 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     const int st = DG_PTAIL(C);
     const float* pt = dg_cptr<float>(ws, wl->ptail);
     int Rt = B;                      // rows the final reduction of the per-graph tail partials runs over
+    const int TR = tail_rows > 0 ? tail_rows : B;      // rows holding the conv5 / conv6 columns [0, DG_PT_WF2)
+    int Rc = TR, stc = st;           // ... their final reduction length and row stride
+    const float* ptc = pt;
     if (!small) {
       // ---- large batches, stage 1 (own launch): per-graph partials -> per-chunk partials, fully coalesced and
       // with (columns x chunks) parallelism; classifier_1's GEMM split over K.  Fixed chunking -> deterministic.
@@ -585,37 +633,45 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       g0.type = WG_FC1W_MFMA_CHUNK; g0.count = nk * 8 * 22; g0.lpo = 64; g0.R = DG_WG_FC1_KCHUNK; g0.block0 = 0;
       g0.stride = 0; g0.aux = B; g0.src = nullptr; g0.out = t2;
       nb1 += dg_cdiv(g0.count, 4);
+      // the partial rows in two column windows: conv5 / conv6 (TR rows: per graph, or per walking workgroup) and classifier_2
+      // (always per graph, written by the classifier kernel); chunk sums laid out [chunks][window]
+      const int nchc = dg_cdiv(TR, DG_WG_ROWS_PER_CHUNK), wf2w = st - DG_PT_WF2;
+      float* t1c = t1;                                      // [nchc][DG_PT_WF2]
+      float* t1f = t1 + (size_t)nchc * DG_PT_WF2;           // [nch][wf2w]
       WgSeg& g1 = S.seg[1];
-      g1.type = WG_REDUCE_CHUNK; g1.count = nch * st; g1.lpo = 1; g1.R = DG_WG_ROWS_PER_CHUNK; g1.block0 = nb1;
-      g1.stride = st; g1.aux = B; g1.src = pt; g1.out = t1;
+      g1.type = WG_REDUCE_CHUNK; g1.count = nchc * DG_PT_WF2; g1.lpo = 1; g1.R = DG_WG_ROWS_PER_CHUNK; g1.block0 = nb1;
+      g1.stride = st; g1.width = DG_PT_WF2; g1.aux = TR; g1.src = pt; g1.out = t1c;
       nb1 += dg_cdiv(g1.count, 256);
-      auto chunked = [&](int k, const float* src, int width, float* out) {
+      auto chunked = [&](int k, const float* src, int width, float* out, int stride = 0) {
         WgSeg& g = S.seg[k];
         g.type = WG_REDUCE_CHUNK; g.count = nch * width; g.lpo = 1; g.R = DG_WG_ROWS_PER_CHUNK; g.block0 = nb1;
-        g.stride = width; g.aux = B; g.src = src; g.out = out;
+        g.stride = stride ? stride : width; g.width = width; g.aux = B; g.src = src; g.out = out;
         nb1 += dg_cdiv(g.count, 256);
       };
       chunked(2, A.gz1, DGCNN_HID1, t3_);
       chunked(3, dg_cptr<float>(ws, wl->lossv), 2, t4_);
       chunked(4, dg_cptr<float>(ws, wl->gb4p), 1, t5_);
-      S.nseg = 5;
+      chunked(5, pt + DG_PT_WF2, wf2w, t1f, st);
+      S.nseg = 6;
       static const bool s1a = dg_knob("DG_WG_S1_ONLY_MFMA"), s1b = dg_knob("DG_WG_S1_ONLY_REDUCE");      // (timing A/B, debug builds)
       if (s1a) { nb1 = g1.block0; S.nseg = 1; }
       if (s1b) { S.seg[0] = S.seg[1]; S.seg[0].block0 = 0; nb1 -= g1.block0; S.nseg = 1; }
       hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
       DG_CHECK_LAUNCH();
-      pt = t1; Rt = nch;
+      ptc = t1c; Rc = nchc; stc = DG_PT_WF2;
+      pt = t1f - DG_PT_WF2; Rt = nch;      // (so that pt + DG_PT_WF2 is the classifier_2 window of the chunk sums)
       add_col(DGCNN_HID1 * DGCNN_FLAT, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
     } else {
       add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                         // classifier_1 weight: MFMA GEMM
     }
     // conv5 / conv6 / classifier_2: k_tail_bwd left one partial per graph; sum the partials per element
-    add_col(DGCNN_C5 * DGCNN_CAT, Rt, grads + pl->off[8], pt + DG_PT_W5, st);
-    add_col(DGCNN_C5, Rt, grads + pl->off[9], pt + DG_PT_B5, st);
-    add_col(DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, Rt, grads + pl->off[10], pt + DG_PT_W6, st);
-    add_col(DGCNN_C6, Rt, grads + pl->off[11], pt + DG_PT_B6, st);
-    add_col(C * DGCNN_HID1, Rt, grads + pl->off[14], pt + DG_PT_WF2, st);
-    add_col(C, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, st);
+    const int stf = small ? st : st - DG_PT_WF2;      // row stride of the classifier_2 window
+    add_col(DGCNN_C5 * DGCNN_CAT, Rc, grads + pl->off[8], ptc + DG_PT_W5, stc);
+    add_col(DGCNN_C5, Rc, grads + pl->off[9], ptc + DG_PT_B5, stc);
+    add_col(DGCNN_C6 * DGCNN_C5 * DGCNN_KW6, Rc, grads + pl->off[10], ptc + DG_PT_W6, stc);
+    add_col(DGCNN_C6, Rc, grads + pl->off[11], ptc + DG_PT_B6, stc);
+    add_col(C * DGCNN_HID1, Rt, grads + pl->off[14], pt + DG_PT_WF2, stf);
+    add_col(C, Rt, grads + pl->off[15], pt + DG_PT_WF2 + C * DGCNN_HID1, stf);
     if (big1) add_col(DGCNN_HID1, nch_, grads + pl->off[13], t3_, DGCNN_HID1);
     else add(WG_FC1B, DGCNN_HID1, 64, B, grads + pl->off[13], nullptr, 0);
     if (metrics) {                                                                        // train.py:44-45 bookkeeping

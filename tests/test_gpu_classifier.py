@@ -119,3 +119,16 @@ def test_batched_classifier_bad_label_poisons_the_loss_and_is_reported():
     torch.cuda.synchronize()
     with pytest.raises(Exception):
         tr.read_metrics()
+
+
+def test_walking_readout_backward_and_column_window_sums_in_a_subprocess():
+    """Above DG_WG_TWO_STAGE_B (1024) graphs the readout backward of a fused training step WALKS four graphs per workgroup and
+    leaves one conv5 / conv6 partial row per workgroup (k_tail_bwd_walk), and k_wgrad sums the partial rows in two column
+    windows.  A child process lowers the threshold through the environment and runs this file's fused-step parity cases
+    (257..540 graphs, batch sizes that are and are not multiples of four, the forced chain cases with sparse slabs)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DG_WG_TWO_STAGE_B="128")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
+                          "training_step_vs_oracle or bad_label"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
