@@ -60,7 +60,9 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   DgStage<NW5, RD_THREADS> st5;
   DgStage<NW6, RD_THREADS> st6;
   DgStage<KCAT, RD_THREADS> stp;
-  if (!MERGED) { st5.load(w.W5, tid); st6.load(w.W6, tid); stp.load(pooled + (size_t)b * KCAT, tid); }
+  // (a walking caller stages conv5 / conv6's weights with its FIRST graph only: pacc_first; they stay in LDS for the others)
+  const bool stage_w = !pacc || pacc_first;
+  if (!MERGED) { if (stage_w) { st5.load(w.W5, tid); st6.load(w.W6, tid); } stp.load(pooled + (size_t)b * KCAT, tid); }
   float lp_ = -INFINITY, g_ = 0.f;          // step 1 operands (wave 0)
   int yb_ = 0;
   if (HEAD && wv == 0) {
@@ -104,7 +106,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
 #pragma unroll
     for (int j = 0; j < (BIG ? 1 : 16); ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
   }
-  if (!MERGED) { st5.store(W5s_own, tid); st6.store(W6s_own, tid); stp.store(sps_own, tid); }     // (waits only for the small loads above)
+  if (!MERGED) { if (stage_w) { st5.store(W5s_own, tid); st6.store(W6s_own, tid); } stp.store(sps_own, tid); }     // (waits only for the small loads above)
   // clear this graph's rows of the dense SortPooling-gradient slabs (scatter comes after barriers)
   // gpsel (large batches whose GCN backward is the chain kernels): instead of the zero rows -- 3 x 128 B per node, 57 MB of the
   // launch's 150 MB of HBM writes at 2048 COLLAB graphs -- one flag word per node; the rows of the <= 30 selected nodes are
