@@ -20,7 +20,7 @@ bash tools/kstats.sh ${T}_b2048_nopipeline --batch 2048 --pool 8 --no-pipeline >
 bash tools/kstats.sh ${T}_b2048 --batch 2048 --pool 8 > /dev/null
 bash tools/pmc.sh ${T}_b50 > $OUT/${T}_pmc_b50.txt 2>&1
 bash tools/pmc.sh ${T}_b2048 --batch 2048 > $OUT/${T}_pmc_b2048.txt 2>&1
-bash tools/pmc_sq.sh ${T}_b2048 "--batch 2048" "k_chain_fwd_q|k_chain_bwd_a|k_chain_bwd_b|k_classifier|k_readout_fwd|k_tail_bwd" > $OUT/${T}_sq_b2048.txt 2>&1
+bash tools/pmc_sq.sh ${T}_b2048 "--batch 2048" "k_chain_fwd_q|k_chain_bwd_a|k_chain_bwd_b|k_classifier|k_readout_fwd|k_tail_bwd_walk|k_wgrad" > $OUT/${T}_sq_b2048.txt 2>&1
 bash tools/pmc_sq.sh ${T}_b50 "" "k_chain_readout_tail|k_gcn_bwd32|k_gcn_bwd1|k_wgrad" > $OUT/${T}_sq_b50.txt 2>&1
 bash tools/pmc_sq.sh ${T}_bf16_b50 "--dtype bf16" "k_chain_fwd_q|k_readout_tail|k_gcn_bwd32|k_gcn_bwd1|k_wgrad" > $OUT/${T}_sq_bf16_b50.txt 2>&1
 ls -la $OUT | tail -30
