@@ -459,7 +459,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     }
     return;
   }
-  if (sg.type == WG_REDUCE_CHUNK && sg.R == 32) {
+  if (sg.type == WG_REDUCE_CHUNK && sg.R == 32 && !A.adam_p && sg.count > sg.width) {
     // stage 1 of the large-batch form: output i = (chunk, column) sums 32 consecutive rows; all 32 loads of a lane in flight
     // (the generic path below issues them 16 at a time); same order of additions: (t[u] + t[u+16]) first, then the tree
     const int i = ((int)blockIdx.x - sg.block0) * 256 + (int)threadIdx.x;
@@ -660,7 +660,16 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       DG_CHECK_LAUNCH();
       ptc = t1c; Rc = nchc; stc = DG_PT_WF2;
       pt = t1f - DG_PT_WF2; Rt = nch;      // (so that pt + DG_PT_WF2 is the classifier_2 window of the chunk sums)
-      add_col(DGCNN_HID1 * DGCNN_FLAT, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
+      if (nk <= 32) {
+        // few chunk rows (<= 4096 graphs): one lane per element, all nk loads in flight, the lane applies Adam -- 176 workgroups
+        // for the 45 k elements instead of 704 four-wave workgroups of which one wave owns the outputs (8.8 us alone)
+        WgSeg& g = A.seg[ns++];
+        g.type = WG_REDUCE_CHUNK; g.count = DGCNN_HID1 * DGCNN_FLAT; g.lpo = 1; g.R = nk; g.block0 = nb;
+        g.stride = DGCNN_HID1 * DGCNN_FLAT; g.width = DGCNN_HID1 * DGCNN_FLAT; g.aux = nk; g.src = t2; g.out = grads + pl->off[12];
+        nb += dg_cdiv(g.count, 256);
+      } else {
+        add_col(DGCNN_HID1 * DGCNN_FLAT, nk, grads + pl->off[12], t2, DGCNN_HID1 * DGCNN_FLAT);
+      }
     } else {
       add_tiles(WG_FC1W_MFMA, 8 * 22, grads + pl->off[12]);                         // classifier_1 weight: MFMA GEMM
     }
