@@ -432,9 +432,13 @@ __device__ __forceinline__ void dg_wg_fc1w_mfma(const WgArgs& A, const WgSeg& sg
   }
 }
 
+// S1: the stage-1 launch of large batches (chunk sums + split-K classifier_1 only).  Its own instantiation because the
+// column-reduction path's 64 loads in flight set the kernel's register count (212: two waves per SIMD) for every segment
+// type compiled into it; stage 1's ~1300 workgroups then ran in 2.5 rounds.
+template <bool S1>
 __global__ void __launch_bounds__(256)
 k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
-  if ((int)blockIdx.x >= nb_host) {   // rider range: phase B of the NEXT batch's graph preparation.  This launch is the
+  if (!S1 && (int)blockIdx.x >= nb_host) {   // rider range: phase B of the NEXT batch's graph preparation.  This launch is the
                                       // step's last and longest short kernel (7.4 us at batch 50): phase B (5 us alone)
                                       // disappears under it, whereas it stretched k_gcn_bwd1 from 4.8 to 6.1 us
     dg_prep_fast_b_body<256>(((int)blockIdx.x - nb_host) * 256 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
@@ -445,7 +449,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
   int si = 0;
   for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
   const WgSeg sg = A.seg[si];
-  if (sg.type == WG_FC1W_MFMA) {      // block-uniform branch: 4 waves = 4 tiles per workgroup
+  if (!S1 && sg.type == WG_FC1W_MFMA) {      // block-uniform branch: 4 waves = 4 tiles per workgroup
     const int tile = ((int)blockIdx.x - sg.block0) * 4 + (threadIdx.x >> 6);
     if (tile < 8 * 22) dg_wg_fc1w_mfma(A, sg, tile, threadIdx.x & 63, 0, A.B, nullptr);
     return;
@@ -478,7 +482,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     }
     return;
   }
-  if (sg.type == WG_REDUCE_COL) {
+  if (!S1 && sg.type == WG_REDUCE_COL) {
     // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS (every load instruction reads 256 contiguous bytes
     // of one partial row), rows dealt round-robin to the 4 waves, up to 64 loads in flight per lane, then a
     // fixed-order combine through LDS.  Lanes-along-rows (WG_REDUCE) touches one 128-B line per 16 useful bytes.
@@ -656,7 +660,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       static const bool s1a = dg_knob("DG_WG_S1_ONLY_MFMA"), s1b = dg_knob("DG_WG_S1_ONLY_REDUCE");      // (timing A/B, debug builds)
       if (s1a) { nb1 = g1.block0; S.nseg = 1; }
       if (s1b) { S.seg[0] = S.seg[1]; S.seg[0].block0 = 0; nb1 -= g1.block0; S.nseg = 1; }
-      hipLaunchKernelGGL(k_wgrad, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
+      hipLaunchKernelGGL(k_wgrad<true>, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
       DG_CHECK_LAUNCH();
       ptc = t1c; Rc = nchc; stc = DG_PT_WF2;
       pt = t1f - DG_PT_WF2; Rt = nch;      // (so that pt + DG_PT_WF2 is the classifier_2 window of the chunk sums)
@@ -697,16 +701,16 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
       const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4)
                      : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 64) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
-      hipLaunchKernelGGL(k_wgrad, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
+      hipLaunchKernelGGL(k_wgrad<false>, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
     }
     if (rider && rider->nblk_b > 0)       // (diagnostic mode: the rider as a launch of its own)
-      hipLaunchKernelGGL(k_wgrad, dim3(4 * rider->nblk_b), dim3(256), 0, s, A, *rider, 0);
+      hipLaunchKernelGGL(k_wgrad<false>, dim3(4 * rider->nblk_b), dim3(256), 0, s, A, *rider, 0);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
   DgPrepRider rd{};
   if (rider) rd = *rider;
-  hipLaunchKernelGGL(k_wgrad, dim3(nb + 4 * rd.nblk_b), dim3(256), 0, s, A, rd, nb);      // (nblk_b counts 1024-thread blocks)
+  hipLaunchKernelGGL(k_wgrad<false>, dim3(nb + 4 * rd.nblk_b), dim3(256), 0, s, A, rd, nb);      // (nblk_b counts 1024-thread blocks)
   DG_CHECK_LAUNCH();
   (void)N;
   return DGCNN_OK;
@@ -728,7 +732,7 @@ int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s) {
   A.nseg = nseg;
   A.grads_base = segs[0].out;
   if (nb == 0) return DGCNN_OK;
-  hipLaunchKernelGGL(k_wgrad, dim3(nb), dim3(256), 0, s, A, DgPrepRider{}, nb);
+  hipLaunchKernelGGL(k_wgrad<false>, dim3(nb), dim3(256), 0, s, A, DgPrepRider{}, nb);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
