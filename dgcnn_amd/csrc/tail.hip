@@ -484,7 +484,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
   }
   if (!S1 && sg.type == WG_REDUCE_COL) {
     // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS (every load instruction reads 256 contiguous bytes
-    // of one partial row), rows dealt round-robin to the 4 waves, up to 64 loads in flight per lane, then a
+    // of one partial row), rows dealt round-robin to the 4 waves, up to 32 loads in flight per lane, then a
     // fixed-order combine through LDS.  Lanes-along-rows (WG_REDUCE) touches one 128-B line per 16 useful bytes.
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -497,15 +497,21 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     const float* sp = sg.src + (live ? c : 0);
     const int R = sg.R, stride = sg.stride;
     float acc = 0.f;
-    for (int rb = w; rb < R; rb += 4 * 64) {
-      float a[64];
+    // DG_WG_COL_DEPTH loads in flight per lane.  32, not 64: the deeper form set the kernel's register count to 212 (two waves
+    // per SIMD) for every segment AND for the graph-preparation rider blocks of the same launch; at the reference's batch of
+    // 50: k_wgrad 9.0 -> 8.15 us (depth 16: 8.6), step 51.2 -> 50.4 us
+#ifndef DG_WG_COL_DEPTH
+#define DG_WG_COL_DEPTH 32
+#endif
+    for (int rb = w; rb < R; rb += 4 * DG_WG_COL_DEPTH) {
+      float a[DG_WG_COL_DEPTH];
 #pragma unroll
-      for (int u = 0; u < 64; ++u) {
+      for (int u = 0; u < DG_WG_COL_DEPTH; ++u) {
         const int r = rb + 4 * u;
         a[u] = (live && r < R) ? sp[(size_t)r * stride] : 0.f;
       }
 #pragma unroll
-      for (int st = 32; st >= 1; st >>= 1)
+      for (int st = DG_WG_COL_DEPTH / 2; st >= 1; st >>= 1)
 #pragma unroll
         for (int u = 0; u < st; ++u) a[u] += a[u + st];
       acc += a[0];
