@@ -483,14 +483,15 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     return;
   }
   if (!S1 && sg.type == WG_REDUCE_COL) {
-    // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS (every load instruction reads 256 contiguous bytes
-    // of one partial row), rows dealt round-robin to the 4 waves, up to 32 loads in flight per lane, then a
-    // fixed-order combine through LDS.  Lanes-along-rows (WG_REDUCE) touches one 128-B line per 16 useful bytes.
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = ((int)blockIdx.x - sg.block0) * 64 + lane;
+    // out[c] = sum_r src[r*stride + c], lanes along the COLUMNS: a workgroup takes 32 columns, its 4 waves x 2 half-waves are
+    // EIGHT row groups (every load instruction reads 2 x 128 contiguous bytes of two partial rows), rows dealt round-robin to
+    // the groups, up to 32 loads in flight per lane, then a fixed-order combine (half-waves by one shuffle, waves through LDS).
+    // Eight groups, not four: the 240 partial rows of the reference's batch of 50 are ONE round of 30 loads per lane.
+    __shared__ float red[4][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, cl = lane & 31, grp = 2 * w + half;
+    const int c = ((int)blockIdx.x - sg.block0) * 32 + cl;
     const bool live = c < sg.count;
-    const bool owner = live && w == 0;
+    const bool owner = live && w == 0 && half == 0;
     float pm = 0.f, pv = 0.f, pp = 0.f;
     const size_t k = (size_t)(sg.out - A.grads_base) + (live ? c : 0);
     if (owner && A.adam_p) { pm = A.adam_m[k]; pv = A.adam_v[k]; pp = A.adam_p[k]; }   // optimizer state: same round trip
@@ -503,11 +504,11 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
 #ifndef DG_WG_COL_DEPTH
 #define DG_WG_COL_DEPTH 32
 #endif
-    for (int rb = w; rb < R; rb += 4 * DG_WG_COL_DEPTH) {
+    for (int rb = grp; rb < R; rb += 8 * DG_WG_COL_DEPTH) {
       float a[DG_WG_COL_DEPTH];
 #pragma unroll
       for (int u = 0; u < DG_WG_COL_DEPTH; ++u) {
-        const int r = rb + 4 * u;
+        const int r = rb + 8 * u;
         a[u] = (live && r < R) ? sp[(size_t)r * stride] : 0.f;
       }
 #pragma unroll
@@ -516,10 +517,11 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
         for (int u = 0; u < st; ++u) a[u] += a[u + st];
       acc += a[0];
     }
-    red[w][lane] = acc;
+    acc += __shfl_xor(acc, 32);
+    if (half == 0) red[w][cl] = acc;
     __syncthreads();
     if (owner) {
-      const float g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      const float g = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
       sg.out[c] = g;
       if (A.adam_p) {
         const float mi = A.b1 * pm + (1.f - A.b1) * g;
@@ -590,7 +592,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     WgSeg& g = A.seg[ns++];
     g.type = WG_REDUCE_COL; g.count = count; g.lpo = 1; g.R = R; g.block0 = nb; g.stride = stride; g.aux = 0;
     g.src = src; g.out = out;
-    nb += dg_cdiv(count, 64);
+    nb += dg_cdiv(count, 32);
   };
   auto add_tiles = [&](int type, int tiles, float* out) {     // one wave per tile, 4 tiles per workgroup
     WgSeg& g = A.seg[ns++];
@@ -706,7 +708,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       WgArgs One = A;
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
       const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4)
-                     : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 64) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
+                     : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 32) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
       hipLaunchKernelGGL(k_wgrad<false>, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
     }
     if (rider && rider->nblk_b > 0)       // (diagnostic mode: the rider as a launch of its own)
@@ -733,7 +735,7 @@ int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s) {
     WgSeg& g = A.seg[k];
     g.type = WG_REDUCE_COL; g.count = segs[k].count; g.lpo = 1; g.R = segs[k].R; g.block0 = nb; g.stride = segs[k].stride;
     g.aux = 0; g.src = segs[k].src; g.out = segs[k].out;
-    nb += dg_cdiv(segs[k].count, 64);
+    nb += dg_cdiv(segs[k].count, 32);
   }
   A.nseg = nseg;
   A.grads_base = segs[0].out;
