@@ -357,6 +357,34 @@ def test_pipelined_step_gives_identical_training(name, total, bs):
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
 
 
+def test_pipelined_epochs_with_mixed_batch_sizes_cross_the_side_stream_threshold():
+    """epochs whose batches alternate between the side-stream route (>= 512 graphs) and the rider route (short last batch,
+    small batches): the look-ahead preparation of a batch may come from either, whatever the size of the step it overlaps
+    with -- parameters and metrics identical to the un-pipelined steps, bit for bit, over two epochs"""
+    from dgcnn_amd.train import Trainer
+    from dgcnn_amd.batch import collate
+    sh = synth.SHAPES["MUTAG"]
+    graphs = synth.make_graphs("MUTAG", 1500, start=7000)
+    cuts = [0, 600, 1200, 1250, 1500]                       # 600 (side), 600 (side), 50 (riders), 250 (riders)
+    batches = [collate(graphs[a:b]).to("cuda") for a, b in zip(cuts[:-1], cuts[1:])]
+    outs = []
+    for pipelined in (False, True):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 9, 0
+        tr = Trainer(m)
+        for _ in range(2):
+            if pipelined:
+                tr.train_epoch(batches, 1500)
+            else:
+                tr.reset_metrics()
+                for b in batches:
+                    tr.train_step(b, b.y)
+        torch.cuda.synchronize()
+        m.check_errors()
+        outs.append((m.flat_params.clone(), tr.metrics.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_pipelined_step_without_rider_fast_path_prepares_in_stream():
     """general edge lists (no coalesced_undirected promise) and edge-less batches cannot ride; the next batch is then
     prepared in-stream after the step -- same results as the unpipelined calls."""
