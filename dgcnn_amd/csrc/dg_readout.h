@@ -22,10 +22,13 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
   const int tid = threadIdx.x, T = blockDim.x;
   const int m = n < DGCNN_K ? n : DGCNN_K;
   if (tid < DGCNN_K) sel[tid] = -1;
-  __syncthreads();
+  // (LDS-only barriers in this path: nothing here depends on an outstanding global store -- a caller whose workgroup wrote
+  //  the keys itself hands in an LDS copy -- so a workgroup's pending row stores drain while it ranks, up to the barrier at the
+  //  end, which the gather of those rows needs anyway)
   if (n <= 256) {
+    dg_lds_barrier();
     if (tid < n) keys[tid] = dg_pack_key(x4[n0 + tid], tid);
-    __syncthreads();
+    dg_lds_barrier();
     if (tid < n) {
       const unsigned long long my = keys[tid];
       int rank = 0;
@@ -33,6 +36,7 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
       if (rank < DGCNN_K) sel[rank] = tid;
     }
   } else {
+    __syncthreads();
     // (graphs of up to SP_LDS_KEYS / 2 nodes keep their packed keys in LDS; larger ones -- DD's 5748-node graph -- re-pack them
     //  from the L2-resident key column in every pass: 4 + 1 scans instead of the 30 scans of a k-round selection, which took
     //  88 us for that graph, or the ~78 barrier-separated passes of a 4096-key bitonic sort)

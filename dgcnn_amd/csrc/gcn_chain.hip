@@ -454,7 +454,9 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
               const unsigned* __restrict__ bits,
               const float* __restrict__ dinv, const float* __restrict__ xs, const ChW& gw, float* __restrict__ axg,
               float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4,
-              unsigned long long* __restrict__ dbg) {
+              unsigned long long* __restrict__ dbg, float* x4_lds = nullptr) {
+  // x4_lds (the one-launch training kernel): conv4's outputs are ALSO left in LDS, indexed by local node -- they are the
+  // SortPooling keys the same workgroup reads next, and from LDS it need not wait for its own global stores to land first
   using C = ChQ<WAVES, W1S, MAXN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -884,7 +886,11 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
           const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            if (mm + rr < n) x4[n0 + mm + rr] = dg_tanh(fmaf(dd[rr], (a4[ti][rr] + s1[ti][rr]) + s2[ti][rr], b4s));
+            if (mm + rr < n) {
+              const float xv = dg_tanh(fmaf(dd[rr], (a4[ti][rr] + s1[ti][rr]) + s2[ti][rr], b4s));
+              x4[n0 + mm + rr] = xv;
+              if (x4_lds) x4_lds[mm + rr] = xv;
+            }
         }
       }
     }
@@ -1023,9 +1029,13 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   }
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
   if (threadIdx.x == 0 && graph_ptr[blockIdx.x + 1] - graph_ptr[blockIdx.x] > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
-  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, nullptr);
-  __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
+  // (the keys' LDS copy lives in the unused second parity set of the dinv array: beyond the readout's LDS plan, which aliases
+  //  the images, and untouched until conv4's backward at the end of this kernel reads the FIRST set)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* keys_lds = reinterpret_cast<float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV) + ChQ<16, W1S, CH_TRAIN_MAXN>::ROWS;
+  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, nullptr,
+                                                   keys_lds);
+  __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
   TbExt ext;
   {
     const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
@@ -1036,7 +1046,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
-    dg_readout_fwd_body(M, b, n0, n, t.C, t.w, x4, n0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
+    dg_readout_fwd_body(M, b, n0, n, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
                         t.training, t.seed, dbg);
   }
   __syncthreads();
