@@ -248,7 +248,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     }
   }
   st5.store(W5s, tid); st6.store(W6s, tid);
-  __syncthreads();
+  dg_lds_barrier();      // (LDS only: nothing below reads what this workgroup stored to global memory -- the pooled rows, perm)
   RD_MARK(9);
   // classifier_1's weights (180 KB, rewritten by the optimizer every step, so never cache-warm) are this
   // kernel's longest memory wait.  VMEM loads complete in order, so they are issued only NOW -- after every
@@ -365,7 +365,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
       maskg[(size_t)b * DGCNN_HID1 + j] = keep;
     }
   }
-  __syncthreads();
+  dg_lds_barrier();
   RD_MARK(12);
   // classifier_2: 128 -> C, wave per class
   for (int c = wv; c < C; c += RD_THREADS / 64) {
@@ -376,7 +376,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     acc = dg_wave_sum(acc);
     if (lane == 0) lg[c] = acc + bs[176 + c];
   }
-  __syncthreads();
+  dg_lds_barrier();
   // log_softmax over C (C <= 64): wave 0
   if (wv == 0) {
     const float v = lane < C ? lg[lane] : -INFINITY;
