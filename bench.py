@@ -15,8 +15,10 @@ Inputs (x, edge_index, batch, y of every batch) are resident in HBM before the t
 
 Timing protocol: W untimed warm-up steps, then the K-step timed loop -- bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks -- is REPEATED until at least
-``--min-seconds`` (3 s: long enough for an outside GPU-busy sampler to see the work) of timed work exists (at least 3 repeats); ``ms_per_step`` / ``value`` are the
-MEDIAN repeat (every repeat's ms/step is listed under "repeats_ms_per_step").
+``--min-seconds`` (8 s: long enough for an outside 5-second GPU-busy sampler to see the work) of timed work exists (at
+least 3 repeats); ``ms_per_step`` / ``value`` are the MEDIAN repeat; the spread is summarised under "repeats_ms_per_step"
+(count, min, p10, median, p90, max -- never the full list: the result line must stay below 6 KB whatever --steps is, so
+that a driver reading the tail of stdout can parse it; tests/test_abi_and_host.py asserts the bound).
 
 Scaling modes (BASELINE config 5 asks for both):
   --scaling weak   (default) every GPU trains ``--batch`` graphs per step (per-GPU work fixed)
@@ -68,7 +70,7 @@ def parse(argv=None):
     ap.add_argument("--pool", type=int, default=40, help="distinct batches resident in HBM per GPU")
     ap.add_argument("--stress-nodes", type=int, default=0,
                     help="force the FIRST graph of every batch to this many nodes (SURVEY D2 item 4: DD with its 5748-node graph)")
-    ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed loop until this much is timed")
+    ap.add_argument("--min-seconds", type=float, default=8.0, help="repeat the K-step timed loop until this much is timed")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE config 3's secondary leg (hs stored bf16, X.W on bf16 MFMA); never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,6 +88,12 @@ def parse(argv=None):
     ap.add_argument("--exchange", choices=["auto", "rccl", "oneshot"], default="auto",
                     help="gradient exchange when --gpus > 1: RCCL all_reduce + Adam launch, or the one-shot peer-memory kernel "
                          "(dgcnn_allreduce_adam_step); auto = one-shot if it sets up and the replicas verify identical, else RCCL")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in route timing (reference loop body verbatim)")
+    ap.add_argument("--prep", choices=["per_batch", "dataset"], default="per_batch",
+                    help="per_batch (headline): every step prepares its batch's graph structures from the int64 edge_index; "
+                         "dataset: batches are drawn from a DeviceDataset whose per-graph structures were prepared once (SURVEY N3)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "",
+                    help="where the long-form notes (also printed on stderr) are written")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-exchange", action="store_true", help=argparse.SUPPRESS)     # child job: try the one-shot exchange, exit 0 / 3
     return ap.parse_args(argv)
@@ -105,8 +113,15 @@ def algorithmic_bytes_chain_fwd(N: int, E_noself: int) -> int:
     return 3 * algorithmic_bytes_agg(N, E_noself, 32) + algorithmic_bytes_agg(N, E_noself, 1)
 
 
+def algorithmic_bytes_sortpool(N: int, B: int, rows: int, s: int = 4) -> int:
+    """SURVEY.md §8(d) D4, sort-pool: 4*N (keys) + 4*(B+1) + s*97*sum_g min(n_g,k) (gather) + s*2910*B (write);
+    `rows` = sum over the batch's graphs of min(n_g, 30)."""
+    return 4 * N + 4 * (B + 1) + s * 97 * rows + s * 2910 * B
+
+
 def algorithmic_bytes_readout_tail(N: int, B: int, C: int) -> int:
-    """SURVEY D4 sort-pool model + the dense tail, forward and backward in the one k_readout_tail launch: keys 4N, graph
+    """NOT a SURVEY figure (reported as `frac_with_tail_model` only): sort-pool model + the dense tail, forward and
+    backward in the one k_chain_readout_tail launch: keys 4N, graph
     pointers, the gathered rows 4*97*30*B, pooled [B,2910] written (forward) and read (backward), the tail weights
     (conv5, conv6, classifier_1, classifier_2: read by both halves, L2-resident), saved activations (conv5 480, conv6 352,
     fc1 128 floats per graph) written and read, per-graph weight-gradient partials written, and the SortPooling gradient
@@ -143,21 +158,23 @@ def cpu_baseline(batches_cpu, F, C):
     B = batches_cpu[0].num_graphs
     table = {}
     t_begin = time.perf_counter()
-    for th in (1, 4, 8, 16, 32):
-        if th > ncpu:
-            continue
+    cand = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})     # up to os.cpu_count()
+    for th in cand:
+        if time.perf_counter() - t_begin > 45.0:      # bounded sample: the counts not reached are named in "sample"
+            break
         torch.set_num_threads(th)
         k = 0
         for _ in range(5):
             ref_ops.train_step(model, opt, batches_cpu[k % n], batches_cpu[k % n].y); k += 1
         ts = []
+        t_th = time.perf_counter()
         for _ in range(30):
             b = batches_cpu[k % n]; k += 1
             t0 = time.perf_counter()
             ref_ops.train_step(model, opt, b, b.y)
             ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_begin > 60.0 and len(ts) >= 10:     # hard bound on a very slow host
-                break
+            if (time.perf_counter() - t_begin > 60.0 or time.perf_counter() - t_th > 8.0) and len(ts) >= 10:     # hard bounds (slow host /
+                break                                                                  # oversubscribed thread count)
         table[th] = statistics.median(ts)
     cores = min(table, key=table.get)
     el = time.perf_counter() - t_begin
@@ -165,10 +182,11 @@ def cpu_baseline(batches_cpu, F, C):
             "value_1_thread": B / table[1],
             "ms_per_step": 1e3 * table[cores],
             "ms_per_step_by_threads": {str(k): round(v * 1e3, 2) for k, v in table.items()},
-            "sample": f"median of 30 sustained training steps (fwd+NLL+bwd+Adam; 5 warm-up) per thread count "
-                      f"{sorted(table)} of oracle/ref_ops.py -- a torch-CPU restatement of the reference op sequence, "
-                      f"NOT PyG itself (unavailable) -- on the same synthetic batches of {B} graphs; best sustained = "
-                      f"{cores} threads; {el:.1f} s of CPU work in total; torch {torch.__version__}; host has {ncpu} logical CPUs"}
+            "host_logical_cpus": ncpu,
+            "sample": f"median of <=30 sustained steps (fwd+NLL+bwd+Adam; 5 warm-up) per thread count {sorted(table)}"
+                      f"{'' if len(table) == len(cand) else ' (time bound hit before ' + str([t for t in cand if t not in table]) + ')'} of "
+                      f"oracle/ref_ops.py (torch-CPU restatement of the reference ops, NOT PyG) on the same batches of {B} graphs; "
+                      f"{el:.1f} s of CPU work; torch {torch.__version__}"}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -266,6 +284,103 @@ def committed_pmc_traffic(B):
         except Exception:                                     # noqa: BLE001
             continue
     return None, None, None
+
+
+RESULT_LINE_MAX = 6000     # bytes: the driver parses the TAIL of stdout (BENCH_r03: a 27 KB line was cut and lost)
+DETAIL = {}                # long-form notes: printed as one JSON object on stderr (and --detail-file), never on the result line
+
+
+def summarize_repeats(reps, steps):
+    """spread of the repeats of the K-step timed loop, in ms per step: a fixed-size summary, never the list"""
+    v = sorted(1e3 * r / steps for r in reps)
+    q = lambda f: v[min(len(v) - 1, int(f * len(v)))]      # noqa: E731
+    return {"count": len(v), "min": round(v[0], 5), "p10": round(q(0.10), 5), "median": round(statistics.median(v), 5),
+            "p90": round(q(0.90), 5), "max": round(v[-1], 5)}
+
+
+def build_result(args, reps, *, gb, world, strong, share, F, C, nb, Bavg, avgN, avgE, exchange, loss_mean, correct_frac,
+                 extra=None, roofline=None, roofline_large=None, cpu=None, dropin=None):
+    """the ONE result line (as a dict): contract fields + roofline + cpu_baseline; fixed size whatever --steps / --min-seconds"""
+    el = statistics.median(reps)
+    value = args.steps * gb / el
+    per_gpu = f"batch_size={args.batch} per GPU" if not strong else f"global batch {gb} sharded over {world} GPU(s)"
+    head = args.workload == "COLLAB" and not strong and args.batch == 50 and args.dtype == "f32"
+    out = {
+        "metric": "graphs/sec fwd+bwd (+Adam step), COLLAB-shape batch=50 per GPU" if head
+                  else f"graphs/sec fwd+bwd (+Adam step), {args.workload}-shape, {per_gpu}" + ("" if args.dtype == "f32" else f", {args.dtype} leg"),
+        "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * el / args.steps, 6), "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "repeats": len(reps), "repeats_ms_per_step": summarize_repeats(reps, args.steps),
+        "timed_seconds_total": round(sum(reps), 3),
+        "timing": "median repeat of the K-step timed loop (each bracketed by barrier + synchronize, max over ranks)",
+        "config": {"workload": (f"{args.workload}-shape synthetic graphs (SURVEY 8(d) D2 cfg: n~N(75,30) clip[32,492], "
+                                f"mean degree ~37, F={F}, C={C})" if args.workload == "COLLAB" else
+                                f"{args.workload}-shape synthetic graphs (F={F}, C={C})") +
+                               (f", first graph of every batch forced to {args.stress_nodes} nodes" if args.stress_nodes else "") +
+                               f", {per_gpu}, {nb} distinct resident batches per GPU",
+                   "global_batch": gb, "avg_graphs_per_rank_per_step": Bavg, "avg_nodes_per_batch": avgN,
+                   "avg_directed_edges_per_batch": avgE,
+                   "parallelism": f"dp{world}" + (" (all ranks on ONE device over gloo: functional check only)" if share else ""),
+                   "gradient_exchange": {"none": "single GPU: Adam fused into the weight-gradient kernel",
+                                         "oneshot": "one-shot peer-memory kernel (rank-ordered sum over hipIpc-mapped gradients + Adam)",
+                                         "rccl": "RCCL all_reduce of the flat 208 KB gradient + dgcnn_adam_step"}[exchange["mode"]] +
+                                        ((" -- " + exchange["note"][:200]) if exchange["note"] else ""),
+                   "prep": args.prep,
+                   "step": "forward + NLL(mean) + backward + fused Adam + zero_grad (+1 flat gradient all-reduce when dp>1); " +
+                           ("graph prep (CSR build from int64 edge_index) of every batch inside the timed region" if args.prep == "per_batch"
+                            else "batches drawn from a DeviceDataset whose per-graph structures were prepared once")},
+        "train_loss_mean": round(loss_mean, 6), "correct_frac": round(correct_frac, 5),
+    }
+    out.update(extra or {})
+    if roofline is not None:
+        out["roofline"] = roofline
+    if roofline_large is not None:
+        out["roofline_large_batch"] = roofline_large
+    if dropin is not None:
+        out["dropin"] = dropin
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 2)
+        out["speedup_vs_cpu_port_1_thread"] = round(value / cpu["value_1_thread"], 2)
+    return out
+
+
+def dropin_loop_us(Model, F, C, batches, dev, K=200):
+    """the reference's loop body VERBATIM (/root/reference/train.py:36-45: forward, NLLLoss, backward, optimizer.step(),
+    zero_grad, two .item() syncs) around this build's Model -- the "drops into train.py unchanged" route, next to the fused
+    Trainer route the headline times.  us per step for torch.optim.Adam and for the one-import change dgcnn_amd.optim.Adam."""
+    import torch
+    from torch import nn
+    from dgcnn_amd.optim import Adam as FlatAdam
+    res = {}
+    for name, mk in (("unchanged_loop_us", lambda m: torch.optim.Adam(m.parameters())),
+                     ("with_dgcnn_amd_optim_adam_us", lambda m: FlatAdam(m.parameters()))):
+        torch.manual_seed(324)
+        m = Model(F, C).to(dev)
+        m.train()
+        opt, crit = mk(m), nn.NLLLoss()
+
+        def loop(n):
+            running, correct = 0.0, 0
+            for i in range(n):
+                data = batches[i % len(batches)]
+                pred = m(data)
+                loss = crit(pred, data.y)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                running += loss.item()
+                correct += (pred.argmax(dim=1) == data.y).sum().item()
+            return running, correct
+        loop(30)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        loop(K)
+        torch.cuda.synchronize(dev)
+        res[name] = round(1e6 * (time.perf_counter() - t0) / K, 1)
+    res["steps"] = K
+    return res
 
 
 def main():
@@ -475,7 +590,7 @@ def main():
             b = batches[i % nb]
             tr.forward_backward(b, b.y, global_batch=gb)
         torch.cuda.synchronize(dev)
-        extra["fwd_bwd_only_graphs_per_s_rank0"] = n2 * Bavg / (time.perf_counter() - t1)
+        extra["fwd_bwd_only_graphs_per_s_rank0"] = round(n2 * Bavg / (time.perf_counter() - t1), 1)
 
     def measure_agg(trainer, bl, bl_cpu, nprof):
         """HIP events attached to the 32-wide aggregation dispatches (conv2 / conv3 round robin; conv1 too when F > 32)"""
@@ -494,6 +609,7 @@ def main():
             fl = mflags | (_lib.FLAG_COALESCED_UNDIRECTED if getattr(b, "coalesced_undirected", False) else 0)
             return L.dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, F, fl, int(b.max_nodes or 0))
         chain_n, tail_n = 0, [0]
+        sp_rows = [int(torch.bincount(b.batch, minlength=b.num_graphs).clamp(max=30).sum()) for b in bl_cpu]
         for i in range(nprof):
             a, bb = ev(), ev()
             which = 1 + i % 2 if F <= 32 else i % 3
@@ -504,15 +620,17 @@ def main():
             ch = 2 if (fm & 4 and not use_dist) else (1 if fm & 2 else 0)     # 2: the one-launch chain + readout training kernel
             chain_n += 1 if ch else 0
             tail_n[0] += 1 if ch == 2 else 0
-            pairs.append((a, bb, b.num_nodes, b.num_edges, ch))
+            pairs.append((a, bb, b.num_nodes, b.num_edges, ch, sp_rows[i % len(bl)]))
         torch.cuda.synchronize(dev)
-        tot_us = tot_bytes = tot_extra = 0.0
-        for k, (a, bb, n_, e_, ch) in enumerate(pairs):
+        tot_us = tot_bytes = tot_extra = tot_tailmodel = 0.0
+        for k, (a, bb, n_, e_, ch, spr) in enumerate(pairs):
             _lib.check(L.dgcnn_event_elapsed_ms(a, bb, ctypes.byref(ms)), "event_elapsed")
             tot_us += ms.value * 1e3
+            # SURVEY §8(d) D4 only: the aggregation calls of the launch (+ D4's sort-pool figure when the launch holds the readout)
             tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else \
-                (algorithmic_bytes_chain_fwd(n_, e_) + (algorithmic_bytes_readout_tail(n_, Bl, C) if ch == 2 else 0)
+                (algorithmic_bytes_chain_fwd(n_, e_) + (algorithmic_bytes_sortpool(n_, Bl, spr) if ch == 2 else 0)
                  if ch else algorithmic_bytes_agg(n_, e_))
+            tot_tailmodel += (algorithmic_bytes_chain_fwd(n_, e_) + algorithmic_bytes_readout_tail(n_, Bl, C)) if ch == 2 else 0.0
             # the next layer's pre-scaled linear output this launch also writes (not part of SURVEY's one-layer model):
             # [N,32] fp32 behind conv1 / conv2, [N] behind conv3
             which = 1 + k % 2 if F <= 32 else k % 3
@@ -524,24 +642,34 @@ def main():
         FUSED_EXTRA["bytes"] = tot_extra / len(pairs)
         FUSED_EXTRA["chain_frac"] = chain_n / len(pairs)
         FUSED_EXTRA["tail_frac"] = tail_n[0] / len(pairs)
+        FUSED_EXTRA["tail_model_bytes"] = tot_tailmodel / len(pairs)
         return fused, avg_us, bytes_per_launch, achieved, len(pairs)
 
-    kernel_note = ("32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA; the library picks per batch between the "
-                   "CSR-gather forms (k_gcn_fwd32 / k_gcn_fwd32p) and the dense per-graph block form on the matrix cores "
-                   "(k_gcn_fwd32d)")
-    chain_note = ("k_chain_fwd_q (gcn_chain.hip): conv1..conv4 of every graph inside one persistent workgroup -- FOUR aggregation "
-                  "calls per launch as dense block products on v_mfma_f32_16x16x32_bf16 (exact in fp32 via the bf16x3 split) "
-                  "from the bit-packed adjacency, the pre-scaled linear outputs resident in LDS (transpose-read layout), "
-                  "next X.W on the fp32 matrix cores; graphs dealt from a sorted static schedule")
-    tail_note = ("k_chain_readout_tail (gcn_chain.hip): the graph-chain forward (conv1..conv4, four aggregation calls: see "
-                 "k_chain_fwd_q) AND the SortPooling readout + dense tail, forward and backward, of one graph per 16-wave "
-                 "workgroup in ONE launch -- the step's dominant kernel by time at this batch size")
-    byte_note_agg = "compulsory-traffic model 4E~+4(N+1)+4N+2*4*N*32 per aggregation call (SURVEY D4)"
-    byte_note_chain = ("SURVEY D4's per-call model x the FOUR aggregation calls one launch processes (F = 32, 32, 32, 1: 106 KB per "
-                       "COLLAB-cfg graph).  The launch's real HBM traffic (`traffic`) is far BELOW this figure -- that is the "
-                       "point of the kernel: hs_2, hs_3, h4s never leave the CU and the adjacency is read once as a bitmap -- so "
-                       "`frac` measures work per time on the survey's byte model, not bytes actually moved; "
-                       "`frac_of_peak_on_measured_traffic` is the physical bandwidth fraction")
+    # Long-form explanations live in DETAIL (one JSON object on STDERR + --detail-file); the result line carries numbers
+    # and short names only, so that it stays below RESULT_LINE_MAX bytes.
+    DETAIL["kernels"] = {
+        "k_chain_readout_tail": "gcn_chain.hip: graph-chain forward (conv1..conv4 = four aggregation calls, dense block products on "
+                                "v_mfma_f32_16x16x32_bf16, exact in fp32 via the bf16x3 split) AND SortPooling readout + dense tail, "
+                                "forward and backward, of one graph per 16-wave workgroup in ONE launch",
+        "k_chain_fwd_q": "gcn_chain.hip: conv1..conv4 of every graph inside one persistent workgroup, linear outputs resident in LDS, "
+                         "graphs dealt from a sorted static schedule",
+        "k_gcn_fwd32*": "32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA: CSR gather (k_gcn_fwd32 / k_gcn_fwd32p) or "
+                        "dense per-graph blocks (k_gcn_fwd32d), chosen per batch",
+        "k_fused_fwd": "graph-per-workgroup forward, LDS-resident (forced only)"}
+    DETAIL["roofline_model"] = (
+        "frac = SURVEY §8(d) D4 algorithmic bytes / avg launch time / 8 TB/s.  One aggregation call: 4E~+4(N+1)+4N+2*4*N*F; a chain "
+        "launch processes FOUR calls (F = 32,32,32,1: 106 KB per COLLAB-cfg graph); the one-launch training kernel adds D4's sort-pool "
+        "figure 4N+4(B+1)+4*97*sum min(n,30)+4*2910*B.  frac_with_tail_model additionally counts bench.py's own byte model of the "
+        "dense tail forward+backward (algorithmic_bytes_readout_tail; NOT a SURVEY figure).  The chain kernels move far FEWER bytes "
+        "than D4's model (hs_2, hs_3, h4s never leave the CU; adjacency read once as a bitmap): frac is work per time on the "
+        "survey's model, frac_of_peak_on_measured_traffic the physical bandwidth fraction.  At 50 graphs a launch is latency-bound "
+        "(one graph per workgroup on 50 of 256 CUs; the largest graph sets its duration): see roofline_large_batch and DESIGN.md.")
+    DETAIL["roofline_timing"] = (
+        "avg_launch_us: HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the launch stream -- they bracket the dispatch "
+        "packet (kernel + ~0.5-1 us); avg_launch_us_kernel_trace: device timestamps of the same kernel from the rocprofv3 "
+        "--kernel-trace of this run's WRITE_SIZE pass (what profiles/*kernel_stats*.csv averages)")
+    DETAIL["traffic"] = ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) spawned by this run over 12 steps of "
+                         "the same workload; (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch (gfx950: FETCH_SIZE halves wide streams)")
 
     def pmc_pick(per, fused):
         for kn in (("k_fused_fwd",) if fused else AGG_KERNELS):
@@ -549,10 +677,26 @@ def main():
                 return kn, per[kn]
         return None, None
 
+    def roofline_obj(fused, chain, tail, kname, avg_us, bpl, achieved, nl, traffic, traffic_src, trace_us, extra_b, tail_model_b):
+        r = {"bound": "hbm",
+             "kernel": "k_fused_fwd" if fused else ("k_chain_readout_tail" if tail else "k_chain_fwd_q" if chain else (kname or "k_gcn_fwd32*")),
+             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+             "model": "SURVEY 8(d) D4: " + ("4 aggregation calls" + (" + sort-pool" if tail else "") if chain else "1 aggregation call"),
+             "algorithmic_bytes_per_launch": round(bpl), "avg_launch_us": round(avg_us, 3),
+             "avg_launch_us_kernel_trace": None if trace_us is None else round(trace_us, 3), "launches_measured": nl,
+             "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
+             "frac_of_peak_on_measured_traffic": None if traffic is None else round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+        if tail:
+            r["frac_with_tail_model"] = round(tail_model_b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if not (fused or chain):
+            r["frac_counting_fused_output"] = round((bpl + extra_b) / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        return r
+
     if rank == 0 and not args.no_roofline:
         fused, avg_us, bpl, achieved, nl = measure_agg(tr, batches, batches_cpu, max(200, min(args.steps, 400)))
         extra_small, chain_small = FUSED_EXTRA["bytes"], FUSED_EXTRA.get("chain_frac", 0.0)
         tail_small = FUSED_EXTRA.get("tail_frac", 0.0) > 0.5
+        tail_model_small = FUSED_EXTRA.get("tail_model_bytes", 0.0)
         traffic = traffic_src = kname = None
         per_small = None
         base_common = ["--workload", args.workload, "--scaling", args.scaling, "--global-batch", str(args.global_batch),
@@ -563,48 +707,18 @@ def main():
             if per_small:
                 kname, traffic = pmc_pick(per_small, fused)
                 if kname:
-                    traffic_src = ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) "
-                                   f"spawned by this run over 12 steps of the same workload; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                                   f"per {kname} dispatch")
+                    traffic_src = "live rocprofv3 --pmc"
             else:
-                extra["pmc_note"] = why
+                extra["pmc_note"] = str(why)[:200]
         trace_small = dict(LIVE_TRACE_US)
         # (the committed counters are of the default workload in fp32: no other shape borrows them)
         default_cfg = args.workload == "COLLAB" and args.dtype == "f32" and not args.stress_nodes
         if traffic is None and default_cfg:
             kname, traffic, src = committed_pmc_traffic(int(Bavg))
-            traffic_src = None if traffic is None else f"committed {src}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes"
+            traffic_src = None if traffic is None else f"committed {src}"
         chain = chain_small > 0.5
-        roofline = {"bound": "hbm", "kernel": "k_fused_fwd (graph-per-workgroup forward, LDS-resident)" if fused else
-                    ((tail_note if tail_small else chain_note) if chain else f"{kname or 'k_gcn_fwd32*'} ({kernel_note})"),
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "frac_of_peak_on_measured_traffic": None if traffic is None else traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": bpl, "avg_launch_us": avg_us, "launches_measured": nl,
-                    "aggregation_calls_per_launch": 4 if chain else 1, "launches_in_chain_form": chain_small,
-                    "avg_launch_us_kernel_trace": trace_small.get(kname) if kname else None,
-                    "frac_counting_fused_output": (bpl + extra_small) / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "timing": "avg_launch_us (used for `achieved`): HIP events attached to the dispatch (hipExtLaunchKernelGGL) "
-                              "on the launch stream -- they bracket the dispatch packet, i.e. the kernel plus ~0.5-1 us of "
-                              "dispatch latency, which matters for a short kernel; avg_launch_us_kernel_trace: device "
-                              "timestamps of the same kernel from the rocprofv3 --kernel-trace of this run's WRITE_SIZE pass "
-                              "(what profiles/*kernel_stats*.csv averages)",
-                    "note": (byte_note_chain if chain else byte_note_agg) +
-                            ("; plus bench.py algorithmic_bytes_readout_tail for the readout half of the launch" if tail_small else "") +
-                            "; at 50 graphs a launch is latency-bound (one graph per "
-                            "workgroup, the largest graph sets its duration) -- see roofline_large_batch and DESIGN.md"}
-        # ---- the step's dominant kernel BY TIME at this batch size: the fused readout (SortPooling + dense tail, fwd + bwd) ----
-        if per_small and "k_readout_tail" in per_small and trace_small.get("k_readout_tail"):
-            t_us = trace_small["k_readout_tail"]
-            rb = algorithmic_bytes_readout_tail(int(avgN), int(Bavg), C)
-            extra["roofline_readout"] = {
-                "bound": "hbm", "kernel": "k_readout_tail (SortPooling top-30 + conv5/pool/conv6/MLP/log_softmax forward AND backward of "
-                                          "one graph per 1024-thread workgroup, one launch)",
-                "achieved": rb / (t_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "traffic": per_small["k_readout_tail"], "algorithmic_bytes_per_launch": rb, "avg_launch_us_kernel_trace": t_us,
-                "note": "byte model: bench.py algorithmic_bytes_readout_tail (SURVEY D4 sort-pool formula + tail weights, activations, "
-                        "per-graph gradient partials, SortPooling-gradient slabs); duration and traffic from the live rocprofv3 passes of "
-                        "this run; latency-bound per-graph chain (B workgroups on B of 256 CUs)"}
+        roofline = roofline_obj(fused, chain, tail_small, kname, avg_us, bpl, achieved, nl, traffic, traffic_src,
+                                trace_small.get(kname) if kname else None, extra_small, tail_model_small)
         # ---- the same kernel family where it is throughput-bound: a large batch ------------------
         if args.large_batch and world == 1 and not strong and args.large_batch > args.batch:
             LB = args.large_batch
@@ -630,76 +744,45 @@ def main():
                 per_l, why_l = live_pmc_traffic(base_common + ["--batch", str(LB)], timeout_s=300)
                 if per_l:
                     kn2, tr2_ = pmc_pick(per_l, False)
-                    src2 = (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately, --kernel-trace) spawned by this run "
-                            f"over 12 steps of {LB} graphs; (2*FETCH_SIZE + WRITE_SIZE)*1024 per {kn2} dispatch")
+                    src2 = "live rocprofv3 --pmc"
                 else:
-                    extra["pmc_note_large_batch"] = why_l
+                    extra["pmc_note_large_batch"] = str(why_l)[:200]
             trace_large = LIVE_TRACE_US.get(kn2) if kn2 else None
             if tr2_ is None and default_cfg:
                 kn2, tr2_, src2c = committed_pmc_traffic(LB)
-                src2 = None if tr2_ is None else f"committed {src2c}, kernel {kn2}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch"
-            roofline_large = {"bound": "hbm", "batch": LB,
-                              "kernel": chain_note if chain_large else
-                              "k_gcn_fwd32d (dense per-graph block form: bit-packed adjacency x bf16x3-split rows on "
-                              "v_mfma_f32_16x16x32_bf16, exact in fp32) when the library's cost model picks it, else k_gcn_fwd32p",
-                              "traffic": tr2_, "traffic_source": src2,
-                              "frac_of_peak_on_measured_traffic": None if tr2_ is None else tr2_ / (avg2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach2 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl2, "avg_launch_us": avg2,
-                              "avg_launch_us_kernel_trace": trace_large,
-                              "aggregation_calls_per_launch": 4 if chain_large else 1,
-                              "frac_counting_fused_output": (bpl2 + extra_large) / (avg2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "launches_measured": n2_, "step_ms": ms_large, "graphs_per_s": LB / (ms_large * 1e-3),
-                              "note": (byte_note_chain if chain_large else byte_note_agg) +
-                                      f"; same code, {LB} {args.workload}-shape graphs per step (secondary figure; the headline "
-                                      f"metric stays batch {args.batch})"}
+                src2 = None if tr2_ is None else f"committed {src2c}"
+            roofline_large = roofline_obj(False, chain_large, False, kn2, avg2, bpl2, ach2, n2_, tr2_, src2, trace_large, extra_large, 0.0)
+            roofline_large.update({"batch": LB, "step_ms": round(ms_large, 5), "graphs_per_s": round(LB / (ms_large * 1e-3), 1)})
             del tr2, lb
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batches_cpu, F, C)
 
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin:
+        dropin = dropin_loop_us(Model, F, C, batches, dev)
+
     if rank == 0:
-        per_gpu = f"batch_size={args.batch} per GPU" if not strong else f"global batch {gb} sharded over {world} GPU(s)"
-        head = args.workload == "COLLAB" and not strong and args.batch == 50 and args.dtype == "f32"
-        out = {
-            "metric": "graphs/sec fwd+bwd (+Adam step), COLLAB-shape batch=50 per GPU" if head
-                      else f"graphs/sec fwd+bwd (+Adam step), {args.workload}-shape, {per_gpu}" + ("" if args.dtype == "f32" else f", {args.dtype} leg"),
-            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "repeats": len(reps), "repeats_ms_per_step": [round(1e3 * r / args.steps, 5) for r in reps],
-            "timing": f"median of {len(reps)} repeats of the {args.steps}-step timed loop (each bracketed by barrier + "
-                      f"synchronize, max over ranks), {total:.3f} s timed in total",
-            "config": {"workload": (f"{args.workload}-shape synthetic graphs (SURVEY §8(d) D2 cfg: n~N(75,30) clip[32,492], "
-                                    f"mean degree ~37, F={F}, C={C})" if args.workload == "COLLAB" else
-                                    f"{args.workload}-shape synthetic graphs (F={F}, C={C})") +
-                                   (f", first graph of every batch forced to {args.stress_nodes} nodes" if args.stress_nodes else "") +
-                                   f", {per_gpu}, {nb} distinct resident batches per GPU",
-                       "global_batch": gb, "avg_graphs_per_rank_per_step": Bavg, "avg_nodes_per_batch": avgN,
-                       "avg_directed_edges_per_batch": avgE,
-                       "parallelism": f"dp{world}" + (" (all ranks on ONE device over gloo: functional check only)" if share else ""),
-                       "gradient_exchange": {"none": "single GPU: Adam fused into the weight-gradient kernel",
-                                             "oneshot": "one-shot peer-memory kernel (dgcnn_allreduce_adam_step: rank-ordered sum over "
-                                                        "hipIpc-mapped gradients + Adam, one launch per rank)",
-                                             "rccl": "RCCL all_reduce of the flat 208 KB gradient + dgcnn_adam_step"}[exchange["mode"]] +
-                                            ((" -- " + exchange["note"]) if exchange["note"] else ""),
-                       "step": "forward + NLL(mean) + backward + fused Adam + zero_grad (+1 flat gradient all-reduce when "
-                               "dp>1); graph prep (CSR build) of every batch inside the timed region" +
-                               (", riding on the step's two graph-per-workgroup launches" if args.pipeline else "")},
-            "train_loss_mean": loss_sum / max(nsteps_total, 1),
-            "correct_frac": correct / max(nsteps_total * gb, 1),
-        }
-        out.update(extra)
-        if roofline is not None:
-            out["roofline"] = roofline
-        if roofline_large is not None:
-            out["roofline_large_batch"] = roofline_large
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-            out["speedup_vs_cpu_port"] = value / cpu["value"]
-            out["speedup_vs_cpu_port_1_thread"] = value / cpu["value_1_thread"]
+        out = build_result(args, reps, gb=gb, world=world, strong=strong, share=share, F=F, C=C, nb=nb, Bavg=Bavg, avgN=avgN, avgE=avgE,
+                           exchange=exchange, loss_mean=loss_sum / max(nsteps_total, 1),
+                           correct_frac=correct / max(nsteps_total * gb, 1), extra=extra, roofline=roofline,
+                           roofline_large=roofline_large, cpu=cpu, dropin=dropin)
         result_line = json.dumps(out)
+        if len(result_line) > RESULT_LINE_MAX:       # never hand the driver a line it cannot parse
+            for k in ("roofline_large_batch", "dropin", "fwd_bwd_only_graphs_per_s_rank0"):
+                out.pop(k, None)
+            out["truncated"] = True
+            result_line = json.dumps(out)
+        DETAIL["result"] = out
+        detail = json.dumps(DETAIL)
+        print(detail, file=sys.stderr)
+        if args.detail_file:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail_file)), exist_ok=True)
+                open(args.detail_file, "w").write(detail + "\n")
+            except OSError:
+                pass
     else:
         result_line = None
     if use_dist:

@@ -246,3 +246,37 @@ def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
     assert f(N2k, E2k, 2048, 1, CU, 600) == 0                      # above the dense bound of 512 nodes
     assert f(N2k, E2k, 2048, 1, CU | NOCHAIN, 250) == 1
     assert f(0, 0, 1, 1, 0, 0) < 0 and f(10, 10, 1, 0, 0, 0) < 0   # bad sizes: error code
+
+
+def test_bench_result_line_stays_parseable_whatever_the_repeat_count():
+    """BENCH_r03 lost its line: 2 961 repeats were listed in front of everything else (27 KB) and the driver, which reads
+    the tail of stdout, could not parse it.  The line is now a fixed-size summary: < 6 KB with 3 000 repeats and every
+    optional object present, and it carries the contract fields, `roofline` and `cpu_baseline`."""
+    import json
+    import random
+    import bench
+    args = bench.parse(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    rnd = random.Random(0)
+    reps = [20 * 50.5e-6 * (1 + 0.01 * rnd.random()) for _ in range(3000)]
+    long_note = "x" * 400
+    roof = {"bound": "hbm", "kernel": "k_chain_readout_tail", "achieved": 209.123, "peak": 8000.0, "unit": "GB/s", "frac": 0.02614,
+            "model": "SURVEY 8(d) D4: 4 aggregation calls + sort-pool", "algorithmic_bytes_per_launch": 6590000, "avg_launch_us": 31.505,
+            "avg_launch_us_kernel_trace": 31.4, "launches_measured": 400, "traffic": 12430000, "traffic_source": "live rocprofv3 --pmc",
+            "frac_of_peak_on_measured_traffic": 0.0493, "frac_with_tail_model": 0.0401}
+    cpu = {"value": 4142.7, "unit": "graphs/s", "cores": 32, "kind": "port", "value_1_thread": 1395.0, "ms_per_step": 12.07,
+           "ms_per_step_by_threads": {str(t): 12.0 for t in (1, 4, 8, 16, 32, 64, 128, 256)}, "host_logical_cpus": 256, "sample": long_note}
+    out = bench.build_result(args, reps, gb=50, world=1, strong=False, share=False, F=1, C=3, nb=40, Bavg=50.0, avgN=3831.2,
+                             avgE=140837.5, exchange={"mode": "none", "note": ""}, loss_mean=1.0986, correct_frac=0.3333,
+                             extra={"fwd_bwd_only_graphs_per_s_rank0": 1.0e6, "pmc_note": long_note[:200]},
+                             roofline=roof, roofline_large=dict(roof, batch=2048, step_ms=0.268, graphs_per_s=7.6e6),
+                             cpu=cpu, dropin={"unchanged_loop_us": 470.0, "with_dgcnn_amd_optim_adam_us": 250.0, "steps": 200})
+    line = json.dumps(out)
+    assert len(line) < bench.RESULT_LINE_MAX == 6000, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["repeats"] == 3000 and back["repeats_ms_per_step"]["count"] == 3000
+    assert isinstance(back["repeats_ms_per_step"], dict)          # a summary, never the list
+    assert abs(back["ms_per_step"] - 0.0507) < 1e-3
+    assert "workload" in back["config"] and "model" not in back["config"]
