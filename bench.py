@@ -158,13 +158,26 @@ def cpu_baseline(batches_cpu, F, C):
     B = batches_cpu[0].num_graphs
     table = {}
     t_begin = time.perf_counter()
-    cand = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})     # up to os.cpu_count()
+    # SURVEY D5 asks for up to os.cpu_count() threads.  The ladder climbs towards it and STOPS once a count is more than
+    # twice as slow as the best so far: on the 256-CPU GPU box the curve has its minimum at 16 threads (14.4 ms), 64 threads take
+    # 93 ms, 128 take 291 ms and 256 take 25 s PER STEP (measured once, round 4: 390 s of CPU work) -- oversubscribed
+    # counts cannot be the best and are not worth minutes of the bench's run time.  Every count is also bounded in time.
+    cand = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})
+    stopped = ""
     for th in cand:
-        if time.perf_counter() - t_begin > 45.0:      # bounded sample: the counts not reached are named in "sample"
+        if time.perf_counter() - t_begin > 25.0:
+            stopped = f"; time bound reached before {th} threads"
             break
         torch.set_num_threads(th)
         k = 0
-        for _ in range(5):
+        t0 = time.perf_counter()
+        ref_ops.train_step(model, opt, batches_cpu[k % n], batches_cpu[k % n].y); k += 1      # first warm-up step, timed as a probe
+        probe = time.perf_counter() - t0
+        if table and probe > 4.0 * min(table.values()) and probe > 0.2:
+            table[th] = probe
+            stopped = f"; ladder stopped at {th} threads (one probe step {1e3 * probe:.0f} ms, > 4x the best): higher counts not timed"
+            break
+        for _ in range(4):
             ref_ops.train_step(model, opt, batches_cpu[k % n], batches_cpu[k % n].y); k += 1
         ts = []
         t_th = time.perf_counter()
@@ -173,18 +186,20 @@ def cpu_baseline(batches_cpu, F, C):
             t0 = time.perf_counter()
             ref_ops.train_step(model, opt, b, b.y)
             ts.append(time.perf_counter() - t0)
-            if (time.perf_counter() - t_begin > 60.0 or time.perf_counter() - t_th > 8.0) and len(ts) >= 10:     # hard bounds (slow host /
-                break                                                                  # oversubscribed thread count)
+            if time.perf_counter() - t_th > 4.0 and len(ts) >= 5:
+                break
         table[th] = statistics.median(ts)
+        if table[th] > 2.0 * min(table.values()):
+            stopped = f"; ladder stopped at {th} threads (> 2x the best): higher counts not timed"
+            break
     cores = min(table, key=table.get)
     el = time.perf_counter() - t_begin
-    return {"value": B / table[cores], "unit": "graphs/s", "cores": cores, "kind": "port",
-            "value_1_thread": B / table[1],
-            "ms_per_step": 1e3 * table[cores],
+    return {"value": round(B / table[cores], 1), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(B / table[1], 1),
+            "ms_per_step": round(1e3 * table[cores], 3),
             "ms_per_step_by_threads": {str(k): round(v * 1e3, 2) for k, v in table.items()},
             "host_logical_cpus": ncpu,
-            "sample": f"median of <=30 sustained steps (fwd+NLL+bwd+Adam; 5 warm-up) per thread count {sorted(table)}"
-                      f"{'' if len(table) == len(cand) else ' (time bound hit before ' + str([t for t in cand if t not in table]) + ')'} of "
+            "sample": f"median of <=30 sustained steps (fwd+NLL+bwd+Adam; 5 warm-up) per thread count {sorted(table)}{stopped} of "
                       f"oracle/ref_ops.py (torch-CPU restatement of the reference ops, NOT PyG) on the same batches of {B} graphs; "
                       f"{el:.1f} s of CPU work; torch {torch.__version__}"}
 

@@ -297,7 +297,7 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
                         dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out), dg_ptr<int32_t>(ws, wl.err),
                         flags, epoch, (hipStream_t)stream, F <= DG_AF_MAX_F ? &lf : nullptr, nullptr,
                         dense ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr,
-                        fm.edge_check);
+                        fm.edge_check, max_nodes);
 }
 
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
@@ -369,7 +369,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                         dg_ptr<int32_t>(ws, wl.graph_eptr), dg_ptr<int32_t>(ws, wl.cnt_in), dg_ptr<int32_t>(ws, wl.cnt_out),
                         dg_ptr<int32_t>(ws, wl.err), flags, epoch, s, use_lf ? &lf : nullptr, &lin_done,
                         bitmap ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr,
-                        (bitmap && fm.plan) ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, fm.edge_check));
+                        (bitmap && fm.plan) ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, fm.edge_check, max_nodes));
   if (fused_d) {
     DG_TRY(dg_launch_fused_fwd_d(N, B, F, C, params, &pl, x, rowptr, colidx, dinv, dg_ptr<int32_t>(ws, wl.graph_ptr),
                                  dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
@@ -745,6 +745,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     if (nf.bitmap) {
       rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = nf.plan ? dg_ptr<int>(next->ws, nl.dmap) : nullptr;
       rd.edge_check = nf.edge_check;
+      rd.max_nodes = next->max_nodes;
     }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
     rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);

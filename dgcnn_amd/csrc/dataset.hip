@@ -1,0 +1,30 @@
+// dataset.hip -- batches from a PREPARED dataset: the copy kernel of dg_assemble.h as a launch of its
+// own, and the planning workgroup (item table + graph schedule of the dense / chain kernels) for batches that need one.
+// The C entry points (dgcnn_dataset_prepare, dgcnn_assemble) live in api.hip next to the form selection they depend on.
+#include "dg_assemble.h"
+
+__global__ void __launch_bounds__(256)
+k_assemble(DgAssemble A) {
+  dg_assemble_body((int)(blockIdx.x * 256 + threadIdx.x), A);
+}
+
+__global__ void __launch_bounds__(1024)
+k_dense_plan(int B, const int* __restrict__ graph_ptr, int* __restrict__ dmap) {
+  dg_prep_dense_plan((int)threadIdx.x, 1024, B, graph_ptr, dmap);
+}
+
+int dg_launch_assemble(const DgAssemble* A, int32_t* dmap, hipStream_t s) {
+  if (!A || A->N <= 0 || A->B <= 0 || A->E < 0 || A->F < 1 || !A->ids || !A->onode || !A->oedge || !A->node_ptr || !A->ds_dinv ||
+      !A->dinv || !A->graph_ptr || !A->graph_eptr || !A->err)
+    return DGCNN_EINVAL;
+  if ((A->rowptr || A->colidx) && (!A->ds_rowptr || (A->E > 0 && !A->ds_colidx))) return DGCNN_EINVAL;
+  if (A->bits && !A->ds_bits) return DGCNN_EINVAL;
+  const int work = dg_assemble_work(A->N, A->E, A->B, A->colidx != nullptr);
+  hipLaunchKernelGGL(k_assemble, dim3(dg_cdiv(work, 256)), dim3(256), 0, s, *A);
+  DG_CHECK_LAUNCH();
+  if (dmap) {
+    hipLaunchKernelGGL(k_dense_plan, dim3(1), dim3(1024), 0, s, A->B, A->graph_ptr, dmap);
+    DG_CHECK_LAUNCH();
+  }
+  return DGCNN_OK;
+}

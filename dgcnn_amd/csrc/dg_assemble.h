@@ -1,0 +1,95 @@
+// dg_assemble.h -- batch assembly from a PREPARED dataset (as written: "pre-built per-graph CSR + dinv
+// stored once per dataset, batch assembly = offset add + concat kernel").
+//
+// The reference collates every batch of every epoch on the host (PyG DataLoader, /root/reference/train.py:108-109) and then
+// re-derives the normalisation of its block-diagonal adjacency inside each of the four GCNConv calls
+// (/root/reference/model.py:27-33).  All of it is a function of the GRAPHS, not of the batch they travel in: a graph's CSR rows,
+// its dinv = (indeg+1)^-1/2, its pre-scaled features dinv*x and its bit-packed adjacency rows are the same in every batch.
+// dgcnn_dataset_prepare builds them ONCE for the whole dataset (one block-diagonal "batch" of all G graphs through the SAME
+// graph-preparation kernels a batch goes through: the numbers are the per-batch ones bit for bit, and the edge lists are
+// verified once); a training batch is then this file's copy kernel:
+//   per node  : dinv, xs row, x row, bitmap row (re-based between the two class-strided layouts), rowptr (offset add)
+//   per edge  : colidx (offset add: dataset-global node id -> batch node id), only where the batch's kernels read a CSR
+//   per graph : graph_ptr, graph_eptr, label
+// No int64 edge list is assembled or read, nothing is checked again (graph ids are range-checked), 8 B instead of 52 B per edge.
+#pragma once
+#ifndef DG_ASSEMBLE_H
+#define DG_ASSEMBLE_H
+#include "dg_common.h"
+#include "dg_prep.h"      // dgd_class, DGD_MAXN: the bitmap's class-strided layout
+
+// (struct DgAssemble: dg_prep.h, beside the rider descriptor that embeds it)
+static inline int dg_assemble_work(int N, int E, int B, bool csr) {       // threads: one per node (+1), per graph (+1), per edge
+  int w = N + 1 > B + 1 ? N + 1 : B + 1;
+  return csr ? w + E : w;
+}
+
+#ifdef __HIPCC__
+// largest g in [0,B) with ptr[g] <= t  (ptr ascending, ptr[0] = 0, t < ptr[B]; empty graphs give equal neighbours)
+__device__ __forceinline__ int dg_asm_seg(const int32_t* __restrict__ ptr, int B, int t) {
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// virtual thread t of dg_assemble_work(...).  Node range first ([0, max(N,B)+1)), then the edge range.
+__device__ __forceinline__ void dg_assemble_body(int t, const DgAssemble& A) {
+  const int N = A.N, E = A.E, B = A.B, F = A.F;
+  const int nw = (N + 1 > B + 1 ? N + 1 : B + 1);
+  if (t < nw) {
+    if (t < N) {
+      const int b = dg_asm_seg(A.onode, B, t);
+      int64_t gid = A.ids[b];
+      if ((uint64_t)gid >= (uint64_t)A.G) { A.err[0] = A.epoch; A.err[2] = ~A.epoch; gid = 0; }
+      const int64_t dn0 = A.node_ptr[gid];
+      const int ng = (int)(A.node_ptr[gid + 1] - dn0);
+      const int ob = A.onode[b];
+      int li = t - ob;
+      if (A.onode[b + 1] - ob != ng) { A.err[1] = A.epoch; A.err[3] = ~A.epoch; }      // the prefix sums are not this graph list's
+      if (li >= ng) li = ng > 0 ? ng - 1 : 0;
+      const int64_t dn = dn0 + li;
+      A.dinv[t] = A.ds_dinv[dn];
+      if (A.ds_xs) for (int f = 0; f < F; ++f) A.xs[(size_t)t * F + f] = A.ds_xs[dn * F + f];
+      if (A.x) for (int f = 0; f < F; ++f) A.x[(size_t)t * F + f] = A.ds_x[dn * F + f];
+      if (A.batch) A.batch[t] = b;
+      if (A.rowptr) A.rowptr[t] = A.ds_rowptr[dn] - A.ds_rowptr[dn0] + A.oedge[b];
+      if (A.bits && A.ds_bits && ng <= DGD_MAXN) {
+        const int S = 1 << dgd_class(ng);
+        const uint32_t* src = A.ds_bits + (size_t)A.Ntot * (S - 1) + (size_t)dn * S;
+        uint32_t* dst = A.bits + (size_t)N * (S - 1) + (size_t)t * S;
+        // (class c starts at word N*(2^c - 1): rows are S-word aligned only relative to that, so the copy is word-wise;
+        //  all S <= 16 loads of a row are in flight together)
+        uint32_t w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = k < S ? src[k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < S) dst[k] = w[k];
+      }
+    }
+    if (t == N && A.rowptr) A.rowptr[N] = E;
+    if (t <= B) {
+      A.graph_ptr[t] = A.onode[t];
+      A.graph_eptr[t] = A.oedge[t];
+      if (t < B && A.y) { const int64_t g = A.ids[t]; A.y[t] = (uint64_t)g < (uint64_t)A.G ? A.ds_y[g] : 0; }
+    }
+    return;
+  }
+  const int e = t - nw;
+  if (e < E && A.colidx) {
+    const int b = dg_asm_seg(A.oedge, B, e);
+    int64_t gid = A.ids[b];
+    if ((uint64_t)gid >= (uint64_t)A.G) gid = 0;                     // (flagged by the node range)
+    const int64_t dn0 = A.node_ptr[gid], dn1 = A.node_ptr[gid + 1];
+    const int e_lo = A.ds_rowptr[dn0], e_hi = A.ds_rowptr[dn1];
+    if (e_hi <= e_lo) { A.colidx[e] = 0; return; }                  // (an edge position inside an edgeless graph: same)
+    int64_t src = (int64_t)e_lo + (e - A.oedge[b]);
+    if (src >= e_hi) src = e_hi > e_lo ? e_hi - 1 : e_lo;           // (inconsistent prefix sums: flagged by the node range; stay in bounds)
+    int c = (int)((int64_t)A.ds_colidx[src] - dn0) + A.onode[b];
+    A.colidx[e] = c < 0 ? 0 : (c >= N ? N - 1 : c);
+  }
+}
+#endif
+#endif

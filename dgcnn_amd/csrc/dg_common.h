@@ -459,7 +459,8 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf = nullptr,
-                   int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr, int edge_check = 0);
+                   int* lin_done = nullptr, uint32_t* bits = nullptr, int32_t* dmap = nullptr, int edge_check = 0,
+                   int max_nodes = 0);
 int dg_launch_prep_sym(const int64_t* edge_index, int E, int N, int B, const int64_t* batch, const int32_t* graph_ptr,
                        const uint32_t* bits, int32_t* err, uint32_t epoch, hipStream_t s);
 int dg_launch_lin_first(int N, int F, const float* x, const float* W, const float* dinv, float* hs,

@@ -4,9 +4,38 @@
 // each; the pipelined training step uses that idle capacity to prepare the NEXT batch's graph structure
 // (extra workgroups appended to the grid; same stream, so ordering is trivially safe).
 #pragma once
+#pragma once
 #include "dg_common.h"
 
+// batch assembly from a prepared dataset (dg_assemble.h: SURVEY N3) -- descriptor of one batch
+struct DgAssemble {
+  // the prepared dataset (device arrays)
+  const int64_t* node_ptr;      // [G+1]
+  const int32_t* ds_rowptr;     // [Ntot+1] CSR by target over the whole dataset
+  const int32_t* ds_colidx;     // [Etot]   dataset-global node ids
+  const float* ds_dinv;         // [Ntot]
+  const float* ds_xs;           // [Ntot,F] dinv*x (F <= 32), else nullptr
+  const float* ds_x;            // [Ntot,F]
+  const uint32_t* ds_bits;      // class-strided by Ntot (31*Ntot words), or nullptr
+  const int64_t* ds_y;          // [G]
+  int64_t G, Ntot;
+  // the batch: graph ids + exclusive prefix sums of their node / edge counts
+  const int64_t* ids;           // [B]
+  const int32_t* onode;         // [B+1]
+  const int32_t* oedge;         // [B+1]
+  int N, E, B, F;
+  // outputs (batch workspace + the batch's own x / batch / y buffers)
+  int32_t* rowptr; int32_t* colidx;        // nullptr: this batch's kernels read no CSR (bitmap forms only)
+  float* dinv; float* xs; float* x; int64_t* batch; int64_t* y;
+  int32_t* graph_ptr; int32_t* graph_eptr;
+  uint32_t* bits;                          // nullptr: no bitmap form for this batch
+  unsigned int* err; unsigned int epoch;
+};
+
 struct DgPrepRider {
+  int mode;        // 0: graph preparation from the batch's int64 edge list (phases A and B below); 1: assembly from a prepared
+                   // dataset (`as`; ONE phase, carried where phase A rides; nblk_b = 0)
+  DgAssemble as;
   const int64_t* ei; const int64_t* batch;
   int E, N, B;
   int *rowptr, *colidx, *rowptr_t, *colidx_t, *graph_ptr, *graph_eptr;
@@ -19,6 +48,8 @@ struct DgPrepRider {
   unsigned int* bits; int* dmap;   // dense per-graph block structures (dg_dense.h); bits == nullptr: not built
   int edge_check;  // 1: the reverse-edge check stays the per-edge binary search of phase B although the bitmap is built
                    // (small batches that take only the chain forward from it: no third launch for the bitmap's symmetry check)
+  int max_nodes;   // the host's per-graph node bound for this batch (0 = none given): phase B flags any graph above it, so that a
+                   // hint that is too small can never make a size-class kernel skip a graph silently
 };
 static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {      // threads of phase A / phase B
   int work = E > N + 1 ? E : N + 1;
@@ -224,6 +255,13 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
     graph_ptr[t] = lo;
   }
 }
+// what a phase-A rider thread does: the first phase of the next batch's preparation, or its whole assembly from a prepared dataset
+__device__ __forceinline__ void dg_assemble_body(int t, const DgAssemble& A);
+__device__ __forceinline__ void dg_rider_phase_a(int t, const DgPrepRider& rd) {
+  if (rd.mode == 1) { dg_assemble_body(t, rd.as); return; }
+  dg_prep_fast_a_body(t, rd.ei, rd.E, rd.N, rd.batch, rd.B, rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err,
+                      rd.epoch, rd.bits);
+}
 // Kernel-B body: dinv per node, graph_eptr, and (per edge (s,d)) the reverse edge (d,s) must be in row d --
 // binary search inside that row only (<= log2(deg) steps).  Needs kernel A's outputs complete.
 // THREADS: threads per block of the hosting launch (sizes the LDS row buffers: 8 bytes per thread -- 2 KB in the 256-thread
@@ -238,7 +276,8 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     float* __restrict__ xs = nullptr, int F = 0,
                                                     const int64_t* __restrict__ batch = nullptr,
                                                     unsigned int* __restrict__ bits = nullptr,
-                                                    int* __restrict__ dmap = nullptr, bool edge_check = false) {
+                                                    int* __restrict__ dmap = nullptr, bool edge_check = false,
+                                                    int max_nodes = 0) {
   if (bits) {
     // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
     // per row: lane l takes neighbours l, l + 8, ... of the row (int32 colidx copy of phase A; the 8 lanes read 8
@@ -344,7 +383,11 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       if (S <= 4) build(std::integral_constant<int, 4>{}); else build_lds();
       if (bad && ok) { err[1] = epoch; err[3] = ~epoch; }
     }
-    if (t < B && graph_ptr[t + 1] - graph_ptr[t] > DGD_MAXN) { err[1] = epoch; err[3] = ~epoch; }      // max_nodes promise (<= 512) broken
+    // max_nodes promise broken: above the dense structures' bound (512), or above the bound the HOST gave -- the kernels behind
+    // this preparation are chosen from that hint (size-class launches skipped, the 256-node chain backward taken), so a graph
+    // above it would be left out of them without a trace
+    // (max_nodes < 0: dataset-level preparation -- graphs above 512 nodes simply get no bitmap rows, dg_assemble.h)
+    if (t < B && max_nodes >= 0 && graph_ptr[t + 1] - graph_ptr[t] > ((max_nodes > 0 && max_nodes < DGD_MAXN) ? max_nodes : DGD_MAXN)) { err[1] = epoch; err[3] = ~epoch; }
   }
   if (t < N) {
     const float di = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
@@ -401,3 +444,4 @@ __device__ __forceinline__ void dg_prep_sym_body(int t, int N, int B, const int6
   if (!(ok & ibit)) { err[1] = epoch; err[3] = ~epoch; }
 }
 #endif
+#include "dg_assemble.h"     // dg_assemble_body (dg_rider_phase_a above calls it)

@@ -1023,8 +1023,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                      float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChTail t,
                      unsigned long long* __restrict__ dbg, DgPrepRider rd) {
   if ((int)blockIdx.x >= B) {
-    dg_prep_fast_a_body(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
-                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
+    dg_rider_phase_a(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd);
     return;
   }
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;

@@ -1093,8 +1093,7 @@ k_fused_fwd_d(int F, int C, FdW gw, TailW tw, const float* __restrict__ xin, con
               int training, uint64_t seed, unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg,
               int B, DgPrepRider rd) {
   if ((int)blockIdx.x >= B) {    // rider range: phase A of the NEXT batch's graph preparation (dg_prep.h), as on k_readout_fwd
-    dg_prep_fast_a_body(((int)blockIdx.x - B) * FD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.batch, rd.B,
-                        rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err, rd.epoch, rd.bits);
+    dg_rider_phase_a(((int)blockIdx.x - B) * FD_THREADS + (int)threadIdx.x, rd);
     return;
   }
 #define FD_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)

@@ -188,9 +188,9 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
               const int* __restrict__ colidx, const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
               float* __restrict__ dinv, unsigned int* __restrict__ err, unsigned int epoch, int F,
               const float* __restrict__ x, float* __restrict__ xs, const int64_t* __restrict__ batch,
-              unsigned int* __restrict__ bits, int* __restrict__ dmap, int edge_check) {
+              unsigned int* __restrict__ bits, int* __restrict__ dmap, int edge_check, int max_nodes) {
   dg_prep_fast_b_body<1024>(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
-                      err, epoch, x, xs, F, batch, bits, dmap, edge_check != 0);
+                      err, epoch, x, xs, F, batch, bits, dmap, edge_check != 0, max_nodes);
   if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 1024, B, graph_ptr, dmap);
 }
 
@@ -220,7 +220,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,
                    int32_t* err, int flags, uint32_t epoch, hipStream_t s, const DgLinFirst* lf, int* lin_done,
-                   uint32_t* bits, int32_t* dmap, int edge_check) {
+                   uint32_t* bits, int32_t* dmap, int edge_check, int max_nodes) {
   if (N <= 0 || E < 0 || B <= 0) return DGCNN_EINVAL;
   if (lin_done) *lin_done = 0;
   if (!bits) dmap = nullptr;                 // (the bitmap alone is a valid request: chain forward of a small batch)
@@ -234,7 +234,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
     const int work_b = dg_prep_fast_work_b(E, N, B, bits != nullptr, edge_check);
     hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 1024)), dim3(1024), 0, s, edge_index, E, N, B, rowptr, colidx,
                        graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
-                       scale ? lf->hs : nullptr, batch, bits, dmap, edge_check);
+                       scale ? lf->hs : nullptr, batch, bits, dmap, edge_check, max_nodes);
     if (scale && lin_done) *lin_done = 1;
     DG_CHECK_LAUNCH();
     if (edge_check) return DGCNN_OK;             // (the reverse edges were checked per edge in phase B)

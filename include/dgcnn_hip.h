@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 15
+#define DGCNN_ABI_VERSION 16
 
 /* error codes */
 #define DGCNN_OK            0
@@ -321,6 +321,7 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
  * Every batch's preparation still runs exactly once inside the training loop; only its position changes.
  * No host synchronisation.  Results are bit-identical to the unpipelined calls.
  * ---------------------------------------------------------------------------------- */
+struct dgcnn_dataset;
 typedef struct dgcnn_step_args {
   int32_t N, E, B, F, C;
   int32_t training;            /* dropout on/off, as model.train() / model.eval() */
@@ -343,6 +344,13 @@ typedef struct dgcnn_step_args {
   float* metrics;              /* optional 2-float accumulator */
   float* exp_avg;              /* Adam moments, or NULL */
   float* exp_avg_sq;
+  /* batch drawn from a PREPARED dataset (below; all NULL otherwise).  Then edge_index is ignored (may be NULL), and x [N,F],
+   * y [B] and batch [N] (optional, may be NULL) are caller-allocated buffers that the ASSEMBLY fills before the forward
+   * reads them; N, E, max_nodes, max_edges are the host-known sums / maxima of the chosen graphs' sizes. */
+  const struct dgcnn_dataset* ds;
+  const int64_t* ds_ids;       /* [B]   graph ids of the batch (device) */
+  const int32_t* ds_onode;     /* [B+1] exclusive prefix sums of their node counts (device) */
+  const int32_t* ds_oedge;     /* [B+1] ... of their directed-edge counts (device) */
 } dgcnn_step_args;
 
 /* Evaluation step, the body of the reference's `test()` loop (/root/reference/train.py:59-64), one call: forward in
@@ -392,6 +400,49 @@ int dgcnn_collate_ids(int B, int F, const int64_t* ids_host, const int64_t* ids_
                       void* ev_uploaded, int64_t Etot, const float* x_all, const int64_t* ei_all, const int64_t* node_ptr,
                       const int64_t* edge_ptr, const int64_t* y_all, int64_t cap_nodes, int64_t cap_edges, float* x,
                       int64_t* edge_index, int64_t* batch, int64_t* y, int64_t* out_sizes, dgcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * PREPARED dataset.  Everything graph preparation derives from a batch -- the CSR by target of the
+ * block-diagonal adjacency, dinv = (indeg+1)^-1/2 (the structural half of PyG gcn_norm, which the reference re-runs in each
+ * of its four GCNConv calls of EVERY batch of EVERY epoch: /root/reference/model.py:30-33), the pre-scaled features dinv*x, the
+ * bit-packed adjacency rows of the dense / chain kernels -- is a function of the graph alone, because a batch is a disjoint
+ * union (/root/reference/train.py:108-109).  dgcnn_dataset_prepare builds it ONCE for all G graphs of a dataset resident in
+ * device memory, by running the SAME preparation kernels over the dataset as one block-diagonal batch (so a graph's numbers
+ * are bit for bit the ones a per-batch preparation produces, and the layout promise is verified once instead of per batch);
+ * dgcnn_assemble then makes a batch of B chosen graphs by a copy with offset adds -- no int64 edge list is built or read.
+ *   node_ptr [G+1] i64: first dataset node of each graph; y [G] i64 labels; x [Ntot,F] f32 raw features      (inputs)
+ *   rowptr [Ntot+1] i32, colidx [Etot] i32 (dataset-global ids, ascending per row), dinv [Ntot] f32,
+ *   xs [Ntot,F] f32 (F <= 32, else NULL), adj_bits [dgcnn_dense_bitmap_words(Ntot)] u32 (or NULL: no graph of
+ *   the dataset may then take a bitmap form -- pass NULL only for datasets whose batches never do)            (outputs)
+ * dgcnn_dataset_prepare inputs: edge_index_global [2,Etot] i64 with DATASET-global node ids (graph-local id + node_ptr of
+ * its graph), batch_all [Ntot] i64 (graph of each node); scratch: 2*(G+1) int32; err4: 4 int32 words, non-zero [0]/[1]
+ * afterwards = node id out of range / edge list not coalesced-undirected-block-diagonal (read them once, after a sync).
+ * Needs DGCNN_FLAG_COALESCED_UNDIRECTED (TU dataset files are; general edge lists stay on the per-batch path).
+ * Graphs above 512 nodes get no bitmap rows (their batches take the CSR kernels, exactly as on the per-batch path).
+ * ---------------------------------------------------------------------------------- */
+typedef struct dgcnn_dataset {
+  int64_t G, Ntot, Etot;
+  int32_t F, reserved_;
+  const int64_t* node_ptr;
+  const int64_t* y;
+  const float* x;
+  int32_t* rowptr;
+  int32_t* colidx;
+  float* dinv;
+  float* xs;
+  uint32_t* adj_bits;
+} dgcnn_dataset;
+int dgcnn_dataset_prepare(const dgcnn_dataset* ds, const int64_t* edge_index_global, const int64_t* batch_all,
+                          int32_t* scratch, int32_t* err4, int flags, dgcnn_stream_t stream);
+/* Batch assembly from a prepared dataset into the workspace `ws` of dgcnn_workspace_bytes(N,E,B,F,C) bytes -- what
+ * dgcnn_model_prepare leaves there for the same graphs in the same order, bit for bit (tests/test_prepared_dataset.py) --
+ * plus the batch's x [N,F], y [B] and (optional) batch [N] buffers.  ids / onode / oedge as in dgcnn_step_args.  flags,
+ * max_nodes, epoch: the values the following dgcnn_model_forward(..., flags | DGCNN_FLAG_PREPARED, ...) is given; flags must
+ * carry DGCNN_FLAG_COALESCED_UNDIRECTED.  A graph id outside [0,G) or prefix sums that do not match the ids are reported
+ * through the workspace's error words like any other input error.  One launch (two when the batch needs a graph schedule). */
+int dgcnn_assemble(const dgcnn_dataset* ds, int B, int N, int E, int C, const int64_t* ids, const int32_t* onode,
+                   const int32_t* oedge, void* ws, float* x, int64_t* batch, int64_t* y, int flags, int max_nodes,
+                   uint32_t epoch, dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Data parallel, one-shot exchange (the reference has no multi-GPU code, train.py:75-79): the ranks'

@@ -13,12 +13,23 @@ XCAT_TOL = 2e-5           # per-node activations after 4 fp32 layers vs the fp64
 KEY_TOL = 2e-5            # sort keys closer than this may legitimately order either way
 
 
-def load_fixture(golden_dir, name):
+def load_fixture(golden_dir, name, coalesced_undirected=False):
+    """`coalesced_undirected`: build the Batch WITH the promise the fixtures' edge lists satisfy (sorted by (src,dst), both
+    directions, no self loops -- asserted here), which routes a fused training step through k_chain_readout_tail"""
     z = np.load(f"{golden_dir}/{name}.npz")
     sd = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
     grads = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad:")}
     b = Batch(torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]), torch.from_numpy(z["batch"]),
               torch.from_numpy(z["y"]))
+    if coalesced_undirected:
+        ei = b.edge_index
+        key = ei[0] * (int(ei.max()) + 1) + ei[1]
+        assert bool((key[1:] > key[:-1]).all()) and bool((ei[0] != ei[1]).all())
+        rkey = ei[1] * (int(ei.max()) + 1) + ei[0]
+        assert torch.equal(torch.sort(rkey).values, key)
+        n_per = torch.bincount(b.batch, minlength=b.num_graphs)
+        e_per = torch.bincount(b.batch[ei[0]], minlength=b.num_graphs)
+        b = Batch(b.x, b.edge_index, b.batch, b.y, b.num_graphs, True, int(n_per.max()), int(e_per.max()))
     return z, sd, grads, b
 
 

@@ -180,3 +180,38 @@ def test_chain_training_steps_match_the_per_layer_family():
         res.append((mm.flat_params.clone(), loss))
     assert abs(res[0][1] - res[1][1]) <= 1e-4
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-4      # six Adam steps of lr 1e-3 from within-rounding gradients
+
+
+@pytest.mark.parametrize("bs,hint", [(300, 256), (300, 200), (700, 256), (50, 100), (1100, 128)])
+def test_chain_path_flags_a_max_nodes_hint_that_is_too_small(bs, hint):
+    """on the chain path the kernels are CHOSEN from the host's max_nodes hint (size-class launch skipped
+    at <= 256, the 256-node chain backward taken), so a graph above the hint would be left out of them and its rows stay stale.
+    Graph preparation now checks the hint on the device: such a batch is flagged (check_errors raises), through the eval
+    forward, the drop-in training forward and the pipelined Trainer step (rider / side-stream preparation)."""
+    from dgcnn_amd import _lib
+    from dgcnn_amd.batch import Batch
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    b = synth.make_batch("COLLAB", bs, start=4000, force_first_n=hint + 7)      # one graph just above the hint
+    assert b.max_nodes >= hint + 7
+    lie = Batch(b.x, b.edge_index, b.batch, b.y, b.num_graphs, True, hint, b.max_edges)
+    m = make_model(sh.num_features, sh.num_classes)
+    m.use_chain = True
+    m.eval()
+    with torch.no_grad():
+        m(lie.to("cuda"))
+    with pytest.raises(_lib.DgcnnError):
+        m.check_errors()
+    # the honest hint on the same graphs is clean
+    with torch.no_grad():
+        m(b.to("cuda"))
+    m.check_errors()
+    # pipelined training: the lie is the NEXT batch of a clean step (its preparation rides / runs on the side stream)
+    m.train()
+    tr = Trainer(m)
+    good, bad = b.to("cuda"), lie.to("cuda")
+    tr.train_step(good, good.y, next_data=bad)
+    tr.train_step(bad, bad.y, next_data=good)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.DgcnnError):
+        tr.read_metrics()

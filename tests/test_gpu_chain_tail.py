@@ -1,0 +1,183 @@
+"""The benched kernel on the benched workload, against the oracle.
+
+``k_chain_readout_tail`` (gcn_chain.hip; DGCNN_FORM_CHAIN_TAIL) is what ``Trainer.train_step`` runs with DEFAULT flags for
+coalesced-undirected batches of <= 256 graphs of <= 256 nodes each: chain forward (conv1..conv4, reference model.py:30-33),
+SortPooling + dense tail forward (model.py:35-45) and the readout backward + conv4's backward (train.py:40) of one graph in
+one workgroup.  It is 63 % of the headline step.  Every case below first asserts that this form IS the one the library
+takes for the batch (``dgcnn_forward_form(...) & DGCNN_FORM_CHAIN_TAIL``), then compares loss, #correct and ALL 16
+gradients with the independent fp64 dense oracle evaluated on the kernel's own dropout mask and SortPooling permutation
+(the permutation itself validated as a legal top-k of the oracle's keys), and the per-node activations [N,97]."""
+import numpy as np
+import pytest
+import torch
+
+from dgcnn_amd import _lib, synth
+from dgcnn_amd.batch import Batch
+from oracle import ref_dense
+from parity_util import KEY_TOL, XCAT_TOL, cpu_state_dict, gpu_xcat, grads_close, load_fixture, make_model
+
+pytestmark = pytest.mark.gpu
+
+FORM_CHAIN_TAIL = 4
+KEYS = ["conv1.lin.weight", "conv1.bias", "conv2.lin.weight", "conv2.bias", "conv3.lin.weight", "conv3.bias",
+        "conv4.lin.weight", "conv4.bias", "conv5.weight", "conv5.bias", "conv6.weight", "conv6.bias",
+        "classifier_1.weight", "classifier_1.bias", "classifier_2.weight", "classifier_2.bias"]
+
+
+def form_of(m, b):
+    fl = m._mode_flags() | (_lib.FLAG_COALESCED_UNDIRECTED if b.coalesced_undirected else 0)
+    return _lib.lib().dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, int(b.x.shape[1]), fl, int(b.max_nodes or 0))
+
+
+def batch_with_small_graphs(name, bs, start, limit=256):
+    """first seeded batch of the shape whose largest graph has <= `limit` nodes (the one-launch kernel's admission bound)"""
+    for k in range(64):
+        b = synth.make_batch(name, bs, start=start + k * bs)
+        if b.max_nodes <= limit:
+            return b
+    raise AssertionError(f"no {name} batch of {bs} graphs with max_nodes <= {limit}")
+
+
+def fused_step_vs_oracle(m, b_cpu, training=True):
+    from dgcnn_amd.train import Trainer
+    sd = cpu_state_dict(m)
+    assert form_of(m, b_cpu) > 0 and form_of(m, b_cpu) & FORM_CHAIN_TAIL, \
+        f"library does not take the one-launch training kernel for this batch (form {form_of(m, b_cpu)})"
+    b = b_cpu.to("cuda")
+    if training:
+        m.train(); m._seed_base, m._fwd_count = 11, 0
+    else:
+        m.eval()
+    tr = Trainer(m)
+    tr.reset_metrics()
+    tr.train_step(b, b.y)
+    torch.cuda.synchronize()
+    m.check_errors()
+    lsum, correct = tr.read_metrics()
+    perm = m.last_workspace_view("perm").cpu()
+    mask = m.last_workspace_view("drop_mask").cpu() if training else None
+    if training:
+        frac = float(mask.float().mean())
+        assert 0.35 < frac < 0.65, frac
+    logp_ref, loss_ref, g_ref, aux = ref_dense.loss_and_grads_dense(sd, b_cpu.x, b_cpu.edge_index, b_cpu.batch, b_cpu.y,
+                                                                    b_cpu.num_graphs, dropout_mask=mask, perm_override=perm)
+    # forward half: activations and the legality of the kernel's selection on the ORACLE's keys
+    err_x = float((gpu_xcat(m).double() - aux["xcat"].detach()).abs().max())
+    assert err_x <= XCAT_TOL, f"per-node activations differ by {err_x:.3e}"
+    ok, msg = ref_dense.check_perm_valid(aux["xcat"], aux["ptr"], perm, tol=KEY_TOL)
+    assert ok, msg
+    assert abs(lsum - float(loss_ref)) < 1e-5, (lsum, float(loss_ref))
+    C = logp_ref.shape[1]
+    top2 = logp_ref.detach().topk(min(2, C), dim=1).values
+    sure = (top2[:, 0] - top2[:, -1]) > 1e-4
+    want = (logp_ref.detach().argmax(1) == b_cpu.y)
+    assert abs(correct - float(want.sum())) <= float((~sure).sum())
+    g = tr.grads.cpu()
+    worst = {}
+    for p, off, key in zip(m._param_list(), m._offsets, KEYS):
+        good, md, sc = grads_close(g[off:off + p.numel()], g_ref[key].reshape(-1))
+        worst[key] = (md, sc)
+        assert good, f"grad {key}: max diff {md:.3e} at scale {sc:.3e}"
+    return tr, sd, worst
+
+
+CASES = [("COLLAB", 50), ("MUTAG", 50), ("PROTEINS", 50), ("IMDB", 50), ("COLLAB", 256), ("COLLAB_REAL", 50), ("COLLAB", 1), ("COLLAB", 7)]
+
+
+@pytest.mark.parametrize("name,bs", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
+def test_one_launch_training_kernel_vs_fp64_oracle(name, bs):
+    """Trainer.train_step, default flags, BASELINE workloads at their batch size (COLLAB-50 is the benched headline;
+    COLLAB-256 config 5's global batch = the kernel's upper admission bound): loss, #correct, all 16 gradients"""
+    sh = synth.SHAPES[name]
+    b_cpu = batch_with_small_graphs(name, bs, start=1000)
+    assert b_cpu.coalesced_undirected
+    m = make_model(sh.num_features, sh.num_classes)
+    fused_step_vs_oracle(m, b_cpu)
+
+
+def test_bench_pool_batches_take_the_one_launch_kernel():
+    """every batch of bench.py's default pool (40 COLLAB batches of 50, graph ids from 0) runs in the form this file tests"""
+    sh = synth.SHAPES["COLLAB"]
+    m = make_model(sh.num_features, sh.num_classes)
+    graphs = synth.make_graphs("COLLAB", 40 * 50, start=0)
+    forms = [form_of(m, synth.collate(graphs[i:i + 50])) for i in range(0, len(graphs), 50)]
+    assert all(f > 0 and f & FORM_CHAIN_TAIL for f in forms), forms
+
+
+def test_admission_bounds_of_the_one_launch_kernel():
+    """257 graphs, a graph above 256 nodes, or no coalesced-undirected promise: another form (each oracle-tested elsewhere)"""
+    sh = synth.SHAPES["COLLAB"]
+    m = make_model(sh.num_features, sh.num_classes)
+    assert not form_of(m, synth.make_batch("COLLAB", 257, start=0)) & FORM_CHAIN_TAIL
+    big = synth.make_batch("COLLAB", 50, start=0, force_first_n=300)
+    assert big.max_nodes == 300 and not form_of(m, big) & FORM_CHAIN_TAIL
+    b = batch_with_small_graphs("COLLAB", 50, 1000)
+    raw = Batch(b.x, b.edge_index, b.batch, b.y)          # no promise
+    assert not form_of(m, raw) & FORM_CHAIN_TAIL
+    m.use_chain = False
+    assert not form_of(m, b) & FORM_CHAIN_TAIL
+
+
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5", "collab_b4"])
+def test_golden_step_fixture_through_the_one_launch_kernel(golden_dir, name):
+    """the committed step fixtures WITH the coalesced-undirected promise their edge lists satisfy,
+    i.e. through k_chain_readout_tail: stored fp64 loss, gradients, parameters after one Adam step, stored permutation"""
+    from dgcnn_amd.train import Trainer
+    z, sd, grads, b = load_fixture(golden_dir, name, coalesced_undirected=True)
+    m = make_model(int(z["num_features"]), int(z["num_classes"]), sd)
+    assert form_of(m, b) & FORM_CHAIN_TAIL
+    m.eval()
+    tr = Trainer(m)
+    tr.reset_metrics()
+    before = m.flat_params.clone()
+    tr.train_step(b.to("cuda"), b.y.to("cuda"))
+    loss, _ = tr.read_metrics()
+    m.check_errors()
+    assert abs(loss - float(z["loss_eval_f64"])) < 1e-5
+    np.testing.assert_array_equal(m.last_workspace_view("perm").cpu().numpy(), z["perm"])
+    flat, g = m.flat_params.cpu(), tr.grads.cpu()
+    for p, off, key in zip(m._param_list(), m._offsets, KEYS):
+        n = p.numel()
+        g_ref = torch.from_numpy(z["grad_eval:" + key]).reshape(-1)
+        a_ref = torch.from_numpy(z["adam1:" + key]).reshape(-1)
+        good, md, sc = grads_close(g[off:off + n], g_ref)
+        assert good, f"grad {key}: max diff {md:.3e} at scale {sc:.3e}"
+        sure = g_ref.abs() > 1e-3 * g_ref.abs().max().clamp_min(1e-30)
+        assert (flat[off:off + n][sure] - a_ref[sure]).abs().max() < 5e-6, key
+        assert torch.equal(flat[off:off + n][g_ref == 0], before.cpu()[off:off + n][g_ref == 0]), key
+
+
+@pytest.mark.parametrize("name", ["mutag_b6", "proteins_b5", "collab_b4"])
+def test_golden_fixture_training_mode_through_the_one_launch_kernel(golden_dir, name):
+    z, sd, grads, b = load_fixture(golden_dir, name, coalesced_undirected=True)
+    m = make_model(int(z["num_features"]), int(z["num_classes"]), sd)
+    fused_step_vs_oracle(m, b)
+    np.testing.assert_array_equal(m.last_workspace_view("perm").cpu().numpy(), z["perm"])
+
+
+def test_pipelined_steps_of_the_one_launch_kernel_track_the_oracle_trajectory():
+    """three consecutive pipelined steps (next batch's graph preparation riding on the previous launch) on COLLAB-50: after
+    every step the gradient matches the oracle evaluated at the parameters the PREVIOUS steps left (read back from the device)"""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    bs_cpu = [batch_with_small_graphs("COLLAB", 50, 2000 + 500 * i) for i in range(3)]
+    bs = [b.to("cuda") for b in bs_cpu]
+    m = make_model(sh.num_features, sh.num_classes)
+    m.train(); m._seed_base, m._fwd_count = 3, 0
+    tr = Trainer(m)
+    for i in range(3):
+        assert form_of(m, bs_cpu[i]) & FORM_CHAIN_TAIL
+        sd = cpu_state_dict(m)
+        tr.reset_metrics()
+        tr.train_step(bs[i], bs[i].y, next_data=bs[(i + 1) % 3])
+        torch.cuda.synchronize()
+        lsum, _ = tr.read_metrics()
+        perm = m.last_workspace_view("perm").cpu(); mask = m.last_workspace_view("drop_mask").cpu()
+        b = bs_cpu[i]
+        _, loss_ref, g_ref, _ = ref_dense.loss_and_grads_dense(sd, b.x, b.edge_index, b.batch, b.y, b.num_graphs,
+                                                               dropout_mask=mask, perm_override=perm)
+        assert abs(lsum - float(loss_ref)) < 1e-5
+        g = tr.grads.cpu()
+        for p, off, key in zip(m._param_list(), m._offsets, KEYS):
+            good, md, sc = grads_close(g[off:off + p.numel()], g_ref[key].reshape(-1))
+            assert good, f"step {i} grad {key}: max diff {md:.3e} at scale {sc:.3e}"
