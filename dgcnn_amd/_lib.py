@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 15
+ABI_VERSION = 16
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -46,7 +46,15 @@ class StepArgs(ctypes.Structure):
                 ("eps", c_float), ("loss_scale", c_float), ("reserved_", ctypes.c_int32),
                 ("params", c_void_p), ("x", c_void_p), ("edge_index", c_void_p), ("batch", c_void_p),
                 ("y", c_void_p), ("ws", c_void_p), ("logp", c_void_p), ("grads", c_void_p), ("metrics", c_void_p),
-                ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p)]
+                ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("ds", c_void_p), ("ds_ids", c_void_p), ("ds_onode", c_void_p), ("ds_oedge", c_void_p)]
+
+
+class Dataset(ctypes.Structure):
+    """``dgcnn_dataset`` of include/dgcnn_hip.h: a dataset's graph structures prepared once"""
+    _fields_ = [("G", c_int64), ("Ntot", c_int64), ("Etot", c_int64), ("F", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("node_ptr", c_void_p), ("y", c_void_p), ("x", c_void_p), ("rowptr", c_void_p), ("colidx", c_void_p),
+                ("dinv", c_void_p), ("xs", c_void_p), ("adj_bits", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/dgcnn_hip.h declares
@@ -87,6 +95,9 @@ SIGNATURES = {
     "dgcnn_collate": (c_int, [c_int, c_int, c_int64, c_int64, c_int64] + [c_void_p] * 13),
     "dgcnn_collate_ids": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64]
                           + [c_void_p] * 5 + [c_int64, c_int64] + [c_void_p] * 5 + [c_void_p]),
+    "dgcnn_dataset_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dgcnn_assemble": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int, c_int, ctypes.c_uint32,
+                               c_void_p]),
     "dgcnn_accumulate_metrics": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dgcnn_peer_alloc": (c_int, [c_int64, ctypes.POINTER(c_void_p), c_void_p]),
     "dgcnn_peer_open": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),

@@ -300,6 +300,74 @@ int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const
                         fm.edge_check, max_nodes);
 }
 
+// ---- batches from a PREPARED dataset (dg_assemble.h) -------------------------------------------------------------
+// descriptor of one batch's assembly into its workspace: which structures the batch's kernels will read follows from the
+// SAME form selection the forward / backward use (dg_form) -- bitmap rows only for the dense / chain forms, a CSR only where a
+// gather kernel runs, the item table / graph schedule (*dmap) only where a persistent kernel deals itself graphs
+static int dg_fill_assemble(const dgcnn_dataset* ds, const int64_t* ids, const int32_t* onode, const int32_t* oedge, int N, int E,
+                            int B, int C, void* ws, float* x, int64_t* batch, int64_t* y, int flags, int max_nodes, uint32_t epoch,
+                            DgAssemble* A, int32_t** dmap) {
+  if (!ds || !ids || !onode || !oedge || !ws || !x || !A || !dmap || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
+  if (!ds->node_ptr || !ds->x || !ds->rowptr || !ds->dinv || ds->G <= 0 || ds->Ntot <= 0 || ds->F < 1 || ds->F > DGCNN_MAX_F ||
+      (ds->Etot > 0 && !ds->colidx))
+    return DGCNN_EINVAL;
+  if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED)) return DGCNN_EUNSUPPORTED;      // (prepared datasets are verified undirected)
+  const int F = ds->F;
+  if (F <= DG_AF_MAX_F && !ds->xs) return DGCNN_EINVAL;
+  DgWs wl;
+  DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
+  const DgForm fm = dg_form(N, E, B, F, flags, max_nodes);
+  if (fm.bitmap && !ds->adj_bits) return DGCNN_EINVAL;
+  A->node_ptr = ds->node_ptr; A->ds_rowptr = ds->rowptr; A->ds_colidx = ds->colidx; A->ds_dinv = ds->dinv;
+  A->ds_xs = F <= DG_AF_MAX_F ? ds->xs : nullptr; A->ds_x = ds->x; A->ds_bits = ds->adj_bits; A->ds_y = ds->y;
+  A->G = ds->G; A->Ntot = ds->Ntot;
+  A->ids = ids; A->onode = onode; A->oedge = oedge; A->N = N; A->E = E; A->B = B; A->F = F;
+  const bool csr = !fm.dense;          // the dense form's forward AND backward read the bitmap only
+  A->rowptr = csr ? dg_ptr<int32_t>(ws, wl.rowptr) : nullptr;
+  A->colidx = csr && E > 0 ? dg_ptr<int32_t>(ws, wl.colidx) : nullptr;
+  A->dinv = dg_ptr<float>(ws, wl.dinv); A->xs = dg_ptr<float>(ws, wl.hsA); A->x = x; A->batch = batch; A->y = ds->y ? y : nullptr;
+  A->graph_ptr = dg_ptr<int32_t>(ws, wl.graph_ptr); A->graph_eptr = dg_ptr<int32_t>(ws, wl.graph_eptr);
+  A->bits = fm.bitmap ? dg_ptr<uint32_t>(ws, wl.adjbits) : nullptr;
+  A->err = dg_ptr<unsigned int>(ws, wl.err); A->epoch = epoch;
+  *dmap = fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr;
+  return DGCNN_OK;
+}
+static int dg_assemble_args(const dgcnn_step_args* a, int flags, uint32_t epoch, hipStream_t s) {
+  DgAssemble A; int32_t* dmap = nullptr;
+  DG_TRY(dg_fill_assemble(a->ds, a->ds_ids, a->ds_onode, a->ds_oedge, a->N, a->E, a->B, a->C, a->ws, const_cast<float*>(a->x),
+                          const_cast<int64_t*>(a->batch), const_cast<int64_t*>(a->y), flags, a->max_nodes, epoch, &A, &dmap));
+  return dg_launch_assemble(&A, dmap, s);
+}
+
+int dgcnn_assemble(const dgcnn_dataset* ds, int B, int N, int E, int C, const int64_t* ids, const int32_t* onode,
+                   const int32_t* oedge, void* ws, float* x, int64_t* batch, int64_t* y, int flags, int max_nodes,
+                   uint32_t epoch, dgcnn_stream_t stream) {
+  DgAssemble A; int32_t* dmap = nullptr;
+  DG_TRY(dg_fill_assemble(ds, ids, onode, oedge, N, E, B, C, ws, x, batch, y, flags, max_nodes, epoch, &A, &dmap));
+  return dg_launch_assemble(&A, dmap, (hipStream_t)stream);
+}
+
+int dgcnn_dataset_prepare(const dgcnn_dataset* ds, const int64_t* edge_index_global, const int64_t* batch_all,
+                          int32_t* scratch, int32_t* err4, int flags, dgcnn_stream_t stream) {
+  if (!ds || !batch_all || !scratch || !err4 || !ds->node_ptr || !ds->x || !ds->rowptr || !ds->dinv || ds->G <= 0 || ds->Ntot <= 0 ||
+      ds->Etot < 0 || ds->F < 1 || ds->F > DGCNN_MAX_F)
+    return DGCNN_EINVAL;
+  if (ds->Ntot > 0x3fffffffLL || ds->Etot > 0x7fffffffLL || ds->G > 0x7ffffff0LL) return DGCNN_EUNSUPPORTED;      // int32 indices inside
+  if (ds->Etot > 0 && (!edge_index_global || !ds->colidx)) return DGCNN_EINVAL;
+  if (!(flags & DGCNN_FLAG_COALESCED_UNDIRECTED) || ds->Etot <= 0) return DGCNN_EUNSUPPORTED;
+  if (ds->F <= DG_AF_MAX_F && !ds->xs) return DGCNN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(err4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return DGCNN_ELAUNCH;
+  const int N = (int)ds->Ntot, E = (int)ds->Etot, G = (int)ds->G;
+  DgLinFirst lf; lf.x = ds->x; lf.W = nullptr; lf.hs = ds->xs; lf.F = ds->F;
+  // the batch-level preparation over the whole dataset as ONE block-diagonal batch: same kernels, hence the same bits per graph.
+  // edge_check = 1: every edge's reverse is looked up in its row (graphs above 512 nodes have no bitmap whose symmetry could
+  // stand in for it); max_nodes = -1: such graphs are not an error here, they simply get no bitmap rows
+  return dg_launch_prep(edge_index_global, E, batch_all, N, G, ds->rowptr, ds->colidx, nullptr, nullptr, ds->dinv, scratch,
+                        scratch + (G + 1), nullptr, nullptr, err4, flags, 1u, s, ds->F <= DG_AF_MAX_F ? &lf : nullptr, nullptr,
+                        ds->adj_bits, nullptr, 1, -1);
+}
+
 // rider_a != null: append phase A of another batch's graph preparation to the readout launch (tiled path only;
 // *rode = 1 when it was attached).  tt != null (training step with labels): the readout forward and the readout
 // backward run as ONE launch when the batch allows it; *tail_done = 1 then tells the backward to skip its first launch.
@@ -322,8 +390,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                  void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                                  int max_edges, uint32_t epoch, dgcnn_stream_t stream, const DgPrepRider* rider_a,
                                  int* rode, const DgTrainTail* tt = nullptr, int* tail_done = nullptr) {
-  if (!params || !x || !batch || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
-  if (E > 0 && !edge_index) return DGCNN_EINVAL;
+  if (!params || !x || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
+  if (!(flags & DGCNN_FLAG_PREPARED) && (!batch || (E > 0 && !edge_index))) return DGCNN_EINVAL;      // (a prepared batch's structures are in ws)
   DgParams pl; DgWs wl;
   DG_TRY(dg_param_layout(F, C, &pl));
   DG_TRY(dg_ws_layout(N, E, B, F, C, &wl));
@@ -696,12 +764,12 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   if (!handle || !cur) return DGCNN_EINVAL;
   DgPipeline* h = static_cast<DgPipeline*>(handle);
   hipStream_t s = (hipStream_t)stream;
-  if (!cur->params || !cur->x || !cur->batch || !cur->y || !cur->ws || !cur->logp || !cur->grads || cur->N <= 0 ||
+  if (!cur->params || !cur->x || (!cur->batch && !cur->ds) || !cur->y || !cur->ws || !cur->logp || !cur->grads || cur->N <= 0 ||
       cur->B <= 0 || cur->E < 0 || cur->epoch == 0)
     return DGCNN_EINVAL;
   if (cur->exp_avg && (!cur->exp_avg_sq || cur->step < 1)) return DGCNN_EINVAL;
-  if (next && (next->ws == cur->ws || !next->ws || !next->batch || !next->x || next->N <= 0 || next->B <= 0 ||
-               next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index)))
+  if (next && (next->ws == cur->ws || !next->ws || (!next->batch && !next->ds) || !next->x || next->N <= 0 || next->B <= 0 ||
+               next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index && !next->ds)))
     return DGCNN_EINVAL;
   // (max_nodes takes part in the choice of the aggregation form, which decides what the preparation built)
   const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B &&
@@ -721,16 +789,39 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   if (side_prep && !h->side) {
     int prio_least = 0, prio_greatest = 0;      // the LOWEST priority: the step's own launches take the CUs first
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    // all three or nothing: a stream without its events would make every later large step fail in hipEventRecord
+    hipStream_t st = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
+      if (e1) (void)hipEventDestroy(e1);
+      if (e2) (void)hipEventDestroy(e2);
+      if (st) (void)hipStreamDestroy(st);
       side_prep = false;                                         // (no side stream to be had: riders / in-stream as before)
-    }
+    } else { h->side = st; h->ev_fork = e1; h->ev_join = e2; }
   }
   DgPrepRider rd{};
   const DgPrepRider* rider = nullptr;
-  if (!side_prep && next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
+  if (cur->ds && !prepared) {        // first batch of a loop drawn from a prepared dataset: assemble in-stream, then run as prepared
+    DG_TRY(dg_assemble_args(cur, flags, epoch, s));
+    flags |= DGCNN_FLAG_PREPARED;
+  }
+  if (!side_prep && next && next->ds) {
+    // the next batch comes from a prepared dataset: its whole assembly (a copy with offset adds, dg_assemble.h) rides where
+    // phase A of a per-batch preparation rides; there is no phase B.  (A batch that needs the planning workgroup -- a forced
+    // dense form below the side-stream regime -- is assembled in-stream after the step instead.)
+    int32_t* ndmap = nullptr;
+    DG_TRY(dg_fill_assemble(next->ds, next->ds_ids, next->ds_onode, next->ds_oedge, next->N, next->E, next->B, next->C, next->ws,
+                            const_cast<float*>(next->x), const_cast<int64_t*>(next->batch), const_cast<int64_t*>(next->y),
+                            next->flags, next->max_nodes, next->epoch, &rd.as, &ndmap));
+    if (!ndmap) {
+      rd.mode = 1;
+      rd.nblk = dg_cdiv(dg_assemble_work(next->N, next->E, next->B, rd.as.colidx != nullptr), 1024);
+      rd.nblk_b = 0;
+      rider = &rd;
+    }
+  } else if (!side_prep && next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
     DgWs nl;
     DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
     rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
@@ -754,7 +845,10 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   int rode = 0, tail_done = 0;
   DgTrainTail tt;
   tt.y = cur->y; tt.loss_scale = cur->loss_scale;
-  g_fork = DgForkRequest{nullptr, 0, false};      // (a request left behind by a step that returned an error half way)
+  g_fork = DgForkRequest{nullptr, 0, false};
+  // whatever way this call returns (every DG_TRY below may), the thread-local fork request is disarmed: a later plain
+  // dgcnn_model_forward on this thread must not record into an event of a pipeline that may be gone by then
+  struct ForkGuard { ~ForkGuard() { g_fork = DgForkRequest{nullptr, 0, false}; } } fork_guard;
   if (side_prep) {
     int at = DG_SIDE_FORK_AT;
 #ifdef DG_DEBUG_KNOBS
@@ -775,9 +869,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   }
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
-                                dg_backward_form(cur->N, cur->E, cur->B, cur->F, flags, cur->max_nodes), rode ? rider : nullptr,
-                                tail_done));
-  if (next && rode && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
+                                dg_backward_form(cur->N, cur->E, cur->B, cur->F, flags, cur->max_nodes),
+                                (rode && rd.mode == 0) ? rider : nullptr, tail_done));
+  if (next && rode && rd.mode == 0 && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
     DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
                               reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));
   if (next) {
@@ -792,12 +886,17 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
       // loads, the preparation's HBM stream stretches them by more than it saves.  Join: whatever the caller enqueues next
       // sees the prepared structure.  (next->ws was last read by the previous step, which precedes the fork.)
       if (hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return DGCNN_ELAUNCH;
+      if (next->ds) DG_TRY(dg_assemble_args(next, next->flags, next->epoch, h->side));
+      else
       DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
                                  next->ws, next->flags, next->max_nodes, next->epoch, (dgcnn_stream_t)h->side));
       if (hipEventRecord(h->ev_join, h->side) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess) return DGCNN_ELAUNCH;
-    } else if (!rode)
+    } else if (!rode) {
+      if (next->ds) DG_TRY(dg_assemble_args(next, next->flags, next->epoch, s));
+      else
       DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch,
                                  next->ws, next->flags, next->max_nodes, next->epoch, stream));
+    }
     h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;
     h->pepoch = next->epoch; h->pmaxn = next->max_nodes;
   }
@@ -805,11 +904,15 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
 }
 
 int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream) {
-  if (!a || !a->params || !a->x || !a->batch || !a->ws || !a->logp || a->N <= 0 || a->B <= 0 || a->E < 0 || a->epoch == 0)
+  if (!a || !a->params || !a->x || (!a->batch && !a->ds) || !a->ws || !a->logp || a->N <= 0 || a->B <= 0 || a->E < 0 || a->epoch == 0)
     return DGCNN_EINVAL;
+  int eflags = a->flags & 0xFFFF & ~DGCNN_FLAG_PREPARED;
+  if (a->ds) {      // batch from a prepared dataset: assemble, then the forward finds its structures in the workspace
+    DG_TRY(dg_assemble_args(a, eflags, a->epoch, (hipStream_t)stream));
+    eflags |= DGCNN_FLAG_PREPARED;
+  }
   DG_TRY(dg_model_forward_impl(a->N, a->E, a->B, a->F, a->C, a->params, a->x, a->edge_index, a->batch, a->ws, a->logp, 0, 0,
-                               a->flags & 0xFFFF & ~DGCNN_FLAG_PREPARED, a->max_nodes, a->max_edges, a->epoch, stream,
-                               nullptr, nullptr));
+                               eflags, a->max_nodes, a->max_edges, a->epoch, stream, nullptr, nullptr));
   if (a->y && a->metrics)
     DG_TRY(dg_launch_eval_metrics(a->B, a->C, a->logp, a->y, a->metrics, a->loss_scale, (hipStream_t)stream));
   return DGCNN_OK;

@@ -19,6 +19,8 @@
 #include "dg_prep.h"      // dgd_class, DGD_MAXN: the bitmap's class-strided layout
 
 // (struct DgAssemble: dg_prep.h, beside the rider descriptor that embeds it)
+// launch of its own (dataset.hip); dmap != null: followed by the planning workgroup (item table + graph schedule)
+int dg_launch_assemble(const DgAssemble* A, int32_t* dmap, hipStream_t s);
 static inline int dg_assemble_work(int N, int E, int B, bool csr) {       // threads: one per node (+1), per graph (+1), per edge
   int w = N + 1 > B + 1 ? N + 1 : B + 1;
   return csr ? w + E : w;

@@ -10,6 +10,14 @@ a numpy cumsum over B node / edge counts.  The resulting :class:`dgcnn_amd.batch
 ``DeviceLoader`` mirrors ``GraphLoader`` / the reference's ``DataLoader(data_set[idx], batch_size, shuffle)``; it keeps a
 small ring of output buffers so the training loop can hold batch i+1 (look-ahead for the pipelined step) while batch
 i computes.
+
+:class:`PreparedDataset` goes one step further (SURVEY N3 as written): a batch is a disjoint union of graphs, so everything
+graph preparation derives from it -- CSR rows, ``dinv = (indeg+1)^-1/2``, the pre-scaled features ``dinv*x``, the bit-packed
+adjacency rows -- is a function of each GRAPH alone.  It is built ONCE per dataset (``dgcnn_dataset_prepare``: the same
+preparation kernels over the whole dataset as one block-diagonal batch), and ``DeviceLoader(..., prepared=True)`` then yields
+:class:`PreparedBatch` objects that launch NOTHING themselves: ``Trainer.train_step(batch, batch.y, next_data=nxt)`` assembles
+``nxt`` (a copy with offset adds, ``csrc/dg_assemble.h``) on spare workgroups of the current step, and no int64 edge list is
+ever built or read again.  Results are bit-identical to the per-batch path (tests/test_prepared_dataset.py).
 """
 from __future__ import annotations
 
@@ -105,16 +113,126 @@ class DeviceDataset:
         return Batch(x, ei, st["bt"][:N], st["y"][:B], B, self.coalesced_undirected, int(sizes[2]), int(sizes[3]))
 
 
+class PreparedBatch:
+    """A batch of a :class:`PreparedDataset`, described, not yet assembled: sizes known on the host, graph ids and prefix
+    sums on the device, and caller-owned buffers ``x`` [N,F], ``batch`` [N], ``y`` [B] that the assembly fills (inside
+    ``Trainer.train_step`` / ``eval_step``, stream-ordered before anything reads them).  Has the duck-typed attributes of
+    :class:`dgcnn_amd.batch.Batch` except ``edge_index`` (None: the point is that no edge list exists)."""
+
+    __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected", "max_nodes", "max_edges",
+                 "num_nodes", "num_edges", "dataset", "ids_ptr", "onode_ptr", "oedge_ptr", "_keep")
+
+    def __init__(self, dataset, x, batch, y, B, N, E, max_nodes, max_edges, ids_ptr, onode_ptr, oedge_ptr, keep=None):
+        self.dataset = dataset
+        self.x, self.edge_index, self.batch, self.y = x, None, batch, y
+        self.num_graphs, self.num_nodes, self.num_edges = int(B), int(N), int(E)
+        self.coalesced_undirected = True
+        self.max_nodes, self.max_edges = int(max_nodes), int(max_edges)
+        self.ids_ptr, self.onode_ptr, self.oedge_ptr = int(ids_ptr), int(onode_ptr), int(oedge_ptr)
+        self._keep = keep
+
+    def to(self, device, non_blocking: bool = False) -> "PreparedBatch":
+        if torch.device(device).type != "cuda":
+            raise _lib.DgcnnError("a PreparedBatch lives on the GPU of its dataset")
+        return self
+
+    def __repr__(self) -> str:
+        return (f"PreparedBatch(graphs={self.num_graphs}, nodes={self.num_nodes}, edges={self.num_edges}, "
+                f"max_nodes={self.max_nodes})")
+
+
+class PreparedDataset(DeviceDataset):
+    """:class:`DeviceDataset` + the graph structures of every graph, prepared once (``dgcnn_dataset_prepare``).
+
+    Replaces, for the whole run, what the reference redoes per batch: the host collate (/root/reference/train.py:108-109),
+    ``remove_self_loops`` (model.py:28) and the four ``gcn_norm`` calls inside the GCNConv layers (model.py:30-33).
+    Needs coalesced undirected graphs (TU dataset files are); raises otherwise -- general edge lists stay on
+    :class:`DeviceDataset`.  ``keep_edge_lists=False`` frees the int64 edge lists after preparation (nothing reads them
+    on the prepared path; ``assemble`` -- the per-batch path -- needs them)."""
+
+    def __init__(self, graphs: Sequence[Graph], device="cuda", keep_edge_lists: bool = True):
+        super().__init__(graphs, device)
+        if not self.coalesced_undirected or self.total_edges <= 0:
+            raise _lib.DgcnnError("PreparedDataset needs coalesced undirected graphs with at least one edge "
+                                  "(every TU dataset file is); use DeviceDataset for general edge lists")
+        dev, G, Nt, Et, F = self.device, self.num_graphs, self.total_nodes, self.total_edges, self.num_features
+        L = _lib.lib()
+        gids = torch.arange(G, device=dev)
+        batch_all = torch.repeat_interleave(gids, torch.from_numpy(self.nodes_per_graph).to(dev))
+        g_of_e = torch.repeat_interleave(gids, torch.from_numpy(self.edges_per_graph).to(dev))
+        ei_global = (self.ei_all + self.node_ptr[g_of_e].unsqueeze(0)).contiguous()        # dataset-global node ids, one-time
+        del g_of_e
+        self.rowptr = torch.empty(Nt + 1, dtype=torch.int32, device=dev)
+        self.colidx = torch.empty(Et, dtype=torch.int32, device=dev)
+        self.dinv = torch.empty(Nt, dtype=torch.float32, device=dev)
+        self.xs = torch.empty(Nt * F, dtype=torch.float32, device=dev) if F <= 32 else None
+        self.adj_bits = torch.empty(int(L.dgcnn_dense_bitmap_words(Nt)), dtype=torch.int32, device=dev)
+        scratch = torch.empty(2 * (G + 1), dtype=torch.int32, device=dev)
+        err = torch.zeros(4, dtype=torch.int32, device=dev)
+        d = _lib.Dataset()
+        d.G, d.Ntot, d.Etot, d.F = G, Nt, Et, F
+        d.node_ptr, d.y, d.x = self.node_ptr.data_ptr(), self.y_all.data_ptr(), self.x_all.data_ptr()
+        d.rowptr, d.colidx, d.dinv = self.rowptr.data_ptr(), self.colidx.data_ptr(), self.dinv.data_ptr()
+        d.xs = self.xs.data_ptr() if self.xs is not None else None
+        d.adj_bits = self.adj_bits.data_ptr()
+        self.desc = d
+        self.desc_ref = _lib.ctypes.addressof(d)
+        stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+        _lib.check(L.dgcnn_dataset_prepare(self.desc_ref, ei_global.data_ptr(), batch_all.data_ptr(), scratch.data_ptr(),
+                                           err.data_ptr(), _lib.FLAG_COALESCED_UNDIRECTED, stream), "dgcnn_dataset_prepare")
+        e = err.cpu().tolist()          # one sync per dataset: the layout promise is verified HERE, not per batch
+        if e[0] != 0:
+            raise _lib.DgcnnError("PreparedDataset: an edge endpoint lies outside its graph's node range")
+        if e[1] != 0:
+            raise _lib.DgcnnError("PreparedDataset: the edge lists are not coalesced + undirected (sorted by (src,dst), no "
+                                  "duplicates, no self loops, both directions present)")
+        del ei_global, batch_all, scratch
+        if not keep_edge_lists:
+            self.ei_all = None
+
+    def describe(self, ids: np.ndarray, out: dict, ids_ptr: int, onode_ptr: int, oedge_ptr: int, N: int, E: int,
+                 max_nodes: int, max_edges: int, keep=None) -> PreparedBatch:
+        """host-only: the PreparedBatch of graphs ``ids`` over the ring slot ``out`` (buffers grown on demand)"""
+        B, F, dev = int(ids.shape[0]), self.num_features, self.device
+        st = out.get("pstate")
+        if st is None or st["capN"] < N or st["capB"] < B:
+            capN = max(int(N * 1.25) + 16, st["capN"] if st else 0)
+            capB = max(B, 64, st["capB"] if st else 0)
+            st = out["pstate"] = {"capN": capN, "capB": capB,
+                                  "x": torch.empty(capN * F, dtype=torch.float32, device=dev),
+                                  "bt": torch.empty(capN, dtype=torch.int64, device=dev),
+                                  "y": torch.empty(capB, dtype=torch.int64, device=dev)}
+        return PreparedBatch(self, st["x"][:N * F].view(N, F), st["bt"][:N], st["y"][:B], B, N, E, max_nodes, max_edges,
+                             ids_ptr, onode_ptr, oedge_ptr, keep)
+
+    def batch_of(self, ids) -> PreparedBatch:
+        """one-off batch (tests, tools): uploads its own ids / prefix sums"""
+        ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int64)
+        nn_, ne_ = self.nodes_per_graph[ids], self.edges_per_graph[ids]
+        on = np.concatenate([[0], np.cumsum(nn_)]).astype(np.int32)
+        oe = np.concatenate([[0], np.cumsum(ne_)]).astype(np.int32)
+        ids_d = torch.from_numpy(ids).to(self.device)
+        meta = torch.from_numpy(np.concatenate([on, oe])).to(self.device)
+        return self.describe(ids, {}, ids_d.data_ptr(), meta.data_ptr(), meta.data_ptr() + 4 * (len(ids) + 1), int(on[-1]),
+                             int(oe[-1]), int(nn_.max()), int(ne_.max()), keep=(ids_d, meta))
+
+
 class DeviceLoader:
     """``DataLoader(data_set[idx], batch_size, shuffle)`` (train.py:108-109) over a :class:`DeviceDataset`.
+
+    ``prepared=True`` (needs a :class:`PreparedDataset`): yields :class:`PreparedBatch` descriptions instead of assembled
+    batches -- per epoch ONE upload (the permutation and every batch's two prefix sums), per batch no launch and no upload.
 
     ``indices``: the subset (a fold's train or test ids); ``shuffle`` draws a fresh permutation per epoch from
     ``generator``.  ``ring`` output-buffer sets are cycled, so a yielded batch stays valid while the next ``ring - 1``
     batches are produced (the training loop's one-batch look-ahead needs 2; default 3)."""
 
     def __init__(self, dataset: DeviceDataset, batch_size: int, indices=None, shuffle: bool = False,
-                 generator: Optional[torch.Generator] = None, ring: int = 3):
+                 generator: Optional[torch.Generator] = None, ring: int = 3, prepared: bool = False):
         self.ds = dataset
+        self.prepared = bool(prepared)
+        if self.prepared and not isinstance(dataset, PreparedDataset):
+            raise _lib.DgcnnError("DeviceLoader(prepared=True) needs a PreparedDataset")
         self.batch_size = int(batch_size)
         self.indices = np.arange(len(dataset), dtype=np.int64) if indices is None else \
             np.asarray(torch.as_tensor(indices).cpu().numpy() if not isinstance(indices, np.ndarray) else indices, dtype=np.int64)
@@ -136,6 +254,26 @@ class DeviceLoader:
         order_dev = torch.from_numpy(order).to(self.ds.device)
         self._order_keep = (getattr(self, "_order_keep", (None, None))[1], order_dev)
         base = order_dev.data_ptr()
+        if self.prepared:
+            # every batch's exclusive prefix sums of node / edge counts, computed for the whole epoch on the host and uploaded once
+            nn_, ne_ = self.ds.nodes_per_graph[order], self.ds.edges_per_graph[order]
+            bs = self.batch_size
+            parts, info, off = [], [], 0
+            for i in range(0, n, bs):
+                a, b = nn_[i:i + bs], ne_[i:i + bs]
+                on = np.concatenate([[0], np.cumsum(a)]); oe = np.concatenate([[0], np.cumsum(b)])
+                parts += [on, oe]
+                info.append((i, len(a), off, int(on[-1]), int(oe[-1]), int(a.max()), int(b.max())))
+                off += 2 * (len(a) + 1)
+            meta = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(self.ds.device)
+            self._order_keep = (self._order_keep[0], (order_dev, meta))
+            mb = meta.data_ptr()
+            for i, B, moff, N, E, mxn, mxe in info:
+                out = self._bufs[self._k % len(self._bufs)]
+                self._k += 1
+                yield self.ds.describe(order[i:i + B], out, base + 8 * i, mb + 4 * moff, mb + 4 * (moff + B + 1), N, E, mxn, mxe,
+                                       keep=(order_dev, meta))
+            return
         for i in range(0, n, self.batch_size):
             out = self._bufs[self._k % len(self._bufs)]
             self._k += 1

@@ -31,6 +31,7 @@ from torch import nn
 from . import _lib
 
 K_SORT = 30
+_NO_EDGES = torch.zeros(2, 0, dtype=torch.int64)      # stands in for edge_index of a PreparedBatch (never dereferenced)
 
 
 class _Lin(nn.Module):
@@ -80,19 +81,27 @@ class _DGCNNFunction(torch.autograd.Function):
     """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
 
     @staticmethod
-    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, max_nodes, max_edges, *params):
+    def forward(ctx, model, x, edge_index, batch, B, training, seed, flags, max_nodes, max_edges, pb, *params):
         L = _lib.lib()
         N, F = x.shape
-        E = edge_index.shape[1]
+        E = edge_index.shape[1] if pb is None else pb.num_edges
         C = model.num_classes
         flat = model.flat_params_fast()
         ws = torch.empty(_lib.workspace_bytes(N, E, B, F, C), dtype=torch.uint8, device=x.device)
         logp = torch.empty(B, C, dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        epoch = model._next_epoch()
+        if pb is not None:
+            # batch of a PreparedDataset (dgcnn_amd/device_data.py): its structures are COPIED into the workspace from the
+            # dataset's (one launch), then the forward runs as on a prepared workspace -- no edge list exists
+            _lib.check(L.dgcnn_assemble(pb.dataset.desc_ref, B, N, E, C, pb.ids_ptr, pb.onode_ptr, pb.oedge_ptr, ws.data_ptr(),
+                                        x.data_ptr(), batch.data_ptr(), pb.y.data_ptr(), flags, max_nodes, epoch, stream),
+                       "dgcnn_assemble")
+            flags |= _lib.FLAG_PREPARED
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
-                                         edge_index.data_ptr() if E else None, batch.data_ptr(),
+                                         edge_index.data_ptr() if (E and pb is None) else None, batch.data_ptr(),
                                          ws.data_ptr(), logp.data_ptr(), int(training), seed, flags,
-                                         max_nodes, max_edges, model._next_epoch(), stream),
+                                         max_nodes, max_edges, epoch, stream),
                    "dgcnn_model_forward")
         ctx.model = model
         ctx.dims = (N, E, B, F, C, int(training), int(flags), int(max_nodes))
@@ -118,7 +127,7 @@ class _DGCNNFunction(torch.autograd.Function):
         # the 16 gradients handed to autograd are views of ONE flat buffer in the parameter layout: autograd keeps them
         # as they are (no copies), so an optimizer that recognises the layout (dgcnn_amd.optim.Adam) updates the
         # whole model with one kernel
-        return (None, None, None, None, None, None, None, None, None, None, *model._grad_views(grads))
+        return (None, None, None, None, None, None, None, None, None, None, None, *model._grad_views(grads))
 
 
 class Model(nn.Module):
@@ -340,10 +349,17 @@ class Model(nn.Module):
 
     def forward(self, data):
         x, edge_index, batch = data.x, data.edge_index, data.batch          # model.py:27
-        self._check_inputs(x, edge_index, batch)
+        pb = data if getattr(data, "dataset", None) is not None else None    # PreparedBatch: no edge list, structures per dataset
+        if pb is not None:
+            edge_index = _NO_EDGES
+            if not x.is_cuda or batch.shape[0] != x.shape[0]:
+                raise _lib.DgcnnError("PreparedBatch buffers must be CUDA tensors [N,F] / [N]")
+        else:
+            self._check_inputs(x, edge_index, batch)
         if x.shape[1] != self.num_features:
             raise _lib.DgcnnError(f"data.x has {x.shape[1]} features, model expects {self.num_features}")
-        x, edge_index, batch = x.contiguous(), edge_index.contiguous(), batch.contiguous()
+        if pb is None:
+            x, edge_index, batch = x.contiguous(), edge_index.contiguous(), batch.contiguous()
         B = _batch_size_of(data)
         flat = self.flat_params_fast()
         if flat.device != x.device:
@@ -351,7 +367,7 @@ class Model(nn.Module):
         training = self.training
         seed = self._next_seed() if training else 0
         return _DGCNNFunction.apply(self, x, edge_index, batch, B, training, seed, self._flags_of(data),
-                                    self._max_nodes_of(data), int(getattr(data, "max_edges", 0) or 0),
+                                    self._max_nodes_of(data), int(getattr(data, "max_edges", 0) or 0), pb,
                                     *self._param_list())
 
     # ---- introspection used by tests / tools ---------------------------------------------

@@ -126,6 +126,8 @@ class Trainer:
 
     def _dims(self, data):
         x, ei = data.x, data.edge_index
+        if getattr(data, "dataset", None) is not None:       # PreparedBatch (device_data.py): sizes are host-known, no edge list
+            return data.num_nodes, data.num_edges, data.num_graphs, x.shape[1], self.model.num_classes
         Model._check_inputs(x, ei, data.batch)
         return x.shape[0], ei.shape[1], _batch_size_of(data), x.shape[1], self.model.num_classes
 
@@ -143,12 +145,18 @@ class Trainer:
         stream = cur.cuda_stream
         training = 1 if m.training else 0
         seed = m._next_seed() if training else 0
-        x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+        pb = data if getattr(data, "dataset", None) is not None else None
+        x, bt = data.x.contiguous(), data.batch.contiguous()
+        ei = data.edge_index.contiguous() if pb is None else None
         flags = m._flags_of(data)
         maxn = m._max_nodes_of(data)
         epoch = m._next_epoch()
+        if pb is not None:
+            _lib.check(L.dgcnn_assemble(pb.dataset.desc_ref, B, N, E, C, pb.ids_ptr, pb.onode_ptr, pb.oedge_ptr, ws.data_ptr(),
+                                        x.data_ptr(), bt.data_ptr(), pb.y.data_ptr(), flags, maxn, epoch, stream), "dgcnn_assemble")
+            flags |= _lib.FLAG_PREPARED
         _lib.check(L.dgcnn_model_forward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(),
-                                         ei.data_ptr() if E else None, bt.data_ptr(), ws.data_ptr(),
+                                         ei.data_ptr() if (E and pb is None) else None, bt.data_ptr(), ws.data_ptr(),
                                          logp.data_ptr(), training, seed, flags, maxn,
                                          int(getattr(data, "max_edges", 0) or 0), epoch, stream), "dgcnn_model_forward")
         scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
@@ -189,13 +197,19 @@ class Trainer:
             return ent
         m = self.model
         N, E, B, F, C = self._dims(data)
-        x, ei, bt = data.x.contiguous(), data.edge_index.contiguous(), data.batch.contiguous()
+        pb = data if getattr(data, "dataset", None) is not None else None
+        x, bt = data.x.contiguous(), data.batch.contiguous()
+        ei = data.edge_index.contiguous() if pb is None else None
         yy = y.contiguous()
         a = _lib.StepArgs()
         a.N, a.E, a.B, a.F, a.C = N, E, B, F, C
         a.max_nodes = m._max_nodes_of(data)
         a.max_edges = int(getattr(data, "max_edges", 0) or 0)
-        a.x, a.edge_index, a.batch, a.y = x.data_ptr(), (ei.data_ptr() if E else None), bt.data_ptr(), yy.data_ptr()
+        a.x, a.edge_index, a.batch, a.y = x.data_ptr(), (ei.data_ptr() if (E and pb is None) else None), bt.data_ptr(), yy.data_ptr()
+        if pb is not None:       # batch of a PreparedDataset: the step (or the previous step's riders) assembles it, no edge list
+            if yy.data_ptr() != pb.y.data_ptr():
+                raise _lib.DgcnnError("a PreparedBatch is trained on its own labels (batch.y): the assembly fills that buffer")
+            a.ds, a.ds_ids, a.ds_onode, a.ds_oedge = pb.dataset.desc_ref, pb.ids_ptr, pb.onode_ptr, pb.oedge_ptr
         a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
         need = _lib.workspace_bytes(N, E, B, F, C)
         if len(self._args_cache) >= self.ARGS_CACHE_MAX:      # bounded: every entry keeps its batch's tensors alive

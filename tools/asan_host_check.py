@@ -46,4 +46,20 @@ assert rc == -3 and sizes[0] == int(nodes[ids].sum()) and sizes[2] == int(nodes[
 bad = np.array([3, 40], dtype=np.int64)
 assert lib.dgcnn_collate_ids(2, 1, P(bad), None, P(nodes), P(edges), c.c_int64(G), P(meta), one, None, c.c_int64(10), one, one, one, one,
                              one, c.c_int64(0), c.c_int64(0), None, None, None, one, P(sizes), None) == -1
+# prepared dataset: descriptor validation runs on the host before any launch
+class DS(c.Structure):
+    _fields_ = [("G", c.c_int64), ("Ntot", c.c_int64), ("Etot", c.c_int64), ("F", c.c_int32), ("r", c.c_int32)] + \
+               [(n, c.c_void_p) for n in ("node_ptr", "y", "x", "rowptr", "colidx", "dinv", "xs", "adj_bits")]
+d = DS(); d.G, d.Ntot, d.Etot, d.F = 10, 100, 400, 1
+assert lib.dgcnn_dataset_prepare(None, None, None, None, None, 1, None) == -1
+assert lib.dgcnn_dataset_prepare(c.byref(d), one, one, one, one, 1, None) == -1            # output arrays missing
+for n in ("node_ptr", "y", "x", "rowptr", "colidx", "dinv", "xs", "adj_bits"): setattr(d, n, 16)
+assert lib.dgcnn_dataset_prepare(c.byref(d), one, one, one, one, 0, None) == -3            # no coalesced-undirected promise
+d.Ntot = 1 << 31
+assert lib.dgcnn_dataset_prepare(c.byref(d), one, one, one, one, 1, None) == -3            # beyond int32 indices
+d.Ntot = 100
+assert lib.dgcnn_assemble(None, 5, 50, 200, 3, one, one, one, one, one, one, one, 1, 20, c.c_uint32(1), None) == -1
+assert lib.dgcnn_assemble(c.byref(d), 5, 50, 200, 3, one, one, one, one, one, one, one, 0, 20, c.c_uint32(1), None) == -3
+assert lib.dgcnn_assemble(c.byref(d), 5, 50, 200, 3, None, one, one, one, one, one, one, 1, 20, c.c_uint32(1), None) == -1
+assert lib.dgcnn_assemble(c.byref(d), 5, 50, 200, 3, one, one, one, one, one, one, one, 1, 20, c.c_uint32(0), None) == -1
 print("ASAN_HOST_OK")

@@ -5,7 +5,7 @@ set -e
 NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$R/dgcnn_amd/variants/obj_$NAME; mkdir -p $D
-for f in api prep gcn gcn_dense gcn_chain tail classifier fused collate peer; do
+for f in $(cd $R/dgcnn_amd/csrc && ls *.hip | sed "s/\.hip$//"); do      # every translation unit of the Makefile
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc $FLAGS \
      -c $R/dgcnn_amd/csrc/$f.hip -o $D/$f.o &
 done
