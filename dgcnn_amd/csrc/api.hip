@@ -385,6 +385,13 @@ static inline int dg_fork_point(int k, hipStream_t s) {
   }
   return DGCNN_OK;
 }
+// DGCNN_STEP_KERNEL=0 in the environment: the one-launch training kernel stops after conv4's backward and conv3 / conv2 / conv1
+// run as the two gather launches (the round-3 form; measurement A/B and a second route for the tests)
+static bool dg_step_kernel_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DGCNN_STEP_KERNEL"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float* params,
                                  const float* x, const int64_t* edge_index, const int64_t* batch,
                                  void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
@@ -466,7 +473,9 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
   if (chain && !bf16 && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
       max_nodes <= dg_chain_train_max_nodes()) {
-    // small training batch: chain forward + readout forward + readout backward of every graph in ONE launch
+    // small training batch: chain forward + readout forward + readout backward + the whole GCN backward of every graph in ONE
+    // launch (one partial row per graph for k_wgrad, the step's only other launch)
+    const bool step_kernel = dg_step_kernel_enabled() && B <= wl.P1 && B <= wl.P32 && dg_wgrad_takes_rider(B);
     DG_TRY(dg_launch_chain_readout_tail(N, B, F, C, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
                                         dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
                                         dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
@@ -476,9 +485,13 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<float>(ws, wl.gp2), dg_ptr<float>(ws, wl.gp3), dg_ptr<float>(ws, wl.gas4),
                                         dg_ptr<float>(ws, wl.gb4p), dg_ptr<float>(ws, wl.lossv), dg_ptr<float>(ws, wl.ptail),
                                         dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
-                                        wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr));
+                                        wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr,
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb3) : nullptr, step_kernel ? dg_ptr<float>(ws, wl.pb2) : nullptr,
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr));
     g_prof_which = -1;
-    *tail_done = B <= wl.P1 ? 2 : 1;       // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too
+    // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
+    // pb2 / pb1 = graph b's partials: k_wgrad sums B rows)
+    *tail_done = step_kernel ? 3 : (B <= wl.P1 ? 2 : 1);
     if (rider_a && rode) *rode = 1;
     return DGCNN_OK;
   }
@@ -650,6 +663,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
       DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                                  dg_ptr<float>(ws, wl.pb1), wl.P32, s));
     }
+  } else if (tail_done == 3) {
+    // the one-launch training kernel ran the whole GCN backward: nothing to launch here
   } else {
   const bool bwd1_hosts_rider = tail_done && !wg_rider && rider_b;      // (then conv4's backward launch carries prep phase B)
   if (tail_done == 2 && !bwd1_hosts_rider) {
@@ -688,7 +703,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // (Running the tail half on a second stream concurrently with the GCN chain was measured SLOWER: its
   // ~2400 workgroups starve the latency-bound 1024-thread GCN workgroups of CU slots: 111 -> 137 us/step.)
   DG_TRY(dg_launch_wgrad(3, N, B, F, C, &pl, &wl, ws, grads, (y != nullptr) ? metrics : nullptr, adam, s,
-                         wg_rider ? rider_b : nullptr, walk ? dg_tail_walk_rows(B) : 0));
+                         wg_rider ? rider_b : nullptr, walk ? dg_tail_walk_rows(B) : 0, (tail_done == 3 && !dense) ? B : 0));
   return DGCNN_OK;
 }
 

@@ -433,7 +433,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* dlogit, float* gz1, float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4,
                                  float* gb4p, float* lossv, float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1,
                                  hipStream_t s, const struct DgPrepRider* rider = nullptr,
-                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                                 float* pb3 = nullptr, float* pb2 = nullptr, float* pb1 = nullptr);
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                         float* x3, float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start = nullptr,
@@ -537,7 +538,7 @@ struct DgAdam {          // optional optimizer step fused into the weight-gradie
 };
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
                     float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const struct DgPrepRider* rider = nullptr,
-                    int tail_rows = 0);
+                    int tail_rows = 0, int gcn_rows = 0);
 int dg_wgrad_takes_rider(int B);
 int dg_launch_adam(float* p, float* g, float* m, float* v, int64_t n, int64_t step, float lr, float b1,
                    float b2, float eps, int zero_grads, hipStream_t s);

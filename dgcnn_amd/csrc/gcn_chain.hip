@@ -927,9 +927,12 @@ k_chain_fwd_q(int N, int B, int F, const int* __restrict__ sched, const int* __r
 // g4p [3][ROWS] bf16, g4t [16 waves][16] and slots [16 waves][64] are scratch.
 __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned* bl, const float* dv, const uint2* tab,
                                                    unsigned short* g4p, int ROWS, float* g4t_all, float* slots_all,
-                                                   const float* __restrict__ gas4, const float* __restrict__ W4,
+                                                   const float* __restrict__ gas4, const float* W4,
                                                    const float* __restrict__ x3, const float* __restrict__ gp3,
-                                                   float* __restrict__ gas3, float* __restrict__ pa4row) {
+                                                   float* __restrict__ gas3, float* __restrict__ pa4row,
+                                                   char* Himg = nullptr, int PS = 0) {
+  // Himg != null (the whole GCN backward follows in this workgroup, ch_gcn_bwd_graph): gas3 goes into the LDS image
+  // [part][plane][row][16] bf16 (plane stride PS; the layout the block products read) instead of global memory
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -988,7 +991,18 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
       s4[c] = ch_row16_sum(ok ? gh * xv[c] : 0.f);
       s3[c] = ch_row16_sum(ga);
     }
-    if (ok) {
+    if (Himg) {        // (rows >= n of a live tile: ga = 0 -> zeros, which the products expect there)
+      const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        unsigned sp[3][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ch_split3(go[4 * hb + rr], sp[0][rr], sp[1][rr], sp[2][rr]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint2*>(Himg + (p * 2 + hb) * PS + m * 32 + wsl) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+      }
+    } else if (ok) {
       float* dst = gas3 + (size_t)(n0 + m) * 32 + 4 * kq;
       *reinterpret_cast<float4*>(dst) = make_float4(go[0], go[1], go[2], go[3]);
       *reinterpret_cast<float4*>(dst + 16) = make_float4(go[4], go[5], go[6], go[7]);
@@ -1001,6 +1015,8 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
       }
     }
   }
+  if (Himg && RU > 16 * T && tid < 192)      // rows 16T .. RU-1 of the image: written by no tile
+    *reinterpret_cast<uint4*>(Himg + (tid >> 5) * PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
   dg_lds_barrier();
   if (tid < 64) {
     float a = 0.f;
@@ -1009,12 +1025,286 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
   }
 }
 
+// conv3's and conv2's backward (the latter carrying conv1's whole weight gradient: aggregate-first conv1) of ONE graph of
+// <= 256 nodes on 16 waves, one tile per wave, appended to the one-launch training kernel behind ch_conv4_bwd_graph<..Himg..>:
+// the arithmetic of k_chain_bwd_a / k_chain_bwd_b (below) per graph, with gas3 AND gas2 in ONE LDS image (gas2 overwrites gas3
+// in place behind a barrier) -- nothing of the GCN backward crosses a launch boundary, the step is this kernel + k_wgrad.
+// Differences from the two-launch form, all for the latency chain of a single graph:
+//   * the block product runs ONCE (lane = node); the lane = column copy of gh that the weight gradient needs comes from a
+//     wave-private LDS transpose (16 x 32 tile) instead of a second product in the other orientation -- the matrix pipe is the
+//     busiest unit of these phases (2..4 waves per SIMD, 32-cycle fp32 matrix instructions);
+//   * W3 / W2 are read from the FORWARD's operand-order tables, still in LDS (a gather with 4-way bank conflicts, 16 reads),
+//     W4 from its bias table: no global reload, no table rebuild.
+//   H: the image (written by conv4's backward), plane stride PS; bl/dv/tab: the chain forward's LDS images of this graph;
+//   W3op / W2op: the forward's tables; gt_all [16 waves][16][CH_GT_LD]: transpose tiles; slots [16 waves][64]: db2 | db1;
+//   red: >= 32 x 4 KB of LDS that is dead by the end (cross-wave sums of dW3 / dW2 / dW1).
+// Output: row of pb3 (dW3 [32][32] | db2), pb2 (dW2 | db1), pb1 (dW1 [32][Fa]) of this graph.
+#define CH_GT_LD 36
+template <int NBA>
+__device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H, int PS, const unsigned* bl, const float* dv,
+                                                 const uint2* tab, const float* W3op, const float* W2op, float* gt_all,
+                                                 float* slots_all, float* red,
+                                                 const float* __restrict__ x2, const float* __restrict__ gp2,
+                                                 const float* __restrict__ x1, const float* __restrict__ gp1,
+                                                 const float* __restrict__ axg, float* __restrict__ pb3row,
+                                                 float* __restrict__ pb2row, float* __restrict__ pb1row,
+                                                 unsigned long long* dbg = nullptr) {
+#define GB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+#ifdef CH_FINE
+#define GB_FINE(k) GB_MARK(k)
+#else
+#define GB_FINE(k) do { } while (0)
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  const int K32 = (n + 31) >> 5, T = (n + 15) >> 4;
+  const int S = 1 << dgd_class(max(n, 1));
+  float* slot = slots_all + wave * 64;
+  float* gt = gt_all + wave * (16 * CH_GT_LD);
+  const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
+  const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
+  const int m = 16 * wave + nl, mt = 16 * wave;
+  const bool live = wave < T, ok = m < n;
+  const unsigned* blr = bl + min(m, max(n - 1, 0)) * S;
+  const float dn = dv[m];
+  // index of W[o = 16 (s>>2) + 4 kq + (s&3)][k = 16 kb + nl] in the forward's table: wlane + ((s>>2) * 8 + kb * 4) * 64 + (s&3)
+  const int wlane = ((nl & 3) << 6) + 4 * kq + ((nl >> 2) << 4);
+  f32x4 accW3[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  f32x4 accW2[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  f32x4 accA[2][NBA];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb) accA[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // block product of this wave's tile with the image, lane = node: acc[nb][rr] = (Adj . img)[node nl][16 nb + 4 kq + rr]
+  auto product = [&](f32x4 (&acc)[2]) {
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* hp = H + rdoff;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < K32) {
+        const bf16x8 bop = ch_bits_operand(ok ? blr[u] : 0u, kq, tab);
+        bf16x8 a[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) a[p][nb] = ch_read_hsT(hp + (p * 2 + nb) * PS + u * 1024);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][nb], bop, acc[nb], 0, 0, 0);
+      }
+    }
+  };
+  // gh = dn * acc (lane = node) -> the wave's tile -> gh in the lane = column layout: ghN[mb][s] = gh[node 4 kq + s][16 mb + nl]
+  auto transpose = [&](const f32x4 (&acc)[2], float (&ghT)[2][4], float (&ghN)[2][4]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) ghT[nb][rr] = dn * acc[nb][rr];
+      *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 16 * nb + 4 * kq) = make_float4(ghT[nb][0], ghT[nb][1], ghT[nb][2], ghT[nb][3]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) ghN[mb][s_] = gt[(4 * kq + s_) * CH_GT_LD + 16 * mb + nl];      // (same wave: program order)
+  };
+  // ======== conv3 backward ========
+  float go[8];
+  if (live) {
+    const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
+    const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
+    const float4 ga_ = *reinterpret_cast<const float4*>(gp2 + ro), gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
+    float xN[2][4];                  // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const int mm = mt + 4 * kq + s_;
+      const float* xr = x2 + (size_t)(n0 + min(mm, n - 1)) * 32 + nl;
+      const float v0 = xr[0], v1 = xr[16];
+      xN[0][s_] = mm < n ? v0 : 0.f; xN[1][s_] = mm < n ? v1 : 0.f;
+    }
+    GB_FINE(32);
+    f32x4 accT[2];
+    product(accT);
+    GB_FINE(33);
+    float ghT[2][4], ghN[2][4];
+    transpose(accT, ghT, ghN);
+    GB_FINE(34);
+    f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // gx2 = gh W3 (A = W3 gathered, B = gh lane = node)
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W3op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], ghT[s_ >> 2][s_ & 3], gx[kb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)     // dW3 += gh^T x2
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          accW3[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghN[mb][s_], xN[nb][s_], accW3[mb][nb], 0, 0, 0);
+    GB_FINE(35);
+    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    const float gpv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
+    float s2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float ga = ok ? (gx[c >> 2][c & 3] + gpv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+      go[c] = dn * ga;
+      s2[c] = ch_row16_sum(ga);
+    }
+    if (nl == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) slot[16 * (c >> 2) + 4 * kq + (c & 3)] = s2[c];      // db2
+    }
+  }
+  GB_FINE(36);
+  dg_lds_barrier();                  // every wave has read the gas3 image: gas2 overwrites it in place
+  GB_FINE(37);
+  if (live) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      unsigned sp[3][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) ch_split3(go[4 * hb + rr], sp[0][rr], sp[1][rr], sp[2][rr]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(H + (p * 2 + hb) * PS + m * 32 + wsl) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
+    }
+  }
+  GB_FINE(38);
+  // operands of conv2's backward in the lane = column layout: requested before the barrier
+  float xN[2][4], gN[2][4], aN[NBA][4];
+  if (live) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const int mm = mt + 4 * kq + s_;
+      const bool okr = mm < n;
+      const size_t ro = (size_t)(n0 + min(mm, n - 1));
+      const float* xr = x1 + ro * 32 + nl;
+      const float* gr = gp1 + ro * 32 + nl;
+      const float g0 = gr[0], g1 = gr[16];
+      const float x0 = xr[0], x1v = xr[16];
+      xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
+      gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NBA; ++nb) {
+        const int f = 16 * nb + nl;
+        const float av = axg[ro * Fa + min(f, Fa - 1)];
+        aN[nb][s_] = (okr && f < Fa) ? av : 0.f;
+      }
+    }
+  }
+  GB_FINE(39);
+  dg_lds_barrier();
+  GB_MARK(18);
+  // ======== conv2 backward + conv1's weight gradient ========
+  if (live) {
+    f32x4 accT[2];
+    product(accT);
+    float ghT[2][4], ghN[2][4];
+    transpose(accT, ghT, ghN);
+    f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // gx1 (lane = column): A = gh lane = node, B = W2 gathered
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghT[s_ >> 2][s_ & 3], W2op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], gx[kb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)       // dW2 += gh^T x1
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          accW2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghN[mb][s_], xN[nb][s_], accW2[mb][nb], 0, 0, 0);
+    float gaN[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float sb = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        gaN[kb][s_] = (gx[kb][s_] + gN[kb][s_]) * (1.f - xN[kb][s_] * xN[kb][s_]);      // (rows >= n: gx = 0, gp = 0)
+        sb += gaN[kb][s_];
+      }
+      sb += __shfl_xor(sb, 16);
+      sb += __shfl_xor(sb, 32);
+      if (kq == 0) slot[32 + 16 * kb + nl] = sb;                                         // db1
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)       // dW1 += ga1^T ax
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBA; ++nb)
+          accA[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaN[mb][s_], aN[nb][s_], accA[mb][nb], 0, 0, 0);
+  }
+  dg_lds_barrier();                  // every wave is done with the image and the tables: `red` may alias them
+  GB_MARK(19);
+  // ---- the graph's partial rows: the live waves' accumulators summed in wave order -------------------------------------------
+  float* red2 = red + 16 * 1024;
+  if (live) {
+    float* my3 = red + wave * 1024;
+    float* my2 = red2 + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          my3[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW3[mb][nb][rr];
+          my2[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW2[mb][nb][rr];
+        }
+  }
+  dg_lds_barrier();
+  for (int t = tid; t < 1056; t += 1024) {
+    float a3 = 0.f, a2 = 0.f;
+    if (t < 1024) { for (int wv_ = 0; wv_ < T; ++wv_) { a3 += red[wv_ * 1024 + t]; a2 += red2[wv_ * 1024 + t]; } }
+    else { for (int wv_ = 0; wv_ < T; ++wv_) { a3 += slots_all[wv_ * 64 + (t - 1024)]; a2 += slots_all[wv_ * 64 + 32 + (t - 1024)]; } }
+    pb3row[t] = a3; pb2row[t] = a2;
+  }
+  GB_MARK(20);
+  dg_lds_barrier();
+  if (live) {
+    float* my = red + wave * 1024;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) my[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accA[mb][nb][rr];
+  }
+  dg_lds_barrier();
+  for (int t = tid; t < 32 * Fa; t += 1024) {
+    const int o = t / Fa, f = t - o * Fa;
+    float a = 0.f;
+    for (int wv_ = 0; wv_ < T; ++wv_) a += red[wv_ * 1024 + o * 32 + f];
+    pb1row[t] = a;                                                                     // W1's own [32,Fa] layout
+  }
+}
+
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
 struct ChTail {
   unsigned int* err; unsigned int epoch;
   const float* W4; float* gas3; float* pa4; int P1;      // conv4's backward rides along when pa4 != null (P1 >= B rows)
+  float *pb3, *pb2, *pb1;                                // != null: conv3 / conv2 / conv1's backward too (one partial row per graph)
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
   const int64_t* y; float loss_scale; float *dlogit, *gz1g, *gz6g, *gz5g, *gp1, *gp2, *gp3, *gas4, *gb4p, *lossv, *ptail;
+};
+// LDS of the one-launch training kernel behind the chain forward's plan: scratch of the GCN backward that must not alias
+// anything the backward still reads (the cross-wave sums of dW3 / dW2 take the first 128 KB)
+template <int W1S>
+struct ChTrainLds {
+  static constexpr int PS = CH_TRAIN_MAXN * 32;          // plane stride of the gas3 / gas2 images (one tile per wave: 256 rows)
+  static constexpr int BASE = ChQ<16, W1S, CH_TRAIN_MAXN>::TOTAL > 131072 ? ChQ<16, W1S, CH_TRAIN_MAXN>::TOTAL : 131072;
+  static constexpr int OFF_SL = BASE;                    // [16 waves][64]: db2 | db1
+  static constexpr int OFF_SL4 = OFF_SL + 4096;          // [16 waves][64]: dW4 | db3 (conv4's backward)
+  static constexpr int OFF_G4T = OFF_SL4 + 4096;         // [16 waves][16]: gh4 of the wave's tile
+  static constexpr int TOTAL = OFF_G4T + 1024;
+  static constexpr int OFF_GT = 6 * PS;                  // behind the image: [16 waves][16][CH_GT_LD] transpose tiles
+  static_assert(OFF_GT + 16 * 16 * CH_GT_LD * 4 <= ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_W1, "image + transpose tiles inside the forward's image region");
 };
 template <int XI, int W1S>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
@@ -1026,6 +1316,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     dg_rider_phase_a(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd);
     return;
   }
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
   if (threadIdx.x == 0 && graph_ptr[blockIdx.x + 1] - graph_ptr[blockIdx.x] > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
   // (the keys' LDS copy lives in the unused second parity set of the dinv array: beyond the readout's LDS plan, which aliases
@@ -1053,16 +1344,45 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                                 t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
                                 t.pooled, dbg, ext);
   if (t.pa4) {
-    __syncthreads();      // (vmcnt(0): this graph's gas4 and gp3 rows are written; the readout's LDS plan is dead)
+    __syncthreads();      // (vmcnt(0): this graph's gas4 and gp1..gp3 rows are written; the readout's LDS plan is dead)
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
     using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
+    using X = ChTrainLds<W1S>;
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
+    const bool full = t.pb3 != nullptr;
+    // W3 / W2 for gx = gh W: gathered from the FORWARD's operand-order tables, which are still in LDS (no global reload)
+    const float* W2op = reinterpret_cast<const float*>(smem + C::OFF_W2);
+    const float* W3op = reinterpret_cast<const float*>(smem + C::OFF_W3);
+#ifdef CH_REPEAT_BWD      // measurement build: the GCN backward twice (second pass: warm instruction cache; results are garbage)
+    int reps_ = 2;
+    asm volatile("" : "+s"(reps_));
+#pragma unroll 1
+    for (int rep_ = 0; rep_ < reps_; ++rep_) {
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && rep_ == 1) { for (int k = 16; k < 22; ++k) dbg[k + 8] = dbg[k]; dbg[16] = clock64(); }
+#endif
     ch_conv4_bwd_graph(n0, n, reinterpret_cast<const unsigned*>(smem + C::OFF_BL), reinterpret_cast<const float*>(smem + C::OFF_DV),
                        reinterpret_cast<const uint2*>(smem + C::OFF_TAB), reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
-                       reinterpret_cast<float*>(smem + 65536), reinterpret_cast<float*>(smem + 65536 + 1024), t.gas4, t.W4, x3, t.gp3,
-                       t.gas3, t.pa4 + (size_t)b * 64);
-    for (int row = b + B; row < t.P1; row += B)       // rows of pa4 no graph owns
-      if (threadIdx.x < 64) t.pa4[(size_t)row * 64 + threadIdx.x] = 0.f;
+                       reinterpret_cast<float*>(smem + X::OFF_G4T), reinterpret_cast<float*>(smem + X::OFF_SL4), t.gas4,
+                       reinterpret_cast<const float*>(smem + C::OFF_BT) + 96 /* W4: the forward's LDS copy */, x3, t.gp3,
+                       t.gas3, t.pa4 + (size_t)b * 64, full ? smem : nullptr, X::PS);
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[17] = clock64();
+    if (full) {
+      constexpr int NBA = W1S == 8 ? 2 : 1;
+      ch_gcn_bwd_graph<NBA>(n0, n, F, smem, X::PS, reinterpret_cast<const unsigned*>(smem + C::OFF_BL),
+                            reinterpret_cast<const float*>(smem + C::OFF_DV), reinterpret_cast<const uint2*>(smem + C::OFF_TAB), W3op, W2op,
+                            reinterpret_cast<float*>(smem + X::OFF_GT), reinterpret_cast<float*>(smem + X::OFF_SL),
+                            reinterpret_cast<float*>(smem), x2, t.gp2, x1, t.gp1, axg,
+                            t.pb3 + (size_t)b * 1056, t.pb2 + (size_t)b * 1056, t.pb1 + (size_t)b * 32 * F, dbg);
+      if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[21] = clock64();
+    } else {
+      for (int row = b + B; row < t.P1; row += B)       // rows of pa4 no graph owns
+        if (threadIdx.x < 64) t.pa4[(size_t)row * 64 + threadIdx.x] = 0.f;
+    }
+#ifdef CH_REPEAT_BWD
+    __syncthreads();
+    }
+#endif
   }
 }
 
@@ -1721,7 +2041,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit, float* gz1,
                                  float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                                  float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1, hipStream_t s,
-                                 const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                                 const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, float* pb3, float* pb2, float* pb1) {
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || !y)
     return DGCNN_EINVAL;
@@ -1731,6 +2051,9 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   ChTail t;
   t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
   t.W4 = gw.W4; t.gas3 = gas3; t.pa4 = (pa4 && gas3 && P1 >= B) ? pa4 : nullptr; t.P1 = P1;
+  // pb3 / pb2 / pb1 (B rows each): the WHOLE GCN backward of a graph follows its conv4 backward in the same workgroup
+  const bool full = t.pa4 && pb3 && pb2 && pb1;
+  t.pb3 = full ? pb3 : nullptr; t.pb2 = full ? pb2 : nullptr; t.pb1 = full ? pb1 : nullptr;
   t.C = C; t.w = dg_tail_w(params, pl); t.pooled = pooled; t.perm = perm; t.a5g = a5; t.a6g = a6; t.a1dg = a1d; t.maskg = drop_mask;
   t.logp = logp; t.training = training; t.seed = seed; t.y = y; t.loss_scale = loss_scale; t.dlogit = dlogit; t.gz1g = gz1;
   t.gz6g = gz6; t.gz5g = gz5; t.gp1 = gp1; t.gp2 = gp2; t.gp3 = gp3; t.gas4 = gas4; t.gb4p = gb4p; t.lossv = lossv; t.ptail = ptail;
@@ -1740,11 +2063,11 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   static bool attr_set = false;
   if (!attr_set) {
 #define CH_ATTR2(XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS>), \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL) != hipSuccess)
+                          hipFuncAttributeMaxDynamicSharedMemorySize, ChTrainLds<WS>::TOTAL) != hipSuccess)
     if (CH_ATTR2(1, 4) || CH_ATTR2(2, 4) || CH_ATTR2(4, 8)) return DGCNN_ELAUNCH;
     attr_set = true;
   }
-#define CH_LT(XI, WS) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS>), dim3(B + rd.nblk), dim3(1024), ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL, s, ev_start, \
+#define CH_LT(XI, WS) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS>), dim3(B + rd.nblk), dim3(1024), ChTrainLds<WS>::TOTAL, s, ev_start, \
                                             ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
   if (F <= 8) CH_LT(1, 4); else if (F <= 16) CH_LT(2, 4); else CH_LT(4, 8);
 #undef CH_LT

@@ -567,8 +567,11 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
 // backward kernels).  The two halves can run on different streams.
 int dg_wgrad_takes_rider(int B) { return B <= dg_wg_two_stage_b() ? 1 : 0; }      // single-launch form only
 int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, const DgWs* wl, const void* ws,
-                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const DgPrepRider* rider, int tail_rows) {
+                    float* grads, float* metrics, const DgAdam* adam, hipStream_t s, const DgPrepRider* rider, int tail_rows,
+                    int gcn_rows) {
   // tail_rows: rows of `ptail` that hold conv5 / conv6 partials (k_tail_bwd_walk: one per workgroup); 0 = one per graph
+  // gcn_rows: rows of pa4 / pb3 / pb2 / pb1 that hold GCN partials (the one-launch training kernel: one per graph); 0 = P1 / P32
+  const int R1 = gcn_rows > 0 ? gcn_rows : wl->P1, R32 = gcn_rows > 0 ? gcn_rows : wl->P32;
   WgArgs A;
   memset(&A, 0, sizeof(A));
   A.B = B; A.C = C;
@@ -612,13 +615,13 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     const float* pb2 = dg_cptr<float>(ws, wl->pb2);
     const float* pb3 = dg_cptr<float>(ws, wl->pb3);
     const float* pa4 = dg_cptr<float>(ws, wl->pa4);
-    add_col(32, wl->P1, grads + pl->off[5], pa4 + 32, 64);                          // db3 (from conv4 backward)
-    add_col(32, wl->P1, grads + pl->off[6], pa4, 64);                               // dW4
-    add_col(1024, wl->P32, grads + pl->off[2], pb2, 1056);                          // dW2
-    add_col(1024, wl->P32, grads + pl->off[4], pb3, 1056);                          // dW3
-    add_col(32 * F, wl->P32, grads + pl->off[0], pb1, 32 * F);                      // dW1
-    add_col(32, wl->P32, grads + pl->off[1], pb2 + 1024, 1056);                     // db1 (from layer-2 backward)
-    add_col(32, wl->P32, grads + pl->off[3], pb3 + 1024, 1056);                     // db2 (from layer-3 backward)
+    add_col(32, R1, grads + pl->off[5], pa4 + 32, 64);                              // db3 (from conv4 backward)
+    add_col(32, R1, grads + pl->off[6], pa4, 64);                                   // dW4
+    add_col(1024, R32, grads + pl->off[2], pb2, 1056);                              // dW2
+    add_col(1024, R32, grads + pl->off[4], pb3, 1056);                              // dW3
+    add_col(32 * F, R32, grads + pl->off[0], pb1, 32 * F);                          // dW1
+    add_col(32, R32, grads + pl->off[1], pb2 + 1024, 1056);                         // db1 (from layer-2 backward)
+    add_col(32, R32, grads + pl->off[3], pb3 + 1024, 1056);                         // db2 (from layer-3 backward)
     if (big1) add(WG_SUMB, 1, 64, nch_, grads + pl->off[7], t5_, 0);                // db4 (chunk partials of stage 1)
     else add(WG_SUMB, 1, 64, B, grads + pl->off[7], dg_cptr<float>(ws, wl->gb4p), 0);    // db4
   }

@@ -10,7 +10,7 @@ b = synth.make_batch("COLLAB", 50, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
 tr = Trainer(m)
-dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 rn = {8: "topk", 9: "gather+Wstage", 10: "conv5", 11: "pool+conv6", 12: "fc1", 13: "fc2+lsm"}
 tn = ["(sync)", "stage+dlogit", "fc2 bwd+partial", "fc1^T", "conv6 bwd", "pool/relu", "W5/W6 partials", "scatter"]
