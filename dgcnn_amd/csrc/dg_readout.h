@@ -219,10 +219,11 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   // conv5/conv6 weights -> LDS first: their global loads fly while the keys are sorted (the key area is
   // the first n*8 <= 4096*8 bytes of region0 only when n > 1456; W5s starts at byte 11648)
   float* bs = M.bias;        // every bias of the tail in LDS: no global load between the prefetch and its use
-  if (tid < 16) bs[tid] = w.b5[tid];
-  else if (tid < 48) bs[tid] = w.b6[tid - 16];
-  else if (tid < 176) bs[tid] = w.bf1[tid - 48];
-  else if (tid < 176 + C) bs[tid] = w.bf2[tid - 176];
+  // (ONE unconditional load through a selected pointer, stored to LDS behind the selection: as four `if (..) bs[tid] = w.b[..]`
+  //  branches each was load -> s_waitcnt vmcnt(0) -> ds_write on the spot, a cold round trip -- the optimizer rewrites the biases
+  //  every step -- in front of the sort)
+  const float* bsrc = tid < 16 ? w.b5 + tid : (tid < 48 ? w.b6 + (tid - 16) : (tid < 176 ? w.bf1 + (tid - 48) : (tid < 176 + C ? w.bf2 + (tid - 176) : w.b5)));
+  const float bval = *bsrc;
   // conv5 / conv6 weights: loads issued now, held in registers over the sort (the key area may overlap W5s/W6s),
   // stored to LDS afterwards -- no memory round trip of theirs is left on the critical path
   DgStage<NW5, RD_THREADS> st5;
@@ -231,6 +232,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   float wf2a = 0.f, wf2b = 0.f;                   // classifier_2 row of class `wv` (used at the very end: no cold load there)
   if (!BIG && wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }
   dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
+  if (tid < 176 + C) bs[tid] = bval;                              // (read behind the barrier that follows the gather)
   if (BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
@@ -381,6 +383,9 @@ __device__ __forceinline__ void dg_readout_fwd_body(
     acc = fmaf(pre ? wf2b : wr[lane + 64], a1s[lane + 64], acc);
     acc = dg_wave_sum(acc);
     if (lane == 0) lg[c] = acc + bs[176 + c];
+    // the prefetched row also goes to LDS (the conv5 partial-tile area, dead since conv5): the merged training kernels'
+    // backward half reads classifier_2's weights from there instead of loading them again
+    if (pre && c < 16) { M.cpart[c * DGCNN_HID1 + lane] = wf2a; M.cpart[c * DGCNN_HID1 + lane + 64] = wf2b; }
   }
   dg_lds_barrier();
   // log_softmax over C (C <= 64): wave 0

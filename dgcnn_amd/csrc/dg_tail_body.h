@@ -14,7 +14,13 @@
 // are capped at 64 so that two workgroups share a CU.  Same arithmetic order: bit-identical results.
 // body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
 // training kernel k_readout_tail (forward readout + this, one launch)
-struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb; };      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb;
+               const float *wf2s, *x4l, *dvl; };     // (optional LDS copies: classifier_2's rows [<= 16][128]; conv4's outputs and dinv by LOCAL node)      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+// the one-launch training kernel whose GCN backward follows in the same workgroup: the SortPooling gradient STAYS IN LDS in its
+// sparse form -- the <= 30 selected nodes' rows gpL [30][96] (columns of x1 | x2 | x3), gas4L [n <= 256] (zero except the
+// selected nodes) and slotmap [n] (node -> row of gpL, -1 = not selected) -- instead of the dense slabs gp1..gp3 [N,32] and
+// gas4 [N] in global memory (no zero fill of 3 x 128 B per node, no scatter, no round trip before conv4's backward)
+struct TbLds { float* gpL; float* gas4L; int* slotmap; };
 // HEAD = false (large batches): classifier_2 / classifier_1's backward ran batched over graphs (classifier.hip) and left
 // the gradient of conv6's output in gz6g -- steps 1-3 are skipped.
 template <bool BIG, bool MERGED = false, bool HEAD = true>
@@ -27,7 +33,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     float* __restrict__ gz5g, float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3,
     float* __restrict__ gas4, float* __restrict__ gb4p, float* __restrict__ lossv,
     float* __restrict__ ptail, const float* __restrict__ pooled, unsigned long long* dbg, TbExt ext = TbExt{},
-    int* __restrict__ gpsel = nullptr, float* pacc = nullptr, bool pacc_first = true, int tid_in = -1) {
+    int* __restrict__ gpsel = nullptr, float* pacc = nullptr, bool pacc_first = true, int tid_in = -1, TbLds L = TbLds{}) {
 #define TB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   TB_MARK(0);
   // MERGED (k_readout_tail): conv5 / conv6 weights, the pooled rows and the log-probabilities are still in the forward
@@ -86,13 +92,21 @@ __device__ __forceinline__ void dg_tail_bwd_body(
     if (MERGED) { const int ls = ext.sel[tid - 64]; node_ = ls >= 0 ? n0 + ls : -1; }
     else node_ = perm[b * DGCNN_K + (tid - 64)];
   }
+  // MERGED with LDS copies of conv4's outputs / dinv (the one-launch training kernel): NO small global load is issued in this
+  // body at all -- the only vector-memory loads in flight are classifier_1's rows below.  (A small load issued before them and
+  // first used after them cannot be waited for precisely: the big loads sit behind a divergent `if`, the compiler cannot count
+  // them and emits vmcnt(0) -- the whole 180 KB awaited a step early; issuing them from all 1024 threads instead made them
+  // countable but cost 80 more wave-level load instructions at ~14 cycles of the CU's address path each.)
+  const bool lds_ops = MERGED && ext.x4l != nullptr;
+  float x4e_ = 0.f, dve_ = 0.f;
+  if (lds_ops && tid >= 64 && tid < 64 + DGCNN_K) { const int ls = ext.sel[tid - 64], lc = ls >= 0 ? ls : 0; x4e_ = ext.x4l[lc]; dve_ = ext.dvl[lc]; }
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
 #pragma unroll
   for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
   if (HEAD && tid < DGCNN_HID1) {
     a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
+    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = (MERGED && ext.wf2s) ? ext.wf2s[c * DGCNN_HID1 + tid] : w.Wf2[c * DGCNN_HID1 + tid];
   }
   // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
   // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only
@@ -111,14 +125,16 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // gpsel (large batches whose GCN backward is the chain kernels): instead of the zero rows -- 3 x 128 B per node, 57 MB of the
   // launch's 150 MB of HBM writes at 2048 COLLAB graphs -- one flag word per node; the rows of the <= 30 selected nodes are
   // written by the scatter below, the consumers skip the others
-  if (gpsel) {
+  if (L.gpL) {
+    if (tid < 256) { L.gas4L[tid] = 0.f; L.slotmap[tid] = -1; }
+  } else if (gpsel) {
     for (int t = tid; t < n; t += RD_THREADS) gpsel[n0 + t] = 0;
   } else {
     for (int t = tid; t < n * 32; t += RD_THREADS) {
       gp1[(size_t)n0 * 32 + t] = 0.f; gp2[(size_t)n0 * 32 + t] = 0.f; gp3[(size_t)n0 * 32 + t] = 0.f;
     }
   }
-  for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
+  if (!L.gpL) for (int t = tid; t < n; t += RD_THREADS) gas4[n0 + t] = 0.f;
   if (tid < DGCNN_K) ga4s[tid] = 0.f;
 
   if (HEAD) {
@@ -149,7 +165,8 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   dg_lds_barrier();
   TB_MARK(1);
   float x4n_ = 0.f, dvn_ = 0.f;             // conv4 output / dst scale of the selected nodes (wave 1; used in step 6)
-  if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
+  if (lds_ops) { x4n_ = node_ >= 0 ? x4e_ : 0.f; dvn_ = node_ >= 0 ? dve_ : 0.f; }
+  else if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
   // 2. through classifier_2, dropout, ReLU
   if (HEAD && tid < DGCNN_HID1) {
     float ga = 0.f;
@@ -301,6 +318,17 @@ __device__ __forceinline__ void dg_tail_bwd_body(
         [&](int sl, int c, float v) {
           if (sl < msel && c < DGCNN_CAT) {
             const int node = selS[sl];
+            if (L.gpL) {
+              if (c < 96) L.gpL[sl * 96 + c] = v;
+              else {
+                const float xv = x4S[sl];
+                const float ga = v * (1.f - xv * xv);      // tanh'
+                L.gas4L[node - n0] = dvS[sl] * ga;
+                L.slotmap[node - n0] = sl;
+                ga4s[sl] = ga;
+              }
+              return;
+            }
             if (gpsel && c == 0) gpsel[node] = 1;      // (behind several barriers of this workgroup: after the clearing store)
             if (c < 32) gp1[(size_t)node * 32 + c] = v;
             else if (c < 64) gp2[(size_t)node * 32 + c - 32] = v;

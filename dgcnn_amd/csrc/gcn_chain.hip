@@ -542,8 +542,12 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
                                         ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
   }
-  const float b4s = gw.b4[0];
+  const float b4v = gw.b4[0];
   __syncthreads();
+  // (consumed HERE, where nothing else is in flight: its first use used to be conv4's epilogue, behind the layers' CONDITIONAL
+  //  row stores -- the compiler cannot count those, so it waited with vmcnt(0) there: every x4 store of a lane drained the
+  //  previous one, eight store round trips in a row per graph)
+  const float b4s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b4v)));
   const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
   const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;         // this lane's node in tile wave / tile wave + WAVES
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
@@ -613,14 +617,26 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
       eN = entry_of(r + 2);
       prefetch(n0N, nN);
     }
-    // this lane's bitmap rows stay in LDS (re-read per layer: 2 x K32 words; in registers they cost 16 at eight waves)
+    // this lane's bitmap rows stay in LDS (re-read per layer: 2 x K32 words; in registers they cost 16 at eight waves) ...
     const unsigned* bl0 = bl + min(mrow0, max(n - 1, 0)) * S;
     const unsigned* bl1 = bl + min(mrow1, max(n - 1, 0)) * S;
-    const bool rv0 = mrow0 < n, rv1 = mrow1 < n;
+    // TWO = false (graphs of at most 16 * WAVES nodes: the one-launch training kernel): a wave never has a second tile -- known
+    // at compile time, so none of its code exists -- and ... the ONE tile's words are read into registers once per graph: the
+    // word read and the nibble-table lookup it feeds were two DEPENDENT LDS round trips per word in front of every layer's matrix
+    // instructions (the per-word `if (u < K32)` blocks keep the compiler from hoisting them itself)
+    constexpr bool TWO = MAXN > 16 * WAVES;
+    const bool rv0 = mrow0 < n, rv1 = TWO && mrow1 < n;
+    unsigned wreg[TWO ? 1 : C::KW];
+    if (!TWO) {
+#pragma unroll
+      for (int u = 0; u < C::KW; ++u) wreg[u] = bl0[min(u, S - 1)];
+#pragma unroll
+      for (int u = 0; u < C::KW; ++u) wreg[u] = (rv0 && u < K32) ? wreg[u] : 0u;
+    }
     const float dn[2] = {dv[mrow0], dv[mrow1]};
     const int mrow[2] = {mrow0, mrow1};
     CH_T(3);
-    const bool live0 = wave < T, live1 = wave + WAVES < T;
+    const bool live0 = wave < T, live1 = TWO && wave + WAVES < T;
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 
     // block products of this wave's tiles with the image: every HS^T operand read once, used by both tiles; the reads of
@@ -633,7 +649,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #pragma unroll
       for (int u = 0; u < C::KW; ++u) {
         if (u < K32) {
-          const bf16x8 bop0 = ch_bits_operand(rv0 ? bl0[u] : 0u, kq, tab);
+          const bf16x8 bop0 = ch_bits_operand(TWO ? (rv0 ? bl0[u] : 0u) : wreg[u], kq, tab);
           const bf16x8 bop1 = ch_bits_operand(rv1 ? bl1[u] : 0u, kq, tab);
           bf16x8 a[NP][NBP];
 #pragma unroll
@@ -867,7 +883,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
           bf16x8 bop;
           unsigned* bu = reinterpret_cast<unsigned*>(&bop);
           bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
-          a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(rv0 ? bl0[u] : 0u, kq, tab), bop, a4[0], 0, 0, 0);
+          a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(TWO ? (rv0 ? bl0[u] : 0u) : wreg[u], kq, tab), bop, a4[0], 0, 0, 0);
           if (live1) a4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(rv1 ? bl1[u] : 0u, kq, tab), bop, a4[1], 0, 0, 0);
         }
       }
@@ -929,10 +945,7 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
                                                    unsigned short* g4p, int ROWS, float* g4t_all, float* slots_all,
                                                    const float* __restrict__ gas4, const float* W4,
                                                    const float* __restrict__ x3, const float* __restrict__ gp3,
-                                                   float* __restrict__ gas3, float* __restrict__ pa4row,
-                                                   char* Himg = nullptr, int PS = 0) {
-  // Himg != null (the whole GCN backward follows in this workgroup, ch_gcn_bwd_graph): gas3 goes into the LDS image
-  // [part][plane][row][16] bf16 (plane stride PS; the layout the block products read) instead of global memory
+                                                   float* __restrict__ gas3, float* __restrict__ pa4row) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -991,18 +1004,7 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
       s4[c] = ch_row16_sum(ok ? gh * xv[c] : 0.f);
       s3[c] = ch_row16_sum(ga);
     }
-    if (Himg) {        // (rows >= n of a live tile: ga = 0 -> zeros, which the products expect there)
-      const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        unsigned sp[3][4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ch_split3(go[4 * hb + rr], sp[0][rr], sp[1][rr], sp[2][rr]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<uint2*>(Himg + (p * 2 + hb) * PS + m * 32 + wsl) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
-      }
-    } else if (ok) {
+    if (ok) {
       float* dst = gas3 + (size_t)(n0 + m) * 32 + 4 * kq;
       *reinterpret_cast<float4*>(dst) = make_float4(go[0], go[1], go[2], go[3]);
       *reinterpret_cast<float4*>(dst + 16) = make_float4(go[4], go[5], go[6], go[7]);
@@ -1015,8 +1017,6 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
       }
     }
   }
-  if (Himg && RU > 16 * T && tid < 192)      // rows 16T .. RU-1 of the image: written by no tile
-    *reinterpret_cast<uint4*>(Himg + (tid >> 5) * PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
   dg_lds_barrier();
   if (tid < 64) {
     float a = 0.f;
@@ -1025,28 +1025,32 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
   }
 }
 
-// conv3's and conv2's backward (the latter carrying conv1's whole weight gradient: aggregate-first conv1) of ONE graph of
-// <= 256 nodes on 16 waves, one tile per wave, appended to the one-launch training kernel behind ch_conv4_bwd_graph<..Himg..>:
-// the arithmetic of k_chain_bwd_a / k_chain_bwd_b (below) per graph, with gas3 AND gas2 in ONE LDS image (gas2 overwrites gas3
-// in place behind a barrier) -- nothing of the GCN backward crosses a launch boundary, the step is this kernel + k_wgrad.
-// Differences from the two-launch form, all for the latency chain of a single graph:
-//   * the block product runs ONCE (lane = node); the lane = column copy of gh that the weight gradient needs comes from a
-//     wave-private LDS transpose (16 x 32 tile) instead of a second product in the other orientation -- the matrix pipe is the
-//     busiest unit of these phases (2..4 waves per SIMD, 32-cycle fp32 matrix instructions);
+// The WHOLE GCN backward (conv4, conv3, conv2 carrying conv1's weight gradient: aggregate-first conv1) of ONE graph of <= 256
+// nodes on 16 waves, one tile per wave, appended to the one-launch training kernel: the arithmetic of ch_conv4_bwd_graph /
+// k_chain_bwd_a / k_chain_bwd_b per graph, with gas3 AND gas2 in ONE LDS image (gas2 overwrites gas3 in place behind a
+// barrier) -- nothing of the GCN backward crosses a launch boundary, the step is this kernel + k_wgrad.
+// Differences from the multi-launch forms, all for the latency chain of a single graph:
+//   * the SortPooling gradient arrives in LDS in its sparse form (TbLds: 30 rows + a node -> row map + gas4): no dense slabs;
+//   * the block product runs ONCE (lane = node); the lane = column copies the weight gradients need (gh, x2, x1, gp1) come from
+//     wave-private LDS transposes of a 16 x 32 tile -- no second product in the other orientation, no transposed global gathers
+//     (a dword-per-lane load costs the CU's address path ~14 cycles per wave-instruction: 20 of them per wave were 2.2 k cycles);
+//   * column sums over the tile's 16 nodes (dW4, db3, db2) through the same tile instead of 4-step DPP row sums per value;
 //   * W3 / W2 are read from the FORWARD's operand-order tables, still in LDS (a gather with 4-way bank conflicts, 16 reads),
-//     W4 from its bias table: no global reload, no table rebuild.
-//   H: the image (written by conv4's backward), plane stride PS; bl/dv/tab: the chain forward's LDS images of this graph;
-//   W3op / W2op: the forward's tables; gt_all [16 waves][16][CH_GT_LD]: transpose tiles; slots [16 waves][64]: db2 | db1;
-//   red: >= 32 x 4 KB of LDS that is dead by the end (cross-wave sums of dW3 / dW2 / dW1).
-// Output: row of pb3 (dW3 [32][32] | db2), pb2 (dW2 | db1), pb1 (dW1 [32][Fa]) of this graph.
+//     W4 from its bias table: no global reload, no table rebuild;
+//   * every global operand of a layer (x3 | x2 | x1, ax rows) is requested one phase ahead.
+//   H: the image, plane stride PS; bl/dv/tab: the chain forward's LDS images of this graph; W3op / W2op / W4: the forward's
+//   tables; g4p [3][ROWS] bf16 and g4t [16 waves][16]: conv4's scratch; gt_all [16 waves][16][CH_GT_LD]: tiles;
+//   slots [16 waves][128]: dW4 | db3 | db2 | db1; red: >= 32 x 4 KB of LDS that is dead by the end (cross-wave sums).
+// Output: this graph's row of pa4 (dW4 | db3), pb3 (dW3 [32][32] | db2), pb2 (dW2 | db1), pb1 (dW1 [32][Fa]).
 #define CH_GT_LD 36
 template <int NBA>
 __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H, int PS, const unsigned* bl, const float* dv,
-                                                 const uint2* tab, const float* W3op, const float* W2op, float* gt_all,
-                                                 float* slots_all, float* red,
-                                                 const float* __restrict__ x2, const float* __restrict__ gp2,
-                                                 const float* __restrict__ x1, const float* __restrict__ gp1,
-                                                 const float* __restrict__ axg, float* __restrict__ pb3row,
+                                                 const uint2* tab, const float* W3op, const float* W2op, const float* W4,
+                                                 unsigned short* g4p, int ROWS, float* g4t_all, float* gt_all,
+                                                 float* slots_all, float* red, const TbLds L,
+                                                 const float* __restrict__ x3, const float* __restrict__ x2,
+                                                 const float* __restrict__ x1, const float* __restrict__ axg,
+                                                 float* __restrict__ pa4row, float* __restrict__ pb3row,
                                                  float* __restrict__ pb2row, float* __restrict__ pb1row,
                                                  unsigned long long* dbg = nullptr) {
 #define GB_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
@@ -1058,15 +1062,21 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
-  const int K32 = (n + 31) >> 5, T = (n + 15) >> 4;
+  const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
   const int S = 1 << dgd_class(max(n, 1));
-  float* slot = slots_all + wave * 64;
+  float* slot = slots_all + wave * 128;
   float* gt = gt_all + wave * (16 * CH_GT_LD);
+  float* g4t = g4t_all + wave * 16;
   const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
   const int m = 16 * wave + nl, mt = 16 * wave;
   const bool live = wave < T, ok = m < n;
   const unsigned* blr = bl + min(m, max(n - 1, 0)) * S;
+  unsigned wreg[8];                  // this lane's bitmap row, once for the three layers (see the forward)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wreg[u] = blr[min(u, S - 1)];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wreg[u] = (ok && u < K32) ? wreg[u] : 0u;
   const float dn = dv[m];
   // index of W[o = 16 (s>>2) + 4 kq + (s&3)][k = 16 kb + nl] in the forward's table: wlane + ((s>>2) * 8 + kb * 4) * 64 + (s&3)
   const int wlane = ((nl & 3) << 6) + 4 * kq + ((nl >> 2) << 4);
@@ -1084,7 +1094,7 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u < K32) {
-        const bf16x8 bop = ch_bits_operand(ok ? blr[u] : 0u, kq, tab);
+        const bf16x8 bop = ch_bits_operand(wreg[u], kq, tab);
         bf16x8 a[3][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -1097,73 +1107,34 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
       }
     }
   };
-  // gh = dn * acc (lane = node) -> the wave's tile -> gh in the lane = column layout: ghN[mb][s] = gh[node 4 kq + s][16 mb + nl]
-  auto transpose = [&](const f32x4 (&acc)[2], float (&ghT)[2][4], float (&ghN)[2][4]) {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) ghT[nb][rr] = dn * acc[nb][rr];
-      *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 16 * nb + 4 * kq) = make_float4(ghT[nb][0], ghT[nb][1], ghT[nb][2], ghT[nb][3]);
-    }
+  // the wave's 16 x 32 tile (row = node of the tile): a lane puts the 8 values of its node (columns 4 kq .. +3, 16 + 4 kq .. +3) ...
+  auto tile_put = [&](const float (&v)[8]) {
+    *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 16 + 4 * kq) = make_float4(v[4], v[5], v[6], v[7]);
+  };
+  // ... and takes the lane = column layout: out[mb][s] = tile[node 4 kq + s][16 mb + nl]      (same wave: program order)
+  auto tile_cols = [&](float (&out)[2][4]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) ghN[mb][s_] = gt[(4 * kq + s_) * CH_GT_LD + 16 * mb + nl];      // (same wave: program order)
+      for (int s_ = 0; s_ < 4; ++s_) out[mb][s_] = gt[(4 * kq + s_) * CH_GT_LD + 16 * mb + nl];
   };
-  // ======== conv3 backward ========
-  float go[8];
-  if (live) {
-    const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
-    const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
-    const float4 ga_ = *reinterpret_cast<const float4*>(gp2 + ro), gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
-    float xN[2][4];                  // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
+  // ... or the column sums over the 16 nodes: lane l receives column l & 31 (both halves of the wave hold it)
+  auto tile_colsum = [&]() {
+    const float* cp = gt + (lane >> 5) * (8 * CH_GT_LD) + (lane & 31);
+    float a = cp[0];
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      const int mm = mt + 4 * kq + s_;
-      const float* xr = x2 + (size_t)(n0 + min(mm, n - 1)) * 32 + nl;
-      const float v0 = xr[0], v1 = xr[16];
-      xN[0][s_] = mm < n ? v0 : 0.f; xN[1][s_] = mm < n ? v1 : 0.f;
-    }
-    GB_FINE(32);
-    f32x4 accT[2];
-    product(accT);
-    GB_FINE(33);
-    float ghT[2][4], ghN[2][4];
-    transpose(accT, ghT, ghN);
-    GB_FINE(34);
-    f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // gx2 = gh W3 (A = W3 gathered, B = gh lane = node)
-#pragma unroll
-    for (int s_ = 0; s_ < 8; ++s_) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W3op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], ghT[s_ >> 2][s_ & 3], gx[kb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_)     // dW3 += gh^T x2
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          accW3[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghN[mb][s_], xN[nb][s_], accW3[mb][nb], 0, 0, 0);
-    GB_FINE(35);
-    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-    const float gpv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
-    float s2[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float ga = ok ? (gx[c >> 2][c & 3] + gpv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
-      go[c] = dn * ga;
-      s2[c] = ch_row16_sum(ga);
-    }
-    if (nl == 0) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) slot[16 * (c >> 2) + 4 * kq + (c & 3)] = s2[c];      // db2
-    }
-  }
-  GB_FINE(36);
-  dg_lds_barrier();                  // every wave has read the gas3 image: gas2 overwrites it in place
-  GB_FINE(37);
-  if (live) {
+    for (int r = 1; r < 8; ++r) a += cp[r * CH_GT_LD];
+    return a + __shfl_xor(a, 32);
+  };
+  // rows of the sparse SortPooling gradient (columns c0 .. of gpL) of this lane's node, zero for a node that was not selected
+  auto gp_row = [&](int slot_, int c0, float (&g)[8]) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* r = L.gpL + max(slot_, 0) * 96 + c0 + 4 * kq;
+    const float4 a = slot_ >= 0 ? *reinterpret_cast<const float4*>(r) : z, b = slot_ >= 0 ? *reinterpret_cast<const float4*>(r + 16) : z;
+    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+  };
+  auto image_store = [&](const float (&go)[8]) {
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       unsigned sp[3][4];
@@ -1173,45 +1144,159 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
       for (int p = 0; p < 3; ++p)
         *reinterpret_cast<uint2*>(H + (p * 2 + hb) * PS + m * 32 + wsl) = make_uint2(sp[p][0] | (sp[p][1] << 16), sp[p][2] | (sp[p][3] << 16));
     }
+  };
+  const size_t ro = (size_t)(n0 + min(m, max(n - 1, 0))) * 32 + 4 * kq;
+  const int myslot = ok ? L.slotmap[m] : -1;
+  // ======== conv4 backward (+ the start of conv3's): gh4 = dinv (Adj gas4), gas3 = dinv (gh4 W4 + gp3)(1 - x3^2) -> image ========
+  // (UNCONDITIONAL loads on clamped addresses, dead waves included: behind `if (live)` the compiler parks the result in a temporary
+  //  and waits for it on the spot -- the whole round trip exposed where the load was meant to be a phase ahead)
+  const float4 x3a = *reinterpret_cast<const float4*>(x3 + ro), x3b = *reinterpret_cast<const float4*>(x3 + ro + 16);
+  const float4 x2a = *reinterpret_cast<const float4*>(x2 + ro), x2b = *reinterpret_cast<const float4*>(x2 + ro + 16);      // (conv3's, a phase ahead)
+  if (tid < RU) {
+    unsigned q0, q1, q2;
+    ch_split3(tid < 256 ? L.gas4L[tid] : 0.f, q0, q1, q2);        // (zero beyond the selected nodes)
+    g4p[tid] = (unsigned short)q0; g4p[ROWS + tid] = (unsigned short)q1; g4p[2 * ROWS + tid] = (unsigned short)q2;
   }
-  GB_FINE(38);
-  // operands of conv2's backward in the lane = column layout: requested before the barrier
-  float xN[2][4], gN[2][4], aN[NBA][4];
+  if (RU > 16 * T && tid < 192)      // rows 16T .. RU-1 of the image: written by no tile
+    *reinterpret_cast<uint4*>(H + (tid >> 5) * PS + (16 * T + ((tid >> 1) & 15)) * 32 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
+  GB_FINE(40);
+  dg_lds_barrier();
+  GB_FINE(41);
   if (live) {
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned short* hq = g4p + min(nl, 2) * ROWS + 4 * kq;
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      const int mm = mt + 4 * kq + s_;
-      const bool okr = mm < n;
-      const size_t ro = (size_t)(n0 + min(mm, n - 1));
-      const float* xr = x1 + ro * 32 + nl;
-      const float* gr = gp1 + ro * 32 + nl;
-      const float g0 = gr[0], g1 = gr[16];
-      const float x0 = xr[0], x1v = xr[16];
-      xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
-      gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NBA; ++nb) {
-        const int f = 16 * nb + nl;
-        const float av = axg[ro * Fa + min(f, Fa - 1)];
-        aN[nb][s_] = (okr && f < Fa) ? av : 0.f;
+    for (int u = 0; u < 8; ++u) {
+      if (u < K32) {
+        uint2 lo = *reinterpret_cast<const uint2*>(hq + 32 * u), hi = *reinterpret_cast<const uint2*>(hq + 32 * u + 16);
+        if (nl >= 3) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+        bf16x8 bop;
+        unsigned* bu = reinterpret_cast<unsigned*>(&bop);
+        bu[0] = lo.x; bu[1] = lo.y; bu[2] = hi.x; bu[3] = hi.y;
+        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch_bits_operand(wreg[u], kq, tab), bop, a4, 0, 0, 0);
       }
     }
+    GB_FINE(42);
+    float tot[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) tot[rr] = (a4[rr] + __shfl_xor(a4[rr], 1)) + __shfl_xor(a4[rr], 2);
+    if (nl == 0) {
+      const float4 dq = *reinterpret_cast<const float4*>(dv + mt + 4 * kq);
+      *reinterpret_cast<float4*>(g4t + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
+    }
+    const float gh = g4t[nl];
+    const float4 w4a = *reinterpret_cast<const float4*>(W4 + 4 * kq), w4b = *reinterpret_cast<const float4*>(W4 + 16 + 4 * kq);
+    const float xv[8] = {x3a.x, x3a.y, x3a.z, x3a.w, x3b.x, x3b.y, x3b.z, x3b.w};
+    const float wv[8] = {w4a.x, w4a.y, w4a.z, w4a.w, w4b.x, w4b.y, w4b.z, w4b.w};
+    float gv[8], go[8], t4[8], t3[8];
+    gp_row(myslot, 64, gv);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float ga = ok ? fmaf(gh, wv[c], gv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+      go[c] = dn * ga;
+      t4[c] = ok ? gh * xv[c] : 0.f;
+      t3[c] = ga;
+    }
+    GB_FINE(43);
+    tile_put(t4);
+    const float s4 = tile_colsum();
+    tile_put(t3);
+    const float s3 = tile_colsum();
+    if (lane < 32) { slot[lane] = s4; slot[32 + lane] = s3; }          // dW4 | db3
+    GB_FINE(44);
+    image_store(go);
+    GB_FINE(45);
   }
-  GB_FINE(39);
+  dg_lds_barrier();
+  GB_MARK(17);
+  // ======== conv3 backward ========
+  float go2[8];
+  // conv2's global operands, a phase ahead (unconditional, see above)
+  const float4 x1a = *reinterpret_cast<const float4*>(x1 + ro), x1b = *reinterpret_cast<const float4*>(x1 + ro + 16);
+  float aN[NBA][4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int mm = mt + 4 * kq + s_;
+    const size_t rr_ = (size_t)(n0 + min(mm, max(n - 1, 0)));
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb) aN[nb][s_] = axg[rr_ * Fa + min(16 * nb + nl, Fa - 1)];
+  }
+  if (live) {
+    const float xv[8] = {x2a.x, x2a.y, x2a.z, x2a.w, x2b.x, x2b.y, x2b.z, x2b.w};
+    float xm[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xm[c] = ok ? xv[c] : 0.f;
+    float xN[2][4];                  // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
+    tile_put(xm);
+    tile_cols(xN);
+    GB_FINE(32);
+    f32x4 accT[2];
+    product(accT);
+    GB_FINE(33);
+    float ghT[8], ghN[2][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ghT[c] = dn * accT[c >> 2][c & 3];
+    tile_put(ghT);
+    tile_cols(ghN);
+    GB_FINE(34);
+    f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // gx2 = gh W3 (A = W3 gathered, B = gh lane = node)
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W3op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], ghT[s_], gx[kb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)     // dW3 += gh^T x2
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          accW3[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghN[mb][s_], xN[nb][s_], accW3[mb][nb], 0, 0, 0);
+    GB_FINE(35);
+    float gpv[8], t2[8];
+    gp_row(myslot, 32, gpv);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float ga = ok ? (gx[c >> 2][c & 3] + gpv[c]) * (1.f - xv[c] * xv[c]) : 0.f;
+      go2[c] = dn * ga;
+      t2[c] = ga;
+    }
+    tile_put(t2);
+    const float s2 = tile_colsum();
+    if (lane < 32) slot[64 + lane] = s2;                                // db2
+  }
+  GB_FINE(36);
+  dg_lds_barrier();                  // every wave has read the gas3 image: gas2 overwrites it in place
+  GB_FINE(37);
+  if (live) image_store(go2);
+  GB_FINE(38);
   dg_lds_barrier();
   GB_MARK(18);
   // ======== conv2 backward + conv1's weight gradient ========
   if (live) {
+    const float x1v[8] = {x1a.x, x1a.y, x1a.z, x1a.w, x1b.x, x1b.y, x1b.z, x1b.w};
+    float xm[8], gm[8], xN[2][4], gN[2][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xm[c] = ok ? x1v[c] : 0.f;
+    tile_put(xm);
+    tile_cols(xN);
+    gp_row(myslot, 0, gm);               // (rows >= n: myslot = -1 -> zeros)
+    tile_put(gm);
+    tile_cols(gN);
     f32x4 accT[2];
     product(accT);
-    float ghT[2][4], ghN[2][4];
-    transpose(accT, ghT, ghN);
+    float ghT[8], ghN[2][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ghT[c] = dn * accT[c >> 2][c & 3];
+    tile_put(ghT);
+    tile_cols(ghN);
     f32x4 gx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // gx1 (lane = column): A = gh lane = node, B = W2 gathered
 #pragma unroll
     for (int s_ = 0; s_ < 8; ++s_) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghT[s_ >> 2][s_ & 3], W2op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], gx[kb], 0, 0, 0);
+        gx[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ghT[s_], W2op[wlane + (((s_ >> 2) * 8 + kb * 4) << 6) + (s_ & 3)], gx[kb], 0, 0, 0);
     }
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)       // dW2 += gh^T x1
@@ -1231,15 +1316,17 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
       }
       sb += __shfl_xor(sb, 16);
       sb += __shfl_xor(sb, 32);
-      if (kq == 0) slot[32 + 16 * kb + nl] = sb;                                         // db1
+      if (kq == 0) slot[96 + 16 * kb + nl] = sb;                                         // db1
     }
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)       // dW1 += ga1^T ax
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NBA; ++nb)
-          accA[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaN[mb][s_], aN[nb][s_], accA[mb][nb], 0, 0, 0);
+        for (int nb = 0; nb < NBA; ++nb) {
+          const float av = (mt + 4 * kq + s_ < n && 16 * nb + nl < Fa) ? aN[nb][s_] : 0.f;
+          accA[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaN[mb][s_], av, accA[mb][nb], 0, 0, 0);
+        }
   }
   dg_lds_barrier();                  // every wave is done with the image and the tables: `red` may alias them
   GB_MARK(19);
@@ -1259,11 +1346,17 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
         }
   }
   dg_lds_barrier();
-  for (int t = tid; t < 1056; t += 1024) {
-    float a3 = 0.f, a2 = 0.f;
-    if (t < 1024) { for (int wv_ = 0; wv_ < T; ++wv_) { a3 += red[wv_ * 1024 + t]; a2 += red2[wv_ * 1024 + t]; } }
-    else { for (int wv_ = 0; wv_ < T; ++wv_) { a3 += slots_all[wv_ * 64 + (t - 1024)]; a2 += slots_all[wv_ * 64 + 32 + (t - 1024)]; } }
-    pb3row[t] = a3; pb2row[t] = a2;
+  for (int t = tid; t < 1024 + 128; t += 1024) {
+    if (t < 1024) {
+      float a3 = 0.f, a2 = 0.f;
+      for (int wv_ = 0; wv_ < T; ++wv_) { a3 += red[wv_ * 1024 + t]; a2 += red2[wv_ * 1024 + t]; }
+      pb3row[t] = a3; pb2row[t] = a2;
+    } else {
+      const int j = t - 1024;            // dW4 | db3 | db2 | db1
+      float a = 0.f;
+      for (int wv_ = 0; wv_ < T; ++wv_) a += slots_all[wv_ * 128 + j];
+      if (j < 64) pa4row[j] = a; else if (j < 96) pb3row[1024 + j - 64] = a; else pb2row[1024 + j - 96] = a;
+    }
   }
   GB_MARK(20);
   dg_lds_barrier();
@@ -1297,14 +1390,16 @@ struct ChTail {
 // anything the backward still reads (the cross-wave sums of dW3 / dW2 take the first 128 KB)
 template <int W1S>
 struct ChTrainLds {
-  static constexpr int PS = CH_TRAIN_MAXN * 32;          // plane stride of the gas3 / gas2 images (one tile per wave: 256 rows)
-  static constexpr int BASE = ChQ<16, W1S, CH_TRAIN_MAXN>::TOTAL > 131072 ? ChQ<16, W1S, CH_TRAIN_MAXN>::TOTAL : 131072;
-  static constexpr int OFF_SL = BASE;                    // [16 waves][64]: db2 | db1
-  static constexpr int OFF_SL4 = OFF_SL + 4096;          // [16 waves][64]: dW4 | db3 (conv4's backward)
-  static constexpr int OFF_G4T = OFF_SL4 + 4096;         // [16 waves][16]: gh4 of the wave's tile
+  using Q = ChQ<16, W1S, CH_TRAIN_MAXN>;
+  static constexpr int PS = CH_TRAIN_MAXN * 32;          // plane stride of the gas3 / gas2 image (one tile per wave: 256 rows)
+  static constexpr int OFF_GT = 6 * PS;                  // behind the image: [16 waves][16][CH_GT_LD] tiles
+  static constexpr int OFF_GPL = OFF_GT + 16 * 16 * CH_GT_LD * 4;      // the selected nodes' gradient rows [30][96]
+  static_assert(OFF_GPL + 30 * 96 * 4 <= Q::OFF_W1, "image + tiles + gradient rows inside the forward's image region");
+  static_assert(OFF_GPL >= 65536, "the gradient rows are written while the readout's LDS plan (first 64 KB) is live");
+  static constexpr int BASE = Q::TOTAL > 131072 ? Q::TOTAL : 131072;      // (the cross-wave sums take the first 128 KB)
+  static constexpr int OFF_SL = BASE;                    // [16 waves][128]: dW4 | db3 | db2 | db1
+  static constexpr int OFF_G4T = OFF_SL + 8192;          // [16 waves][16]: gh4 of the wave's tile
   static constexpr int TOTAL = OFF_G4T + 1024;
-  static constexpr int OFF_GT = 6 * PS;                  // behind the image: [16 waves][16][CH_GT_LD] transpose tiles
-  static_assert(OFF_GT + 16 * 16 * CH_GT_LD * 4 <= ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_W1, "image + transpose tiles inside the forward's image region");
 };
 template <int XI, int W1S>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
@@ -1326,13 +1421,15 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, nullptr,
                                                    keys_lds);
   __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
-  TbExt ext;
+  TbExt ext{};
   {
     const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
     const float* sp = reinterpret_cast<const float*>(M.region0);
     ext.sp = sp; ext.W5s = sp + 2912; ext.W6s = sp + 2912 + NW5; ext.lg = M.lg;
     ext.flat = M.flat; ext.a5s = M.a5s; ext.a1s = M.a1s; ext.sel = M.sel;
     ext.yb = yb;
+    ext.wf2s = t.C <= 16 ? M.cpart : nullptr;       // (classes beyond 16 are not staged by the forward half)
+    ext.x4l = keys_lds; ext.dvl = reinterpret_cast<const float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV);
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
@@ -1340,20 +1437,24 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                         t.training, t.seed, dbg);
   }
   __syncthreads();
+  using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
+  using X = ChTrainLds<W1S>;
+  const bool full = t.pa4 && t.pb3;      // the whole GCN backward of this graph follows in this workgroup
+  TbLds L{};
+  if (full) {   // ... and takes the SortPooling gradient from LDS (regions nothing of the readout / its backward touches)
+    L.gpL = reinterpret_cast<float*>(smem + X::OFF_GPL);
+    L.gas4L = reinterpret_cast<float*>(smem + C::OFF_H4 + 3072);     // (the second parity set of h4s: unused with one graph per workgroup)
+    L.slotmap = reinterpret_cast<int*>(smem + C::OFF_H4 + 4096);
+  }
   dg_tail_bwd_body<false, true>((int)blockIdx.x, B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
                                 t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
-                                t.pooled, dbg, ext);
-  if (t.pa4) {
-    __syncthreads();      // (vmcnt(0): this graph's gas4 and gp1..gp3 rows are written; the readout's LDS plan is dead)
+                                t.pooled, dbg, ext, nullptr, nullptr, true, -1, L);
+  if (full) {
+    // (the body ended with a barrier; nothing below reads what this workgroup stored to global memory since the chain's barrier)
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
-    using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
-    using X = ChTrainLds<W1S>;
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
-    const bool full = t.pb3 != nullptr;
-    // W3 / W2 for gx = gh W: gathered from the FORWARD's operand-order tables, which are still in LDS (no global reload)
-    const float* W2op = reinterpret_cast<const float*>(smem + C::OFF_W2);
-    const float* W3op = reinterpret_cast<const float*>(smem + C::OFF_W3);
+    constexpr int NBA = W1S == 8 ? 2 : 1;
 #ifdef CH_REPEAT_BWD      // measurement build: the GCN backward twice (second pass: warm instruction cache; results are garbage)
     int reps_ = 2;
     asm volatile("" : "+s"(reps_));
@@ -1361,28 +1462,29 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     for (int rep_ = 0; rep_ < reps_; ++rep_) {
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && rep_ == 1) { for (int k = 16; k < 22; ++k) dbg[k + 8] = dbg[k]; dbg[16] = clock64(); }
 #endif
-    ch_conv4_bwd_graph(n0, n, reinterpret_cast<const unsigned*>(smem + C::OFF_BL), reinterpret_cast<const float*>(smem + C::OFF_DV),
-                       reinterpret_cast<const uint2*>(smem + C::OFF_TAB), reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
-                       reinterpret_cast<float*>(smem + X::OFF_G4T), reinterpret_cast<float*>(smem + X::OFF_SL4), t.gas4,
-                       reinterpret_cast<const float*>(smem + C::OFF_BT) + 96 /* W4: the forward's LDS copy */, x3, t.gp3,
-                       t.gas3, t.pa4 + (size_t)b * 64, full ? smem : nullptr, X::PS);
-    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[17] = clock64();
-    if (full) {
-      constexpr int NBA = W1S == 8 ? 2 : 1;
-      ch_gcn_bwd_graph<NBA>(n0, n, F, smem, X::PS, reinterpret_cast<const unsigned*>(smem + C::OFF_BL),
-                            reinterpret_cast<const float*>(smem + C::OFF_DV), reinterpret_cast<const uint2*>(smem + C::OFF_TAB), W3op, W2op,
-                            reinterpret_cast<float*>(smem + X::OFF_GT), reinterpret_cast<float*>(smem + X::OFF_SL),
-                            reinterpret_cast<float*>(smem), x2, t.gp2, x1, t.gp1, axg,
-                            t.pb3 + (size_t)b * 1056, t.pb2 + (size_t)b * 1056, t.pb1 + (size_t)b * 32 * F, dbg);
-      if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[21] = clock64();
-    } else {
-      for (int row = b + B; row < t.P1; row += B)       // rows of pa4 no graph owns
-        if (threadIdx.x < 64) t.pa4[(size_t)row * 64 + threadIdx.x] = 0.f;
-    }
+    // W2 / W3 / W4: the FORWARD's operand-order tables and its bias table, still in LDS
+    ch_gcn_bwd_graph<NBA>(n0, n, F, smem, X::PS, reinterpret_cast<const unsigned*>(smem + C::OFF_BL),
+                          reinterpret_cast<const float*>(smem + C::OFF_DV), reinterpret_cast<const uint2*>(smem + C::OFF_TAB),
+                          reinterpret_cast<const float*>(smem + C::OFF_W3), reinterpret_cast<const float*>(smem + C::OFF_W2),
+                          reinterpret_cast<const float*>(smem + C::OFF_BT) + 96, reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
+                          reinterpret_cast<float*>(smem + X::OFF_G4T), reinterpret_cast<float*>(smem + X::OFF_GT),
+                          reinterpret_cast<float*>(smem + X::OFF_SL), reinterpret_cast<float*>(smem), L, x3, x2, x1, axg,
+                          t.pa4 + (size_t)b * 64, t.pb3 + (size_t)b * 1056, t.pb2 + (size_t)b * 1056, t.pb1 + (size_t)b * 32 * F, dbg);
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[21] = clock64();
 #ifdef CH_REPEAT_BWD
     __syncthreads();
     }
 #endif
+  } else if (t.pa4) {
+    __syncthreads();      // (vmcnt(0): this graph's gas4 and gp3 rows are written; the readout's LDS plan is dead)
+    const int b = blockIdx.x;
+    const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
+    ch_conv4_bwd_graph(n0, n, reinterpret_cast<const unsigned*>(smem + C::OFF_BL), reinterpret_cast<const float*>(smem + C::OFF_DV),
+                       reinterpret_cast<const uint2*>(smem + C::OFF_TAB), reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
+                       reinterpret_cast<float*>(smem + 65536), reinterpret_cast<float*>(smem + 65536 + 1024), t.gas4, t.W4, x3, t.gp3,
+                       t.gas3, t.pa4 + (size_t)b * 64);
+    for (int row = b + B; row < t.P1; row += B)       // rows of pa4 no graph owns
+      if (threadIdx.x < 64) t.pa4[(size_t)row * 64 + threadIdx.x] = 0.f;
   }
 }
 

@@ -239,7 +239,7 @@ k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* _
     dg_rider_phase_a(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd);
     return;
   }
-  TbExt ext;
+  TbExt ext{};
   {
     __shared__ __attribute__((aligned(16))) unsigned long long region0[RD_REGION0_BYTES / 8];
     __shared__ __attribute__((aligned(16))) char small[RD_SMALL_BYTES];

@@ -34,8 +34,10 @@ for it in range(4):
     if v[29]:      # -DCH_REPEAT_BWD build: slots 24..29 = the first (cold) pass, 16..21 = the second (warm) one
         gb += " || COLD pass: " + " ".join(f"{gn[k]}={v[k + 8] - (v[7] if k == 16 else v[k + 7])}" for k in range(16, 22))
         gb = gb.replace("sync=", "restart=", 1)
-    if v[39]:      # -DCH_FINE build: stamps inside conv3's backward
-        fn = {32: "loads issued", 33: "product", 34: "transpose", 35: "gx+dW mfma", 36: "epilogue", 37: "barrier", 38: "image store", 39: "conv2 loads issued"}
-        gb += " || conv3 fine: " + " ".join(f"{fn[k]}={v[k] - (v[17] if k == 32 else v[k-1])}" for k in range(32, 40))
+    if v[38]:      # -DCH_FINE build: stamps inside conv4's / conv3's backward (wave 0)
+        f4 = {40: "loads+stage", 41: "barrier", 42: "product", 43: "gh+ga", 44: "colsums", 45: "image store"}
+        f3 = {32: "x2 transpose+loads", 33: "product", 34: "gh transpose", 35: "gx+dW mfma", 36: "epilogue+colsum", 37: "barrier", 38: "image store"}
+        gb += " || conv4 fine: " + " ".join(f"{f4[k]}={v[k] - (v[16] if k == 40 else v[k-1])}" for k in range(40, 46))
+        gb += " || conv3 fine: " + " ".join(f"{f3[k]}={v[k] - (v[17] if k == 32 else v[k-1])}" for k in range(32, 39))
     print(f"it{it} kernel={max(v[21], v[17], v[7]) - v[15]} chain={v[14]-v[15]} readout+tail={v[7]-v[14]} :: FWD {fw} :: BWD {bw} :: GCN-BWD {gb}")
 L.dgcnn_debug_phase_clocks(None)
