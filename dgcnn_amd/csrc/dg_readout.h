@@ -38,7 +38,14 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     const bool on = i < n;
     const unsigned long long my = keys[on ? i : 0];
     int rank = 0;
-    for (int j = part; j < n; j += P) rank += keys[j] < my ? 1 : 0;
+    // (eight keys per trip, all eight reads in flight: one LDS round trip per trip instead of one per key)
+    for (int j0 = part; j0 < n; j0 += 8 * P) {
+      unsigned long long kj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kj[u] = keys[min(j0 + u * P, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rank += (j0 + u * P < n && kj[u] < my) ? 1 : 0;
+    }
     for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o);
     if (on && part == 0 && rank < DGCNN_K) sel[rank] = i;
   } else {

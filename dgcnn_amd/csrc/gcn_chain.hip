@@ -1262,14 +1262,16 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
       go2[c] = dn * ga;
       t2[c] = ga;
     }
-    tile_put(t2);
-    const float s2 = tile_colsum();
-    if (lane < 32) slot[64 + lane] = s2;                                // db2
+    tile_put(t2);                      // (db2's column sums are taken behind the image store: the round trip hides under its VALU work)
   }
   GB_FINE(36);
   dg_lds_barrier();                  // every wave has read the gas3 image: gas2 overwrites it in place
   GB_FINE(37);
-  if (live) image_store(go2);
+  if (live) {
+    image_store(go2);
+    const float s2 = tile_colsum();
+    if (lane < 32) slot[64 + lane] = s2;                                // db2
+  }
   GB_FINE(38);
   dg_lds_barrier();
   GB_MARK(18);
@@ -1332,49 +1334,72 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   GB_MARK(19);
   // ---- the graph's partial rows: the live waves' accumulators summed in wave order -------------------------------------------
   float* red2 = red + 16 * 1024;
+  // dW1 joins the first round when its 16 x 32 x Fa floats fit behind the live waves' dW3 rows (T <= 12, Fa <= 8)
+  const bool one_round = T <= 12 && 32 * Fa <= 256;
+  float* redA = red + 12 * 1024;
+  auto put_acc_a = [&](float* my, int ld) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int f = nb * 16 + nl;
+          if (f < ld) my[(mb * 16 + kq * 4 + rr) * ld + f] = accA[mb][nb][rr];
+        }
+  };
+  // (a wave's accumulators go out LANE-MAJOR -- element ((mb, nb), lane, rr) at ((2 mb + nb) 64 + lane) 4 + rr: one 16-byte store
+  //  per accumulator, conflict-free -- and summing thread t takes element t of that order and works out which weight it is:
+  //  row-major [o][k] stores from the accumulator layout were 32 dword stores per lane with 4-way bank conflicts)
   if (live) {
     float* my3 = red + wave * 1024;
     float* my2 = red2 + wave * 1024;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          my3[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW3[mb][nb][rr];
-          my2[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accW2[mb][nb][rr];
-        }
+      for (int nb = 0; nb < 2; ++nb) {
+        *reinterpret_cast<float4*>(my3 + ((2 * mb + nb) * 64 + lane) * 4) = make_float4(accW3[mb][nb][0], accW3[mb][nb][1], accW3[mb][nb][2], accW3[mb][nb][3]);
+        *reinterpret_cast<float4*>(my2 + ((2 * mb + nb) * 64 + lane) * 4) = make_float4(accW2[mb][nb][0], accW2[mb][nb][1], accW2[mb][nb][2], accW2[mb][nb][3]);
+      }
+    if (one_round) put_acc_a(redA + wave * 256, 8);
   }
   dg_lds_barrier();
-  for (int t = tid; t < 1024 + 128; t += 1024) {
-    if (t < 1024) {
-      float a3 = 0.f, a2 = 0.f;
-      for (int wv_ = 0; wv_ < T; ++wv_) { a3 += red[wv_ * 1024 + t]; a2 += red2[wv_ * 1024 + t]; }
-      pb3row[t] = a3; pb2row[t] = a2;
-    } else {
-      const int j = t - 1024;            // dW4 | db3 | db2 | db1
+  {
+    const int q_ = tid >> 8, l_ = (tid >> 2) & 63;
+    const int wel = ((q_ >> 1) * 16 + (l_ >> 4) * 4 + (tid & 3)) * 32 + (q_ & 1) * 16 + (l_ & 15);      // this thread's element of W [32][32]
+    float a3 = 0.f, a2 = 0.f;
+#pragma unroll 1
+    for (int w0 = 0; w0 < T; w0 += 4) {      // four waves' rows per trip: eight reads in flight (all 32 at once spilled)
+      float v3[4], v2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int wc = min(w0 + u, T - 1); v3[u] = red[wc * 1024 + tid]; v2[u] = red2[wc * 1024 + tid]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (w0 + u < T) { a3 += v3[u]; a2 += v2[u]; }
+    }
+    pb3row[wel] = a3; pb2row[wel] = a2;
+    if (tid < 128) {                   // dW4 | db3 | db2 | db1
       float a = 0.f;
-      for (int wv_ = 0; wv_ < T; ++wv_) a += slots_all[wv_ * 128 + j];
-      if (j < 64) pa4row[j] = a; else if (j < 96) pb3row[1024 + j - 64] = a; else pb2row[1024 + j - 96] = a;
+      for (int wv_ = 0; wv_ < T; ++wv_) a += slots_all[wv_ * 128 + tid];
+      if (tid < 64) pa4row[tid] = a; else if (tid < 96) pb3row[1024 + tid - 64] = a; else pb2row[1024 + tid - 96] = a;
+    }
+    if (one_round && tid >= 128 && tid < 128 + 32 * Fa) {
+      const int t = tid - 128, o = t / Fa, f = t - o * Fa;
+      float a = 0.f;
+      for (int wv_ = 0; wv_ < T; ++wv_) a += redA[wv_ * 256 + o * 8 + f];
+      pb1row[t] = a;                                                                   // W1's own [32,Fa] layout
     }
   }
   GB_MARK(20);
-  dg_lds_barrier();
-  if (live) {
-    float* my = red + wave * 1024;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) my[(mb * 16 + kq * 4 + rr) * 32 + nb * 16 + nl] = accA[mb][nb][rr];
-  }
-  dg_lds_barrier();
-  for (int t = tid; t < 32 * Fa; t += 1024) {
-    const int o = t / Fa, f = t - o * Fa;
-    float a = 0.f;
-    for (int wv_ = 0; wv_ < T; ++wv_) a += red[wv_ * 1024 + o * 32 + f];
-    pb1row[t] = a;                                                                     // W1's own [32,Fa] layout
+  if (!one_round) {
+    dg_lds_barrier();
+    if (live) put_acc_a(red + wave * 1024, 32);
+    dg_lds_barrier();
+    for (int t = tid; t < 32 * Fa; t += 1024) {
+      const int o = t / Fa, f = t - o * Fa;
+      float a = 0.f;
+      for (int wv_ = 0; wv_ < T; ++wv_) a += red[wv_ * 1024 + o * 32 + f];
+      pb1row[t] = a;                                                                   // W1's own [32,Fa] layout
+    }
   }
 }
 
