@@ -1544,7 +1544,8 @@ struct ChB {
   static constexpr int OFF_TAB = OFF_BL + 4 * KW * MAXN;
   static constexpr int OFF_GT = OFF_TAB + 128;           // per wave: gh4 of its two tiles [2][16]
   static constexpr int OFF_SL = OFF_GT + WAVES * 128;    // per wave: dW4 [32] | db3 [32] | db2 [32]
-  static constexpr int TOTAL = OFF_SL + WAVES * 384;
+  static constexpr int OFF_GS = OFF_SL + WAVES * 384;    // two sets: the graph's SortPooling-gradient row flags [ROWS] (sparse slabs)
+  static constexpr int TOTAL = OFF_GS + 2 * 4 * ROWS;
 };
 
 // sum over the 16 lanes of each row (lanes sharing kq): every lane of the row receives the total (fixed order)
@@ -1585,14 +1586,19 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
     return make_int2(e.x, (li < ns && e.y <= MAXN) ? e.y : 0);
   };
   int2 eC = entry_of(0), eN = LOOP ? entry_of(1) : make_int2(0, 0);
-  unsigned pbit[C::PB]; float pdv = 0.f, pg4 = 0.f;
+  unsigned pbit[C::PB]; float pdv = 0.f, pg4 = 0.f; int pgs = 1;
+  // (gpsel, the row flags of the sparse SortPooling-gradient slabs, travels with the graph's prefetch and is staged in LDS: read
+  //  per tile from global memory it was a round trip of its own IN FRONT of the conditional row loads it guards -- two dependent
+  //  global round trips per tile and layer, the first one waited for with vmcnt(0), i.e. together with the next graph's prefetch)
+  const int* gsrc = gpsel ? gpsel : graph_ptr;      // (unconditional load; the value is ignored without gpsel)
+  const int gmax = gpsel ? N - 1 : 0;
   auto prefetch = [&](int pn0, int pn) {
     const int pS = 1 << dgd_class(max(pn, 1));
     const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
     const int last = max(pn * pS - 1, 0), lr = pn0 + min(tid, max(pn - 1, 0));
 #pragma unroll
     for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
-    pdv = dinv[lr]; pg4 = gas4[lr];
+    pdv = dinv[lr]; pg4 = gas4[lr]; pgs = gsrc[min(lr, gmax)];
   };
   int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
   prefetch(n0, n);
@@ -1626,8 +1632,10 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
       if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
+    int* gsl = reinterpret_cast<int*>(smem + C::OFF_GS) + par * C::ROWS;
     if (tl < C::ROWS) {
       dv[tl] = tl < n ? pdv : 0.f;
+      gsl[tl] = (!gpsel || pgs != 0) ? 1 : 0;
       if (tl < RU) {
         unsigned q0, q1, q2;
         ch_split3(tl < n ? pg4 : 0.f, q0, q1, q2);
@@ -1660,10 +1668,11 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         const float4 xa = *reinterpret_cast<const float4*>(x3 + ro), xb = *reinterpret_cast<const float4*>(x3 + ro + 16);
         // (gpsel: the readout backward of a large batch writes the SortPooling-gradient rows of the SELECTED nodes only and
         //  a per-node flag -- no 57 MB of zero rows written there and read back here; a row without the flag is garbage)
-        float4 ga_ = make_float4(0.f, 0.f, 0.f, 0.f), gb_ = ga_;
-        if (!gpsel || gpsel[n0 + min(m, n - 1)] != 0) {
-          ga_ = *reinterpret_cast<const float4*>(gp3 + ro); gb_ = *reinterpret_cast<const float4*>(gp3 + ro + 16);
-        }
+        // (unconditional loads: lanes of rows without the flag read ONE shared line, selected away below)
+        const bool sel3 = gsl[min(m, n - 1)] != 0;
+        const float* gq = gp3 + (sel3 ? ro : (size_t)(4 * kq));
+        float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
+        if (!sel3) { ga_ = make_float4(0.f, 0.f, 0.f, 0.f); gb_ = ga_; }
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
         const unsigned short* hq = g4p + min(nl, 2) * C::ROWS + 4 * kq;
 #pragma unroll
@@ -1727,10 +1736,10 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         const bool ok = rv[ti];
         const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
         const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
-        float4 ga_ = make_float4(0.f, 0.f, 0.f, 0.f), gb_ = ga_;
-        if (!gpsel || gpsel[n0 + min(m, n - 1)] != 0) {
-          ga_ = *reinterpret_cast<const float4*>(gp2 + ro); gb_ = *reinterpret_cast<const float4*>(gp2 + ro + 16);
-        }
+        const bool sel2 = gsl[min(m, n - 1)] != 0;
+        const float* gq = gp2 + (sel2 ? ro : (size_t)(4 * kq));
+        float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
+        if (!sel2) { ga_ = make_float4(0.f, 0.f, 0.f, 0.f); gb_ = ga_; }
         // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
         const int mt = 16 * (wave + WAVES * ti);
         float xN[2][4];
@@ -1873,14 +1882,16 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
     return make_int2(e.x, (li < ns && e.y <= MAXN) ? e.y : 0);
   };
   int2 eC = entry_of(0), eN = LOOP ? entry_of(1) : make_int2(0, 0);
-  unsigned pbit[C::PB]; float pdv = 0.f;
+  unsigned pbit[C::PB]; float pdv = 0.f; int pgs = 1;
+  const int* gsrc = gpsel ? gpsel : graph_ptr;      // (row flags of the sparse slabs: with the prefetch, see k_chain_bwd_a)
+  const int gmax = gpsel ? N - 1 : 0;
   auto prefetch = [&](int pn0, int pn) {
     const int pS = 1 << dgd_class(max(pn, 1));
     const unsigned* bp = bits + (size_t)N * (pS - 1) + (size_t)pn0 * pS;
-    const int last = max(pn * pS - 1, 0);
+    const int last = max(pn * pS - 1, 0), lr = pn0 + min(tid, max(pn - 1, 0));
 #pragma unroll
     for (int j = 0; j < C::PB; ++j) pbit[j] = bp[min(tid + C::THREADS * j, last)];
-    pdv = dinv[pn0 + min(tid, max(pn - 1, 0))];
+    pdv = dinv[lr]; pgs = gsrc[min(lr, gmax)];
   };
   int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
   prefetch(n0, n);
@@ -1914,7 +1925,8 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
       if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
-    if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
+    int* gsl = reinterpret_cast<int*>(smem + C::OFF_GS) + par * C::ROWS;
+    if (tl < C::ROWS) { dv[tl] = tl < n ? pdv : 0.f; gsl[tl] = (!gpsel || pgs != 0) ? 1 : 0; }
     for (int it0 = 0; it0 < RU * 8; it0 += 2 * C::THREADS) {        // two items per thread in flight
       float4 v[2];
 #pragma unroll
@@ -1962,9 +1974,10 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
           const bool okr = mm < n;
           const size_t ro = (size_t)(n0 + min(mm, n - 1));
           const float* xr = x1 + ro * 32 + nl;
-          const float* gr = gp1 + ro * 32 + nl;
-          float g0 = 0.f, g1 = 0.f;
-          if (!gpsel || gpsel[ro] != 0) { g0 = gr[0]; g1 = gr[16]; }
+          const bool selr = gsl[min(mm, n - 1)] != 0;
+          const float* gr = gp1 + (selr ? ro * 32 : (size_t)0) + nl;      // (rows without the flag: one shared line, selected away)
+          float g0 = gr[0], g1 = gr[16];
+          if (!selr) { g0 = 0.f; g1 = 0.f; }
           const float x0 = xr[0], x1v = xr[16];
           xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
           gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
