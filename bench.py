@@ -457,6 +457,15 @@ def main():
             batches_cpu = [synth.collate(graphs[i:i + B]) for i in range(0, len(graphs), B)]
         gb = B * world
     batches = [b.to(dev) for b in batches_cpu]
+    if args.prep == "dataset":
+        # the graphs' CSR / dinv / dinv*x / bitmap rows are built ONCE for the whole pool (PreparedDataset), the timed
+        # steps draw PreparedBatch descriptions from it: no int64 edge list exists per batch, the step (or the previous step's
+        # launches) assembles the batch's structures by a copy with offset adds (dgcnn_assemble)
+        if strong or args.stress_nodes > 0 or world > 1:
+            sys.exit("--prep dataset: weak scaling on one GPU without --stress-nodes only")
+        from dgcnn_amd.device_data import PreparedDataset
+        pds = PreparedDataset(graphs, dev)
+        batches = [pds.batch_of(range(i, i + B)) for i in range(0, len(graphs), B)]
     nb = len(batches)
     Bavg = sum(b.num_graphs for b in batches_cpu) / nb
     avgN = sum(b.num_nodes for b in batches_cpu) / nb

@@ -800,7 +800,9 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   h->prep_ws = nullptr;
 
   static const bool no_side = dg_knob("DG_NO_SIDE_PREP");      // A/B switch (DG_DEBUG_KNOBS builds only)
-  bool side_prep = next && cur->B >= DG_SIDE_PREP_MIN_B && !no_side;
+  // (a batch of a PREPARED dataset is never assembled on the side stream: the copy takes 16 us alone at 2048 graphs, but beside the
+  //  GCN backward it stretched k_chain_bwd_b from 31 to 52 us and itself to 50 -- in-stream behind the step: 250.7 -> see DESIGN)
+  bool side_prep = next && cur->B >= DG_SIDE_PREP_MIN_B && !no_side && !next->ds;
   if (side_prep && !h->side) {
     int prio_least = 0, prio_greatest = 0;      // the LOWEST priority: the step's own launches take the CUs first
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);

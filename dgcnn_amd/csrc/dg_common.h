@@ -261,6 +261,18 @@ __device__ __forceinline__ void dg_mfma_tile16(int m0, int n0, int K, int lane, 
   for (int r = 0; r < 4; ++r) st(m0 + kq * 4 + r, n0 + mi, d[r]);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process-wide `static bool` guard raised the LDS limit on the
+// first GPU a process drove and on no other (launches above 64 KB then fail there).  One bit per device ordinal, atomic.
+#include <atomic>
+struct DgPerDeviceOnce {
+  std::atomic<unsigned long long> mask{0ull};
+  static int current() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d & 63; }
+  bool needed() const {                             // true: the calling thread's device has not been set up yet (set-ups are idempotent)
+    return ((mask.load(std::memory_order_acquire) >> current()) & 1ull) == 0ull;
+  }
+  void done() { mask.fetch_or(1ull << current(), std::memory_order_release); }
+};
+
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {

@@ -290,12 +290,12 @@ int dg_launch_fused_fwd(int N, int B, int F, int C, int nmax, int emax, const fl
   const size_t r0 = fg_region0_bytes(nmax, F);
   const size_t lds = fg_lds_bytes(nmax, F, emax_lds);
   if (lds > FG_LDS_CAP) return DGCNN_EUNSUPPORTED;
-  static bool attr_set = false;      // raise the dynamic-LDS cap once per process (idempotent)
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;      // raise the dynamic-LDS cap once per process (idempotent)
+  if (attr_once.needed()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                             FG_LDS_CAP) != hipSuccess)
       return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
   FgW gw;
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1];

@@ -2132,8 +2132,8 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   using CL = ChCfg<16, 2, false>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
 #define CH_ATTR(W, XI, WS, LP) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP, false>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<W, WS>::TOTAL) != hipSuccess || \
                                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_q<W, XI, WS, LP, true>), \
@@ -2143,7 +2143,7 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CL::TOTAL) != hipSuccess)
       return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
   const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
   const int* nbig = dmap ? dmap + DGD_NBIG + (CH_SMALL_ROWS == 256 ? 1 : 0) : nullptr;      // graphs above the size class = first entry of the class
@@ -2200,12 +2200,12 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static_assert(ChQ<16, 4, CH_TRAIN_MAXN>::TOTAL >= RD_REGION0_BYTES + RD_SMALL_BYTES, "the readout's LDS plan aliases the chain's images");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
 #define CH_ATTR2(XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS>), \
                           hipFuncAttributeMaxDynamicSharedMemorySize, ChTrainLds<WS>::TOTAL) != hipSuccess)
     if (CH_ATTR2(1, 4) || CH_ATTR2(2, 4) || CH_ATTR2(4, 8)) return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
 #define CH_LT(XI, WS) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS>), dim3(B + rd.nblk), dim3(1024), ChTrainLds<WS>::TOTAL, s, ev_start, \
                                             ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
@@ -2227,12 +2227,12 @@ int dg_launch_chain_bwd_a(int N, int B, const int32_t* graph_ptr, const uint32_t
   if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
   using CB8 = ChB<8, CH_BWD_MAXN>;
   using CB16 = ChB<16, CH_BWD_MAXN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_a<8, true, CH_BWD_MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize, CB8::TOTAL) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_a<16, false, CH_BWD_MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize, CB16::TOTAL) != hipSuccess)
       return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
   static_assert(CB8::BUF >= 8 * 4096 && CB16::BUF >= 16 * 4096, "the final reduction aliases the image");
   const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
@@ -2262,14 +2262,14 @@ int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const 
   if (!dmap && dg_chain_needs_schedule(B)) return DGCNN_EINVAL;
   using CB8 = ChB<8, CH_BWD_MAXN>;
   using CB16 = ChB<16, CH_BWD_MAXN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
 #define CH_ATTRB(W, LP, NB, TOT) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_b<W, LP, CH_BWD_MAXN, NB>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, TOT) != hipSuccess)
     if (CH_ATTRB(8, true, 1, CB8::TOTAL) || CH_ATTRB(8, true, 2, CB8::TOTAL) || CH_ATTRB(16, false, 1, CB16::TOTAL) ||
         CH_ATTRB(16, false, 2, CB16::TOTAL))
       return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
   const int* sched = dmap ? dmap + dgd_sched0(N, B) : nullptr;
   const int* nbig = dmap ? dmap + DGD_NBIG + 1 : nullptr;

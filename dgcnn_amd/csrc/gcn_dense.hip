@@ -1351,12 +1351,12 @@ int dg_launch_fused_fwd_d(int N, int B, int F, int C, const float* params, const
   DgPrepRider rd{};
   if (rider) rd = *rider;
   static_assert(2 * FD_HT * 2 >= RD_REGION0_BYTES, "the readout's region aliases the hs buffers");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused_fwd_d), hipFuncAttributeMaxDynamicSharedMemorySize,
                             FD_LDS_BYTES) != hipSuccess)
       return DGCNN_ELAUNCH;
-    attr_set = true;
+    attr_once.done();
   }
   FdW gw;
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];

@@ -26,7 +26,9 @@ struct DgPeers {
 //   [0] READY   : tag of the newest gradient this rank has completed
 //   [1] DECIDED : tag of the newest step for which this rank has decided go / abort
 //   [2] GO      : this rank's own grid-wide verdict for the step, tag | (abort << 31) -- polled by its other workgroups
-//   [3] ABORTED : tag of the newest step this rank aborted (0: never)
+//   [3] ABORTED : tag of the FIRST step this rank aborted (0: never) -- sticky: written once, never cleared; a peer aborts
+//                 every step with tag >= it.  (A word holding the NEWEST aborted tag had a hole: a rank that aborted `tag` and
+//                 then `tag + 1` overwrote it, and a very late peer at `tag` saw `tag + 1 != tag` and applied the step.)
 #define DG_PW_READY 0
 #define DG_PW_DECIDED 1
 #define DG_PW_GO 2
@@ -61,17 +63,32 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
         }
         return true;
       };
-      if (!wait_for(DG_PW_READY)) good = 0;
-      if (!good) __hip_atomic_store(mine + DG_PW_ABORTED, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      auto mark_aborted = [&]() {            // sticky: the first aborted tag stays (only this workgroup ever writes the word)
+        if (__hip_atomic_load(mine + DG_PW_ABORTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+          __hip_atomic_store(mine + DG_PW_ABORTED, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      };
+      auto aborted_by = [&](int r) {         // rank r gave up on this step or on an earlier one
+        const unsigned int a = __hip_atomic_load(P.flag[r] + DG_PW_ABORTED, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return a != 0u && (int)(a - tag) <= 0;
+      };
+      if (aborted_by(rank)) good = 0;        // an earlier step of ours was aborted: nothing is applied any more (the host refuses too)
+      if (good && !wait_for(DG_PW_READY)) good = 0;
+      if (!good) mark_aborted();             // published BEFORE the verdict word: whoever sees DECIDED sees it
       __hip_atomic_store(mine + DG_PW_DECIDED, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (!wait_for(DG_PW_DECIDED)) good = 0;
+      if (!wait_for(DG_PW_DECIDED)) {
+        // a peer's verdict did not arrive: peers that already read ours may apply this step while we do not -- the sticky
+        // word makes every rank abort every LATER step, and the host refuses further steps once it has seen err[0]
+        good = 0; mark_aborted();
+      }
       for (int r = 0; r < world && good; ++r)
-        if (r != rank && __hip_atomic_load(P.flag[r] + DG_PW_ABORTED, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag) good = 0;
+        if (r != rank && aborted_by(r)) good = 0;
       if (!good) err[0] = tag;
-      __hip_atomic_store(mine + DG_PW_GO, good ? tag : (tag | 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // (SYSTEM scope like the peer words: the other workgroups go on to read PEER memory behind this acquire, and whether an
+      //  agent-scope acquire orders that for fine-grained memory of another device has never been exercised -- no multi-GPU box)
+      __hip_atomic_store(mine + DG_PW_GO, good ? tag : (tag | 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       unsigned int spins = 0, g;
-      while (((g = __hip_atomic_load(mine + DG_PW_GO, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & 0x7fffffffu) != tag) {
+      while (((g = __hip_atomic_load(mine + DG_PW_GO, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) & 0x7fffffffu) != tag) {
         __builtin_amdgcn_s_sleep(32);
         if (++spins > 4u * max_spins + 1024u) { g = 0x80000000u; err[1] = tag; break; }    // (workgroup 0 always decides first)
       }

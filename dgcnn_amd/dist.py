@@ -123,6 +123,24 @@ def _host_id() -> str:
     return socket.gethostname()
 
 
+def _device_identity(device: torch.device) -> str:
+    """physical identity of ``device``: its uuid, else its PCI bus id -- NOT the local ordinal: ranks launched with their own
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES all see index 0, and different GPUs must not look like one device to the
+    same-device test that admits coarse-grained exchange memory"""
+    try:
+        props = torch.cuda.get_device_properties(device)
+        for attr in ("uuid", "pci_bus_id"):
+            v = getattr(props, attr, None)
+            if v not in (None, "", 0):
+                dom = getattr(props, "pci_domain_id", 0)
+                return f"{attr}:{dom}:{v}" if attr == "pci_bus_id" else f"uuid:{v}"
+    except Exception:
+        pass
+    # no identity available: every rank counts as its own device (coarse-grained memory is then refused across ranks)
+    import os
+    return f"unknown:{_host_id()}:{os.getpid()}"
+
+
 class PeerExchange:
     """One-shot gradient all-reduce + Adam over peer-mapped memory (``dgcnn_allreduce_adam_step``, csrc/peer.hip).
 
@@ -161,8 +179,7 @@ class PeerExchange:
             self._own = own.value
             self.fine_grained = bool(L.dgcnn_peer_last_alloc_finegrained())
         infos = [None] * self.world
-        mine = (bytes(handle.raw), fail, int(self.device.index if self.device.index is not None else torch.cuda.current_device()),
-                bool(getattr(self, "fine_grained", False)), _host_id())
+        mine = (bytes(handle.raw), fail, _device_identity(self.device), bool(getattr(self, "fine_grained", False)), _host_id())
         if self.world > 1:
             dist.all_gather_object(infos, mine, group=process_group)
         else:
@@ -212,6 +229,9 @@ class PeerExchange:
     def step(self, tag: int, params: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, adam_step: int,
              lr: float, betas, eps: float, stream: int, grad_sum_out: Optional[torch.Tensor] = None) -> None:
         """sum of every rank's buffer ``tag & 1`` in rank order + Adam on this replica; ``tag`` = 1, 2, 3, ..."""
+        if getattr(self, "_aborted", False):
+            raise self._lib.DgcnnError("one-shot all-reduce: an earlier step was aborted (lost or stalled rank); the replicas "
+                                       "may have diverged by that step -- no further step is issued")
         rc = self._lib.lib().dgcnn_allreduce_adam_step(
             self.world, self.rank, self._grads[tag & 1], self._flags, tag, params.data_ptr(), exp_avg.data_ptr(),
             exp_avg_sq.data_ptr(), None if grad_sum_out is None else grad_sum_out.data_ptr(), self.numel, adam_step,
@@ -221,9 +241,11 @@ class PeerExchange:
     def check(self) -> None:
         """host-side check (a sync): did a step of the exchange time out?  The kernel's verdict is agreed by all ranks (a
         step any rank gave up on is applied by none), so every rank raises here for the same step."""
-        if int(self.err[0].item()) != 0:
+        if getattr(self, "_aborted", False) or int(self.err[0].item()) != 0:
+            self._aborted = True          # sticky, like the kernel's word: no further step is issued (step() refuses)
             raise self._lib.DgcnnError("one-shot all-reduce: a peer did not publish its gradient within the bounded wait "
-                                       "(lost or stalled rank); the step was applied on NO rank "
+                                       "(lost or stalled rank); the step was applied on no rank unless a peer's verdict itself was lost, and "
+                                       "no further step is applied anywhere "
                                        "(dgcnn_peer_set_timeout_ms raises the bound)")
 
     def release_local(self) -> None:
