@@ -113,6 +113,13 @@ def algorithmic_bytes_chain_fwd(N: int, E_noself: int) -> int:
     return 3 * algorithmic_bytes_agg(N, E_noself, 32) + algorithmic_bytes_agg(N, E_noself, 1)
 
 
+def algorithmic_bytes_chain_bwd(N: int, E_noself: int) -> int:
+    """the aggregation calls of the GCN BACKWARD that the one-launch training kernel runs since round 4 ("bwd the
+    same four again (layer-1 input grad skipped)"): conv4's (F = 1), conv3's and conv2's (F = 32) -- conv1's has no aggregation
+    here (aggregate-first: dW1 from the saved A_hat x), so THREE calls are counted, not four"""
+    return 2 * algorithmic_bytes_agg(N, E_noself, 32) + algorithmic_bytes_agg(N, E_noself, 1)
+
+
 def algorithmic_bytes_sortpool(N: int, B: int, rows: int, s: int = 4) -> int:
     """SURVEY.md §8(d) D4, sort-pool: 4*N (keys) + 4*(B+1) + s*97*sum_g min(n_g,k) (gather) + s*2910*B (write);
     `rows` = sum over the batch's graphs of min(n_g, 30)."""
@@ -230,6 +237,7 @@ def self_launch(args) -> int:
 # HBM traffic of the aggregation kernel from rocprofv3 PMC passes spawned by this run
 # ------------------------------------------------------------------------------------------------------
 LIVE_TRACE_US = {}       # kernel -> mean duration (us) from the kernel trace of the last live --pmc pass
+STEPK = [0]      # launches of the last measure_agg that were the one-launch training kernel WITH the GCN backward (form bit 8)
 FUSED_EXTRA = {"bytes": 0.0}   # mean bytes of the fused next-layer output per measured launch (last measure_agg)
 
 
@@ -633,6 +641,7 @@ def main():
             fl = mflags | (_lib.FLAG_COALESCED_UNDIRECTED if getattr(b, "coalesced_undirected", False) else 0)
             return L.dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, F, fl, int(b.max_nodes or 0))
         chain_n, tail_n = 0, [0]
+        STEPK[0] = 0
         sp_rows = [int(torch.bincount(b.batch, minlength=b.num_graphs).clamp(max=30).sum()) for b in bl_cpu]
         for i in range(nprof):
             a, bb = ev(), ev()
@@ -642,8 +651,11 @@ def main():
             trainer.train_step(b, b.y, global_batch=gb) if not use_dist else trainer.forward_backward(b, b.y, global_batch=gb)
             fm = 0 if fused else form_of(bl_cpu[i % len(bl)])
             ch = 2 if (fm & 4 and not use_dist) else (1 if fm & 2 else 0)     # 2: the one-launch chain + readout training kernel
+            if ch == 2 and fm & 8:
+                ch = 3                                                        # 3: ... which also runs the whole GCN backward
             chain_n += 1 if ch else 0
-            tail_n[0] += 1 if ch == 2 else 0
+            tail_n[0] += 1 if ch >= 2 else 0
+            STEPK[0] += 1 if ch == 3 else 0
             pairs.append((a, bb, b.num_nodes, b.num_edges, ch, sp_rows[i % len(bl)]))
         torch.cuda.synchronize(dev)
         tot_us = tot_bytes = tot_extra = tot_tailmodel = 0.0
@@ -652,9 +664,11 @@ def main():
             tot_us += ms.value * 1e3
             # SURVEY §8(d) D4 only: the aggregation calls of the launch (+ D4's sort-pool figure when the launch holds the readout)
             tot_bytes += algorithmic_bytes_fused_fwd(n_, e_, Bl, F) if fused else \
-                (algorithmic_bytes_chain_fwd(n_, e_) + (algorithmic_bytes_sortpool(n_, Bl, spr) if ch == 2 else 0)
+                (algorithmic_bytes_chain_fwd(n_, e_) + (algorithmic_bytes_sortpool(n_, Bl, spr) if ch >= 2 else 0) +
+                 (algorithmic_bytes_chain_bwd(n_, e_) if ch == 3 else 0)
                  if ch else algorithmic_bytes_agg(n_, e_))
-            tot_tailmodel += (algorithmic_bytes_chain_fwd(n_, e_) + algorithmic_bytes_readout_tail(n_, Bl, C)) if ch == 2 else 0.0
+            tot_tailmodel += (algorithmic_bytes_chain_fwd(n_, e_) + algorithmic_bytes_readout_tail(n_, Bl, C) +
+                              (algorithmic_bytes_chain_bwd(n_, e_) if ch == 3 else 0)) if ch >= 2 else 0.0
             # the next layer's pre-scaled linear output this launch also writes (not part of SURVEY's one-layer model):
             # [N,32] fp32 behind conv1 / conv2, [N] behind conv3
             which = 1 + k % 2 if F <= 32 else k % 3
@@ -673,8 +687,9 @@ def main():
     # and short names only, so that it stays below RESULT_LINE_MAX bytes.
     DETAIL["kernels"] = {
         "k_chain_readout_tail": "gcn_chain.hip: graph-chain forward (conv1..conv4 = four aggregation calls, dense block products on "
-                                "v_mfma_f32_16x16x32_bf16, exact in fp32 via the bf16x3 split) AND SortPooling readout + dense tail, "
-                                "forward and backward, of one graph per 16-wave workgroup in ONE launch",
+                                "v_mfma_f32_16x16x32_bf16, exact in fp32 via the bf16x3 split), SortPooling readout + dense tail forward and "
+                                "backward, AND the GCN backward (conv4, conv3, conv2 + conv1's weight gradient) of one graph per 16-wave "
+                                "workgroup in ONE launch: the training step is this kernel + k_wgrad",
         "k_chain_fwd_q": "gcn_chain.hip: conv1..conv4 of every graph inside one persistent workgroup, linear outputs resident in LDS, "
                          "graphs dealt from a sorted static schedule",
         "k_gcn_fwd32*": "32-wide GCN aggregation + bias + tanh + fused next X.W on MFMA: CSR gather (k_gcn_fwd32 / k_gcn_fwd32p) or "
@@ -683,7 +698,8 @@ def main():
     DETAIL["roofline_model"] = (
         "frac = SURVEY §8(d) D4 algorithmic bytes / avg launch time / 8 TB/s.  One aggregation call: 4E~+4(N+1)+4N+2*4*N*F; a chain "
         "launch processes FOUR calls (F = 32,32,32,1: 106 KB per COLLAB-cfg graph); the one-launch training kernel adds D4's sort-pool "
-        "figure 4N+4(B+1)+4*97*sum min(n,30)+4*2910*B.  frac_with_tail_model additionally counts bench.py's own byte model of the "
+        "figure 4N+4(B+1)+4*97*sum min(n,30)+4*2910*B and, since round 4 (form bit 8: the whole GCN backward runs in the same launch), the "
+        "backward's three aggregation calls (F = 1,32,32; conv1's needs none: aggregate-first).  frac_with_tail_model additionally counts bench.py's own byte model of the "
         "dense tail forward+backward (algorithmic_bytes_readout_tail; NOT a SURVEY figure).  The chain kernels move far FEWER bytes "
         "than D4's model (hs_2, hs_3, h4s never leave the CU; adjacency read once as a bitmap): frac is work per time on the "
         "survey's model, frac_of_peak_on_measured_traffic the physical bandwidth fraction.  At 50 graphs a launch is latency-bound "
@@ -705,7 +721,8 @@ def main():
         r = {"bound": "hbm",
              "kernel": "k_fused_fwd" if fused else ("k_chain_readout_tail" if tail else "k_chain_fwd_q" if chain else (kname or "k_gcn_fwd32*")),
              "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-             "model": "SURVEY 8(d) D4: " + ("4 aggregation calls" + (" + sort-pool" if tail else "") if chain else "1 aggregation call"),
+             "model": "SURVEY 8(d) D4: " + ((("7 aggregation calls (fwd 32,32,32,1 + bwd 1,32,32)" if (tail and STEPK[0] * 2 > nl) else "4 aggregation calls") +
+                                             (" + sort-pool" if tail else "")) if chain else "1 aggregation call"),
              "algorithmic_bytes_per_launch": round(bpl), "avg_launch_us": round(avg_us, 3),
              "avg_launch_us_kernel_trace": None if trace_us is None else round(trace_us, 3), "launches_measured": nl,
              "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,

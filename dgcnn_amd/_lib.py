@@ -84,6 +84,7 @@ SIGNATURES = {
     "dgcnn_debug_phase_clocks": (c_int, [c_void_p]),
     "dgcnn_model_prepare": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int, ctypes.c_uint32, c_void_p]),
     "dgcnn_forward_form": (c_int, [c_int] * 6),
+    "dgcnn_step_kernel_enable": (c_int, [c_int]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_int, c_int,

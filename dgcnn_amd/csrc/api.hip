@@ -271,12 +271,26 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
   return G;
 }
 
+// DGCNN_STEP_KERNEL=0 in the environment: the one-launch training kernel stops after conv4's backward and conv3 / conv2 / conv1
+// run as the two gather launches (the round-3 form; measurement A/B and a second route for the tests)
+static int g_step_kernel = -1;
+static bool dg_step_kernel_enabled() {
+  if (g_step_kernel < 0) { const char* e = getenv("DGCNN_STEP_KERNEL"); g_step_kernel = (e && e[0] == '0') ? 0 : 1; }
+  return g_step_kernel != 0;
+}
+int dgcnn_step_kernel_enable(int on) {
+  const int prev = dg_step_kernel_enabled() ? 1 : 0;
+  g_step_kernel = on ? 1 : 0;
+  return prev;
+}
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
   const bool chain_tail = f.chain && !(flags & DGCNN_FLAG_BF16) && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
                           max_nodes <= dg_chain_train_max_nodes();
-  return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0);
+  const bool step = chain_tail && dg_step_kernel_enabled() && B <= dg_grid1(N) && B <= dg_grid32(N) && dg_wgrad_takes_rider(B);
+  return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0) |
+         (step ? DGCNN_FORM_STEP : 0);
 }
 
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
@@ -384,13 +398,6 @@ static inline int dg_fork_point(int k, hipStream_t s) {
     g_fork.done = true;
   }
   return DGCNN_OK;
-}
-// DGCNN_STEP_KERNEL=0 in the environment: the one-launch training kernel stops after conv4's backward and conv3 / conv2 / conv1
-// run as the two gather launches (the round-3 form; measurement A/B and a second route for the tests)
-static bool dg_step_kernel_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DGCNN_STEP_KERNEL"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
 }
 static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float* params,
                                  const float* x, const int64_t* edge_index, const int64_t* batch,

@@ -239,7 +239,13 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 #define DGCNN_FORM_DENSE 1
 #define DGCNN_FORM_CHAIN 2
 #define DGCNN_FORM_CHAIN_TAIL 4   /* a TRAINING step with labels runs chain forward + readout forward + readout backward as one launch */
+#define DGCNN_FORM_STEP 8         /* ... and the whole GCN backward of every graph in that same launch (round 4): the step is
+                                   * k_chain_readout_tail + k_wgrad.  (DGCNN_STEP_KERNEL=0 in the environment keeps the round-3 form.) */
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
+/* Test / measurement switch of DGCNN_FORM_STEP (process-wide; the environment variable DGCNN_STEP_KERNEL=0 sets the initial
+ * value): on = 0 keeps the GCN backward of small training batches in launches of its own (the round-3 form), on = 1 restores the
+ * default.  Returns the previous setting.  Replaces nothing of the reference (/root/reference/train.py:40 is one backward). */
+int dgcnn_step_kernel_enable(int on);
 
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
  * forward that depends on the batch only, not on the parameters -- CSR by target / by source, dinv, graph ranges and

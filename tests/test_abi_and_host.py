@@ -230,7 +230,8 @@ def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
                                                       _lib.FLAG_AGG_SPARSE, _lib.FLAG_NO_CHAIN, _lib.FLAG_BF16, _lib.FLAG_FORCE_TILED)
     f = L.dgcnn_forward_form
     N50, E50 = 3800, 140000
-    assert f(N50, E50, 50, 1, CU, 180) == 2 | 4                    # chain forward + one-launch training kernel
+    assert f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8                # chain forward + one-launch training kernel + its in-kernel GCN backward
+    assert f(40, 80, 50, 1, CU, 4) == 2 | 4                        # fewer 16-node tiles than graphs: no partial row per graph, round-3 form
     assert f(N50, E50, 50, 1, CU, 300) == 0                        # a graph above 256 nodes in a small batch: gather kernels
     assert f(N50, E50, 50, 1, CU | CHAIN, 300) == 2                # ... unless asked for (no one-launch kernel above 256 nodes)
     assert f(N50, E50, 50, 1, 0, 180) == 0                         # no coalesced + undirected promise: no bitmap

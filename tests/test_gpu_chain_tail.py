@@ -19,6 +19,7 @@ from parity_util import KEY_TOL, XCAT_TOL, cpu_state_dict, gpu_xcat, grads_close
 pytestmark = pytest.mark.gpu
 
 FORM_CHAIN_TAIL = 4
+FORM_STEP = 8          # ... with the whole GCN backward inside the same launch (round 4)
 KEYS = ["conv1.lin.weight", "conv1.bias", "conv2.lin.weight", "conv2.bias", "conv3.lin.weight", "conv3.bias",
         "conv4.lin.weight", "conv4.bias", "conv5.weight", "conv5.bias", "conv6.weight", "conv6.bias",
         "classifier_1.weight", "classifier_1.bias", "classifier_2.weight", "classifier_2.bias"]
@@ -92,7 +93,54 @@ def test_one_launch_training_kernel_vs_fp64_oracle(name, bs):
     b_cpu = batch_with_small_graphs(name, bs, start=1000)
     assert b_cpu.coalesced_undirected
     m = make_model(sh.num_features, sh.num_classes)
+    # round 4: the kernel also runs conv4 / conv3 / conv2's backward and conv1's weight gradient of its graph (FORM_STEP) --
+    # the eight GCN gradients checked below come out of k_chain_readout_tail's partial rows, one per graph
+    assert form_of(m, b_cpu) & FORM_STEP, form_of(m, b_cpu)
     fused_step_vs_oracle(m, b_cpu)
+
+
+STEP_CASES = [("COLLAB", 50), ("MUTAG", 50), ("PROTEINS", 50), ("COLLAB", 256), ("COLLAB", 3)]
+
+
+@pytest.mark.parametrize("name,bs", STEP_CASES, ids=[f"{c[0]}-{c[1]}" for c in STEP_CASES])
+def test_in_kernel_gcn_backward_equals_the_launch_per_layer_form(name, bs):
+    """the same training step with the GCN backward inside k_chain_readout_tail (default) and as the round-3 launches
+    (conv4's in the kernel, conv3 / conv2 as gather kernels; dgcnn_step_kernel_enable(0)): same dropout mask, same selection,
+    identical loss, gradients equal to fp32 summation-order noise; eval mode and a 190-node graph (12 live waves) included"""
+    from dgcnn_amd.train import Trainer
+    L = _lib.lib()
+    sh = synth.SHAPES[name]
+    b_cpu = batch_with_small_graphs(name, bs, start=2000)
+    if name == "COLLAB" and bs == 50:
+        for k in range(64):                                                        # T = 12 live waves, K32 = 6
+            b_cpu = synth.make_batch("COLLAB", 50, start=2000 + 50 * k, force_first_n=190)
+            if b_cpu.max_nodes <= 256:
+                break
+        assert 190 <= b_cpu.max_nodes <= 256
+    res = []
+    prev = L.dgcnn_step_kernel_enable(1)
+    try:
+        for on in (1, 0):
+            L.dgcnn_step_kernel_enable(on)
+            m = make_model(sh.num_features, sh.num_classes)
+            assert bool(form_of(m, b_cpu) & FORM_STEP) == bool(on)
+            m.train(); m._seed_base, m._fwd_count = 5, 0
+            tr = Trainer(m)
+            tr.reset_metrics()
+            b = b_cpu.to("cuda")
+            tr.train_step(b, b.y)
+            torch.cuda.synchronize()
+            m.check_errors()
+            res.append((tr.read_metrics(), tr.grads.cpu().clone(), m.last_workspace_view("perm").cpu().clone(),
+                        m.flat_params.detach().cpu().clone()))
+    finally:
+        L.dgcnn_step_kernel_enable(prev)
+    (ma, ga, pa, wa), (mb, gb, pb, wb) = res
+    assert torch.equal(pa, pb)
+    assert ma == mb, (ma, mb)                                   # the forward half is the same code: bitwise
+    sc = float(gb.abs().max())
+    assert float((ga - gb).abs().max()) <= 2e-5 * sc + 1e-9, (float((ga - gb).abs().max()), sc)
+    assert float((wa - wb).abs().max()) <= 2.1e-3               # one Adam step: |dw| <= lr on either route
 
 
 def test_bench_pool_batches_take_the_one_launch_kernel():
