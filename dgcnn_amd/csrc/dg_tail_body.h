@@ -23,7 +23,9 @@ struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* s
 struct TbLds { float* gpL; float* gas4L; int* slotmap; };
 // HEAD = false (large batches): classifier_2 / classifier_1's backward ran batched over graphs (classifier.hip) and left
 // the gradient of conv6's output in gz6g -- steps 1-3 are skipped.
-template <bool BIG, bool MERGED = false, bool HEAD = true>
+// LDSOPS (the one-launch chain training kernel): ext.wf2s / ext.x4l / ext.dvl are valid -- a COMPILE-TIME promise: selecting
+// between an LDS and a global pointer at run time made the loads FLAT instructions (both counters, vector-memory latency).
+template <bool BIG, bool MERGED = false, bool HEAD = true, bool LDSOPS = false>
 __device__ __forceinline__ void dg_tail_bwd_body(
     int b, int B, int C, const TailW& w, const int* __restrict__ graph_ptr, const int* __restrict__ perm,
     const float* __restrict__ dinv, const float* __restrict__ x4, const float* __restrict__ a5g,
@@ -97,7 +99,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // first used after them cannot be waited for precisely: the big loads sit behind a divergent `if`, the compiler cannot count
   // them and emits vmcnt(0) -- the whole 180 KB awaited a step early; issuing them from all 1024 threads instead made them
   // countable but cost 80 more wave-level load instructions at ~14 cycles of the CU's address path each.)
-  const bool lds_ops = MERGED && ext.x4l != nullptr;
+  constexpr bool lds_ops = MERGED && LDSOPS;
   float x4e_ = 0.f, dve_ = 0.f;
   if (lds_ops && tid >= 64 && tid < 64 + DGCNN_K) { const int ls = ext.sel[tid - 64], lc = ls >= 0 ? ls : 0; x4e_ = ext.x4l[lc]; dve_ = ext.dvl[lc]; }
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
@@ -106,7 +108,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   if (HEAD && tid < DGCNN_HID1) {
     a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = (MERGED && ext.wf2s) ? ext.wf2s[c * DGCNN_HID1 + tid] : w.Wf2[c * DGCNN_HID1 + tid];
+    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = lds_ops ? ext.wf2s[c * DGCNN_HID1 + tid] : w.Wf2[c * DGCNN_HID1 + tid];
   }
   // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
   // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only

@@ -409,6 +409,8 @@ k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __r
 // =================================================================================================================
 #ifdef CH_TIMING
 #define CH_T(k) do { if (dbg && tid == 0) { const unsigned long long now_ = clock64(); dbg[blockIdx.x * 16 + (k)] += now_ - tprev_; tprev_ = now_; } } while (0)
+#elif defined(CH_FINE)      // absolute stamps of workgroup 0 in slots 48.. (tools/phase_step_kernel.py; the one-launch training kernel only)
+#define CH_T(k) do { if (dbg && blockIdx.x == 0 && tid == 0) dbg[48 + (k)] = clock64(); } while (0)
 #else
 #define CH_T(k) do { } while (0)
 #endif
@@ -504,19 +506,20 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
   int n0 = __builtin_amdgcn_readfirstlane(eC.x), n = __builtin_amdgcn_readfirstlane(eC.y);
   prefetch(n0, n);                            // the first graph's data travels while the weight tables are set up
   // ---- once per workgroup: weight tables in MFMA-operand order (coalesced loads, scattered on the LDS side) ------------
-  {
-    float w2[C::WJ], w3[C::WJ], w1[C::WJ];
+  // The loads are issued here, BEHIND the first graph's prefetch; one graph per workgroup (LOOP = false): the table stores wait
+  // until the graph is staged -- the weights are cold every step (the optimizer has just rewritten them on other XCDs), the
+  // graph's data is not, loads return in order, and every load in between is unconditional so that the compiler can count:
+  // the staging's ~2 k cycles of VALU work run under the weights' latency instead of behind it (and one barrier goes).
+  float w2r[C::WJ], w3r[C::WJ], w1r[C::WJ];
 #pragma unroll
-    for (int j = 0; j < C::WJ; ++j) {
-      const int e = tid + C::THREADS * j;
-      w2[j] = gw.W2[e]; w3[j] = gw.W3[e]; w1[j] = e < 32 * F ? gw.W1[e] : 0.f;
-    }
-    float bv = 0.f;
-    if (tid < 128) {
-      const int which = tid >> 5, idx = tid & 31;
-      const float* src = which == 0 ? gw.b1 : (which == 1 ? gw.b2 : (which == 2 ? gw.b3 : gw.W4));
-      bv = src[idx];
-    }
+  for (int j = 0; j < C::WJ; ++j) {
+    const int e = tid + C::THREADS * j;
+    w2r[j] = gw.W2[e]; w3r[j] = gw.W3[e]; w1r[j] = gw.W1[min(e, 32 * F - 1)];
+  }
+  const float* bsrc_ = (tid >> 5) == 0 ? gw.b1 : ((tid >> 5) == 1 ? gw.b2 : ((tid >> 5) == 2 ? gw.b3 : gw.W4));
+  const float bvr = bsrc_[tid & 31];                      // (unconditional; lanes >= 128 re-read W4)
+  const float b4v = gw.b4[0];
+  auto store_tables = [&]() {
     // W[o][k] -> [ob = o >> 4][s = 4 (k >> 4) + (k & 3)][lane = (o & 15) + 16 ((k >> 2) & 3)], S steps per ob
     auto slot_of = [](int o, int k, int S) {
       return (((o >> 4) * S + ((k >> 4) << 2) + (k & 3)) << 6) + (o & 15) + (((k >> 2) & 3) << 4);
@@ -531,23 +534,26 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
       if (BF) {     // bf16 A operands of X.W^T: [ob][lane][8]: W[16 ob + (lane & 15)][k], k = 4kq + j (j < 4), 16 + 4kq + j - 4
         const int o = e >> 5, k = e & 31;
         const int d = ((((o >> 4) << 6) + (o & 15) + (((k >> 2) & 3) << 4)) << 3) + (k & 3) + ((k >> 4) << 2);
-        reinterpret_cast<unsigned short*>(W2op)[d] = (unsigned short)ch_f2bf(w2[j]);
-        reinterpret_cast<unsigned short*>(W3op)[d] = (unsigned short)ch_f2bf(w3[j]);
+        reinterpret_cast<unsigned short*>(W2op)[d] = (unsigned short)ch_f2bf(w2r[j]);
+        reinterpret_cast<unsigned short*>(W3op)[d] = (unsigned short)ch_f2bf(w3r[j]);
       } else {
-      W2op[slot_of(e >> 5, e & 31, 8)] = w2[j]; W3op[slot_of(e >> 5, e & 31, 8)] = w3[j];
+      W2op[slot_of(e >> 5, e & 31, 8)] = w2r[j]; W3op[slot_of(e >> 5, e & 31, 8)] = w3r[j];
       }
-      if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F, W1S)] = w1[j]; }
+      if (e < 32 * F) { const int o = e / F; W1op[slot_of(o, e - o * F, W1S)] = w1r[j]; }
     }
-    if (tid < 128) bt[tid] = bv;
+    if (tid < 128) bt[tid] = bvr;
     if (tid < 16) tab[tid] = make_uint2(((tid & 1) ? 0x3f80u : 0u) | ((tid & 2) ? 0x3f800000u : 0u),
                                         ((tid & 4) ? 0x3f80u : 0u) | ((tid & 8) ? 0x3f800000u : 0u));
+  };
+  float b4s = 0.f;
+  if (LOOP) {
+    store_tables();
+    __syncthreads();
+    // (consumed HERE, where nothing else is in flight: its first use used to be conv4's epilogue, behind the layers' CONDITIONAL
+    //  row stores -- the compiler cannot count those, so it waited with vmcnt(0) there: every x4 store of a lane drained the
+    //  previous one, eight store round trips in a row per graph)
+    b4s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b4v)));
   }
-  const float b4v = gw.b4[0];
-  __syncthreads();
-  // (consumed HERE, where nothing else is in flight: its first use used to be conv4's epilogue, behind the layers' CONDITIONAL
-  //  row stores -- the compiler cannot count those, so it waited with vmcnt(0) there: every x4 store of a lane drained the
-  //  previous one, eight store round trips in a row per graph)
-  const float b4s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b4v)));
   const int rdoff = (4 * kq + (nl >> 2)) * 32 + 8 * ((nl & 3) ^ kq);
   const int mrow0 = 16 * wave + nl, mrow1 = mrow0 + 16 * WAVES;         // this lane's node in tile wave / tile wave + WAVES
   const int wsl = 8 * (kq ^ ((nl >> 2) & 3));
@@ -609,6 +615,10 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
         *reinterpret_cast<uint4*>(H + pong + (tl >> 5) * C::PS + (16 * T + ((tl >> 1) & 15)) * 32 + 16 * (tl & 1)) = make_uint4(0u, 0u, 0u, 0u);
     }
     CH_T(1);                                              // 1: wait for the prefetched data + staging stores
+    if (!LOOP) {          // (one graph per workgroup: the weight tables go to LDS only now, see the loads above)
+      store_tables();
+      b4s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b4v)));
+    }
     dg_lds_barrier();
     CH_T(2);
     int n0N = 0, nN = 0;
@@ -896,17 +906,24 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
         int kqv = kq;
         asm volatile("" : "+v"(kqv));        // (see the staging: nothing below may be hoisted out of the graph walk)
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < (TWO ? 2 : 1); ++ti) {
           const int mm = 16 * (wave + WAVES * ti) + 4 * kqv;
           const float4 dq = *reinterpret_cast<const float4*>(dv + mm);
           const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+          // (all four values first, branch-free, then the predicated stores: as four `if (row < n) { tanh; store; store }` blocks
+          //  each block was its own chain of LDS read -> transcendental -> store)
+          float xq[4];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            if (mm + rr < n) {
-              const float xv = dg_tanh(fmaf(dd[rr], (a4[ti][rr] + s1[ti][rr]) + s2[ti][rr], b4s));
-              x4[n0 + mm + rr] = xv;
-              if (x4_lds) x4_lds[mm + rr] = xv;
-            }
+          for (int rr = 0; rr < 4; ++rr) xq[rr] = dg_tanh(fmaf(dd[rr], (a4[ti][rr] + s1[ti][rr]) + s2[ti][rr], b4s));
+          if (!TWO && x4_lds) {
+            if (mm < n) *reinterpret_cast<float4*>(x4_lds + mm) = make_float4(xq[0], xq[1], xq[2], xq[3]);      // (rows >= n: never read)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) if (mm + rr < n) x4[n0 + mm + rr] = xq[rr];
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              if (mm + rr < n) { x4[n0 + mm + rr] = xq[rr]; if (x4_lds) x4_lds[mm + rr] = xq[rr]; }
+          }
         }
       }
     }
@@ -1443,7 +1460,12 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   //  the images, and untouched until conv4's backward at the end of this kernel reads the FIRST set)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* keys_lds = reinterpret_cast<float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV) + ChQ<16, W1S, CH_TRAIN_MAXN>::ROWS;
-  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, nullptr,
+#ifdef CH_FINE
+  unsigned long long* const chain_dbg = dbg;
+#else
+  unsigned long long* const chain_dbg = nullptr;
+#endif
+  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, chain_dbg,
                                                    keys_lds);
   __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
   TbExt ext{};
@@ -1453,7 +1475,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     ext.sp = sp; ext.W5s = sp + 2912; ext.W6s = sp + 2912 + NW5; ext.lg = M.lg;
     ext.flat = M.flat; ext.a5s = M.a5s; ext.a1s = M.a1s; ext.sel = M.sel;
     ext.yb = yb;
-    ext.wf2s = t.C <= 16 ? M.cpart : nullptr;       // (classes beyond 16 are not staged by the forward half)
+    ext.wf2s = M.cpart;       // (rows of the first 16 classes, staged by the forward half; the backward prefetches 8, reads the rest in place)
     ext.x4l = keys_lds; ext.dvl = reinterpret_cast<const float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV);
     const int b = blockIdx.x;
     const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
@@ -1471,9 +1493,9 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     L.gas4L = reinterpret_cast<float*>(smem + C::OFF_H4 + 3072);     // (the second parity set of h4s: unused with one graph per workgroup)
     L.slotmap = reinterpret_cast<int*>(smem + C::OFF_H4 + 4096);
   }
-  dg_tail_bwd_body<false, true>((int)blockIdx.x, B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y, t.loss_scale,
-                                t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv, t.ptail,
-                                t.pooled, dbg, ext, nullptr, nullptr, true, -1, L);
+  dg_tail_bwd_body<false, true, true, true>((int)blockIdx.x, B, t.C, t.w, graph_ptr, t.perm, dinv, x4, t.a5g, t.a6g, t.a1dg, t.logp, nullptr, t.y,
+                                            t.loss_scale, t.training, t.dlogit, t.gz1g, t.gz6g, t.gz5g, t.gp1, t.gp2, t.gp3, t.gas4, t.gb4p, t.lossv,
+                                            t.ptail, t.pooled, dbg, ext, nullptr, nullptr, true, -1, L);
   if (full) {
     // (the body ended with a barrier; nothing below reads what this workgroup stored to global memory since the chain's barrier)
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();

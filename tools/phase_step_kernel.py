@@ -20,7 +20,7 @@ print(f"{name} x {G}: workgroup 0 = graph of {graphs[order[0]].num_nodes} nodes 
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
 tr = Trainer(m)
-dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(80, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 rn = {8: "topk", 9: "gather+Wstage", 10: "conv5", 11: "pool+conv6", 12: "fc1", 13: "fc2+lsm"}
 tn = ["(sync)", "stage+dlogit", "fc2 bwd+partial", "fc1^T", "conv6 bwd", "pool/relu", "W5/W6 partials", "scatter"]
@@ -39,5 +39,14 @@ for it in range(4):
         f3 = {32: "x2 transpose+loads", 33: "product", 34: "gh transpose", 35: "gx+dW mfma", 36: "epilogue+colsum", 37: "barrier", 38: "image store"}
         gb += " || conv4 fine: " + " ".join(f"{f4[k]}={v[k] - (v[16] if k == 40 else v[k-1])}" for k in range(40, 46))
         gb += " || conv3 fine: " + " ".join(f"{f3[k]}={v[k] - (v[17] if k == 32 else v[k-1])}" for k in range(32, 39))
+    if v[48 + 10]:  # -DCH_FINE build: stamps inside the chain forward (wave 0)
+        cn = {0: "set-up", 14: "bitmap+dinv stage", 15: "xs split+stage", 1: "zero fill", 2: "barrier", 3: "rows->regs", 4: "conv1", 5: "hs2 store+barrier",
+              6: "conv2", 7: "hs3 store+barrier", 8: "conv3", 9: "barrier", 10: "conv4"}
+        order = [0, 14, 15, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+        prev = v[15]
+        parts = []
+        for k in order:
+            parts.append(f"{cn[k]}={v[48 + k] - prev}"); prev = v[48 + k]
+        gb += " || chain fine: " + " ".join(parts)
     print(f"it{it} kernel={max(v[21], v[17], v[7]) - v[15]} chain={v[14]-v[15]} readout+tail={v[7]-v[14]} :: FWD {fw} :: BWD {bw} :: GCN-BWD {gb}")
 L.dgcnn_debug_phase_clocks(None)
