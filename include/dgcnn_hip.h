@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 16
+#define DGCNN_ABI_VERSION 17
 
 /* error codes */
 #define DGCNN_OK            0
