@@ -26,25 +26,29 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
   //  the keys itself hands in an LDS copy -- so a workgroup's pending row stores drain while it ranks, up to the barrier at the
   //  end, which the gather of those rows needs anyway)
   if (n <= 256) {
-    dg_lds_barrier();
-    if (tid < n) keys[tid] = dg_pack_key(x4[n0 + tid], tid);
-    dg_lds_barrier();
     // rank by counting, P lanes per key (P = the largest power of two with P * n <= T, at most 16): lane `part` of key i counts
     // the keys j = part, part + P, ... below it; the P counts are added by xor-shuffles inside the aligned lane group.
-    // (one thread per key walked all n keys: 126 dependent LDS reads = 3.8 k of a 126-node graph's 6.1 k cycles here)
+    // (one thread per key walked all n keys: 126 dependent LDS reads = 3.8 k of a 126-node graph's 6.1 k cycles here.)
+    // The key area is padded to a multiple of 8 P entries with a sentinel no key is above, so that the counting loop -- eight
+    // keys per trip, all eight reads in flight -- has no bounds checks: 3 instructions per key instead of 8 (the loop is
+    // executed by all 16 waves, 4 per SIMD: its instruction count times ~18 cycles is its duration).
     int lp = 0;
     while (lp < 4 && (n << (lp + 1)) <= T) ++lp;
     const int P = 1 << lp, i = tid >> lp, part = tid & (P - 1);
+    const int npad = (n + 8 * P - 1) & ~(8 * P - 1);          // <= 256 + 127: inside the caller's SP_LDS_KEYS slots
+    dg_lds_barrier();
+    for (int t = tid; t < npad; t += T) keys[t] = t < n ? dg_pack_key(x4[n0 + t], t) : ~0ull;
+    dg_lds_barrier();
     const bool on = i < n;
     const unsigned long long my = keys[on ? i : 0];
     int rank = 0;
-    // (eight keys per trip, all eight reads in flight: one LDS round trip per trip instead of one per key)
-    for (int j0 = part; j0 < n; j0 += 8 * P) {
+    const unsigned long long* kp = keys + part;
+    for (int j0 = 0; j0 < npad; j0 += 8 * P) {
       unsigned long long kj[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) kj[u] = keys[min(j0 + u * P, n - 1)];
+      for (int u = 0; u < 8; ++u) kj[u] = kp[j0 + u * P];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rank += (j0 + u * P < n && kj[u] < my) ? 1 : 0;
+      for (int u = 0; u < 8; ++u) rank += kj[u] < my ? 1 : 0;
     }
     for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o);
     if (on && part == 0 && rank < DGCNN_K) sel[rank] = i;

@@ -10,7 +10,8 @@ from dgcnn_amd.train import Trainer
 L = _lib.lib()
 name, G = (sys.argv[1] if len(sys.argv) > 1 else "COLLAB"), int(sys.argv[2]) if len(sys.argv) > 2 else 50
 sh = synth.SHAPES[name]
-graphs = synth.make_graphs(name, G, start=0)
+force = int(sys.argv[4]) if len(sys.argv) > 4 else None          # force the first graph to this many nodes
+graphs = synth.make_graphs(name, G, start=0, force_first_n=force)
 order = sorted(range(G), key=lambda i: -graphs[i].num_nodes)
 which = sys.argv[3] if len(sys.argv) > 3 else "largest"
 if which == "median": order = order[G // 2:] + order[:G // 2]
