@@ -247,23 +247,21 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   if (BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   RD_MARK(8);
   if (tid < DGCNN_K) perm[b * DGCNN_K + tid] = sel[tid] >= 0 ? n0 + sel[tid] : -1;
-  {   // SortPooling gather: all row loads in flight, then the LDS / global stores
-    constexpr int IT = (KCAT + RD_THREADS - 1) / RD_THREADS;
-    float gv[IT];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int o = tid + i * RD_THREADS;
-      gv[i] = 0.f;
-      if (o < KCAT) {
-        const int s = o / DGCNN_CAT, c = o - s * DGCNN_CAT;
-        const int ln = sel[s];
-        if (ln >= 0) gv[i] = dg_cat_load(x1, x2, x3, x4, n0 + ln, c);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int o = tid + i * RD_THREADS;
-      if (o < KCAT) { sp[o] = gv[i]; pooled[(size_t)b * KCAT + o] = gv[i]; }
+  {   // SortPooling gather, ROW-WISE: 32 lanes per selected node copy its x1 | x2 | x3 rows (three coalesced 128-byte loads on a
+      // clamped row, selected afterwards) and lane 0 its x4 -- no division by 97, no four-way slab branch per element (the
+      // element-wise form was ~75 instructions per thread, executed by all 16 waves)
+    static_assert(RD_THREADS == 32 * 32 && DGCNN_K <= 32 && DGCNN_CAT == 97, "one 32-lane group per SortPooling slot");
+    const int s = tid >> 5, c = tid & 31;
+    const int ln = s < DGCNN_K ? sel[s] : -1;
+    const size_t node = (size_t)(n0 + (ln > 0 ? ln : 0));
+    float v1 = x1[node * 32 + c], v2 = x2[node * 32 + c], v3 = x3[node * 32 + c], v4 = x4[node];
+    if (ln < 0) { v1 = 0.f; v2 = 0.f; v3 = 0.f; v4 = 0.f; }
+    if (s < DGCNN_K) {
+      float* sr = sp + s * DGCNN_CAT;
+      float* pr = pooled + (size_t)b * KCAT + s * DGCNN_CAT;
+      sr[c] = v1; sr[32 + c] = v2; sr[64 + c] = v3;
+      pr[c] = v1; pr[32 + c] = v2; pr[64 + c] = v3;
+      if (c == 0) { sr[96] = v4; pr[96] = v4; }
     }
   }
   st5.store(W5s, tid); st6.store(W6s, tid);
