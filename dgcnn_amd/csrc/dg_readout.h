@@ -284,33 +284,58 @@ __device__ __forceinline__ void dg_readout_fwd_body(
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   }
-  // conv5 on the matrix cores: z5[s][o] = sum_m sp[s][m] W5[o][m]  ->  [32(30) x 16] = [32 x 100(97)] . [100 x 16]:
-  // two 16x16 tiles, K split over 4 waves each (28 + 24 + 24 + 24 columns), partial tiles combined in a fixed
-  // order; ReLU + bias at the combine.  output index o*30+s ([B,16,30])
-  {
-    float* part = M.cpart;                       // [4][32][16]
-    if (wv < 8) {
-      const int mt = wv >> 2, kc = wv & 3;
-      const int kb = kc == 0 ? 0 : 28 + (kc - 1) * 24, kl = kc == 0 ? 28 : 24;
-      dg_mfma_tile16(
-          mt * 16, 0, kl, lane,
-          [&](int s, int kk) { const int m = kb + kk; return (s < DGCNN_K && m < DGCNN_CAT) ? sp[s * DGCNN_CAT + m] : 0.f; },
-          [&](int kk, int o) { const int m = kb + kk; return m < DGCNN_CAT ? W5s[o * DGCNN_CAT + m] : 0.f; },
-          [&](int s, int o, float v) { part[(kc * 32 + s) * 16 + o] = v; });
-    }
-    dg_lds_barrier();
-    if (!BIG) {
+  // conv5 + bias + ReLU + MaxPool1d(2,2) as ONE phase on two waves (round 4; was: K split over 4 waves per tile -> barrier ->
+  // combine on 480 threads -> barrier -> pool on 240 threads -> barrier).  z5[s][o] = sum_m sp[s][m] W5[o][m]:
+  // [32(30) x 16] = [32 x 100(97)] . [100 x 16], wave mt owns slots s = 16 mt .. 16 mt + 15, 25 k-steps in two accumulator
+  // chains.  The accumulator lane (o = lane & 15, kq) holds s = 16 mt + 4 kq + 0..3 -- two pooling pairs: bias, ReLU and the
+  // pool happen in registers.  (A phase executed by 2 waves costs their instruction count once; the three phases it replaces
+  // were executed by 8, 8 and 4 waves and separated by barriers.)  output index o*30+s ([B,16,30])
+  if (wv < 2) {
+    const int mt = wv, mi = lane & 15, kq = lane >> 4;
+    const int srow = 16 * mt + mi;
+    const bool sok = srow < DGCNN_K;
+    const float* ap = sp + (sok ? srow : 0) * DGCNN_CAT + kq;
+    const float* bp = W5s + mi * DGCNN_CAT + kq;
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
+    for (int u0 = 0; u0 < 25; u0 += 9) {           // operands of nine steps at a time (all 25 held 50 registers beside the prefetch)
+      float av[9], bv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {                // m = 4 u + kq; the last step holds m = 96 only (kq = 0)
+        const int u = u0 + q;
+        if (u < 25) {
+          const bool mok = u < 24 || kq == 0;
+          const float a_ = ap[mok ? 4 * u : 0], b_ = bp[mok ? 4 * u : 0];
+          av[q] = (sok && mok) ? a_ : 0.f;
+          bv[q] = mok ? b_ : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int u = u0 + q;
+        if (u < 25) {
+          if (u & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], d1, 0, 0, 0);
+          else d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], d0, 0, 0, 0);
+        }
+      }
     }
-    if (tid < DGCNN_C5 * DGCNN_K) {
-      const int o = tid / DGCNN_K, s = tid - o * DGCNN_K;
-      const float v = (part[(0 * 32 + s) * 16 + o] + part[(1 * 32 + s) * 16 + o]) +
-                      (part[(2 * 32 + s) * 16 + o] + part[(3 * 32 + s) * 16 + o]);
-      const float acc = fmaxf(v + bs[o], 0.f);
-      a5s[tid] = acc;
-      a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + tid] = acc;
-    }
+    const float bias = bs[mi];
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf((d0[r] + d1[r]) + bias, 0.f);
+    const int s0 = 16 * mt + 4 * kq;              // this lane's four slots s0 .. s0 + 3 of channel o = mi
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (s0 + r < DGCNN_K) {
+        a5s[mi * DGCNN_K + s0 + r] = v[r];
+        a5g[(size_t)b * (DGCNN_C5 * DGCNN_K) + mi * DGCNN_K + s0 + r] = v[r];
+      }
+    if (s0 < DGCNN_K) p5[mi * DGCNN_T5 + (s0 >> 1)] = fmaxf(v[0], v[1]);           // MaxPool1d(2,2): [16,30] -> [16,15]
+    if (s0 + 2 < DGCNN_K) p5[mi * DGCNN_T5 + (s0 >> 1) + 1] = fmaxf(v[2], v[3]);
+  }
+  if (!BIG) {
+#pragma unroll
+    for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   }
   dg_lds_barrier();
   RD_MARK(10);
@@ -318,33 +343,39 @@ __device__ __forceinline__ void dg_readout_fwd_body(
 #pragma unroll
     for (int jq = 8; jq < 11; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   }
-  // MaxPool1d(2,2): [16,30] -> [16,15]
-  if (tid < DGCNN_C5 * DGCNN_T5) {
-    const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
-    p5[tid] = fmaxf(a5s[c * DGCNN_K + 2 * u], a5s[c * DGCNN_K + 2 * u + 1]);
-  }
-  dg_lds_barrier();
-  // conv6 on the matrix cores: z6[oc][t] = sum_{c,d} W6[oc][c][d] p5[c][t+d]  ->  [32 x 16(11)] = [32 x 80] . [80 x 16],
-  // two 16x16 tiles, K split over 4 waves each (20 columns = 5 MFMA steps per wave instead of 20), partial tiles
-  // combined in a fixed order with bias + ReLU; flat index oc*11+t (x.view(B,-1), model.py:40)
-  {
-    float* part = M.cpart;                       // [4][32][16], free again after conv5's combine
-    if (wv < 8) {
-      const int mt = wv >> 2, kc = wv & 3, kb = kc * 20;
-      dg_mfma_tile16(
-          mt * 16, 0, 20, lane,
-          [&](int oc, int kk) { return W6s[oc * (DGCNN_C5 * DGCNN_KW6) + kb + kk]; },
-          [&](int kk, int t) { const int k = kb + kk; return t < DGCNN_T6 ? p5[(k / DGCNN_KW6) * DGCNN_T5 + t + (k % DGCNN_KW6)] : 0.f; },
-          [&](int oc, int t, float v) { part[(kc * 32 + oc) * 16 + t] = v; });
+  // conv6 + bias + ReLU as ONE phase on two waves: z6[oc][t] = sum_{c,d} W6[oc][c][d] p5[c][t+d] -> [32 x 16(11)] = [32 x 80] . [80 x 16],
+  // wave mt owns oc = 16 mt .. 16 mt + 15; k-slot of (step u, lane group kq) = 20 kq + u, so that c = 4 kq + u / 5 and d = u % 5
+  // are affine in kq (no division); flat index oc*11+t (x.view(B,-1), model.py:40)
+  if (wv < 2) {
+    const int mt = wv, mi = lane & 15, kq = lane >> 4;
+    const float* ap = W6s + (16 * mt + mi) * (DGCNN_C5 * DGCNN_KW6) + 20 * kq;
+    const bool tok = mi < DGCNN_T6;
+    const float* bp = p5 + (4 * kq) * DGCNN_T5 + (tok ? mi : 0);
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u0 = 0; u0 < 20; u0 += 10) {
+      float av[10], bv[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const int u = u0 + q;
+        av[q] = ap[u];
+        const float b_ = bp[(u / DGCNN_KW6) * DGCNN_T5 + (u % DGCNN_KW6)];
+        bv[q] = tok ? b_ : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        if ((u0 + q) & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], d1, 0, 0, 0);
+        else d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], d0, 0, 0, 0);
+      }
     }
-    dg_lds_barrier();
-    if (tid < DGCNN_FLAT) {
-      const int oc = tid / DGCNN_T6, t = tid - oc * DGCNN_T6;
-      const float v = (part[(0 * 32 + oc) * 16 + t] + part[(1 * 32 + oc) * 16 + t]) +
-                      (part[(2 * 32 + oc) * 16 + t] + part[(3 * 32 + oc) * 16 + t]);
-      const float acc = fmaxf(v + bs[16 + oc], 0.f);
-      flat[tid] = acc;
-      a6g[(size_t)b * DGCNN_FLAT + tid] = acc;
+    if (tok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = 16 * mt + 4 * kq + r;
+        const float acc = fmaxf((d0[r] + d1[r]) + bs[16 + oc], 0.f);
+        flat[oc * DGCNN_T6 + mi] = acc;
+        a6g[(size_t)b * DGCNN_FLAT + oc * DGCNN_T6 + mi] = acc;
+      }
     }
   }
   if (!HEAD) return;

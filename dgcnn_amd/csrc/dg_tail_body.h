@@ -82,12 +82,13 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // operands of the later steps that live in global memory: loaded NOW (their round trips overlap steps 1-2)
   float a6_ = 0.f, a5a_ = 0.f, a5b_ = 0.f;
   if (tid < DGCNN_FLAT)                                                                // step 3: ReLU mask of conv6
-    a6_ = !HEAD ? gz6g[(size_t)b * DGCNN_FLAT + tid] : MERGED ? ext.flat[tid] : a6g[(size_t)b * DGCNN_FLAT + tid];      // (HEAD = false: the finished gradient)
+    a6_ = !HEAD ? gz6g[(size_t)b * DGCNN_FLAT + tid] : MERGED ? 0.f : a6g[(size_t)b * DGCNN_FLAT + tid];      // (HEAD = false: the finished gradient)
+  // (MERGED: operands the forward half left in LDS are read WHERE THEY ARE USED, not here: held from the prologue they were ~16
+  //  registers live across classifier_1's 64-register prefetch, and the kernel sits at its 128-register limit)
   if (tid < DGCNN_C5 * DGCNN_T5) {                                                     // step 5: MaxPool argmax
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
-    if (MERGED) { a5a_ = ext.a5s[c * DGCNN_K + 2 * u]; a5b_ = ext.a5s[c * DGCNN_K + 2 * u + 1]; }
-    else { a5a_ = a5g[base]; a5b_ = a5g[base + 1]; }
+    if (!MERGED) { a5a_ = a5g[base]; a5b_ = a5g[base + 1]; }
   }
   int node_ = -1;                                                                      // step 6: scatter targets
   if (tid >= 64 && tid < 64 + DGCNN_K) {
@@ -101,14 +102,14 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // countable but cost 80 more wave-level load instructions at ~14 cycles of the CU's address path each.)
   constexpr bool lds_ops = MERGED && LDSOPS;
   float x4e_ = 0.f, dve_ = 0.f;
-  if (lds_ops && tid >= 64 && tid < 64 + DGCNN_K) { const int ls = ext.sel[tid - 64], lc = ls >= 0 ? ls : 0; x4e_ = ext.x4l[lc]; dve_ = ext.dvl[lc]; }
+  (void)x4e_; (void)dve_;
   float a1_ = 0.f, wf2_[8];                 // step 2 operands (threads 0..127); classes beyond 8 are read in place
 #pragma unroll
   for (int c = 0; c < 8; ++c) wf2_[c] = 0.f;
   if (HEAD && tid < DGCNN_HID1) {
-    a1_ = MERGED ? ext.a1s[tid] : a1dg[(size_t)b * DGCNN_HID1 + tid];
+    if (!MERGED) a1_ = a1dg[(size_t)b * DGCNN_HID1 + tid];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) if (c < C) wf2_[c] = lds_ops ? ext.wf2s[c * DGCNN_HID1 + tid] : w.Wf2[c * DGCNN_HID1 + tid];
+    for (int c = 0; c < 8; ++c) if (c < C && !lds_ops) wf2_[c] = w.Wf2[c * DGCNN_HID1 + tid];
   }
   // ---- then the big one: classifier_1's weights for step 3 (this thread's column m, 64 rows; 180 KB per
   // workgroup, rewritten by the optimizer every step).  Issued LAST and consumed in step 3; in between only
@@ -167,15 +168,17 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   dg_lds_barrier();
   TB_MARK(1);
   float x4n_ = 0.f, dvn_ = 0.f;             // conv4 output / dst scale of the selected nodes (wave 1; used in step 6)
-  if (lds_ops) { x4n_ = node_ >= 0 ? x4e_ : 0.f; dvn_ = node_ >= 0 ? dve_ : 0.f; }
+  if (lds_ops) {
+    if (tid >= 64 && tid < 64 + DGCNN_K && node_ >= 0) { const int ls = node_ - n0; x4n_ = ext.x4l[ls]; dvn_ = ext.dvl[ls]; }
+  }
   else if (node_ >= 0) { x4n_ = x4[node_]; dvn_ = dinv[node_]; }
   // 2. through classifier_2, dropout, ReLU
   if (HEAD && tid < DGCNN_HID1) {
     float ga = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) if (c < C) ga = fmaf(dl[c], wf2_[c], ga);
+    for (int c = 0; c < 8; ++c) if (c < C) ga = fmaf(dl[c], lds_ops ? ext.wf2s[c * DGCNN_HID1 + tid] : wf2_[c], ga);
     for (int c = 8; c < C; ++c) ga = fmaf(dl[c], w.Wf2[c * DGCNN_HID1 + tid], ga);
-    const float a = a1_;
+    const float a = MERGED ? ext.a1s[tid] : a1_;
     const float gz = (a != 0.f) ? (training ? ga * 2.0f : ga) : 0.f;
     gz1s[tid] = gz;
     a1ds[tid] = a;
@@ -232,7 +235,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   if (HEAD && tid < DGCNN_FLAT) {     // ... and the ReLU after conv6 ; the 8 row-group partials in a fixed order
     const float gf = ((gfh[0][tid] + gfh[1][tid]) + (gfh[2][tid] + gfh[3][tid])) +
                      ((gfh[4][tid] + gfh[5][tid]) + (gfh[6][tid] + gfh[7][tid]));
-    const float g6 = a6_ > 0.f ? gf : 0.f;
+    const float g6 = ((MERGED && HEAD) ? ext.flat[tid] : a6_) > 0.f ? gf : 0.f;
     gz6s[tid] = g6;
     gz6g[(size_t)b * DGCNN_FLAT + tid] = g6;
   }
@@ -261,7 +264,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
-    const float a0 = a5a_, a1 = a5b_;
+    const float a0 = MERGED ? ext.a5s[c * DGCNN_K + 2 * u] : a5a_, a1 = MERGED ? ext.a5s[c * DGCNN_K + 2 * u + 1] : a5b_;
     p5s[tid] = fmaxf(a0, a1);                      // MaxPool1d output, needed for conv6's weight gradient
     const float gp = gp5[tid];
     const bool first = !(a1 > a0);
