@@ -273,6 +273,27 @@ struct DgPerDeviceOnce {
   void done() { mask.fetch_or(1ull << current(), std::memory_order_release); }
 };
 
+// the same tile with a COMPILE-TIME K (the dense tail's products: K = 40, 12, 32, 16): exactly ceil(K/4) steps, no run-time
+// trip counts or per-step bounds tests on k0 -- every operand fetched up front (<= 10 steps) or 8 steps at a time
+template <int K, typename FA, typename FB, typename ST>
+__device__ __forceinline__ void dg_mfma_tile16_k(int m0, int n0, int lane, FA fa, FB fb, ST st) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  const int mi = lane & 15, kq = lane >> 4;
+  constexpr int STEPS = (K + 3) / 4, CH = STEPS <= 10 ? STEPS : 8;
+#pragma unroll
+  for (int s0 = 0; s0 < STEPS; s0 += CH) {
+    float av[CH], bv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (s0 + u < STEPS) { const int k = 4 * (s0 + u) + kq; av[u] = fa(m0 + mi, k); bv[u] = fb(k, n0 + mi); }
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (s0 + u < STEPS) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) st(m0 + kq * 4 + r, n0 + mi, d[r]);
+}
+
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {

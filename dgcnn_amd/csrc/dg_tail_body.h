@@ -52,7 +52,6 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   __shared__ float gz1s[DGCNN_HID1];
   __shared__ __attribute__((aligned(16))) float gfh[8][DGCNN_FLAT];
   __shared__ float gz6s[DGCNN_FLAT];
-  __shared__ float gp5[DGCNN_C5 * DGCNN_T5];
   __shared__ float gp5q[4][DGCNN_C5 * DGCNN_T5];
   __shared__ float gz5s[DGCNN_C5 * DGCNN_K];
   __shared__ float ga4s[DGCNN_K];
@@ -245,28 +244,39 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // 4. conv6 data gradient on the matrix cores: gp5[c][u] = sum_{oc,d} W6[oc][c][d] gz6[oc][u-d]
   //    -> [16 x 16(15)] = [16 x 160] . [160 x 16]; K split over 4 waves (40 each), combined in a fixed order
   if (wv < 4) {
-    const int kbase = wv * 40;
-    dg_mfma_tile16(
-        0, 0, 40, lane,
-        [&](int c, int kk) { const int k = kbase + kk; return W6s[((k / DGCNN_KW6) * DGCNN_C5 + c) * DGCNN_KW6 + (k % DGCNN_KW6)]; },
-        [&](int kk, int u) {
-          const int k = kbase + kk;
-          const int tt = u - (k % DGCNN_KW6);
-          return (u < DGCNN_T5 && tt >= 0 && tt < DGCNN_T6) ? gz6s[(k / DGCNN_KW6) * DGCNN_T6 + tt] : 0.f;
-        },
-        [&](int c, int u, float v) { if (u < DGCNN_T5) gp5q[wv][c * DGCNN_T5 + u] = v; });
+    // (by hand: wave wv takes output channels oc = 8 wv .. 8 wv + 7 of conv6, k-slot of (step u, lane group kq) = (oc = 8 wv + 2 kq
+    //  + u / 5, d = u % 5): affine in kq, no division by 5 per operand; two accumulator chains)
+    const int mi = lane & 15, kq = lane >> 4;
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    float av[10], bv[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int oc = 8 * wv + 2 * kq + u / DGCNN_KW6, dd = u % DGCNN_KW6;
+      av[u] = W6s[(oc * DGCNN_C5 + mi) * DGCNN_KW6 + dd];                  // A[c = mi][k]
+      const int tt = mi - dd;
+      const bool okb = mi < DGCNN_T5 && tt >= 0 && tt < DGCNN_T6;
+      const float g_ = gz6s[oc * DGCNN_T6 + (okb ? tt : 0)];               // B[k][u = mi]
+      bv[u] = okb ? g_ : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      if (u & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d1, 0, 0, 0);
+      else d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d0, 0, 0, 0);
+    }
+    if (mi < DGCNN_T5) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gp5q[wv][(4 * kq + r) * DGCNN_T5 + mi] = d0[r] + d1[r];
+    }
   }
   __syncthreads();
-  if (tid < DGCNN_C5 * DGCNN_T5) gp5[tid] = (gp5q[0][tid] + gp5q[1][tid]) + (gp5q[2][tid] + gp5q[3][tid]);
-  __syncthreads();
-  TB_MARK(4);
+  TB_MARK(4);      // (the four K-split partial tiles are combined by their only consumer, step 5: one phase and one barrier fewer)
   // 5. MaxPool (first max wins ties, like ATen) + ReLU after conv5 -> [16,30]
   if (tid < DGCNN_C5 * DGCNN_T5) {
     const int c = tid / DGCNN_T5, u = tid - c * DGCNN_T5;
     const size_t base = (size_t)b * (DGCNN_C5 * DGCNN_K) + c * DGCNN_K + 2 * u;
     const float a0 = MERGED ? ext.a5s[c * DGCNN_K + 2 * u] : a5a_, a1 = MERGED ? ext.a5s[c * DGCNN_K + 2 * u + 1] : a5b_;
     p5s[tid] = fmaxf(a0, a1);                      // MaxPool1d output, needed for conv6's weight gradient
-    const float gp = gp5[tid];
+    const float gp = (gp5q[0][tid] + gp5q[1][tid]) + (gp5q[2][tid] + gp5q[3][tid]);
     const bool first = !(a1 > a0);
     const float g0 = (first && a0 > 0.f) ? gp : 0.f;
     const float g1 = (!first && a1 > 0.f) ? gp : 0.f;
@@ -282,21 +292,50 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   //     pooled rows); k_wgrad then only sums B contiguous partials per element (coalesced)
   // conv6: pW6[oc][(c,d)] = sum_t gz6[oc][t] p5[c][t+d]   -> [32 x 80] = [32 x 12(11)] . [12 x 80]   (10 tiles)
   // conv5: pW5[o][m]      = sum_s gz5[o][s] sp[s][m]       -> [16 x 112(97)] = [16 x 32(30)] . [32 x 112] (7 tiles)
+  // (written out per product: the generic tile helper's per-operand bounds tests and index arithmetic were most of these
+  //  phases' instructions, and every wave of the workgroup executes them)
   for (int job = wv; job < 17; job += RD_THREADS / 64) {
+    const int mi = lane & 15, kq = lane >> 4;
     if (job < 10) {
       const int mt = job / 5, nt = job - mt * 5;
-      dg_mfma_tile16(
-          mt * 16, nt * 16, 12, lane,
-          [&](int oc, int t) { return t < DGCNN_T6 ? gz6s[oc * DGCNN_T6 + t] : 0.f; },
-          [&](int t, int n) { return t < DGCNN_T6 ? p5s[(n / DGCNN_KW6) * DGCNN_T5 + t + (n % DGCNN_KW6)] : 0.f; },
-          [&](int oc, int n, float v) { put(DG_PT_W6 + oc * (DGCNN_C5 * DGCNN_KW6) + n, v); });
+      const int n = nt * 16 + mi;                                    // column (c, d) of W6 [32][80]
+      const float* ap = gz6s + (mt * 16 + mi) * DGCNN_T6 + kq;       // A[oc][t], t = 4 u + kq
+      const float* bp = p5s + (n / DGCNN_KW6) * DGCNN_T5 + (n % DGCNN_KW6) + kq;      // B[t][n] = p5[c][t + d]
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      float av[3], bv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const bool tok = u < 2 || kq < DGCNN_T6 - 8;                 // t = 8 + kq < 11
+        const float a_ = ap[tok ? 4 * u : 0], b_ = bp[tok ? 4 * u : 0];
+        av[u] = tok ? a_ : 0.f; bv[u] = tok ? b_ : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) put(DG_PT_W6 + (mt * 16 + 4 * kq + r) * (DGCNN_C5 * DGCNN_KW6) + n, d[r]);
     } else {
       const int nt = job - 10;
-      dg_mfma_tile16(
-          0, nt * 16, 32, lane,
-          [&](int o, int sl) { return sl < DGCNN_K ? gz5s[o * DGCNN_K + sl] : 0.f; },
-          [&](int sl, int m) { return (sl < DGCNN_K && m < DGCNN_CAT) ? sps[sl * DGCNN_CAT + m] : 0.f; },
-          [&](int o, int m, float v) { if (m < DGCNN_CAT) put(DG_PT_W5 + o * DGCNN_CAT + m, v); });
+      const int m = nt * 16 + mi;                                    // column of W5 [16][97]
+      const bool mok = m < DGCNN_CAT;
+      const float* ap = gz5s + mi * DGCNN_K + kq;                    // A[o][sl], sl = 4 u + kq
+      const float* bp = sps + kq * DGCNN_CAT + (mok ? m : 0);        // B[sl][m]
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool sok = u < 7 || kq < DGCNN_K - 28;                 // sl = 28 + kq < 30
+        const float a_ = ap[sok ? 4 * u : 0], b_ = bp[sok ? 4 * u * DGCNN_CAT : 0];
+        av[u] = sok ? a_ : 0.f; bv[u] = (sok && mok) ? b_ : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d1, 0, 0, 0);
+        else d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d0, 0, 0, 0);
+      }
+      if (mok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put(DG_PT_W5 + (4 * kq + r) * DGCNN_CAT + m, d0[r] + d1[r]);
+      }
     }
   }
   if (tid < DGCNN_C6) {
@@ -316,11 +355,21 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // gsp[s][c] = sum_oc gz5[oc][s] W5[oc][c]  -> [32(30) x 112(97)] = [32 x 16] . [16 x 112]  (14 tiles, one wave each)
   for (int job = wv; job < 14; job += RD_THREADS / 64) {
     const int mt = job / 7, nt = job - mt * 7;
-    dg_mfma_tile16(
-        mt * 16, nt * 16, DGCNN_C5, lane,
-        [&](int sl, int oc) { return sl < DGCNN_K ? gz5s[oc * DGCNN_K + sl] : 0.f; },
-        [&](int oc, int c) { return c < DGCNN_CAT ? W5s[oc * DGCNN_CAT + c] : 0.f; },
-        [&](int sl, int c, float v) {
+    const int mi = lane & 15, kq = lane >> 4;
+    const int srow = mt * 16 + mi, ccol = nt * 16 + mi;
+    const bool sok = srow < DGCNN_K, cok = ccol < DGCNN_CAT;
+    const float* ap = gz5s + kq * DGCNN_K + (sok ? srow : 0);        // A[s][oc] = gz5[oc][s], oc = 4 u + kq
+    const float* bp = W5s + kq * DGCNN_CAT + (cok ? ccol : 0);       // B[oc][c] = W5[oc][c]
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a_ = ap[4 * u * DGCNN_K], b_ = bp[4 * u * DGCNN_CAT];
+      av[u] = sok ? a_ : 0.f; bv[u] = cok ? b_ : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d, 0, 0, 0);
+    auto st = [&](int sl, int c, float v) {
           if (sl < msel && c < DGCNN_CAT) {
             const int node = selS[sl];
             if (L.gpL) {
@@ -345,7 +394,9 @@ __device__ __forceinline__ void dg_tail_bwd_body(
               ga4s[sl] = ga;
             }
           }
-        });
+        };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st(mt * 16 + 4 * kq + r, ccol, d[r]);
   }
   __syncthreads();
   TB_MARK(7);
