@@ -10,6 +10,7 @@ name, G = (sys.argv[1] if len(sys.argv) > 1 else "COLLAB"), int(sys.argv[2]) if 
 sh = synth.SHAPES[name]
 graphs = synth.make_graphs(name, G, labels="structure")
 for kind in ("host GraphLoader", "DeviceLoader", "DeviceLoader(prepared)"):
+    torch.manual_seed(324)          # same initial weights for every loader: the three runs train the same trajectory
     m = Model(sh.num_features, sh.num_classes).to("cuda"); tr = Trainer(m)
     gen = torch.Generator().manual_seed(1)
     ld = GraphLoader(graphs, 50, shuffle=True, generator=gen, device="cuda") if kind.startswith("host") else \
