@@ -147,12 +147,19 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
       const int g = base + tid;
       int n0 = 0, n = 0;
       const int bin = g < B ? bin_of(g, n0, n) : 33;
-      int myrank = 0;
-      for (int b = 0; b < 33; ++b) {
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(bin == b);
-        if (bin == b) myrank = __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-        if (lane == 0) swc[wave][b] = __builtin_popcountll(mk);
+      // rank inside the wave among the lanes of the same bin, and the wave's count per bin: SIX ballots (one per bit of the bin
+      // number; the lanes that agree with this lane on every bit are its bin's lanes) instead of one ballot per bin (33)
+      unsigned long long same = ~0ull;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const bool bit = (bin >> k) & 1;
+        const unsigned long long bk = __builtin_amdgcn_ballot_w64(bit);
+        same &= bit ? bk : ~bk;
       }
+      const unsigned long long below = same & ((1ull << lane) - 1ull);
+      const int myrank = __builtin_popcountll(below);
+      if (lane < 33) swc[wave][lane] = 0;                      // (the wave's own row: program order, no barrier)
+      if (below == 0ull && bin < 33) swc[wave][bin] = __builtin_popcountll(same);
       __syncthreads();
       if (g < B) {
         int off = sstart[bin] + scarry[bin] + myrank;
@@ -201,7 +208,10 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
       int* rec = dmap + DGD_REC0 + 3 * w;
       rec[0] = n0; rec[1] = n; rec[2] = r * DGD_ROWS;
       const long long c0 = coff + (long long)r * ic, c1 = c0 + ic;
-      const int klo = (int)(c0 * DGD_SPLITS / tot) + 1, khi = (int)(c1 * DGD_SPLITS / tot);
+      int klo, khi;
+      if (tot < (1ll << 20)) {       // (c * 3072 < 2^32; the usual case: 32-bit divisions -- the 64-bit ones are ~150 instructions each; same values)
+        klo = (int)((unsigned)c0 * (unsigned)DGD_SPLITS / (unsigned)tot) + 1; khi = (int)((unsigned)c1 * (unsigned)DGD_SPLITS / (unsigned)tot);
+      } else { klo = (int)(c0 * DGD_SPLITS / tot) + 1; khi = (int)(c1 * DGD_SPLITS / tot); }
       for (int k = klo; k <= khi && k <= DGD_SPLITS; ++k) dmap[k] = w + 1;
     }
     __syncthreads();                                          // everybody has read the carries and the wave totals
