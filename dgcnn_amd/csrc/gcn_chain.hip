@@ -1161,10 +1161,13 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   };
   // rows of the sparse SortPooling gradient (columns c0 .. of gpL) of this lane's node, zero for a node that was not selected
   auto gp_row = [&](int slot_, int c0, float (&g)[8]) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (two unconditional 16-byte reads on a clamped row, selected afterwards: written as `slot >= 0 ? load : 0` they became
+    //  eight predicated dword reads, each in an exec-mask block of its own)
     const float* r = L.gpL + max(slot_, 0) * 96 + c0 + 4 * kq;
-    const float4 a = slot_ >= 0 ? *reinterpret_cast<const float4*>(r) : z, b = slot_ >= 0 ? *reinterpret_cast<const float4*>(r + 16) : z;
-    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 16);
+    const bool on = slot_ >= 0;
+    g[0] = on ? a.x : 0.f; g[1] = on ? a.y : 0.f; g[2] = on ? a.z : 0.f; g[3] = on ? a.w : 0.f;
+    g[4] = on ? b.x : 0.f; g[5] = on ? b.y : 0.f; g[6] = on ? b.z : 0.f; g[7] = on ? b.w : 0.f;
   };
   auto image_store = [&](const float (&go)[8]) {
 #pragma unroll
