@@ -324,7 +324,14 @@ class Model(nn.Module):
         for ws, dims in workspaces:
             if ws is None:
                 continue
-            u = [v & 0xFFFFFFFF for v in _lib.ws_view(ws, "err", *dims).cpu().tolist()]
+            self._check_err_words(_lib.ws_view(ws, "err", *dims).cpu().tolist(), since, now)
+
+    @staticmethod
+    def _check_err_words(words, since: int, now: int) -> None:
+        """the four epoch-tagged error words of ONE workspace, already on the host (``Trainer.read_metrics`` fetches the words
+        of both of its workspace slots together with the metrics in a single device-to-host copy)"""
+        u = [v & 0xFFFFFFFF for v in words]
+        if True:
             for k, msg in ((0, "edge_index holds a node id outside [0, N)"),
                            (1, "a host-side promise about the batch does not hold: coalesced_undirected "
                                "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
