@@ -286,7 +286,7 @@ int dgcnn_step_kernel_enable(int on) {
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
-  const bool chain_tail = f.chain && !(flags & DGCNN_FLAG_BF16) && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+  const bool chain_tail = f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
                           max_nodes <= dg_chain_train_max_nodes();
   const bool step = chain_tail && dg_step_kernel_enabled() && B <= dg_grid1(N) && B <= dg_grid32(N) && dg_wgrad_takes_rider(B);
   return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0) |
@@ -478,7 +478,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   }
   // conv1 linear (raw features), then 4 aggregation launches; each one also produces the next
   // layer's pre-scaled linear output on MFMA, so X.W never takes a launch of its own after this.
-  if (chain && !bf16 && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+  if (chain && tt && tail_done && !dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
       max_nodes <= dg_chain_train_max_nodes()) {
     // small training batch: chain forward + readout forward + readout backward + the whole GCN backward of every graph in ONE
     // launch (one partial row per graph for k_wgrad, the step's only other launch)
@@ -494,7 +494,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
                                         wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr,
                                         step_kernel ? dg_ptr<float>(ws, wl.pb3) : nullptr, step_kernel ? dg_ptr<float>(ws, wl.pb2) : nullptr,
-                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr));
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16));
     g_prof_which = -1;
     // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
     // pb2 / pb1 = graph b's partials: k_wgrad sums B rows)

@@ -1459,7 +1459,7 @@ struct ChTrainLds {
   static constexpr int OFF_G4T = OFF_SL + 8192;          // [16 waves][16]: gh4 of the wave's tile
   static constexpr int TOTAL = OFF_G4T + 1024;
 };
-template <int XI, int W1S>
+template <int XI, int W1S, bool BF = false>      // BF: the bf16 leg's forward (hs_2 / hs_3 as one bf16 part); the backward is fp32 in either case
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits,
                      const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
@@ -1481,9 +1481,19 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
 #else
   unsigned long long* const chain_dbg = nullptr;
 #endif
-  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4, chain_dbg,
-                                                   keys_lds);
+  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN, BF>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4,
+                                                       chain_dbg, keys_lds);
   __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
+  if (BF && t.pa4 && t.pb3) {
+    // bf16 leg: the forward's W2 / W3 tables hold bf16 operands; the fp32 backward below reads fp32 tables in the fp32 forward's
+    // operand order -- rebuilt here, in place (the forward is done with them; nothing of the readout touches the region)
+    float* W2op = reinterpret_cast<float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_W2);
+    float* W3op = reinterpret_cast<float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_W3);
+    const int e = threadIdx.x, o = e >> 5, k = e & 31;
+    const int d = (((o >> 4) * 8 + ((k >> 4) << 2) + (k & 3)) << 6) + (o & 15) + (((k >> 2) & 3) << 4);
+    const float w2 = gw.W2[e], w3 = gw.W3[e];
+    W2op[d] = w2; W3op[d] = w3;
+  }
   TbExt ext{};
   {
     const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
@@ -2215,7 +2225,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* dlogit, float* gz1,
                                  float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                                  float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1, hipStream_t s,
-                                 const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, float* pb3, float* pb2, float* pb1) {
+                                 const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, float* pb3, float* pb2, float* pb1,
+                                 int bf16) {
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || !y)
     return DGCNN_EINVAL;
@@ -2236,14 +2247,18 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   static_assert(ChQ<16, 4, CH_TRAIN_MAXN>::TOTAL >= RD_REGION0_BYTES + RD_SMALL_BYTES, "the readout's LDS plan aliases the chain's images");
   static DgPerDeviceOnce attr_once;
   if (attr_once.needed()) {
-#define CH_ATTR2(XI, WS) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS>), \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, ChTrainLds<WS>::TOTAL) != hipSuccess)
-    if (CH_ATTR2(1, 4) || CH_ATTR2(2, 4) || CH_ATTR2(4, 8)) return DGCNN_ELAUNCH;
+#define CH_ATTR2(XI, WS, BFV) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS, BFV>), \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ChTrainLds<WS>::TOTAL) != hipSuccess)
+    if (CH_ATTR2(1, 4, false) || CH_ATTR2(2, 4, false) || CH_ATTR2(4, 8, false) || CH_ATTR2(1, 4, true) || CH_ATTR2(2, 4, true) ||
+        CH_ATTR2(4, 8, true))
+      return DGCNN_ELAUNCH;
     attr_once.done();
   }
-#define CH_LT(XI, WS) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS>), dim3(B + rd.nblk), dim3(1024), ChTrainLds<WS>::TOTAL, s, ev_start, \
-                                            ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
-  if (F <= 8) CH_LT(1, 4); else if (F <= 16) CH_LT(2, 4); else CH_LT(4, 8);
+#define CH_LT(XI, WS, BFV) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS, BFV>), dim3(B + rd.nblk), dim3(1024), ChTrainLds<WS>::TOTAL, s, \
+                                                 ev_start, ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t,        \
+                                                 dg_debug_buffer(), rd)
+  if (bf16) { if (F <= 8) CH_LT(1, 4, true); else if (F <= 16) CH_LT(2, 4, true); else CH_LT(4, 8, true); }
+  else { if (F <= 8) CH_LT(1, 4, false); else if (F <= 16) CH_LT(2, 4, false); else CH_LT(4, 8, false); }
 #undef CH_LT
   DG_CHECK_LAUNCH();
   return DGCNN_OK;

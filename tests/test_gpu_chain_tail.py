@@ -99,14 +99,19 @@ def test_one_launch_training_kernel_vs_fp64_oracle(name, bs):
     fused_step_vs_oracle(m, b_cpu)
 
 
-STEP_CASES = [("COLLAB", 50), ("MUTAG", 50), ("PROTEINS", 50), ("COLLAB", 256), ("COLLAB", 3)]
+STEP_CASES = [("COLLAB", 50, "fp32"), ("MUTAG", 50, "fp32"), ("PROTEINS", 50, "fp32"), ("COLLAB", 256, "fp32"), ("COLLAB", 3, "fp32"),
+              ("COLLAB", 50, "bf16"), ("PROTEINS", 50, "bf16"), ("MUTAG", 50, "bf16")]
 
 
-@pytest.mark.parametrize("name,bs", STEP_CASES, ids=[f"{c[0]}-{c[1]}" for c in STEP_CASES])
-def test_in_kernel_gcn_backward_equals_the_launch_per_layer_form(name, bs):
+@pytest.mark.parametrize("name,bs,dtype", STEP_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in STEP_CASES])
+def test_in_kernel_gcn_backward_equals_the_launch_per_layer_form(name, bs, dtype):
     """the same training step with the GCN backward inside k_chain_readout_tail (default) and as the round-3 launches
     (conv4's in the kernel, conv3 / conv2 as gather kernels; dgcnn_step_kernel_enable(0)): same dropout mask, same selection,
-    identical loss, gradients equal to fp32 summation-order noise; eval mode and a 190-node graph (12 live waves) included"""
+    identical loss, gradients equal to fp32 summation-order noise; eval mode and a 190-node graph (12 live waves) included.
+    bf16 cases (BASELINE config 3): the kernel's forward half keeps hs_2 / hs_3 as one bf16 part, its backward is the same fp32
+    code reading fp32 weight tables rebuilt in LDS; a third run takes the nn.Module route (k_chain_fwd_q's bf16 form, the
+    readout and the backward as separate launches: the route test_gpu_configs.py checks against the fp64 oracle) on the same
+    dropout seed"""
     from dgcnn_amd.train import Trainer
     L = _lib.lib()
     sh = synth.SHAPES[name]
@@ -123,6 +128,7 @@ def test_in_kernel_gcn_backward_equals_the_launch_per_layer_form(name, bs):
         for on in (1, 0):
             L.dgcnn_step_kernel_enable(on)
             m = make_model(sh.num_features, sh.num_classes)
+            m.compute_dtype = dtype
             assert bool(form_of(m, b_cpu) & FORM_STEP) == bool(on)
             m.train(); m._seed_base, m._fwd_count = 5, 0
             tr = Trainer(m)
@@ -141,6 +147,25 @@ def test_in_kernel_gcn_backward_equals_the_launch_per_layer_form(name, bs):
     sc = float(gb.abs().max())
     assert float((ga - gb).abs().max()) <= 2e-5 * sc + 1e-9, (float((ga - gb).abs().max()), sc)
     assert float((wa - wb).abs().max()) <= 2.1e-3               # one Adam step: |dw| <= lr on either route
+    if dtype == "bf16":
+        m = make_model(sh.num_features, sh.num_classes)
+        m.compute_dtype = dtype
+        m.train(); m._seed_base, m._fwd_count = 5, 0
+        b = b_cpu.to("cuda")
+        out = m(b)
+        torch.nn.functional.nll_loss(out, b.y).backward()
+        m.check_errors()
+        assert torch.equal(m.last_workspace_view("perm").cpu(), pa)
+        for p, off in zip(m._param_list(), m._offsets):
+            d = float((ga[off:off + p.numel()] - p.grad.detach().reshape(-1).cpu()).abs().max())
+            assert d <= 2e-5 * sc + 1e-9, (off, d, sc)
+        # ... and the leg really ran in bf16: the fp32 step's gradients differ by more than order noise
+        m32 = make_model(sh.num_features, sh.num_classes)
+        m32.train(); m32._seed_base, m32._fwd_count = 5, 0
+        t32 = Trainer(m32)
+        t32.train_step(b, b.y)
+        torch.cuda.synchronize()
+        assert float((t32.grads.cpu() - ga).abs().max()) > 1e-4 * sc
 
 
 def test_bench_pool_batches_take_the_one_launch_kernel():
