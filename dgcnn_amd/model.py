@@ -77,6 +77,9 @@ def _batch_size_of(data) -> int:
     return int(B)
 
 
+_WS_BYTES = {}      # (N, E, B, F, C) -> dgcnn_workspace_bytes: a pure function of the dimensions, memoised (one ctypes call per step otherwise)
+
+
 class _DGCNNFunction(torch.autograd.Function):
     """forward = dgcnn_model_forward, backward = dgcnn_model_backward (one C call each)."""
 
@@ -87,7 +90,13 @@ class _DGCNNFunction(torch.autograd.Function):
         E = edge_index.shape[1] if pb is None else pb.num_edges
         C = model.num_classes
         flat = model.flat_params_fast()
-        ws = torch.empty(_lib.workspace_bytes(N, E, B, F, C), dtype=torch.uint8, device=x.device)
+        wkey = (N, E, B, F, C)
+        nbytes = _WS_BYTES.get(wkey)
+        if nbytes is None:
+            if len(_WS_BYTES) > 4096:
+                _WS_BYTES.clear()
+            nbytes = _WS_BYTES[wkey] = _lib.workspace_bytes(N, E, B, F, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         logp = torch.empty(B, C, dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         epoch = model._next_epoch()
@@ -106,8 +115,9 @@ class _DGCNNFunction(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (N, E, B, F, C, int(training), int(flags), int(max_nodes))
         ctx.save_for_backward(x, ws, logp)
-        model._last_ws = ws
-        model._last_dims = (N, E, B, F, C)
+        md = model.__dict__          # (nn.Module.__setattr__ costs ~2 us per assignment)
+        md["_last_ws"] = ws
+        md["_last_dims"] = wkey
         return logp
 
     @staticmethod
@@ -123,7 +133,7 @@ class _DGCNNFunction(torch.autograd.Function):
         _lib.check(L.dgcnn_model_backward(N, E, B, F, C, flat.data_ptr(), x.data_ptr(), ws.data_ptr(),
                                           logp.data_ptr(), glogp.data_ptr(), None, 0.0, training,
                                           grads.data_ptr(), None, flags, max_nodes, stream), "dgcnn_model_backward")
-        model._last_flat_grad = grads
+        model.__dict__["_last_flat_grad"] = grads
         # the 16 gradients handed to autograd are views of ONE flat buffer in the parameter layout: autograd keeps them
         # as they are (no copies), so an optimizer that recognises the layout (dgcnn_amd.optim.Adam) updates the
         # whole model with one kernel

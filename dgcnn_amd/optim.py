@@ -21,6 +21,11 @@ from torch.optim import Optimizer
 from . import _lib
 
 
+def _global_step_hooks() -> bool:
+    from torch.optim import optimizer as _o
+    return bool(getattr(_o, "_global_optimizer_pre_hooks", None)) or bool(getattr(_o, "_global_optimizer_post_hooks", None))
+
+
 class Adam(Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  amsgrad: bool = False):
@@ -80,9 +85,32 @@ class Adam(Optimizer):
         super().load_state_dict(state_dict)
         self._flat.clear()
 
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """``Optimizer.zero_grad``; the default (``set_to_none=True``) without torch's profiler range and per-device grouping"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
     # ---- step -----------------------------------------------------------------------------------------
-    @torch.no_grad()
     def step(self, closure=None):
+        # (torch wraps every optimizer's ``step`` in a profiler range + hook dispatch, ~25 us of host time per call: this
+        #  method is marked ``hooked`` so that the wrapper is not installed, and takes the wrapped route itself whenever a
+        #  step hook is registered, on the optimizer or globally)
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_step_hooks():
+            return self._hooked_step(closure)
+        return self._step_impl(closure)
+
+    step.hooked = True
+
+    def _hooked_step(self, closure=None):
+        fn = self.__dict__.get("_wrapped_impl")
+        if fn is None:
+            fn = self.__dict__["_wrapped_impl"] = Optimizer.profile_hook_step(Adam._step_impl)
+        return fn(self, closure)
+
+    def _step_impl(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -90,47 +118,57 @@ class Adam(Optimizer):
         for group in self.param_groups:
             params = group["params"]
             if not self._fused_step(group, params):
-                self._torch_step(group, params)
+                with torch.no_grad():
+                    self._torch_step(group, params)
         return loss
 
     def _fused_step(self, group, params) -> bool:
-        if not params or not params[0].is_cuda or any(p.grad is None for p in params):
+        if not params:
             return False
         key = id(group)
         ent = self._flat.get(key)
-        if ent is None or ent[0].untyped_storage().data_ptr() != params[0].untyped_storage().data_ptr():
+        p0 = params[0]
+        if ent is None or ent[0].data_ptr() != p0.data_ptr() - 4 * ent[3][0] or ent[6] != len(params):
+            if not p0.is_cuda or any(p.grad is None for p in params):
+                return False
             rec = self._flat_of(params)
             if rec is None:
                 return False
             pflat, offs = rec
-            m, v, shared = self._state_views(group, pflat, offs)
-            ent = self._flat[key] = [pflat, m, v, offs, shared, int(shared.item())]
-        pflat, m, v, offs, shared, nstep = ent
-        if self.state[params[0]]["step"] is not shared:       # a state_dict was loaded: adopt its counter
-            shared.fill_(float(self.state[params[0]]["step"]))
+            with torch.no_grad():
+                m, v, shared = self._state_views(group, pflat, offs)
+            ent = self._flat[key] = [pflat, m, v, offs, shared, int(shared.item()), len(params)]
+        pflat, m, v, offs, shared, nstep, _ = ent
+        if self.state[p0]["step"] is not shared:       # a state_dict was loaded: adopt its counter
+            shared.fill_(float(self.state[p0]["step"]))
             nstep = ent[5] = int(shared.item())
             for p in params:
                 self.state[p]["step"] = shared
-        g0 = params[0].grad
-        gst = g0.untyped_storage().data_ptr()
-        gbase = g0.storage_offset() - offs[0]
-        if gbase < 0:
+        # parameters AND gradients must mirror the flat layout: parameter i at pflat + offs[i] (a parameter re-pointed by hand
+        # since the layout was recognised fails here), its gradient at the same offset of ONE gradient buffer, dense fp32
+        g0 = p0.grad
+        if g0 is None:
             return False
-        for p, off in zip(params, offs):                # gradients must mirror the parameter layout in ONE buffer
+        pbase = pflat.data_ptr()
+        gbase = g0.data_ptr() - 4 * offs[0]
+        f32 = torch.float32
+        for p, off in zip(params, offs):
             g = p.grad
-            if g.untyped_storage().data_ptr() != gst or g.storage_offset() - gbase != off or not g.is_contiguous() \
-                    or g.dtype != torch.float32:
+            if g is None or g.data_ptr() != gbase + 4 * off or p.data_ptr() != pbase + 4 * off or g.dtype is not f32 \
+                    or not g.is_contiguous():
                 return False
+        # ... and that buffer is one allocation spanning the whole layout (the alignment gaps included)
         n = pflat.numel()
-        if gbase + n > g0.untyped_storage().nbytes() // 4:
+        gst = g0.untyped_storage()
+        lo = gbase - gst.data_ptr()
+        if lo < 0 or lo + 4 * n > gst.nbytes() or g0.device != pflat.device:
             return False
-        gflat = torch.empty(0, dtype=torch.float32, device=pflat.device).set_(g0.untyped_storage(), gbase, (n,))
         step = nstep + 1
         b1, b2 = group["betas"]
         stream = torch.cuda.current_stream(pflat.device).cuda_stream
         # the gaps between segments hold zeros in both buffers (zero gradient -> zero update), so one launch over the
         # whole span is exact
-        _lib.check(_lib.lib().dgcnn_adam_step(pflat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), n, step,
+        _lib.check(_lib.lib().dgcnn_adam_step(pbase, gbase, m.data_ptr(), v.data_ptr(), n, step,
                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]), 0, stream),
                    "dgcnn_adam_step")
         shared += 1

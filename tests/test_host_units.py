@@ -42,3 +42,36 @@ def test_step_kernel_switch_is_exported_and_reports_its_previous_value():
         assert not f(3800, 140000, 50, 1, CU, 180) & 8
     finally:
         L.dgcnn_step_kernel_enable(prev)
+
+
+def test_flat_adam_without_torchs_step_wrapper_still_runs_hooks_schedulers_and_the_fallback():
+    """dgcnn_amd.optim.Adam marks its ``step`` as hooked (no profiler range / hook dispatch per call); step hooks registered on
+    the optimizer or globally, LR schedulers and ``zero_grad`` must behave as with torch.optim.Adam -- checked on CPU
+    parameters, i.e. through the fallback to torch's own Adam (same numbers)"""
+    import torch
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    from dgcnn_amd.optim import Adam as FlatAdam
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+    b.load_state_dict(a.state_dict())
+    oa, ob = FlatAdam(a.parameters(), lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    assert getattr(type(oa).step, "hooked", False) and type(oa).step.__name__ == "step"      # torch installed no wrapper
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, 2, 0.5), torch.optim.lr_scheduler.StepLR(ob, 2, 0.5)
+    calls = []
+    h1 = oa.register_step_post_hook(lambda opt, args, kwargs: calls.append("post"))
+    h2 = oa.register_step_pre_hook(lambda opt, args, kwargs: calls.append("pre"))
+    x = torch.randn(7, 5)
+    for it in range(5):
+        if it == 3:
+            h1.remove(); h2.remove()
+            h3 = register_optimizer_step_post_hook(lambda opt, args, kwargs: calls.append("global"))
+        for m, o, s in ((a, oa, sa), (b, ob, sb)):
+            m(x).square().sum().backward()
+            o.step(); o.zero_grad(); s.step()
+            assert all(p.grad is None for p in m.parameters())
+    h3.remove()
+    assert calls[:6] == ["pre", "post"] * 3 and calls.count("global") >= 2
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 1e-2 * 0.25
+    oa.zero_grad(set_to_none=False)
