@@ -376,32 +376,39 @@ def dropin_loop_us(Model, F, C, batches, dev, K=200):
     import torch
     from torch import nn
     from dgcnn_amd.optim import Adam as FlatAdam
-    res = {}
-    for name, mk in (("unchanged_loop_us", lambda m: torch.optim.Adam(m.parameters())),
-                     ("with_dgcnn_amd_optim_adam_us", lambda m: FlatAdam(m.parameters()))):
-        torch.manual_seed(324)
-        m = Model(F, C).to(dev)
-        m.train()
-        opt, crit = mk(m), nn.NLLLoss()
+    res, runs = {}, {}
+    # three interleaved repeats per optimizer, best one reported: the first pass over this loop runs 25-50 % slower than the
+    # steady state (autograd's device thread, the caching allocator's pools and the host's clocks warm up over a few hundred
+    # steps -- 30 warm-up steps are not enough), and the other repeats are listed beside it
+    for rep in range(3):
+        for name, mk in (("unchanged_loop_us", lambda m: torch.optim.Adam(m.parameters())),
+                         ("with_dgcnn_amd_optim_adam_us", lambda m: FlatAdam(m.parameters()))):
+            torch.manual_seed(324)
+            m = Model(F, C).to(dev)
+            m.train()
+            opt, crit = mk(m), nn.NLLLoss()
 
-        def loop(n):
-            running, correct = 0.0, 0
-            for i in range(n):
-                data = batches[i % len(batches)]
-                pred = m(data)
-                loss = crit(pred, data.y)
-                loss.backward()
-                opt.step()
-                opt.zero_grad()
-                running += loss.item()
-                correct += (pred.argmax(dim=1) == data.y).sum().item()
-            return running, correct
-        loop(30)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        loop(K)
-        torch.cuda.synchronize(dev)
-        res[name] = round(1e6 * (time.perf_counter() - t0) / K, 1)
+            def loop(n):
+                running, correct = 0.0, 0
+                for i in range(n):
+                    data = batches[i % len(batches)]
+                    pred = m(data)
+                    loss = crit(pred, data.y)
+                    loss.backward()
+                    opt.step()
+                    opt.zero_grad()
+                    running += loss.item()
+                    correct += (pred.argmax(dim=1) == data.y).sum().item()
+                return running, correct
+            loop(30)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            loop(K)
+            torch.cuda.synchronize(dev)
+            runs.setdefault(name, []).append(round(1e6 * (time.perf_counter() - t0) / K, 1))
+    for name, v in runs.items():
+        res[name] = min(v)
+    res["repeats_us"] = runs
     res["steps"] = K
     return res
 
