@@ -1,3 +1,5 @@
+"""GPU-box helper: steady-state us per step of the drop-in route (reference loop body verbatim, torch / flat Adam), three interleaved
+repeats, with and without autograd multithreading (the first pass is 25-50 % slower than the steady state)."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from torch import nn
