@@ -18,8 +18,14 @@ __device__ __forceinline__ unsigned long long dg_pack_key(float key, int idx) {
 // selects the first min(n,K) nodes of graph [n0, n0+n) into sel[0..K) (local indices, -1 = none).
 // Works for any workgroup size that is a multiple of 64 (<= 1024).
 __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int n0, int n, unsigned long long* keys,
-                               unsigned long long* red, int* sel) {
+                               unsigned long long* red, int* sel, unsigned long long* dbg = nullptr) {
+#ifdef RD_FINE      // measurement build (tools/build_variant.sh rdfine "-DRD_FINE"; tools/phase_step_kernel.py prints the stamps)
+#define SK_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[60 + (k)] = clock64(); } while (0)
+#else
+#define SK_MARK(k) do { } while (0)
+#endif
   const int tid = threadIdx.x, T = blockDim.x;
+  SK_MARK(0);
   const int m = n < DGCNN_K ? n : DGCNN_K;
   if (tid < DGCNN_K) sel[tid] = -1;
   // (LDS-only barriers in this path: nothing here depends on an outstanding global store -- a caller whose workgroup wrote
@@ -37,8 +43,10 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     const int P = 1 << lp, i = tid >> lp, part = tid & (P - 1);
     const int npad = (n + 8 * P - 1) & ~(8 * P - 1);          // <= 256 + 127: inside the caller's SP_LDS_KEYS slots
     dg_lds_barrier();
+    SK_MARK(1);
     for (int t = tid; t < npad; t += T) keys[t] = t < n ? dg_pack_key(x4[n0 + t], t) : ~0ull;
     dg_lds_barrier();
+    SK_MARK(2);
     const bool on = i < n;
     const unsigned long long my = keys[on ? i : 0];
     int rank = 0;
@@ -50,8 +58,10 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
 #pragma unroll
       for (int u = 0; u < 8; ++u) rank += kj[u] < my ? 1 : 0;
     }
+    SK_MARK(3);
     for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o);
     if (on && part == 0 && rank < DGCNN_K) sel[rank] = i;
+    SK_MARK(4);
   } else {
     __syncthreads();
     // (graphs of up to SP_LDS_KEYS / 2 nodes keep their packed keys in LDS; larger ones -- DD's 5748-node graph -- re-pack them
@@ -144,7 +154,12 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
       }
     }
   }
-  __syncthreads();
+  // (LDS only -- `sel`: a full barrier here would also wait, with vmcnt(0), for every global load the CALLER has in flight, i.e.
+  //  the readout's cold parameter prefetch.  Every caller places a full barrier between its own stores of the rows / keys and
+  //  this function.)
+  dg_lds_barrier();
+  SK_MARK(5);
+#undef SK_MARK
 }
 
 __device__ __forceinline__ float dg_cat_load(const float* __restrict__ x1, const float* __restrict__ x2,
@@ -242,7 +257,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   if (!BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   float wf2a = 0.f, wf2b = 0.f;                   // classifier_2 row of class `wv` (used at the very end: no cold load there)
   if (!BIG && wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }
-  dg_select_topk(keys, key_n0, n, M.region0, M.red, sel);        // ends with a barrier
+  dg_select_topk(keys, key_n0, n, M.region0, M.red, sel, dbg);   // ends with a barrier
   if (tid < 176 + C) bs[tid] = bval;                              // (read behind the barrier that follows the gather)
   if (BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   RD_MARK(8);

@@ -49,5 +49,7 @@ for it in range(4):
         for k in order:
             parts.append(f"{cn[k]}={v[48 + k] - prev}"); prev = v[48 + k]
         gb += " || chain fine: " + " ".join(parts)
+    if v[65]:      # -DRD_FINE build: stamps inside the top-k selection
+        gb += " || topk fine: " + " ".join(f"{nm}={v[60 + k] - (v[14] if k == 0 else v[59 + k])}" for k, nm in enumerate(["entry", "barrier", "keys+barrier", "count", "shuffle+sel", "barrier"])) + f" rest={v[8] - v[65]}"
     print(f"it{it} kernel={max(v[21], v[17], v[7]) - v[15]} chain={v[14]-v[15]} readout+tail={v[7]-v[14]} :: FWD {fw} :: BWD {bw} :: GCN-BWD {gb}")
 L.dgcnn_debug_phase_clocks(None)
