@@ -178,6 +178,13 @@ class Adam(Optimizer):
     def _torch_step(self, group, params) -> None:
         """torch's own multi-tensor Adam on this group (layout not recognised)"""
         from torch.optim.adam import adam as _adam
+        # a group that HAS taken the flat route shares one step counter between its parameters: torch's multi-tensor Adam would
+        # increment that one tensor once per parameter.  Back to one counter per parameter (the moments stay views of the flat
+        # buffers, which is fine), and the flat entry is dropped: the next step whose layout checks out rebuilds it from the state.
+        ent = self._flat.pop(id(group), None)
+        if ent is not None:
+            for p in params:
+                self.state[p]["step"] = ent[4].clone()
         with_grad = [p for p in params if p.grad is not None]
         if not with_grad:
             return

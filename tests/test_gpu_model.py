@@ -547,6 +547,35 @@ def test_dropin_optimizer_resume_from_loaded_state_continues_the_same_trajectory
     assert float(opt.state_dict()["state"][0]["step"]) == 6.0
 
 
+def test_dropin_optimizer_fallback_after_the_flat_route_keeps_adams_step_count():
+    """a step whose gradients do NOT mirror the flat layout (here: one ``p.grad`` replaced by a copy, as a user-side gradient
+    transform would) after steps that did: the fallback to torch's Adam must count ONE step (the flat route keeps one shared
+    counter for the 16 parameters; handed to torch's multi-tensor Adam as it is, it was incremented 16 times), and later steps
+    return to the flat route from the same moments"""
+    from dgcnn_amd.optim import Adam as FlatAdam
+    sh = synth.SHAPES["PROTEINS"]
+    batches = [b.to("cuda") for b in synth.make_batches("PROTEINS", 30, 10, start=7)]
+    res = []
+    for kind in ("torch", "flat"):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 11, 0
+        opt = torch.optim.Adam(m.parameters()) if kind == "torch" else FlatAdam(m.parameters())
+        crit = torch.nn.NLLLoss()
+        for it in range(6):
+            data = batches[it % len(batches)]
+            crit(m(data), data.y).backward()
+            if it == 2:
+                m.classifier_2.bias.grad = m.classifier_2.bias.grad.clone()       # no longer a view of the flat gradient buffer
+            opt.step(); opt.zero_grad()
+            if kind == "flat":
+                assert len(opt._flat) == (0 if it == 2 else 1), it
+        torch.cuda.synchronize()
+        if kind == "flat":
+            assert [float(v["step"]) for v in opt.state_dict()["state"].values()] == [6.0] * 16
+        res.append(m.flat_params.clone())
+    torch.testing.assert_close(res[0], res[1], rtol=1e-4, atol=5e-6)
+
+
 def test_dropin_optimizer_falls_back_for_foreign_parameters():
     from dgcnn_amd.optim import Adam as FlatAdam
     lin = torch.nn.Linear(5, 3).cuda()
