@@ -99,6 +99,49 @@ def test_one_launch_training_kernel_vs_fp64_oracle(name, bs):
     fused_step_vs_oracle(m, b_cpu)
 
 
+@pytest.mark.parametrize("F", [2, 8, 9, 13, 16, 17, 24, 31, 32])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_one_launch_training_kernel_raw_feature_widths(F, dtype):
+    """every instantiation of the step kernel by feature width (F <= 8, <= 16, <= 32: staging items per thread, conv1's weight
+    table depth, the in-kernel conv1 weight gradient with one or two column blocks, its one- and two-round cross-wave sums):
+    Trainer.train_step vs the fp64 oracle, all 16 gradients; a 150-node graph (10 live waves) and a 230-node graph (15) in
+    the batch.  bf16: equal to the nn.Module route of the same leg (the one held to the leg's stated tolerances)"""
+    from dgcnn_amd.train import Trainer
+    base = None
+    for k in range(64):
+        base = synth.make_batch("COLLAB" if F % 2 else "PROTEINS", 14, start=300 + 14 * k, force_first_n=150 if F % 2 else 230)
+        if base.max_nodes <= 256:
+            break
+    assert base.max_nodes <= 256
+    g = torch.Generator().manual_seed(F)
+    b_cpu = Batch(torch.randn(base.x.shape[0], F, generator=g), base.edge_index, base.batch, base.y, base.num_graphs,
+                  base.coalesced_undirected, base.max_nodes, base.max_edges)
+    m = make_model(F, 3)
+    m.compute_dtype = dtype
+    assert form_of(m, b_cpu) & FORM_STEP, form_of(m, b_cpu)
+    if dtype == "fp32":
+        fused_step_vs_oracle(m, b_cpu)
+        return
+    m.train(); m._seed_base, m._fwd_count = 5, 0
+    tr = Trainer(m)
+    b = b_cpu.to("cuda")
+    tr.train_step(b, b.y)
+    torch.cuda.synchronize()
+    m.check_errors()
+    ga, pa = tr.grads.cpu().clone(), m.last_workspace_view("perm").cpu().clone()
+    m2 = make_model(F, 3)
+    m2.compute_dtype = dtype
+    m2.train(); m2._seed_base, m2._fwd_count = 5, 0
+    out = m2(b)
+    torch.nn.functional.nll_loss(out, b.y).backward()
+    m2.check_errors()
+    assert torch.equal(m2.last_workspace_view("perm").cpu(), pa)
+    sc = float(ga.abs().max())
+    for p, off in zip(m2._param_list(), m2._offsets):
+        d = float((ga[off:off + p.numel()] - p.grad.detach().reshape(-1).cpu()).abs().max())
+        assert d <= 2e-5 * sc + 1e-9, (off, d, sc)
+
+
 STEP_CASES = [("COLLAB", 50, "fp32"), ("MUTAG", 50, "fp32"), ("PROTEINS", 50, "fp32"), ("COLLAB", 256, "fp32"), ("COLLAB", 3, "fp32"),
               ("COLLAB", 50, "bf16"), ("PROTEINS", 50, "bf16"), ("MUTAG", 50, "bf16")]
 
