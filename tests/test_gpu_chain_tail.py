@@ -142,6 +142,19 @@ def test_one_launch_training_kernel_raw_feature_widths(F, dtype):
         assert d <= 2e-5 * sc + 1e-9, (off, d, sc)
 
 
+@pytest.mark.parametrize("C", [2, 7, 8, 9, 16, 17, 33, 64])
+def test_one_launch_training_kernel_class_counts(C):
+    """classifier_2 / log_softmax / the loss gradient of the step kernel by class count (a wave per class in the forward; the
+    backward keeps the first 8 rows of classifier_2 in registers, rows 8..15 in LDS, the rest in place): vs the fp64 oracle"""
+    base = batch_with_small_graphs("COLLAB", 20, start=640)
+    g = torch.Generator().manual_seed(C)
+    y = torch.randint(0, C, (base.num_graphs,), generator=g)
+    b_cpu = Batch(base.x, base.edge_index, base.batch, y, base.num_graphs, base.coalesced_undirected, base.max_nodes, base.max_edges)
+    m = make_model(1, C)
+    assert form_of(m, b_cpu) & FORM_STEP
+    fused_step_vs_oracle(m, b_cpu)
+
+
 STEP_CASES = [("COLLAB", 50, "fp32"), ("MUTAG", 50, "fp32"), ("PROTEINS", 50, "fp32"), ("COLLAB", 256, "fp32"), ("COLLAB", 3, "fp32"),
               ("COLLAB", 50, "bf16"), ("PROTEINS", 50, "bf16"), ("MUTAG", 50, "bf16")]
 
