@@ -155,6 +155,23 @@ def test_one_launch_training_kernel_class_counts(C):
     fused_step_vs_oracle(m, b_cpu)
 
 
+@pytest.mark.parametrize("sizes,isolated", [
+    ([31, 32, 33, 63, 64, 65], ()), ([127, 128, 129, 16, 15, 17], ()), ([191, 192, 193, 1, 2, 3], (0, 2)),
+    ([255, 256, 29, 30, 31], ()), ([1, 1, 1, 40], ()), ([2], ()), ([96, 97, 111, 112, 113, 209, 240], (1, 5))],
+    ids=["words", "tile_boundary", "mixed", "max256_and_k", "single_nodes", "one_tiny_graph", "tile_gap"])
+def test_one_launch_training_kernel_boundary_sizes_isolated_and_single_node_graphs(sizes, isolated):
+    """graph sizes at the 32-node bitmap-word and 16-node tile boundaries, at SortPooling's k = 30 and at the kernel's bound of
+    256 nodes, single-node graphs (no edge at all) and nodes without neighbours: Trainer.train_step vs the fp64 oracle"""
+    from test_gpu_dense import _sized_batch
+    b_cpu = _sized_batch(sizes, seed=sum(sizes), isolated=isolated)
+    m = make_model(3, 2)
+    # (more graphs than 16-node tiles in the batch -- three single-node graphs and one of 40 nodes -- leaves the GCN backward to
+    #  the launch-per-layer kernels: one partial row per graph would exceed the rows k_wgrad's workspace holds)
+    want = FORM_CHAIN_TAIL if sizes == [1, 1, 1, 40] else FORM_STEP
+    assert form_of(m, b_cpu) & want, form_of(m, b_cpu)
+    fused_step_vs_oracle(m, b_cpu)
+
+
 STEP_CASES = [("COLLAB", 50, "fp32"), ("MUTAG", 50, "fp32"), ("PROTEINS", 50, "fp32"), ("COLLAB", 256, "fp32"), ("COLLAB", 3, "fp32"),
               ("COLLAB", 50, "bf16"), ("PROTEINS", 50, "bf16"), ("MUTAG", 50, "bf16")]
 
