@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 17
+ABI_VERSION = 18
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -85,6 +85,7 @@ SIGNATURES = {
     "dgcnn_model_prepare": (c_int, [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int, ctypes.c_uint32, c_void_p]),
     "dgcnn_forward_form": (c_int, [c_int] * 6),
     "dgcnn_step_kernel_enable": (c_int, [c_int]),
+    "dgcnn_narrow_gather_enable": (c_int, [c_int]),
     "dgcnn_fused_max_nodes": (c_int, [c_int]),
     "dgcnn_fused_fits": (c_int, [c_int, c_int, c_int]),
     "dgcnn_model_backward": (c_int, [c_int] * 5 + [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_int, c_int,

@@ -283,6 +283,7 @@ int dgcnn_step_kernel_enable(int on) {
   g_step_kernel = on ? 1 : 0;
   return prev;
 }
+int dgcnn_narrow_gather_enable(int on) { return dg_narrow_gather_enable(on); }
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   if (N <= 0 || B <= 0 || E < 0 || F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
@@ -531,12 +532,12 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   } else {
     if (!lin_done) DG_TRY(dg_launch_lin_first(N, F, x, params + pl.off[0], dinv, hsA, 32, s));
     DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsA, params + pl.off[1], x1, params + pl.off[2], hsB, s,
-                               DG_PROF_A(0), DG_PROF_B(0)));
+                               DG_PROF_A(0), DG_PROF_B(0), E));
   }
   DG_TRY(dg_launch_gcn_fwd32(0, N, rowptr, colidx, dinv, hsB, params + pl.off[3], x2, params + pl.off[4], hsA, s,
-                             DG_PROF_A(1), DG_PROF_B(1)));
+                             DG_PROF_A(1), DG_PROF_B(1), E));
   DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
-                             DG_PROF_A(2), DG_PROF_B(2)));
+                             DG_PROF_A(2), DG_PROF_B(2), E));
   g_prof_which = -1;
   DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
   }
@@ -677,7 +678,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   if (tail_done == 2 && !bwd1_hosts_rider) {
     // conv4's backward ran inside the one-launch training kernel: gas3 is in gasA, {dW4, db3} in pa4
     DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
-                               dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+                               dg_ptr<float>(ws, wl.pb3), wl.P32, s, nullptr, 0, nullptr, E));
   } else if (bf.chain && !bwd1_hosts_rider) {
     const DgDense G = dg_dense_view(ws, wl, N, B);
     DG_TRY(dg_launch_chain_bwd_a(N, B, G.graph_ptr, G.bits, dinv, gas4, params + pl.off[6], params + pl.off[4], x3, gp3, x2, gp2,
@@ -689,7 +690,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                             dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
-                             dg_ptr<float>(ws, wl.pb3), wl.P32, s));
+                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, nullptr, 0, nullptr, E));
   }
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
   if (F <= DG_AF_MAX_F) {
@@ -699,7 +700,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
                                dg_ptr<float>(ws, wl.pb1)));
   } else {
     DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
-                               dg_ptr<float>(ws, wl.pb2), wl.P32, s));
+                               dg_ptr<float>(ws, wl.pb2), wl.P32, s, nullptr, 0, nullptr, E));
     // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
     DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
                                dg_ptr<float>(ws, wl.pb1), wl.P32, s));

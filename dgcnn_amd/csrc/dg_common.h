@@ -504,7 +504,8 @@ int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s);
 // mode: 0 = fused next 32x32 linear (MFMA), 1 = fused next 32->1 dot, 2 = no post-step
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int E = -1);
+int dg_narrow_gather_enable(int on);      // run-time A/B switch of the eight-lanes-per-node forms (gcn.hip); returns the previous setting
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                        const float* h4s, const float* bias, float* x4, hipStream_t s);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
@@ -522,7 +523,7 @@ int dg_readout_tail_max_b();
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const float* ax = nullptr, int Fa = 0, float* part1 = nullptr);
+                        const float* ax = nullptr, int Fa = 0, float* part1 = nullptr, int E = -1);
 // conv1 aggregate-first forward (F <= DG_AF_MAX_F): ax = A_hat x saved, x1 = tanh(ax W1^T + b1), hs_next = dinv*(x1 Wnext^T)
 int dg_launch_gcn_fwd_af(int N, int F, const int32_t* rowptr, const int32_t* colidx, const float* dinv, const float* x,
                          const float* W1, const float* bias, float* ax, float* xout, const float* Wnext,

@@ -83,6 +83,113 @@ k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict
   }
 }
 
+// Staged form (F <= DG_LIN_STAGE_MAX_F, 16-byte aligned x and W): a 16-row tile of the raw input is ONE contiguous run of
+// 16 F floats whose start is 64-byte aligned (tile row = multiple of 16), so a wave brings it in with 16-byte loads that
+// cover whole cache lines and keeps it in a wave-private LDS tile; W stays in its own [32][F] layout in LDS (a flat copy:
+// the transposing copy above writes one bank 64 times per instruction).  The form above reads the A operand straight from
+// global memory -- one dword per lane, 16 different lines per instruction, and again for the second output block: at DD's
+// 14.5 k x 90 input 10.9 us.  Row stride F in both tiles: the 16 rows of an operand read fall on 16 different banks for every
+// F that is 2 mod 4 or odd (for the others the reads are 2- to 4-way conflicted: still cheaper than the global form).
+// SAME matrix-instruction sequence on the SAME operand values as the form above (and as the fused kernels): bit-identical.
+#define DG_LIN_STAGE_MAX_F 128
+template <bool BF>
+__global__ void __launch_bounds__(256)
+k_lin_first32s(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
+               const float* __restrict__ dinv, void* __restrict__ hsv) {
+  float* hs = reinterpret_cast<float*>(hsv);
+  unsigned short* hb = reinterpret_cast<unsigned short*>(hsv);
+  extern __shared__ __attribute__((aligned(16))) float lsm[];     // [32][F] weights | 4 x [16][F] tiles | 4 floats of slack
+  float* Ws = lsm;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* xs = lsm + 32 * F + w * 16 * F;                 // this wave's tile (32 F and 16 F floats: multiples of 16 bytes)
+  const int tiles = (N + 15) >> 4;
+  const int mi = lane & 15, kq = lane >> 4;
+  constexpr int XQ = DG_LIN_STAGE_MAX_F * 16 / 4 / 64;   // 16-byte pieces of a tile per lane (8 at the largest F)
+  constexpr int WQ = DG_LIN_STAGE_MAX_F * 32 / 4 / 256;  // ... of the weights per thread (4)
+  const int nq = 4 * F;                                  // 16-byte pieces of a full tile
+  int tile = blockIdx.x * 4 + w;
+  float4 v[XQ], wv[WQ];
+  float dv[4];
+  // (a macro, not a lambda: captured by reference the register arrays stay in scratch)
+#define DG_LS_LOAD_TILE()                                                                                               \
+  do {                                                                                                                  \
+    const int r0_ = tile * 16;                                                                                          \
+    const int nfl = tile < tiles ? min(16, N - r0_) * F : 0;      /* floats of this tile that exist */                  \
+    const float* xt = x + (size_t)r0_ * F;                                                                              \
+    _Pragma("unroll") for (int i = 0; i < XQ; ++i) {                                                                    \
+      const int p = lane + 64 * i;                                                                                      \
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                           \
+      if (p < nq) {                                                                                                     \
+        if (4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);                                       \
+        else {                                      /* the batch's last tile: rows beyond N read as zeros */            \
+          if (4 * p + 0 < nfl) v[i].x = xt[4 * p + 0];                                                                  \
+          if (4 * p + 1 < nfl) v[i].y = xt[4 * p + 1];                                                                  \
+          if (4 * p + 2 < nfl) v[i].z = xt[4 * p + 2];                                                                  \
+        }                                                                                                               \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) { const int m = r0_ + kq * 4 + r; dv[r] = m < N ? dinv[m] : 0.f; }    \
+  } while (0)
+  // every load of the set-up in flight before the first LDS store
+#pragma unroll
+  for (int i = 0; i < WQ; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < 8 * F) wv[i] = *reinterpret_cast<const float4*>(W + 4 * p);
+  }
+  DG_LS_LOAD_TILE();
+#pragma unroll
+  for (int i = 0; i < WQ; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    if (p < 8 * F) *reinterpret_cast<float4*>(Ws + 4 * p) = wv[i];
+  }
+  bool first = true;
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      const int p = lane + 64 * i;
+      if (p < nq) *reinterpret_cast<float4*>(xs + 4 * p) = v[i];
+    }
+    if (first) { __syncthreads(); first = false; }       // (outside any wave-dependent condition: the weights are staged)
+    if (tile >= tiles) break;
+    const int r0 = tile * 16;
+    // the two 16-column output blocks advance together on one read of the A operand; per accumulator the sequence is
+    // dg_mfma_tile16's: 8 k-steps per round, operands beyond F are zeros, steps beyond F are not issued
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < F; k0 += 32) {
+      float av[8], b0[8], b1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 4 * u + kq;
+        const float a_ = xs[mi * F + k], p_ = Ws[mi * F + k], q_ = Ws[(16 + mi) * F + k];     // (k up to F + 34: inside the LDS block)
+        av[u] = k < F ? a_ : 0.f; b0[u] = k < F ? p_ : 0.f; b1[u] = k < F ? q_ : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 4 * u < F) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b0[u], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b1[u], d1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + kq * 4 + r;
+      if (row < N) {
+        const float o0 = dv[r] * d0[r], o1 = dv[r] * d1[r];
+        if (BF) {
+          unsigned u0 = __float_as_uint(o0), u1 = __float_as_uint(o1);
+          u0 += 0x7fffu + ((u0 >> 16) & 1u); u1 += 0x7fffu + ((u1 >> 16) & 1u);
+          hb[(size_t)row * 32 + mi] = (unsigned short)(u0 >> 16); hb[(size_t)row * 32 + 16 + mi] = (unsigned short)(u1 >> 16);
+        } else { hs[(size_t)row * 32 + mi] = o0; hs[(size_t)row * 32 + 16 + mi] = o1; }
+      }
+    }
+    tile += gridDim.x * 4;
+    if (tile >= tiles) break;
+    DG_LS_LOAD_TILE();
+  }
+#undef DG_LS_LOAD_TILE
+}
+
 __global__ void __launch_bounds__(256)
 k_lin_first1(int N, int F, const float* __restrict__ x, const float* __restrict__ W,
              const float* __restrict__ dinv, float* __restrict__ hs) {
@@ -102,7 +209,12 @@ int dg_launch_lin_first(int N, int F, const float* x, const float* W, const floa
   if (Fout == 32) {
     int grid = dg_cdiv(dg_cdiv(N, 16), 4);
     if (grid > 4096) grid = 4096;
-    if (bf16_out) hipLaunchKernelGGL(k_lin_first32<true>, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, (void*)hs);
+    const bool staged = F <= DG_LIN_STAGE_MAX_F && (((uintptr_t)x | (uintptr_t)W) & 15) == 0;
+    const size_t lds_s = sizeof(float) * (96 * F + 32);       // weights + four tiles + the slack the last k-round reads into
+    if (staged) {
+      if (bf16_out) hipLaunchKernelGGL(k_lin_first32s<true>, dim3(grid), dim3(256), lds_s, s, N, F, x, W, dinv, (void*)hs);
+      else hipLaunchKernelGGL(k_lin_first32s<false>, dim3(grid), dim3(256), lds_s, s, N, F, x, W, dinv, (void*)hs);
+    } else if (bf16_out) hipLaunchKernelGGL(k_lin_first32<true>, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, (void*)hs);
     else hipLaunchKernelGGL(k_lin_first32<false>, dim3(grid), dim3(256), sizeof(float) * 32 * F, s, N, F, x, W, dinv, (void*)hs);
   } else if (Fout == 1) {
     int grid = dg_cdiv(N, 4);
@@ -348,12 +460,145 @@ k_gcn_fwd32p(int N, int numTiles, const int* __restrict__ rowptr, const int* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NARROW forms for sparse batches of many nodes (mean in-degree <= DG_NARROW_MAX_DEG: the DD / PROTEINS / ENZYMES / MUTAG
+// shapes; DD at the reference's batch of 50 is 14.5 k nodes of degree 5).  A wave per destination node leaves 7 of its 8
+// neighbour groups idle at degree 5, and 910 sixteen-wave workgroups are two rounds of a four-round-trip latency chain
+// (row pointers -> neighbour ids -> rows -> tile product): 8.9 us per layer.  Here EIGHT LANES own a destination node (lane =
+// 8 g + q: node g of the wave's eight, 16-byte column chunk q of its 128-byte row), a wave owns 8 nodes and a 256-thread
+// workgroup 32 nodes = two 16-row tiles of the matrix-core epilogue: an eighth of the waves, one round.
+// The eight accumulators a[u] (u = position of the neighbour modulo 8) and their combine
+//     ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7))
+// are dg_gather_row32's eight lane groups and its xor-8 / 16 / 32 butterfly: the SAME fp32 additions in the same order --
+// results are bit-identical to the wave-per-node kernels (tests/test_gpu_kernels.py compares the two forms exactly).
+// ---------------------------------------------------------------------------------------------
+#define DG_NARROW_MAX_DEG 8
+static int g_narrow = 1;
+int dg_narrow_gather_enable(int on) { const int prev = g_narrow; g_narrow = on ? 1 : 0; return prev; }
+// E: directed edges of the batch without the self loops (< 0: unknown -> the wave-per-node forms)
+static inline bool dg_use_narrow(int N, int E) {
+  return g_narrow && E >= 0 && dg_cdiv(N, DG_TILE) > DG_SMALL_GRID_TILES && (int64_t)E <= (int64_t)DG_NARROW_MAX_DEG * N;
+}
+__device__ __forceinline__ float4 dg_gather_row32_n(const float* __restrict__ src, const int* __restrict__ col, int start,
+                                                    int cnt, int self, bool valid, int lane) {
+  const int q = lane & 7, gb = lane & ~7;
+  const float* sq = src + 4 * q;
+  float4 a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 vself = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) vself = *reinterpret_cast<const float4*>(sq + (size_t)self * 32);      // issued first, added last
+  int mx = cnt;                                          // trip count: the longest row among the wave's eight nodes
+  mx = max(mx, __shfl_xor(mx, 8)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+  mx = __builtin_amdgcn_readfirstlane(mx);
+  for (int base = 0; base < mx; base += 8) {
+    const int cj = base + q < cnt ? col[start + base + q] : 0;      // the node's next eight neighbour ids: 32 contiguous bytes
+    int j[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) j[u] = __shfl(cj, gb + u);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                          // eight row loads in flight per lane
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (base + u < cnt) v[u] = *reinterpret_cast<const float4*>(sq + (size_t)j[u] * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + u < cnt) a[u] = dg_add4(a[u], v[u]);
+  }
+  if (valid) a[0] = dg_add4(a[0], vself);                // self loop term, added last in group 0 (PyG appends self loops at the end)
+  return dg_add4(dg_add4(dg_add4(a[0], a[1]), dg_add4(a[2], a[3])), dg_add4(dg_add4(a[4], a[5]), dg_add4(a[6], a[7])));
+}
+
+#define DG_NB 32                   // destination nodes per 256-thread workgroup of the narrow forms
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_gcn_fwd32n(int N, int numBlocks, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+             const float* __restrict__ dinv, const float* __restrict__ hs, const float* __restrict__ bias,
+             float* __restrict__ xout, const float* __restrict__ Wn, float* __restrict__ hs_next) {
+  __shared__ __attribute__((aligned(16))) float xt[DG_NB][DG_LDS_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+  const int tt = wave >> 1, nb = wave & 1;                 // epilogue: 16-row tile tt of the block, 16-column output block nb
+  float wreg[8];
+  if (MODE == 0) {   // B operand of the post-step: B[k][n] = Wn[n][k]
+    const int c = nb * 16 + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wn[c * 32 + 4 * kk + (lane >> 4)];
+  }
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1) w4 = *reinterpret_cast<const float4*>(Wn + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+  for (int bl = blockIdx.x; bl < numBlocks; bl += gridDim.x) {
+    const int blk = (gridDim.x == (unsigned)numBlocks) ? dg_xcd_tile(bl, numBlocks) : bl;
+    const int i = blk * DG_NB + wave * 8 + g;
+    const bool valid = i < N;
+    int start = 0, end = 0;
+    float di = 0.f;
+    if (valid) { start = rowptr[i]; end = rowptr[i + 1]; di = dinv[i]; }
+    float dpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {       // dst scales of the epilogue rows: issued with the row pointers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = blk * DG_NB + tt * 16 + (lane >> 4) * 4 + r;
+        dpre[r] = node < N ? dinv[node] : 0.f;
+      }
+    }
+    const float4 acc = dg_gather_row32_n(hs, colidx, start, end - start, i, valid, lane);
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      val.x = dg_tanh(fmaf(di, acc.x, b4.x));
+      val.y = dg_tanh(fmaf(di, acc.y, b4.y));
+      val.z = dg_tanh(fmaf(di, acc.z, b4.z));
+      val.w = dg_tanh(fmaf(di, acc.w, b4.w));
+      *reinterpret_cast<float4*>(xout + (size_t)i * 32 + 4 * q) = val;
+    }
+    if (MODE == 0) *reinterpret_cast<float4*>(&xt[wave * 8 + g][4 * q]) = val;
+    if (MODE == 1) {
+      float p = val.x * w4.x;
+      p = fmaf(val.y, w4.y, p);
+      p = fmaf(val.z, w4.z, p);
+      p = fmaf(val.w, w4.w, p);
+      p += __shfl_xor(p, 1);
+      p += __shfl_xor(p, 2);
+      p += __shfl_xor(p, 4);
+      if (valid && q == 0) hs_next[i] = di * p;
+    }
+    if (MODE == 0) {
+      __syncthreads();
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float a = xt[tt * 16 + (lane & 15)][4 * kk + (lane >> 4)];
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = blk * DG_NB + tt * 16 + (lane >> 4) * 4 + r;
+        if (node < N) hs_next[(size_t)node * 32 + nb * 16 + (lane & 15)] = dpre[r] * d[r];
+      }
+      if (bl + (int)gridDim.x < numBlocks) __syncthreads();
+    }
+  }
+}
+
 int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                         const float* hs, const float* bias, float* xout, const float* Wnext, float* hs_next,
-                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int E) {
   if (N <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   const int grid = tiles;          // one workgroup per tile (XCD-aware order inside the kernel)
+  if (dg_use_narrow(N, E)) {       // sparse batch of many nodes: eight lanes per node (bit-identical results)
+    const int nblk = dg_cdiv(N, DG_NB);
+#define DG_FWD32N_LAUNCH(M) hipExtLaunchKernelGGL((k_gcn_fwd32n<M>), dim3(nblk), dim3(256), 0, s, ev_start, ev_stop, 0, N, nblk, \
+                                                  rowptr, colidx, dinv, hs, bias, xout, Wnext, hs_next)
+    if (mode == 0) DG_FWD32N_LAUNCH(0); else if (mode == 1) DG_FWD32N_LAUNCH(1); else DG_FWD32N_LAUNCH(2);
+#undef DG_FWD32N_LAUNCH
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
   // hipExtLaunchKernelGGL attaches the events to THIS dispatch (its own start/end timestamps, the
   // same ones rocprofv3 reports); with null events it is a plain launch.
 #define DG_FWD32_LAUNCH(M, D) hipExtLaunchKernelGGL((k_gcn_fwd32<M, D>), dim3(grid), dim3(DG_TILE_THREADS), 0, s, ev_start, \
@@ -765,13 +1010,132 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NARROW form of the 32-wide layer backward (layers 3 and 2 without the aggregate-first rider; see k_gcn_fwd32n): eight lanes
+// per node, 32 nodes = two 16-row tiles per 256-thread workgroup and trip.  Every accumulator sees the additions of
+// k_gcn_bwd32 in the same order -- the chunk of tiles a workgroup owns is the same, its tiles are taken in order (two per
+// trip), wave w < 2 runs the data-gradient block nb = w of BOTH tiles one after the other (db accumulates tile by tile), wave
+// w runs weight-gradient block (mb, nb) = (w >> 1, w & 1) of both tiles: partial rows are bit-identical to the wide form's.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gcn_bwd32n(int N, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
+             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
+             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
+             float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float ght[DG_NB][DG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float xt[DG_NB][DG_LDS_PAD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+  float wreg[8];
+  f32x4 accW = {0.f, 0.f, 0.f, 0.f};
+  float pb = 0.f;
+  if (wave < 2) {   // B operand of gx = gh . W_l : B[k][n] = W_l[k][nb*16+n]
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wreg[kk] = Wl[(4 * kk + (lane >> 4)) * 32 + wave * 16 + (lane & 15)];
+  }
+  const int mbW = wave >> 1, nbW = wave & 1;
+  const int chunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = dg_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tile_end = min(numTiles, (wg + 1) * chunk);
+  for (int tile = wg * chunk; tile < tile_end; tile += 2) {
+    const int nt = __builtin_amdgcn_readfirstlane(min(2, tile_end - tile));      // tiles of this trip
+    const int j = tile * DG_TILE + wave * 8 + g;
+    const bool valid = j < N && (wave >> 1) < nt;
+    int start = 0, end = 0;
+    float dj = 0.f;
+    float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      start = rowptr_t[j]; end = rowptr_t[j + 1]; dj = dinv[j];
+      xrow = *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
+    }
+    // operands of the matrix-core epilogue (SortPooling gradient rows, dst scales): loads issued before the gather
+    float gpp[2][4], dnn[2][4];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gpp[t2][r] = 0.f; dnn[t2][r] = 0.f;
+        const int node = (tile + t2) * DG_TILE + (lane >> 4) * 4 + r;
+        if (wave < 2 && t2 < nt && node < N) {
+          gpp[t2][r] = gpprev[(size_t)node * 32 + wave * 16 + (lane & 15)];
+          dnn[t2][r] = dinv[node];
+        }
+      }
+    float4 acc = dg_gather_row32_n(gas, colidx_t, start, end - start, j, valid, lane);
+    acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
+    *reinterpret_cast<float4*>(&ght[wave * 8 + g][4 * q]) = acc;       // (rows beyond N / beyond the chunk: zeros)
+    *reinterpret_cast<float4*>(&xt[wave * 8 + g][4 * q]) = xrow;
+    __syncthreads();
+    if (wave < 2) {
+      const int c = wave * 16 + (lane & 15);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (t2 < nt) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const float a = ght[t2 * 16 + (lane & 15)][4 * kk + (lane >> 4)];
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[kk], d, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            const int node = (tile + t2) * DG_TILE + row;
+            if (node < N) {
+              const float xv = xt[t2 * 16 + row][c];
+              const float gx = d[r] + gpp[t2][r];
+              const float ga = gx * (1.f - xv * xv);
+              gas_prev[(size_t)node * 32 + c] = dnn[t2][r] * ga;
+              pb += ga;
+            }
+          }
+        }
+      }
+    }
+    // dW block (mbW, nbW): A[m][k] = ght[k][mb*16+m], B[k][n] = xt[k][nb*16+n], K = the tile's 16 nodes
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      if (t2 < nt) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = t2 * 16 + 4 * kk + (lane >> 4);
+          const float a = ght[k][mbW * 16 + (lane & 15)];
+          const float b = xt[k][nbW * 16 + (lane & 15)];
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accW, 0, 0, 0);
+        }
+      }
+    }
+    if (tile + 2 < tile_end) __syncthreads();
+  }
+  float* dst = part + (size_t)blockIdx.x * 1056;
+  if (wave < 2) {
+    // lanes l, l+16, l+32, l+48 hold the same column: fixed-order combine
+    pb += __shfl_xor(pb, 16);
+    pb += __shfl_xor(pb, 32);
+    if (lane < 16) dst[1024 + wave * 16 + lane] = pb;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = mbW * 16 + (lane >> 4) * 4 + r;     // output channel of W_l
+    const int col = nbW * 16 + (lane & 15);             // input channel
+    dst[row * 32 + col] = accW[r];
+  }
+}
+
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const float* ax, int Fa, float* part1) {
+                        const float* ax, int Fa, float* part1, int E) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   const bool small = tiles <= DG_SMALL_GRID_TILES;
+  if (!first && !ax && dg_use_narrow(N, E)) {
+    hipLaunchKernelGGL(k_gcn_bwd32n, dim3(P32), dim3(256), 0, s, N, tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev,
+                       gas_prev, part);
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
 #define DG_BWD32_LAUNCH(FI, AFV, D, LDS, FF, AX, FA, P1)                                                                 \
   hipLaunchKernelGGL((k_gcn_bwd32<FI, AFV, D>), dim3(P32), dim3(DG_TILE_THREADS), LDS, s, N, FF, tiles, rowptr_t, colidx_t, \
                      dinv, gas, Wl, xprev, gpprev, gas_prev, part, AX, FA, P1)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 17
+#define DGCNN_ABI_VERSION 18
 
 /* error codes */
 #define DGCNN_OK            0
@@ -246,6 +246,11 @@ int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
  * value): on = 0 keeps the GCN backward of small training batches in launches of its own (the round-3 form), on = 1 restores the
  * default.  Returns the previous setting.  Replaces nothing of the reference (/root/reference/train.py:40 is one backward). */
 int dgcnn_step_kernel_enable(int on);
+/* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
+ * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:
+ * DD at the reference's batch of 50, /root/reference/model.py:30-33 + train.py:40): on = 0 keeps the wave-per-node kernels, whose
+ * results the narrow forms reproduce bit for bit; on = 1 restores the default.  Returns the previous setting (process-wide). */
+int dgcnn_narrow_gather_enable(int on);
 
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
  * forward that depends on the batch only, not on the parameters -- CSR by target / by source, dinv, graph ranges and
