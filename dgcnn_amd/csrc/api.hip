@@ -258,6 +258,17 @@ static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   f.edge_check = (f.bitmap && !f.dense) ? 1 : 0;       // chain forward over a gather backward: phase B keeps the per-edge check
   return f;
 }
+// Sparse many-node batches on the launch-per-layer gather route (the narrow kernels' regime, gcn.hip: DD at the reference's
+// batch of 50): the readout backward leaves the SortPooling-gradient slabs gp1..gp3 SPARSE -- rows of the <= 30 selected nodes of
+// a graph + one flag word per node in the h4s region (dead once conv4's forward has run) -- instead of writing 3 x 128 B of zeros
+// for every other node (a 661-node graph's workgroup spent 6.4 k of its 40 k cycles storing zeros, the 5748-node stress graph's
+// 50 k), and the three consumers (k_gcn_bwd1, k_gcn_bwd32 / k_gcn_bwd32n) select on the flag.  A pure function of the numbers the
+// forward and the backward call of a batch share, so producer and consumers always agree.
+static bool dg_sparse_gp_gather(int N, int E, int B, int F, int flags, int max_nodes) {
+  if (flags & DGCNN_FLAG_FORCE_FUSED) return false;
+  const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
+  return !f.dense && !f.chain && dg_narrow_applies(N, E) != 0;
+}
 // the backward of a batch takes the form its forward took (same flags and max_nodes; the fused graph-per-workgroup
 // forward never builds the bitmap)
 static bool dg_backward_dense(int N, int E, int B, int flags, int max_nodes) {
@@ -550,7 +561,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                   dg_ptr<float>(ws, wl.gz1), dg_ptr<float>(ws, wl.gz6), dg_ptr<float>(ws, wl.gz5),
                                   dg_ptr<float>(ws, wl.gp1), dg_ptr<float>(ws, wl.gp2), dg_ptr<float>(ws, wl.gp3),
                                   dg_ptr<float>(ws, wl.gas4), dg_ptr<float>(ws, wl.gb4p), dg_ptr<float>(ws, wl.lossv),
-                                  dg_ptr<float>(ws, wl.ptail), s, rider_a));
+                                  dg_ptr<float>(ws, wl.ptail), s, rider_a,
+                                  dg_sparse_gp_gather(N, E, B, F, flags, max_nodes) ? dg_ptr<int32_t>(ws, wl.h4s) : nullptr));
     *tail_done = 1;
     if (rider_a && rode) *rode = 1;
     return DGCNN_OK;
@@ -589,9 +601,10 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 // form of a batch's backward: `dense` = the dense per-layer kernels (else CSR gather); `chain` = conv4 + conv3 as one
 // graph-chain launch (gcn_chain.hip: needs the bitmap the forward's preparation built and graphs of <= 256 nodes);
 // `plan` = the item table / graph schedule exists (batches above one graph per persistent workgroup)
-struct DgBwdForm { bool dense, chain, plan, sym; };
+struct DgBwdForm { bool dense, chain, plan, sym, sparse_gp; };
 static DgBwdForm dg_backward_form(int N, int E, int B, int F, int flags, int max_nodes) {
-  DgBwdForm b{false, false, false, dg_csr_symmetric(flags, E)};
+  DgBwdForm b{false, false, false, dg_csr_symmetric(flags, E), false};
+  b.sparse_gp = dg_sparse_gp_gather(N, E, B, F, flags, max_nodes);
   if (flags & DGCNN_FLAG_FORCE_FUSED) return b;            // (the fused graph-per-workgroup forward never builds the bitmap)
   const DgForm f = dg_form(N, E, B, F, flags, max_nodes);
   b.dense = f.dense; b.plan = f.plan;
@@ -626,7 +639,8 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   // large batches whose three GCN backward layers are the two chain launches: the SortPooling-gradient slabs gp1..gp3 stay
   // SPARSE -- rows of the selected nodes + a flag word per node (in the h4s region, which nothing of a chain step uses)
   // instead of 3 x 128 B of zeros for every other node (2048 COLLAB graphs: 57 MB less written by k_tail_bwd, 35 MB less read)
-  int32_t* gpsel = (head_done && dense && bf.chain && F <= DG_AF_MAX_F) ? dg_ptr<int32_t>(ws, wl.h4s) : nullptr;
+  int32_t* gpsel = ((head_done && dense && bf.chain && F <= DG_AF_MAX_F) || (bf.sparse_gp && !dense && !bf.chain && tail_done < 2))
+                       ? dg_ptr<int32_t>(ws, wl.h4s) : nullptr;
   const bool wg_rider = tail_done && rider_b && !dense && dg_wgrad_takes_rider(B);
   // large batches (two-stage weight gradients) behind the batched classifier, nothing riding: the walking form of the readout
   // backward -- one conv5 / conv6 partial row per workgroup of DG_TAIL_WALK graphs
@@ -687,23 +701,23 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr, gpsel));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
-                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, nullptr, 0, nullptr, E));
+                             dg_ptr<float>(ws, wl.pb3), wl.P32, s, nullptr, 0, nullptr, E, gpsel));
   }
   // conv2 backward: gas2 (gasB) -> gas1 (gasA), partial {dW2, db1}
   if (F <= DG_AF_MAX_F) {
     // ... carrying conv1's whole backward: dW1 = ga1^T . (A_hat x), from the ax slab the forward saved
     DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
                                dg_ptr<float>(ws, wl.pb2), wl.P32, s, dg_cptr<float>(ws, wl.ax), F,
-                               dg_ptr<float>(ws, wl.pb1)));
+                               dg_ptr<float>(ws, wl.pb1), E, gpsel));
   } else {
     DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasB, params + pl.off[2], x1, gp1, gasA,
-                               dg_ptr<float>(ws, wl.pb2), wl.P32, s, nullptr, 0, nullptr, E));
+                               dg_ptr<float>(ws, wl.pb2), wl.P32, s, nullptr, 0, nullptr, E, gpsel));
     // conv1 backward: gas1 (gasA) -> partial dW1 (data.x needs no gradient)
     DG_TRY(dg_launch_gcn_bwd32(1, N, F, rowptr_t, colidx_t, dinv, gasA, nullptr, x, nullptr, nullptr,
-                               dg_ptr<float>(ws, wl.pb1), wl.P32, s));
+                               dg_ptr<float>(ws, wl.pb1), wl.P32, s, nullptr, 0, nullptr, E));
   }
   }
   DG_TRY(dg_fork_point(6, s));

@@ -510,20 +510,23 @@ int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, cons
                        const float* h4s, const float* bias, float* x4, hipStream_t s);
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+                       float* gas3, float* pa4, int P1, hipStream_t s, const struct DgPrepRider* rider = nullptr,
+                       const int32_t* gpsel = nullptr);
 // readout forward + readout backward of a training step (labels) as ONE launch (tail.hip)
 int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                            const float* x1, const float* x2, const float* x3, const float* x4, float* pooled, int32_t* perm,
                            float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed,
                            const float* dinv, const int64_t* y, float loss_scale, float* dlogit, float* gz1, float* gz6,
                            float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
-                           float* ptail, hipStream_t s, const struct DgPrepRider* rider = nullptr);
+                           float* ptail, hipStream_t s, const struct DgPrepRider* rider = nullptr, int32_t* gpsel = nullptr);
 int dg_readout_tail_max_b();
 // which: 3 or 2 -> MFMA gx + partial gW(32x32) ; 1 -> first layer (partial gW1 [32,F] only)
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const float* ax = nullptr, int Fa = 0, float* part1 = nullptr, int E = -1);
+                        const float* ax = nullptr, int Fa = 0, float* part1 = nullptr, int E = -1,
+                        const int32_t* gpsel = nullptr);      // gpsel: flag word per node of SPARSE SortPooling-gradient slabs
+int dg_narrow_applies(int N, int E);      // the narrow forms take a batch of N nodes / E directed edges (gcn.hip)
 // conv1 aggregate-first forward (F <= DG_AF_MAX_F): ax = A_hat x saved, x1 = tanh(ax W1^T + b1), hs_next = dinv*(x1 Wnext^T)
 int dg_launch_gcn_fwd_af(int N, int F, const int32_t* rowptr, const int32_t* colidx, const float* dinv, const float* x,
                          const float* W1, const float* bias, float* ax, float* xout, const float* Wnext,

@@ -479,6 +479,7 @@ int dg_narrow_gather_enable(int on) { const int prev = g_narrow; g_narrow = on ?
 static inline bool dg_use_narrow(int N, int E) {
   return g_narrow && E >= 0 && dg_cdiv(N, DG_TILE) > DG_SMALL_GRID_TILES && (int64_t)E <= (int64_t)DG_NARROW_MAX_DEG * N;
 }
+int dg_narrow_applies(int N, int E) { return dg_use_narrow(N, E) ? 1 : 0; }
 __device__ __forceinline__ float4 dg_gather_row32_n(const float* __restrict__ src, const int* __restrict__ col, int start,
                                                     int cnt, int self, bool valid, int lane) {
   const int q = lane & 7, gb = lane & ~7;
@@ -757,11 +758,17 @@ int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, cons
 //   partials: dW4 += gh4[j] * x3[j]   (32)  ,  db3 += ga3[j]   (32)
 // wave per node; lanes 0..31 = channel.  pa4[P1][64] = per-workgroup partial {dW4, db3}.
 // ---------------------------------------------------------------------------------------------
+// a row of zeros: where a node has no row in the SPARSE SortPooling-gradient slabs (flag word 0) the consumers below redirect
+// their row load to it -- unconditional loads on a selected address (a load under a lane-divergent branch is waited for on
+// the spot), all of them hits on one cached line; reading the node's unwritten row instead brought 5.6 MB
+// of never-used lines in from HBM per layer at DD's batch of 50 (k_gcn_bwd32n 6.9 -> 9.0 us)
+__device__ __attribute__((aligned(128))) float dg_zero_row[32];
+__device__ int dg_one_word = 1;      // ... and the flag word read where the slabs are dense (no branch around the flag load either)
 __global__ void __launch_bounds__(1024)
 k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
            const float* __restrict__ dinv, const float* __restrict__ gas4, const float* __restrict__ W4,
            const float* __restrict__ x3, const float* __restrict__ gp3, float* __restrict__ gas3,
-           float* __restrict__ pa4, int P1, DgPrepRider rd) {
+           float* __restrict__ pa4, int P1, DgPrepRider rd, const int* __restrict__ gpsel) {
   if ((int)blockIdx.x >= P1) {   // rider range: phase B of the NEXT batch's graph preparation, when the step's readout
                                  // forward + backward ran as one launch (k_readout_tail carried phase A)
     dg_prep_fast_b_body(((int)blockIdx.x - P1) * 1024 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
@@ -779,7 +786,9 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
     const int start = rowptr_t[j], end = rowptr_t[j + 1];
     // issue everything that does not depend on the gather before it
     float xv = 0.f, gpv = 0.f;
-    if (lane < 32) { xv = x3[(size_t)j * 32 + c]; gpv = gp3[(size_t)j * 32 + c]; }
+    const int gsel = *(gpsel ? gpsel + j : &dg_one_word);      // (sparse SortPooling-gradient slabs: a row exists only where the flag word says so)
+    const float* gprow = gsel ? gp3 + (size_t)j * 32 : dg_zero_row;
+    xv = x3[(size_t)j * 32 + c]; gpv = gprow[c];      // (all 64 lanes, c = lane & 31: no lane-divergent branch around the loads)
     const float dj = dinv[j], gself = gas4[j];
     const float s = dg_gather_row1(gas4, colidx_t, start, end, lane) + gself;
     const float gh = dj * s;
@@ -807,12 +816,12 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
 
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider) {
+                       float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider, const int32_t* gpsel) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
   hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rd.nblk_b), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,
-                     pa4, P1, rd);
+                     pa4, P1, rd, gpsel);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
@@ -837,7 +846,8 @@ __global__ void __launch_bounds__(DG_TILE_THREADS) __attribute__((amdgpu_waves_p
 k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
             const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
             const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
-            float* __restrict__ part, const float* __restrict__ axin, int Fa, float* __restrict__ part1) {
+            float* __restrict__ part, const float* __restrict__ axin, int Fa, float* __restrict__ part1,
+            const int* __restrict__ gpsel) {
   __shared__ __attribute__((aligned(16))) float ght[DG_TILE][DG_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xt[DG_TILE][DG_LDS_PAD];
   __shared__ float gat[AF ? DG_TILE : 1][DG_LDS_PAD];          // AF: ga_1 tile
@@ -900,7 +910,8 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
       for (int r = 0; r < 4; ++r) {
         const int node = tile * DG_TILE + (lane >> 4) * 4 + r;
         if (node < N) {
-          gpp[r] = gpprev[(size_t)node * 32 + wave * 16 + (lane & 15)];
+          const int gs = *(gpsel ? gpsel + node : &dg_one_word);      // (sparse slabs: see k_gcn_bwd1)
+          gpp[r] = (gs ? gpprev + (size_t)node * 32 : dg_zero_row)[wave * 16 + (lane & 15)];
           dnn[r] = dinv[node];
         }
       }
@@ -1021,7 +1032,7 @@ __global__ void __launch_bounds__(256)
 k_gcn_bwd32n(int N, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
              const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ Wl,
              const float* __restrict__ xprev, const float* __restrict__ gpprev, float* __restrict__ gas_prev,
-             float* __restrict__ part) {
+             float* __restrict__ part, const int* __restrict__ gpsel) {
   __shared__ __attribute__((aligned(16))) float ght[DG_NB][DG_LDS_PAD];
   __shared__ __attribute__((aligned(16))) float xt[DG_NB][DG_LDS_PAD];
   const int lane = threadIdx.x & 63;
@@ -1049,19 +1060,31 @@ k_gcn_bwd32n(int N, int numTiles, const int* __restrict__ rowptr_t, const int* _
       start = rowptr_t[j]; end = rowptr_t[j + 1]; dj = dinv[j];
       xrow = *reinterpret_cast<const float4*>(xprev + (size_t)j * 32 + 4 * q);
     }
-    // operands of the matrix-core epilogue (SortPooling gradient rows, dst scales): loads issued before the gather
+    // operands of the matrix-core epilogue (SortPooling gradient rows, dst scales): loads issued before the gather, every one
+    // UNCONDITIONAL on a clamped node (a load under a lane-divergent branch is waited for on the spot: with the flag word of the
+    // sparse slabs in front of the row that was eight exposed round trips, 6.9 -> 8.7 us); rows without a flag come from
+    // dg_zero_row, rows beyond N / beyond the chunk are never used
     float gpp[2][4], dnn[2][4];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gpp[t2][r] = 0.f; dnn[t2][r] = 0.f;
-        const int node = (tile + t2) * DG_TILE + (lane >> 4) * 4 + r;
-        if (wave < 2 && t2 < nt && node < N) {
-          gpp[t2][r] = gpprev[(size_t)node * 32 + wave * 16 + (lane & 15)];
-          dnn[t2][r] = dinv[node];
+      for (int r = 0; r < 4; ++r) { gpp[t2][r] = 0.f; dnn[t2][r] = 0.f; }
+    if (wave < 2) {
+      int nc[2][4], gs[2][4];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          nc[t2][r] = min((tile + t2) * DG_TILE + (lane >> 4) * 4 + r, N - 1);
+          gs[t2][r] = *(gpsel ? gpsel + nc[t2][r] : &dg_one_word);
+          dnn[t2][r] = dinv[nc[t2][r]];
         }
-      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          gpp[t2][r] = (gs[t2][r] ? gpprev + (size_t)nc[t2][r] * 32 : dg_zero_row)[wave * 16 + (lane & 15)];
+    }
     float4 acc = dg_gather_row32_n(gas, colidx_t, start, end - start, j, valid, lane);
     acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
     *reinterpret_cast<float4*>(&ght[wave * 8 + g][4 * q]) = acc;       // (rows beyond N / beyond the chunk: zeros)
@@ -1123,22 +1146,124 @@ k_gcn_bwd32n(int N, int numTiles, const int* __restrict__ rowptr_t, const int* _
   }
 }
 
+// NARROW form of conv1's own backward when conv1 ran linear-first (raw feature width F in (32, DG_LIN_STAGE_MAX_F], 16-byte
+// aligned x): only dW_1 [32,F] = gh^T . x is produced (data.x needs no gradient, /root/reference/train.py:36-40).  The raw
+// rows of a trip's 32 nodes are ONE contiguous, 64-byte aligned run of 32 F floats (as in k_lin_first32s): 16-byte loads, flat
+// copy into the LDS tile [32][F].  The 2 x ceil(F/16) output tiles are dealt round-robin to the FOUR waves (k_gcn_bwd32<FIRST>:
+// to sixteen); each accumulator takes the workgroup's tiles in the same order, four matrix steps per tile: identical partials.
+#define DG_N1_ACC ((2 * (DG_LIN_STAGE_MAX_F / 16)) / 4)
+__global__ void __launch_bounds__(256)
+k_gcn_bwd32n1(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t,
+              const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ xraw,
+              float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float ght[DG_NB][DG_LDS_PAD];
+  extern __shared__ __attribute__((aligned(16))) float xs[];    // [32][F]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 3, q = lane & 7;
+  f32x4 acc1[DG_N1_ACC];
+#pragma unroll
+  for (int u = 0; u < DG_N1_ACC; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntile1 = 2 * ((F + 15) >> 4);
+  constexpr int XQ = DG_LIN_STAGE_MAX_F * DG_NB / 4 / 256;     // 16-byte pieces of the raw tile per thread (4 at the largest F)
+  const int nq = 8 * F;                                        // 16-byte pieces of a full 32-row tile
+  const int chunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = dg_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tile_end = min(numTiles, (wg + 1) * chunk);
+  for (int tile = wg * chunk; tile < tile_end; tile += 2) {
+    const int nt = __builtin_amdgcn_readfirstlane(min(2, tile_end - tile));      // tiles of this trip
+    const int r0 = tile * DG_TILE;
+    const int j = r0 + wave * 8 + g;
+    const bool valid = j < N && (wave >> 1) < nt;
+    int start = 0, end = 0;
+    float dj = 0.f;
+    if (valid) { start = rowptr_t[j]; end = rowptr_t[j + 1]; dj = dinv[j]; }
+    const int nfl = max(0, min(nt * DG_TILE, N - r0)) * F;     // floats of the raw tile that exist (rows beyond: zeros)
+    const float* xt = xraw + (size_t)r0 * F;
+    float4 v[XQ];
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      const int p = (int)threadIdx.x + 256 * i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < nq) {
+        if (4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);
+        else {
+          if (4 * p + 0 < nfl) v[i].x = xt[4 * p + 0];
+          if (4 * p + 1 < nfl) v[i].y = xt[4 * p + 1];
+          if (4 * p + 2 < nfl) v[i].z = xt[4 * p + 2];
+        }
+      }
+    }
+    float4 acc = dg_gather_row32_n(gas, colidx_t, start, end - start, j, valid, lane);
+    acc.x *= dj; acc.y *= dj; acc.z *= dj; acc.w *= dj;
+    *reinterpret_cast<float4*>(&ght[wave * 8 + g][4 * q]) = acc;
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      const int p = (int)threadIdx.x + 256 * i;
+      if (p < nq) *reinterpret_cast<float4*>(xs + 4 * p) = v[i];
+    }
+    __syncthreads();
+    // dW1[c][k] += sum_node ght[node][c] * xs[node][k]: A[m][kk] = ght[kk][mb*16+m], B[kk][n] = xs[kk][nb*16+n], K = a tile's 16 nodes
+#pragma unroll
+    for (int u = 0; u < DG_N1_ACC; ++u) {
+      const int t = u * 4 + wave;
+      if (t < ntile1) {
+        const int mb = t & 1, nb = t >> 1;
+        const int col = nb * 16 + (lane & 15);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          if (t2 < nt) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int nd = t2 * 16 + 4 * kk + (lane >> 4);
+              const float a = ght[nd][mb * 16 + (lane & 15)];
+              const float b = col < F ? xs[nd * F + col] : 0.f;
+              acc1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1[u], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (tile + 2 < tile_end) __syncthreads();
+  }
+  float* dst = part + (size_t)blockIdx.x * 32 * F;
+#pragma unroll
+  for (int u = 0; u < DG_N1_ACC; ++u) {
+    const int t = u * 4 + wave;
+    if (t < ntile1) {
+      const int mb = t & 1, nb = t >> 1;
+      const int k = nb * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = mb * 16 + (lane >> 4) * 4 + r;
+        if (k < F) dst[c * F + k] = acc1[u][r];     // stored in W1's own [32,F] layout
+      }
+    }
+  }
+}
+
 int dg_launch_gcn_bwd32(int first, int N, int F, const int32_t* rowptr_t, const int32_t* colidx_t,
                         const float* dinv, const float* gas, const float* Wl, const float* xprev,
                         const float* gpprev, float* gas_prev, float* part, int P32, hipStream_t s,
-                        const float* ax, int Fa, float* part1, int E) {
+                        const float* ax, int Fa, float* part1, int E, const int32_t* gpsel) {
   if (N <= 0 || P32 <= 0) return DGCNN_EINVAL;
   const int tiles = dg_cdiv(N, DG_TILE);
   const bool small = tiles <= DG_SMALL_GRID_TILES;
+  if (first && F > 32 && F <= DG_LIN_STAGE_MAX_F && ((uintptr_t)xprev & 15) == 0 && dg_use_narrow(N, E)) {
+    hipLaunchKernelGGL(k_gcn_bwd32n1, dim3(P32), dim3(256), sizeof(float) * DG_NB * F, s, N, F, tiles, rowptr_t, colidx_t, dinv, gas,
+                       xprev, part);
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
   if (!first && !ax && dg_use_narrow(N, E)) {
     hipLaunchKernelGGL(k_gcn_bwd32n, dim3(P32), dim3(256), 0, s, N, tiles, rowptr_t, colidx_t, dinv, gas, Wl, xprev, gpprev,
-                       gas_prev, part);
+                       gas_prev, part, gpsel);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
   }
 #define DG_BWD32_LAUNCH(FI, AFV, D, LDS, FF, AX, FA, P1)                                                                 \
   hipLaunchKernelGGL((k_gcn_bwd32<FI, AFV, D>), dim3(P32), dim3(DG_TILE_THREADS), LDS, s, N, FF, tiles, rowptr_t, colidx_t, \
-                     dinv, gas, Wl, xprev, gpprev, gas_prev, part, AX, FA, P1)
+                     dinv, gas, Wl, xprev, gpprev, gas_prev, part, AX, FA, P1, gpsel)
   if (first) {
     if (F < 1 || F > DGCNN_MAX_F) return DGCNN_EINVAL;
     if (small) DG_BWD32_LAUNCH(true, false, DG_DEPTH_SMALL, sizeof(float) * DG_TILE * F, F, nullptr, 0, nullptr);

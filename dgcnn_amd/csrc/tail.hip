@@ -234,7 +234,7 @@ k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* _
                float* __restrict__ dlogit, float* __restrict__ gz1g, float* __restrict__ gz6g, float* __restrict__ gz5g,
                float* __restrict__ gp1, float* __restrict__ gp2, float* __restrict__ gp3, float* __restrict__ gas4,
                float* __restrict__ gb4p, float* __restrict__ lossv, float* __restrict__ ptail, unsigned long long* dbg,
-               int B, DgPrepRider rd) {
+               int B, DgPrepRider rd, int* gpsel) {
   if ((int)blockIdx.x >= B) {
     dg_rider_phase_a(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd);
     return;
@@ -258,7 +258,7 @@ k_readout_tail(int C, TailW w, const int* __restrict__ graph_ptr, const float* _
   }
   __syncthreads();        // (full barrier, vmcnt(0): this graph's activations / perm are written)
   dg_tail_bwd_body<false, true>((int)blockIdx.x, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, a1dg, logp, nullptr, y, loss_scale, training,
-                                dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg, ext);
+                                dlogit, gz1g, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, lossv, ptail, pooled, dbg, ext, gpsel);
 }
 
 int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
@@ -266,13 +266,13 @@ int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgPar
                            float* a5, float* a6, float* a1d, uint8_t* drop_mask, float* logp, int training, uint64_t seed,
                            const float* dinv, const int64_t* y, float loss_scale, float* dlogit, float* gz1, float* gz6,
                            float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
-                           float* ptail, hipStream_t s, const DgPrepRider* rider) {
+                           float* ptail, hipStream_t s, const DgPrepRider* rider, int32_t* gpsel) {
   if (B <= 0 || B >= DG_TAIL_BIG_MIN_B || N <= 0 || C < 1 || C > DGCNN_MAX_C || !y) return DGCNN_EINVAL;
   DgPrepRider rd{};
   if (rider) rd = *rider;
   hipLaunchKernelGGL(k_readout_tail, dim3(B + rd.nblk), dim3(RD_THREADS), 0, s, C, dg_tail_w(params, pl), graph_ptr, x1, x2, x3,
                      x4, pooled, perm, a5, a6, a1d, drop_mask, logp, training, seed, dinv, y, loss_scale, dlogit, gz1, gz6, gz5,
-                     gp1, gp2, gp3, gas4, gb4p, lossv, ptail, dg_debug_buffer(), B, rd);
+                     gp1, gp2, gp3, gas4, gb4p, lossv, ptail, dg_debug_buffer(), B, rd, gpsel);
   DG_CHECK_LAUNCH();
   return DGCNN_OK;
 }
