@@ -348,6 +348,10 @@ struct WgSeg {
 };
 struct WgArgs {
   int nseg, B, C;
+  // first block of every segment, contiguous (INT_MAX beyond nseg): a workgroup finds its segment from ONE batch of scalar loads.
+  // (Walking seg[k].block0 -- one 48-byte record per step, the kernel arguments cold in the scalar cache at every launch -- was a
+  //  chain of ~9 dependent scalar-cache misses in front of every workgroup's first useful load: ~1.5 us of the 7.6 us launch.)
+  int blk0[WG_MAX_SEG];
   const float *gz1, *a6;               // classifier_1 operands: d(loss)/d(pre-activation) [B,128], input [B,352]
   // optional fused Adam (torch.optim.Adam defaults semantics): applied by the lane that owns the output
   float *adam_p, *adam_m, *adam_v;     // flat buffers (same layout as grads); null = no optimizer step here
@@ -445,7 +449,8 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
     return;
   }
   int si = 0;
-  for (int k = 1; k < A.nseg; ++k) if ((int)blockIdx.x >= A.seg[k].block0) si = k;
+#pragma unroll
+  for (int k = 1; k < WG_MAX_SEG; ++k) si = (int)blockIdx.x >= A.blk0[k] ? k : si;      // (block0 ascends; INT_MAX beyond nseg)
   const WgSeg sg = A.seg[si];
   if (!S1 && sg.type == WG_FC1W_MFMA) {      // block-uniform branch: 4 waves = 4 tiles per workgroup
     const int tile = ((int)blockIdx.x - sg.block0) * 4 + (threadIdx.x >> 6);
@@ -563,6 +568,9 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
   }
 }
 
+static void dg_wg_finish(WgArgs& A) {      // the segment table is complete: fill the contiguous first-block table
+  for (int k = 0; k < WG_MAX_SEG; ++k) A.blk0[k] = k < A.nseg ? A.seg[k].block0 : 0x7fffffff;
+}
 // which: bit 0 = tail parameters (depend on k_tail_bwd only), bit 1 = GCN parameters (depend on the GCN
 // backward kernels).  The two halves can run on different streams.
 int dg_wgrad_takes_rider(int B) { return B <= dg_wg_two_stage_b() ? 1 : 0; }      // single-launch form only
@@ -669,6 +677,7 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
       static const bool s1a = dg_knob("DG_WG_S1_ONLY_MFMA"), s1b = dg_knob("DG_WG_S1_ONLY_REDUCE");      // (timing A/B, debug builds)
       if (s1a) { nb1 = g1.block0; S.nseg = 1; }
       if (s1b) { S.seg[0] = S.seg[1]; S.seg[0].block0 = 0; nb1 -= g1.block0; S.nseg = 1; }
+      dg_wg_finish(S);
       hipLaunchKernelGGL(k_wgrad<true>, dim3(nb1), dim3(256), 0, s, S, DgPrepRider{}, nb1);
       DG_CHECK_LAUNCH();
       ptc = t1c; Rc = nchc; stc = DG_PT_WF2;
@@ -702,12 +711,14 @@ int dg_launch_wgrad(int which, int N, int B, int F, int C, const DgParams* pl, c
     }
   }
   A.nseg = ns;
+  dg_wg_finish(A);
   if (nb == 0) return DGCNN_OK;
   static const bool split = dg_knob("DG_WGRAD_SPLIT");     // diagnostic (DG_DEBUG_KNOBS builds only): one launch per segment
   if (split) {
     for (int k = 0; k < ns; ++k) {
       WgArgs One = A;
       One.nseg = 1; One.seg[0] = A.seg[k]; One.seg[0].block0 = 0;
+      dg_wg_finish(One);
       const int g1 = A.seg[k].type == WG_FC1W_MFMA ? dg_cdiv(A.seg[k].count, 4)
                      : (A.seg[k].type == WG_REDUCE_COL ? dg_cdiv(A.seg[k].count, 32) : dg_cdiv(A.seg[k].count * A.seg[k].lpo, 256));
       hipLaunchKernelGGL(k_wgrad<false>, dim3(g1), dim3(256), 0, s, One, DgPrepRider{}, g1);
@@ -739,6 +750,7 @@ int dg_launch_reduce_cols(int nseg, const DgRedSeg* segs, hipStream_t s) {
     nb += dg_cdiv(segs[k].count, 32);
   }
   A.nseg = nseg;
+  dg_wg_finish(A);
   A.grads_base = segs[0].out;
   if (nb == 0) return DGCNN_OK;
   hipLaunchKernelGGL(k_wgrad<false>, dim3(nb), dim3(256), 0, s, A, DgPrepRider{}, nb);
