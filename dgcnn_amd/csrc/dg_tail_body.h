@@ -15,7 +15,7 @@
 // body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
 // training kernel k_readout_tail (forward readout + this, one launch)
 struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb;
-               const float *wf2s, *x4l, *dvl; };     // (optional LDS copies: classifier_2's rows [<= 16][128]; conv4's outputs and dinv by LOCAL node)      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+               const float *wf2s, *x4l, *dvl; int n0, n; };     // (LDSOPS: n0 / n = the graph's node range, read once by the caller)     // (optional LDS copies: classifier_2's rows [<= 16][128]; conv4's outputs and dinv by LOCAL node)      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
 // the one-launch training kernel whose GCN backward follows in the same workgroup: the SortPooling gradient STAYS IN LDS in its
 // sparse form -- the <= 30 selected nodes' rows gpL [30][96] (columns of x1 | x2 | x3), gas4L [n <= 256] (zero except the
 // selected nodes) and slotmap [n] (node -> row of gpL, -1 = not selected) -- instead of the dense slabs gp1..gp3 [N,32] and
@@ -60,7 +60,9 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // (tid_in: a walking caller hands in an OPAQUE per-iteration copy of the thread index, so that nothing derived from it is
   //  loop-invariant for the compiler to hoist out of the walk and spill)
   const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+  // (the one-launch training kernel hands the range in: re-read behind a barrier it is a scalar-memory round trip in front of
+  //  the phase's first address -- the barriers' memory clobber forbids the compiler to keep the first read)
+  const int n0 = LDSOPS ? ext.n0 : graph_ptr[b], n = LDSOPS ? ext.n : graph_ptr[b + 1] - n0;
   const int msel = n < DGCNN_K ? n : DGCNN_K;
 
   // ---- every small global load of steps 0-2 first (VMEM loads complete in order) ----

@@ -1471,7 +1471,10 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
-  if (threadIdx.x == 0 && graph_ptr[blockIdx.x + 1] - graph_ptr[blockIdx.x] > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
+  // this graph's node range, read ONCE (scalar loads; the three later phases re-read it behind their barriers: a scalar-memory
+  // round trip in front of each phase's first address)
+  const int gn0 = graph_ptr[blockIdx.x], gn = graph_ptr[blockIdx.x + 1] - gn0;
+  if (threadIdx.x == 0 && gn > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
   // (the keys' LDS copy lives in the unused second parity set of the dinv array: beyond the readout's LDS plan, which aliases
   //  the images, and untouched until conv4's backward at the end of this kernel reads the FIRST set)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1503,8 +1506,9 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     ext.yb = yb;
     ext.wf2s = M.cpart;       // (rows of the first 16 classes, staged by the forward half; the backward prefetches 8, reads the rest in place)
     ext.x4l = keys_lds; ext.dvl = reinterpret_cast<const float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV);
+    ext.n0 = gn0; ext.n = gn;
     const int b = blockIdx.x;
-    const int n0 = graph_ptr[b], n = graph_ptr[b + 1] - n0;
+    const int n0 = gn0, n = gn;
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
     dg_readout_fwd_body(M, b, n0, n, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
                         t.training, t.seed, dbg);
@@ -1526,7 +1530,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     // (the body ended with a barrier; nothing below reads what this workgroup stored to global memory since the chain's barrier)
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
     const int b = blockIdx.x;
-    const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
+    const int n0 = gn0, n = min(gn, CH_TRAIN_MAXN);
     constexpr int NBA = W1S == 8 ? 2 : 1;
 #ifdef CH_REPEAT_BWD      // measurement build: the GCN backward twice (second pass: warm instruction cache; results are garbage)
     int reps_ = 2;
@@ -1551,7 +1555,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   } else if (t.pa4) {
     __syncthreads();      // (vmcnt(0): this graph's gas4 and gp3 rows are written; the readout's LDS plan is dead)
     const int b = blockIdx.x;
-    const int n0 = graph_ptr[b], n = min(graph_ptr[b + 1] - n0, CH_TRAIN_MAXN);
+    const int n0 = gn0, n = min(gn, CH_TRAIN_MAXN);
     ch_conv4_bwd_graph(n0, n, reinterpret_cast<const unsigned*>(smem + C::OFF_BL), reinterpret_cast<const float*>(smem + C::OFF_DV),
                        reinterpret_cast<const uint2*>(smem + C::OFF_TAB), reinterpret_cast<unsigned short*>(smem + C::OFF_H4), C::ROWS,
                        reinterpret_cast<float*>(smem + 65536), reinterpret_cast<float*>(smem + 65536 + 1024), t.gas4, t.W4, x3, t.gp3,
