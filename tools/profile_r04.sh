@@ -23,10 +23,15 @@ bash tools/kstats.sh ${T}_b256 --batch 256 --pool 8 --no-dropin > /dev/null
 bash tools/kstats.sh ${T}_b2048_nopipeline --batch 2048 --pool 8 --no-pipeline --no-dropin > /dev/null
 bash tools/kstats.sh ${T}_b2048 --batch 2048 --pool 8 --no-dropin > /dev/null
 bash tools/kstats.sh ${T}_b2048_dataset --batch 2048 --pool 8 --no-dropin --prep dataset > /dev/null
+bash tools/kstats.sh ${T}_dd --workload DD --no-dropin > /dev/null
+bash tools/kstats.sh ${T}_dd_stress --workload DD --stress-nodes 5748 --no-dropin > /dev/null
 bash tools/pmc.sh ${T}_b50 --no-dropin > $OUT/${T}_pmc_b50.txt 2>&1
 bash tools/pmc.sh ${T}_b2048 --batch 2048 --no-dropin > $OUT/${T}_pmc_b2048.txt 2>&1
 bash tools/pmc_sq.sh ${T}_b50 "--no-dropin" "k_chain_readout_tail|k_wgrad" > $OUT/${T}_sq_b50.txt 2>&1
 bash tools/pmc_sq.sh ${T}_b2048 "--batch 2048 --no-dropin" "k_chain_fwd_q|k_chain_bwd_a|k_chain_bwd_b|k_classifier|k_readout_fwd|k_tail_bwd_walk|k_wgrad" > $OUT/${T}_sq_b2048.txt 2>&1
 python tools/phase_step_kernel.py COLLAB 50 > $OUT/${T}_phase_step_kernel.txt 2>&1
 python tools/epoch_time.py COLLAB 1000 > $OUT/${T}_epoch_time.txt 2>&1
+python tools/epoch_time.py COLLAB 5000 >> $OUT/${T}_epoch_time.txt 2>&1
+python tools/eval_time.py COLLAB 50 > $OUT/${T}_eval_time.txt 2>&1
+python tools/phase_readout_tail_dd.py > $OUT/${T}_phase_readout_tail_dd.txt 2>&1
 ls -la $OUT | tail -40
