@@ -116,18 +116,24 @@ k_lin_first32s(int N, int F, const float* __restrict__ x, const float* __restric
     const int r0_ = tile * 16;                                                                                          \
     const int nfl = tile < tiles ? min(16, N - r0_) * F : 0;      /* floats of this tile that exist */                  \
     const float* xt = x + (size_t)r0_ * F;                                                                              \
-    _Pragma("unroll") for (int i = 0; i < XQ; ++i) {                                                                    \
-      const int p = lane + 64 * i;                                                                                      \
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                           \
-      if (p < nq) {                                                                                                     \
-        if (4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);                                       \
-        else {                                      /* the batch's last tile: rows beyond N read as zeros */            \
-          if (4 * p + 0 < nfl) v[i].x = xt[4 * p + 0];                                                                  \
-          if (4 * p + 1 < nfl) v[i].y = xt[4 * p + 1];                                                                  \
-          if (4 * p + 2 < nfl) v[i].z = xt[4 * p + 2];                                                                  \
-        }                                                                                                               \
-      }                                                                                                                 \
-    }                                                                                                                   \
+    /* nfl is wave-uniform.  A multiple of 4 (every full tile): no 16-byte piece straddles the end, pieces beyond it load      \
+       nothing.  Otherwise (the batch's last tile): dword loads, every one UNCONDITIONAL on a clamped index and selected --     \
+       under the lane-divergent test of the first version the straddling piece was waited for on the spot, one exposed round   \
+       trip on the one wave whose end is the kernel's end */                                                                   \
+    if ((nfl & 3) == 0) {                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < XQ; ++i) {                                                                         \
+        const int p = lane + 64 * i;                                                                                           \
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                \
+        if (p < nq && 4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);                                    \
+      }                                                                                                                        \
+    } else {                                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < XQ; ++i) {                                                                         \
+        const int e = 4 * (lane + 64 * i);                                                                                     \
+        const float t0 = xt[min(e, nfl - 1)], t1 = xt[min(e + 1, nfl - 1)], t2 = xt[min(e + 2, nfl - 1)],                      \
+                    t3 = xt[min(e + 3, nfl - 1)];                                                                              \
+        v[i] = make_float4(e < nfl ? t0 : 0.f, e + 1 < nfl ? t1 : 0.f, e + 2 < nfl ? t2 : 0.f, e + 3 < nfl ? t3 : 0.f);        \
+      }                                                                                                                        \
+    }                                                                                                                          \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) { const int m = r0_ + kq * 4 + r; dv[r] = m < N ? dinv[m] : 0.f; }    \
   } while (0)
   // every load of the set-up in flight before the first LDS store
@@ -1181,17 +1187,19 @@ k_gcn_bwd32n1(int N, int F, int numTiles, const int* __restrict__ rowptr_t, cons
     const int nfl = max(0, min(nt * DG_TILE, N - r0)) * F;     // floats of the raw tile that exist (rows beyond: zeros)
     const float* xt = xraw + (size_t)r0 * F;
     float4 v[XQ];
+    if ((nfl & 3) == 0) {      // (workgroup-uniform; see k_lin_first32s: no piece straddles the end)
 #pragma unroll
-    for (int i = 0; i < XQ; ++i) {
-      const int p = (int)threadIdx.x + 256 * i;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < nq) {
-        if (4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);
-        else {
-          if (4 * p + 0 < nfl) v[i].x = xt[4 * p + 0];
-          if (4 * p + 1 < nfl) v[i].y = xt[4 * p + 1];
-          if (4 * p + 2 < nfl) v[i].z = xt[4 * p + 2];
-        }
+      for (int i = 0; i < XQ; ++i) {
+        const int p = (int)threadIdx.x + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < nq && 4 * p + 3 < nfl) v[i] = *reinterpret_cast<const float4*>(xt + 4 * p);
+      }
+    } else {                   // the batch's last rows: unconditional dword loads on clamped indices, selected
+#pragma unroll
+      for (int i = 0; i < XQ; ++i) {
+        const int e = 4 * ((int)threadIdx.x + 256 * i);
+        const float t0 = xt[min(e, nfl - 1)], t1 = xt[min(e + 1, nfl - 1)], t2 = xt[min(e + 2, nfl - 1)], t3 = xt[min(e + 3, nfl - 1)];
+        v[i] = make_float4(e < nfl ? t0 : 0.f, e + 1 < nfl ? t1 : 0.f, e + 2 < nfl ? t2 : 0.f, e + 3 < nfl ? t3 : 0.f);
       }
     }
     float4 acc = dg_gather_row32_n(gas, colidx_t, start, end - start, j, valid, lane);

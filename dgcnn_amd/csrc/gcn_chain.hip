@@ -2032,8 +2032,10 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
 #pragma unroll
           for (int nb = 0; nb < NBA; ++nb) {
             const int f = 16 * nb + nl;
+            // (multiplied by a 0 / 1 mask, not selected: the compiler SINKS the load of `cond ? load : 0` into the branch, where
+            //  it is waited for on the spot -- four exposed L2 round trips per tile in the ISA; the clamped element is real data)
             const float av = axg[ro * Fa + min(f, Fa - 1)];
-            aN[nb][s_] = (okr && f < Fa) ? av : 0.f;
+            aN[nb][s_] = av * ((okr && f < Fa) ? 1.f : 0.f);
           }
         }
         f32x4 accT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accN[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};

@@ -545,16 +545,34 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
   float a[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) a[u] = 0.f;
-  if (live) {
-    const int R = sg.R;
-    int r = r0;
-    for (; r + 15 * lpo < R; r += 16 * lpo) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
+  {
+    // term r of output i = base[r * rs] for r < Rl, whatever the segment type (block-uniform): ONE load site, every load
+    // UNCONDITIONAL on a clamped row and selected.  (dg_wg_term's switch put each of the 16 loads of a trip into branch blocks
+    // of its own, where it was waited for on the spot -- 16 dependent round trips per trip in the ISA: at 256 graphs the 64-lane
+    // sums of classifier_1's bias gradient, db4 and the metrics were FOUR round trips deep instead of one.)  Same order of
+    // additions as before: a[u] takes rows r0 + (16 k + u) lpo in k order.
+    const float* base = sg.src ? sg.src : A.gz1;
+    int rs = 1, Rl = 0;
+    if (live) {
+      Rl = sg.R;
+      switch (sg.type) {
+        case WG_REDUCE_CHUNK: {
+          const int ch = i / sg.width, col = i - ch * sg.width;
+          base = sg.src + (size_t)ch * sg.R * sg.stride + col; rs = sg.stride; Rl = max(0, min(sg.R, sg.aux - ch * sg.R)); break; }
+        case WG_SUMB:   base = sg.src; rs = 1; break;
+        case WG_METRIC: base = sg.src + i; rs = 2; break;
+        case WG_FC1B:   base = A.gz1 + i; rs = DGCNN_HID1; break;
+        default: Rl = 0;
+      }
     }
+    const int rc = max(Rl - 1, 0);
+    for (int r = r0; r - r0 < sg.R; r += 16 * lpo) {       // (block-uniform trip count)
+      float t[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (r + u * lpo < R) a[u] += dg_wg_term(A, sg, i, r + u * lpo);
+      for (int u = 0; u < 16; ++u) t[u] = base[(size_t)min(r + u * lpo, rc) * rs];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] += (r + u * lpo < Rl) ? t[u] : 0.f;
+    }
   }
 #pragma unroll
   for (int w = 8; w >= 1; w >>= 1)
