@@ -1584,6 +1584,10 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
 // over the 16 node lanes on the DPP path, then one read-modify-write by the owning lanes: no other wave touches the slot).
 // The final fixed-order sum over the waves writes ONE partial row per workgroup in the layouts k_wgrad already reduces.
 // =================================================================================================================
+// a row of zeros: rows WITHOUT a flag in the sparse SortPooling-gradient slabs are read from it (an unconditional load on a
+// redirected address: no select behind the load -- the select was scheduled right behind its load and waited for it there,
+// an exposed L2 round trip per tile and layer in the ISA)
+__device__ __attribute__((aligned(128))) float ch_zero_row[32];
 template <int WAVES, int MAXN>
 struct ChB {
   static constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES, KW = MAXN / 32, PS = ROWS * 32, BUF = 6 * PS;
@@ -1720,11 +1724,10 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         const float4 xa = *reinterpret_cast<const float4*>(x3 + ro), xb = *reinterpret_cast<const float4*>(x3 + ro + 16);
         // (gpsel: the readout backward of a large batch writes the SortPooling-gradient rows of the SELECTED nodes only and
         //  a per-node flag -- no 57 MB of zero rows written there and read back here; a row without the flag is garbage)
-        // (unconditional loads: lanes of rows without the flag read ONE shared line, selected away below)
+        // (unconditional loads: lanes of rows without the flag read the row of zeros)
         const bool sel3 = gsl[min(m, n - 1)] != 0;
-        const float* gq = gp3 + (sel3 ? ro : (size_t)(4 * kq));
-        float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
-        if (!sel3) { ga_ = make_float4(0.f, 0.f, 0.f, 0.f); gb_ = ga_; }
+        const float* gq = sel3 ? gp3 + ro : ch_zero_row + 4 * kq;
+        const float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
         const unsigned short* hq = g4p + min(nl, 2) * C::ROWS + 4 * kq;
 #pragma unroll
@@ -1787,9 +1790,8 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         const size_t ro = (size_t)(n0 + min(m, n - 1)) * 32 + 4 * kq;
         const float4 xa = *reinterpret_cast<const float4*>(x2 + ro), xb = *reinterpret_cast<const float4*>(x2 + ro + 16);
         const bool sel2 = gsl[min(m, n - 1)] != 0;
-        const float* gq = gp2 + (sel2 ? ro : (size_t)(4 * kq));
-        float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
-        if (!sel2) { ga_ = make_float4(0.f, 0.f, 0.f, 0.f); gb_ = ga_; }
+        const float* gq = sel2 ? gp2 + ro : ch_zero_row + 4 * kq;
+        const float4 ga_ = *reinterpret_cast<const float4*>(gq), gb_ = *reinterpret_cast<const float4*>(gq + 16);
         // x2 in the lane = column layout: rows 4kq + s of column 16nb + nl (B operand of dW3)
         const int mt = 16 * (wave + WAVES * ti);
         float xN[2][4];
@@ -2023,9 +2025,8 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
           const size_t ro = (size_t)(n0 + min(mm, n - 1));
           const float* xr = x1 + ro * 32 + nl;
           const bool selr = gsl[min(mm, n - 1)] != 0;
-          const float* gr = gp1 + (selr ? ro * 32 : (size_t)0) + nl;      // (rows without the flag: one shared line, selected away)
-          float g0 = gr[0], g1 = gr[16];
-          if (!selr) { g0 = 0.f; g1 = 0.f; }
+          const float* gr = (selr ? gp1 + ro * 32 : ch_zero_row) + nl;      // (rows without the flag: the row of zeros)
+          const float g0 = gr[0], g1 = gr[16];
           const float x0 = xr[0], x1v = xr[16];
           xN[0][s_] = okr ? x0 : 0.f; xN[1][s_] = okr ? x1v : 0.f;
           gN[0][s_] = okr ? g0 : 0.f; gN[1][s_] = okr ? g1 : 0.f;
