@@ -42,9 +42,13 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     while (lp < 4 && (n << (lp + 1)) <= T) ++lp;
     const int P = 1 << lp, i = tid >> lp, part = tid & (P - 1);
     const int npad = (n + 8 * P - 1) & ~(8 * P - 1);          // <= 256 + 127: inside the caller's SP_LDS_KEYS slots
+    // (this thread's first key is requested BEFORE the barrier, unconditionally on a clamped node: behind it the load was a round
+    //  trip of its own in front of the LDS store)
+    const float k0 = x4[n0 + max(min(tid, n - 1), 0)];
     dg_lds_barrier();
     SK_MARK(1);
-    for (int t = tid; t < npad; t += T) keys[t] = t < n ? dg_pack_key(x4[n0 + t], t) : ~0ull;
+    if (tid < npad) keys[tid] = tid < n ? dg_pack_key(k0, tid) : ~0ull;
+    for (int t = tid + T; t < npad; t += T) keys[t] = t < n ? dg_pack_key(x4[n0 + t], t) : ~0ull;
     dg_lds_barrier();
     SK_MARK(2);
     const bool on = i < n;
