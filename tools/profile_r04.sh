@@ -30,6 +30,9 @@ bash tools/pmc.sh ${T}_b2048 --batch 2048 --no-dropin > $OUT/${T}_pmc_b2048.txt 
 bash tools/pmc_sq.sh ${T}_b50 "--no-dropin" "k_chain_readout_tail|k_wgrad" > $OUT/${T}_sq_b50.txt 2>&1
 bash tools/pmc_sq.sh ${T}_b2048 "--batch 2048 --no-dropin" "k_chain_fwd_q|k_chain_bwd_a|k_chain_bwd_b|k_classifier|k_readout_fwd|k_tail_bwd_walk|k_wgrad" > $OUT/${T}_sq_b2048.txt 2>&1
 python tools/phase_step_kernel.py COLLAB 50 > $OUT/${T}_phase_step_kernel.txt 2>&1
+# the data-parallel code path on ONE GPU (1-rank group): one-shot exchange kernel and RCCL route
+BENCH_FORCE_DIST=1 python bench.py --steps 400 --warmup 40 $Q --exchange oneshot 2>> $OUT/${T}_bench.err | grep '^{' > $OUT/${T}_bench_dp1_oneshot.json
+BENCH_FORCE_DIST=1 python bench.py --steps 400 --warmup 40 $Q --exchange rccl 2>> $OUT/${T}_bench.err | grep '^{' > $OUT/${T}_bench_dp1_rccl.json
 python tools/epoch_time.py COLLAB 1000 > $OUT/${T}_epoch_time.txt 2>&1
 python tools/epoch_time.py COLLAB 5000 >> $OUT/${T}_epoch_time.txt 2>&1
 python tools/eval_time.py COLLAB 50 > $OUT/${T}_eval_time.txt 2>&1
