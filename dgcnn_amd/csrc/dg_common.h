@@ -294,6 +294,20 @@ __device__ __forceinline__ void dg_mfma_tile16_k(int m0, int n0, int lane, FA fa
   for (int r = 0; r < 4; ++r) st(m0 + kq * 4 + r, n0 + mi, d[r]);
 }
 
+// One element of torch.optim.Adam (defaults semantics; /root/reference/train.py:41,99) with the operation sequence PINNED: the
+// two moment updates as separately rounded products and one add, the parameter update as one fused multiply-add.  That is
+// what the compiler made of `b1 * m + (1 - b1) * g` etc. in k_adam; left to the contraction heuristic, the same source
+// expression in the exchange kernel's four-elements-per-thread form became v_pk_fma -- and the one-shot route stopped being
+// bit-identical to the all_reduce + k_adam route (tests/test_dist_gloo.py compares them bit for bit).
+__device__ __forceinline__ void dg_adam_elem(float g, float m, float v, float p, float lr_over_bc1, float b1, float b2, float eps,
+                                             float bc2_sqrt, float& mo, float& vo, float& po) {
+#pragma clang fp contract(off)      // (HIP's __fmul_rn / __fadd_rn are plain operators in this toolchain and contract like them)
+  const float mi = b1 * m + (1.f - b1) * g;
+  const float vi = b2 * v + ((1.f - b2) * g) * g;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  mo = mi; vo = vi;
+  po = __builtin_fmaf(-lr_over_bc1, mi / denom, p);
+}
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
 __device__ __forceinline__ void dg_lds_barrier() {

@@ -47,11 +47,24 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
                  float* __restrict__ v, float* __restrict__ gsum_out, int64_t n, float lr, float b1, float b2, float eps,
                  float bc1, float bc2_sqrt, unsigned int* __restrict__ err, unsigned int max_spins) {
   __shared__ int ok;
+  // this thread's FOUR elements.  Everything local -- the own gradient (written by the previous kernel of this stream) and the
+  // optimizer state -- is requested BEFORE the flag protocol: those loads land while workgroup 0 talks to the peers (two
+  // cross-device flag round trips), only the peers' gradients wait for the verdict.  (One element per thread meant 407
+  // workgroups polling the GO word of a 104 k-parameter model; four per thread: 102.)
+  // (READY goes out FIRST: a release store waits for every earlier load of its wave, the prefetch below must not delay it)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(P.flag[rank] + DG_PW_READY, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = i4 < n;                                        // (n is a multiple of 4: dg_param_layout)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t ic = live ? i4 : 0;
+  const f4 gown = __builtin_nontemporal_load(reinterpret_cast<const f4*>(P.grad[rank] + ic));
+  const f4 m0 = *reinterpret_cast<const f4*>(m + ic), v0 = *reinterpret_cast<const f4*>(v + ic),
+           p0 = *reinterpret_cast<const f4*>(params + ic);
   if (threadIdx.x == 0) {
     unsigned int* mine = P.flag[rank];
     int good = 1;
     if (blockIdx.x == 0) {
-      __hip_atomic_store(mine + DG_PW_READY, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       auto wait_for = [&](int word) {        // every peer's `word` has reached this step's tag (tags only grow)
         for (int r = 0; r < world; ++r) {
           if (r == rank) continue;
@@ -97,18 +110,19 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
     ok = good;
   }
   __syncthreads();
-  if (!ok) return;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float g = 0.f;
+  if (!ok || !live) return;
+  f4 g = {0.f, 0.f, 0.f, 0.f};
   for (int r = 0; r < world; ++r)                              // fixed rank order on every rank
-    g += __builtin_nontemporal_load(P.grad[r] + i);
-  if (gsum_out) gsum_out[i] = g;
-  const float mi = b1 * m[i] + (1.f - b1) * g;
-  const float vi = b2 * v[i] + (1.f - b2) * g * g;
-  m[i] = mi; v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  params[i] = params[i] - (lr / bc1) * (mi / denom);
+    g += r == rank ? gown : __builtin_nontemporal_load(reinterpret_cast<const f4*>(P.grad[r] + i4));
+  if (gsum_out) *reinterpret_cast<f4*>(gsum_out + i4) = g;
+  f4 mo, vo, po;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {      // (the pinned operation sequence of k_adam: the two routes stay bit-identical)
+    float mi, vi, pi;
+    dg_adam_elem(g[k], m0[k], v0[k], p0[k], lr / bc1, b1, b2, eps, bc2_sqrt, mi, vi, pi);
+    mo[k] = mi; vo[k] = vi; po[k] = pi;
+  }
+  *reinterpret_cast<f4*>(m + i4) = mo; *reinterpret_cast<f4*>(v + i4) = vo; *reinterpret_cast<f4*>(params + i4) = po;
 }
 
 extern "C" {
@@ -174,7 +188,10 @@ int dgcnn_allreduce_adam_step(int world, int rank, const float* const* peer_grad
   }
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(k_allreduce_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, world, rank,
+  if ((n & 3) != 0 || (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grad_sum_out) & 15) != 0)
+    return DGCNN_EINVAL;                                       // (the flat layout is a multiple of 4 floats, 16-byte aligned)
+  for (int r = 0; r < world; ++r) if ((uintptr_t)peer_grads[r] & 15) return DGCNN_EINVAL;
+  hipLaunchKernelGGL(k_allreduce_adam, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, world, rank,
                      tag, params, exp_avg, exp_avg_sq, grad_sum_out, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
                      err, g_peer_spins);
   DG_CHECK_LAUNCH();

@@ -785,11 +785,10 @@ k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, floa
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
-  const float mi = b1 * m[i] + (1.f - b1) * gi;          // exp_avg.lerp_(grad, 1-beta1)
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-  m[i] = mi; v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - (lr / bc1) * (mi / denom);
+  // exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+  float mi, vi, pi;
+  dg_adam_elem(gi, m[i], v[i], p[i], lr / bc1, b1, b2, eps, bc2_sqrt, mi, vi, pi);
+  m[i] = mi; v[i] = vi; p[i] = pi;
   if (zero_grads) g[i] = 0.f;
 }
 
