@@ -526,3 +526,32 @@ def test_one_shot_exchange_two_ranks_on_two_streams_apply_the_identical_step():
     assert int(errs[0][0]) == 0 and int(errs[1][0]) == 0
     assert torch.equal(p[0], p[1])
     assert torch.allclose(p[0], ref.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [104128, 4, 5000, 52004])
+def test_one_shot_exchange_adam_equals_k_adam_bit_for_bit(n):
+    """the exchange kernel's Adam (four elements per thread, operands requested before the flag protocol) against
+    dgcnn_adam_step on the same gradient, state and step number: identical bits in the parameters and both moments (the
+    Adam element has a pinned operation sequence, dg_adam_elem: left to the contraction heuristic the two kernels compiled to
+    different fused / unfused forms).  Also: a length that is not a multiple of 4 floats is refused."""
+    L = _lib.lib()
+    dev = "cuda"
+    torch.manual_seed(n)
+    g = torch.randn(n, device=dev) * 1e-2
+    p0 = torch.randn(n, device=dev); m0 = torch.randn(n, device=dev) * 1e-3; v0 = torch.rand(n, device=dev) * 1e-4
+    pa, ma, va, ga = p0.clone(), m0.clone(), v0.clone(), g.clone()
+    _lib.check(L.dgcnn_adam_step(pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 3, 1e-3, 0.9, 0.999, 1e-8, 0,
+                                 _stream()), "adam")
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    flags = [torch.zeros(16, dtype=torch.int32, device=dev)]
+    err = torch.zeros(4, dtype=torch.int32, device=dev)
+    gp = (ctypes.c_void_p * 1)(g.data_ptr()); fp = (ctypes.c_void_p * 1)(flags[0].data_ptr())
+    rc = L.dgcnn_allreduce_adam_step(1, 0, gp, fp, 1, pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, n, 3, 1e-3, 0.9, 0.999,
+                                     1e-8, err.data_ptr(), _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    if n > 8:
+        assert L.dgcnn_allreduce_adam_step(1, 0, gp, fp, 2, pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), None, n - 1, 3, 1e-3, 0.9,
+                                           0.999, 1e-8, err.data_ptr(), _stream()) == -1
