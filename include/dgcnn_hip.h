@@ -249,7 +249,10 @@ int dgcnn_step_kernel_enable(int on);
 /* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
  * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:
  * DD at the reference's batch of 50, /root/reference/model.py:30-33 + train.py:40): on = 0 keeps the wave-per-node kernels, whose
- * results the narrow forms reproduce bit for bit; on = 1 restores the default.  Returns the previous setting (process-wide). */
+ * results the narrow forms reproduce bit for bit; on = 1 restores the default.  Returns the previous setting (process-wide).
+ * Do not toggle it between dgcnn_model_forward and dgcnn_model_backward of the SAME batch: on this route the switch also decides
+ * whether the readout backward leaves the SortPooling-gradient slabs sparse (flag word per node), and the backward's layer
+ * kernels must read them the way the forward half of the step wrote them. */
 int dgcnn_narrow_gather_enable(int on);
 
 /* Graph preparation of dgcnn_model_forward as a call of its own, writing into the workspace `ws`: everything of the
