@@ -80,43 +80,63 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     // (scratch in the upper half of the key area -- every caller provides SP_LDS_KEYS slots: no static LDS of its own,
     //  the graph-per-workgroup kernels have none to spare)
     unsigned long long* cand = keys + SP_LDS_KEYS / 2;                               // [256]
-    unsigned int* hist = reinterpret_cast<unsigned int*>(cand + 256);                // [256]
-    unsigned int& s_prefix = hist[256]; unsigned int& s_mask = hist[257];
-    unsigned int& s_need = hist[258]; unsigned int& s_cnt = hist[259];
+    unsigned int* hist = reinterpret_cast<unsigned int*>(cand + 256);                // [2048] + 8 words of state
+    unsigned int& s_prefix = hist[2048]; unsigned int& s_mask = hist[2049];
+    unsigned int& s_need = hist[2050]; unsigned int& s_cnt = hist[2051]; unsigned int& s_stop = hist[2052];
+    static_assert(256 * 8 + (2048 + 8) * 4 <= (SP_LDS_KEYS / 2) * 8, "candidates + histogram inside the upper half of the key area");
     if (in_lds) for (int t = tid; t < n; t += T) keys[t] = dg_pack_key(x4[n0 + t], t);
-    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = (unsigned)m; s_cnt = 0u; }
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 24 - 8 * pass;
-      for (int b = tid; b < 256; b += T) hist[b] = 0u;
+    if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = (unsigned)m; s_cnt = 0u; s_stop = 0u; }
+    // Digits of 11 + 11 + 10 bits (2048-bin LDS histogram), EARLY EXIT once the keys below the chosen bin plus the bin itself are
+    // at most 256: they are ranked directly (below).  The keys are tanh outputs: sign + exponent hardly separate them, so with
+    // 8-bit digits the first pass resolved almost nothing and all four passes -- three barriers and a scan of the keys each -- ran
+    // (661-node DD graph: 11.6 k of the readout's 40 k cycles); the first 11-bit digit reaches two mantissa bits, the second
+    // leaves a handful of keys per bin: two passes.  Same selection: the candidates are exactly the keys <= the bin's upper end,
+    // ranked by their full 64-bit keys.
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0), wbits = pass == 2 ? 10 : 11;
+      const unsigned int dmask = (1u << wbits) - 1u;
+      for (int b = tid; b < 2048; b += T) hist[b] = 0u;
       __syncthreads();
       const unsigned int prefix = s_prefix, mask = s_mask, need = s_need;
       for (int t = tid; t < n; t += T) {
         const unsigned int u = (unsigned int)(key_at(t) >> 32);
-        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
       }
       __syncthreads();
-      if (tid < 64) {            // wave 0: lane l owns bins 4l .. 4l+3 (ascending digit = ascending key)
-        const unsigned int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-        const unsigned int sum = c0 + c1 + c2 + c3;
+      if (tid < 64) {            // wave 0: lane l owns bins 32 l .. 32 l + 31 (ascending digit = ascending key)
+        unsigned int c[32];
+        const uint4* hp = reinterpret_cast<const uint4*>(hist + 32 * tid);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const uint4 v = hp[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
+        unsigned int sum = 0u;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) sum += c[q];
         unsigned int incl = sum;
         for (int o = 1; o < 64; o <<= 1) { const unsigned int a = __shfl_up(incl, o); if (tid >= o) incl += a; }
         const unsigned int excl = incl - sum;
         if (excl < need && need <= incl) {             // exactly one lane
-          unsigned int before = excl, bin = 4 * tid;
-          if (before + c0 < need) { before += c0; ++bin;
-            if (before + c1 < need) { before += c1; ++bin;
-              if (before + c2 < need) { before += c2; ++bin; } } }
+          unsigned int before = excl, bin = 32 * tid, cbin = 0u;
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            if (!found) {
+              if (before + c[q] < need) { before += c[q]; ++bin; }
+              else { found = true; cbin = c[q]; }
+            }
+          }
           s_prefix = prefix | (bin << shift);
-          s_mask = mask | (255u << shift);
+          s_mask = mask | (dmask << shift);
           s_need = need - before;
+          if (((unsigned)m - (need - before)) + cbin <= 256u) s_stop = 1u;      // (keys below the bin) + (keys in it)
         }
       }
       __syncthreads();
+      if (s_stop) break;         // (uniform: read behind the barrier)
     }
-    const unsigned int ustar = s_prefix;                // value of the K-th key
+    const unsigned int ustar = s_prefix, umask = s_mask;      // the K-th key's value in the digits resolved so far
     for (int t = tid; t < n; t += T) {
       const unsigned long long k = key_at(t);
-      if ((unsigned int)(k >> 32) <= ustar) {
+      if (((unsigned int)(k >> 32) & umask) <= ustar) {
         const unsigned int pos = atomicAdd(&s_cnt, 1u);
         if (pos < 256u) cand[pos] = k;
       }
