@@ -495,6 +495,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
     // small training batch: chain forward + readout forward + readout backward + the whole GCN backward of every graph in ONE
     // launch (one partial row per graph for k_wgrad, the step's only other launch)
     const bool step_kernel = dg_step_kernel_enabled() && B <= wl.P1 && B <= wl.P32 && dg_wgrad_takes_rider(B);
+    int fused_b = 0;      // (phase B of the rider joined this launch: *rode = 2, nothing is left to ride on k_wgrad)
     DG_TRY(dg_launch_chain_readout_tail(N, B, F, C, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
                                         dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
                                         dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
@@ -506,12 +507,12 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
                                         wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr,
                                         step_kernel ? dg_ptr<float>(ws, wl.pb3) : nullptr, step_kernel ? dg_ptr<float>(ws, wl.pb2) : nullptr,
-                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16));
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16, (rider_a && rode) ? &fused_b : nullptr));
     g_prof_which = -1;
     // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
     // pb2 / pb1 = graph b's partials: k_wgrad sums B rows)
     *tail_done = step_kernel ? 3 : (B <= wl.P1 ? 2 : 1);
-    if (rider_a && rode) *rode = 1;
+    if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
     return DGCNN_OK;
   }
   if (chain) {
@@ -764,6 +765,10 @@ struct DgPipeline {
   // stream at the start of the step and joined at its end (created at the first such step, destroyed with the pipeline)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // small batches: BOTH phases of the next batch's preparation ride on the one-launch training kernel; the phase-B workgroups wait on
+  // this device counter for the phase-A workgroups of the same launch (dg_prep.h).  Created at the first rider, freed with the pipeline.
+  unsigned int* sync_ctr = nullptr;
+  unsigned int sync_count = 0;
 };
 // From this many graphs per step on the next batch's preparation leaves the rider slots of the step's launches for the side
 // stream.  Why: at 2048 COLLAB graphs every launch of the step fills the chip, so rider blocks are ADDED time (k_readout_fwd
@@ -792,6 +797,7 @@ int dgcnn_pipeline_destroy(void* handle) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->sync_ctr) (void)hipFree(h->sync_ctr);
   delete h;
   return DGCNN_OK;
 }
@@ -879,6 +885,14 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
     rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);
+    if (!h->sync_ctr) {      // (once per pipeline; a failure only means that phase B keeps riding on k_wgrad)
+      unsigned int* c = nullptr;
+      if (hipMalloc(&c, 64) == hipSuccess) {
+        if (hipMemsetAsync(c, 0, 64, s) == hipSuccess) { h->sync_ctr = c; h->sync_count = 0; }
+        else { (void)hipGetLastError(); (void)hipFree(c); }
+      } else (void)hipGetLastError();
+    }
+    rd.sync_ctr = h->sync_ctr; rd.sync_host = h->sync_ctr ? &h->sync_count : nullptr;
     rider = &rd;
   }
   int rode = 0, tail_done = 0;
@@ -909,7 +923,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   DG_TRY(dg_model_backward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->ws, cur->logp, nullptr,
                                 cur->y, cur->loss_scale, cur->training ? 1 : 0, cur->grads, cur->metrics, adam, s,
                                 dg_backward_form(cur->N, cur->E, cur->B, cur->F, flags, cur->max_nodes),
-                                (rode && rd.mode == 0) ? rider : nullptr, tail_done));
+                                (rode == 1 && rd.mode == 0) ? rider : nullptr, tail_done));      // (rode == 2: phase B already ran)
   if (next && rode && rd.mode == 0 && rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap the riders just built
     DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
                               reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));

@@ -481,7 +481,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* gb4p, float* lossv, float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1,
                                  hipStream_t s, const struct DgPrepRider* rider = nullptr,
                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                                 float* pb3 = nullptr, float* pb2 = nullptr, float* pb1 = nullptr, int bf16 = 0);
+                                 float* pb3 = nullptr, float* pb2 = nullptr, float* pb1 = nullptr, int bf16 = 0,
+                                 int* fused_b_out = nullptr);      // != nullptr: phase B of the rider may join this launch; says if it did
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                         float* x3, float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start = nullptr,

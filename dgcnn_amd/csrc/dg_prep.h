@@ -50,6 +50,15 @@ struct DgPrepRider {
                    // (small batches that take only the chain forward from it: no third launch for the bitmap's symmetry check)
   int max_nodes;   // the host's per-graph node bound for this batch (0 = none given): phase B flags any graph above it, so that a
                    // hint that is too small can never make a size-class kernel skip a graph silently
+  // BOTH phases in the launch that carries phase A (the one-launch training kernel, whose graph workgroups leave most CUs idle
+  // at the reference's batch of 50): `fused_b` phase-B workgroups follow the `nblk` phase-A ones in the grid and wait on a
+  // device counter until every phase-A workgroup has published its stores.  Workgroups are dispatched in index order, so a
+  // waiting phase-B workgroup can never keep a phase-A workgroup from starting.  (As rider blocks of k_wgrad phase B was that
+  // launch's longest chain: 7.0 us against 5.1 us without it.)
+  unsigned int* sync_ctr;      // device counter (monotonic over the pipeline's life); nullptr: not available
+  unsigned int* sync_host;     // host copy of the count of phase-A workgroups launched so far
+  unsigned int sync_target;    // value the counter reaches when this launch's phase A is complete
+  int fused_b;                 // phase-B workgroups in phase A's launch (0: phase B rides on a later launch / runs on its own)
 };
 static inline int dg_prep_fast_work(int E, int N, int B, bool dense = false) {      // threads of phase A / phase B
   int work = E > N + 1 ? E : N + 1;
@@ -222,6 +231,19 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
 
 // Kernel-A body, thread t of max(E, N+1, B+1): range / self-loop / strict (src,dst) order checks, colidx copies,
 // rowptr by ROW-BOUNDARY detection, graph_ptr by binary search on the sorted batch vector.
+// COH (both phases inside ONE launch, dg_prep.h's fused form): what phase A hands to phase B goes through agent-coherent accesses
+// (relaxed atomics: sc1 stores written through to memory, sc1 loads that take no stale line of another XCD's L2) instead of a
+// release / acquire fence pair -- a fence writes back / invalidates the XCD's whole L2, and the graph workgroups of the same
+// launch live out of that L2 (first version, one acquire per phase-B workgroup: the launch took 80-98 us instead of 36).
+template <bool COH> __device__ __forceinline__ int dg_ldc(const int* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COH> __device__ __forceinline__ void dg_stc(int* p, int v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH = false>
 __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __restrict__ ei, int E, int N,
                                                     const int64_t* __restrict__ batch, int B, int* __restrict__ rowptr,
                                                     int* __restrict__ colidx, int* __restrict__ rowptr_t,
@@ -249,12 +271,12 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
     const int pc = ps < 0 ? -1 : (ps >= N ? N - 1 : (int)ps);
     // (an undirected edge list's CSR by source IS its CSR by target: the model-level callers pass null for the second copy
     //  and their backward reads the first -- 8 of phase A's 24 bytes per edge; dgcnn_graph_prep still fills both)
-    colidx[t] = dc;
+    dg_stc<COH>(colidx + t, dc);
     if (colidx_t) colidx_t[t] = dc;
     if (pc < sc || t == 0)
-      for (int k = pc + 1; k <= sc; ++k) { rowptr[k] = t; if (rowptr_t) rowptr_t[k] = t; }
+      for (int k = pc + 1; k <= sc; ++k) { dg_stc<COH>(rowptr + k, t); if (rowptr_t) rowptr_t[k] = t; }
     if (t == E - 1)
-      for (int k = sc + 1; k <= N; ++k) { rowptr[k] = E; if (rowptr_t) rowptr_t[k] = E; }
+      for (int k = sc + 1; k <= N; ++k) { dg_stc<COH>(rowptr + k, E); if (rowptr_t) rowptr_t[k] = E; }
   }
   if (t <= B) {
     int lo = 0, hi = N;
@@ -262,14 +284,15 @@ __device__ __forceinline__ void dg_prep_fast_a_body(int t, const int64_t* __rest
       const int mid = (lo + hi) >> 1;
       if (batch[mid] < (int64_t)t) lo = mid + 1; else hi = mid;
     }
-    graph_ptr[t] = lo;
+    dg_stc<COH>(graph_ptr + t, lo);
   }
 }
 // what a phase-A rider thread does: the first phase of the next batch's preparation, or its whole assembly from a prepared dataset
 __device__ __forceinline__ void dg_assemble_body(int t, const DgAssemble& A);
+template <bool COH = false>
 __device__ __forceinline__ void dg_rider_phase_a(int t, const DgPrepRider& rd) {
   if (rd.mode == 1) { dg_assemble_body(t, rd.as); return; }
-  dg_prep_fast_a_body(t, rd.ei, rd.E, rd.N, rd.batch, rd.B, rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err,
+  dg_prep_fast_a_body<COH>(t, rd.ei, rd.E, rd.N, rd.batch, rd.B, rd.rowptr, rd.colidx, rd.rowptr_t, rd.colidx_t, rd.graph_ptr, rd.err,
                       rd.epoch, rd.bits);
 }
 // Kernel-B body: dinv per node, graph_eptr, and (per edge (s,d)) the reverse edge (d,s) must be in row d --
@@ -277,7 +300,7 @@ __device__ __forceinline__ void dg_rider_phase_a(int t, const DgPrepRider& rd) {
 // THREADS: threads per block of the hosting launch (sizes the LDS row buffers: 8 bytes per thread -- 2 KB in the 256-thread
 // launches; as a fixed 8 KB it kept the GCN backward chain kernels' workgroups, which need 2 x 70 KB of a CU's 160 KB, from being
 // placed beside a few blocks of the preparation running on the pipeline's side stream)
-template <int THREADS = 1024>
+template <int THREADS = 1024, bool EXTBUF = false, bool COH = false>      // EXTBUF: the 8-byte-per-thread LDS row buffer is handed in (rowbuf_ext)
 __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __restrict__ ei, int E, int N, int B,
                                                     const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                                     const int* __restrict__ graph_ptr, int* __restrict__ graph_eptr,
@@ -287,7 +310,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     const int64_t* __restrict__ batch = nullptr,
                                                     unsigned int* __restrict__ bits = nullptr,
                                                     int* __restrict__ dmap = nullptr, bool edge_check = false,
-                                                    int max_nodes = 0) {
+                                                    int max_nodes = 0, unsigned int* rowbuf_ext = nullptr) {
   if (bits) {
     // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
     // per row: lane l takes neighbours l, l + 8, ... of the row (int32 colidx copy of phase A; the 8 lanes read 8
@@ -306,10 +329,10 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       const bool live = row < N;
       const int rowc = live ? row : 0;
       const int gload = N > 0 ? (int)batch[rowc] : -1;
-      const int rs0 = N > 0 ? rowptr[rowc] : 0, re0 = N > 0 ? rowptr[rowc + 1] : 0;
+      const int rs0 = N > 0 ? dg_ldc<COH>(rowptr + (rowc)) : 0, re0 = N > 0 ? dg_ldc<COH>(rowptr + (rowc + 1)) : 0;
       const int g = live ? gload : -1;
       const int gc = (unsigned)g < (unsigned)B ? g : 0;
-      int n0 = B > 0 ? graph_ptr[gc] : 0, ng = B > 0 ? graph_ptr[gc + 1] - n0 : 0;
+      int n0 = B > 0 ? dg_ldc<COH>(graph_ptr + (gc)) : 0, ng = B > 0 ? dg_ldc<COH>(graph_ptr + (gc + 1)) - n0 : 0;
       if ((unsigned)g >= (unsigned)B) { n0 = 0; ng = 0; }
       const int sj = row - n0;
       const bool ok = live && (unsigned)g < (unsigned)B && sj >= 0 && sj < ng && ng <= DGD_MAXN;
@@ -324,7 +347,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
         for (int e = rs + l8; e < re; e += 64) {
           int jj[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) jj[u] = colidx[min(e + 8 * u, re - 1)] - n0;
+          for (int u = 0; u < 8; ++u) jj[u] = dg_ldc<COH>(colidx + (min(e + 8 * u, re - 1))) - n0;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             int j = jj[u];
@@ -353,8 +376,8 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
       // per neighbour.  The 8 lanes are in one wave and LDS operations of a wave execute in order: no barrier, only the
       // counter wait.  (2048 COLLAB graphs, phase B riding on k_tail_bwd: that launch 57 -> 51 us.)
       auto build_lds = [&]() {
-        __shared__ unsigned int rowbuf[(THREADS / 8) * 16];
-        unsigned int* rb = rowbuf + (threadIdx.x >> 3) * 16;
+        __shared__ unsigned int rowbuf[EXTBUF ? 1 : (THREADS / 8) * 16];
+        unsigned int* rb = (EXTBUF ? rowbuf_ext : rowbuf) + (threadIdx.x >> 3) * 16;
         rb[l8] = 0u; rb[l8 + 8] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         unsigned int cur = 0u;
@@ -362,7 +385,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
         for (int e = rs + l8; e < re; e += 64) {
           int jj[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) jj[u] = colidx[min(e + 8 * u, re - 1)] - n0;
+          for (int u = 0; u < 8; ++u) jj[u] = dg_ldc<COH>(colidx + (min(e + 8 * u, re - 1))) - n0;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             if (e + 8 * u < re) {
@@ -397,26 +420,52 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
     // this preparation are chosen from that hint (size-class launches skipped, the 256-node chain backward taken), so a graph
     // above it would be left out of them without a trace
     // (max_nodes < 0: dataset-level preparation -- graphs above 512 nodes simply get no bitmap rows, dg_assemble.h)
-    if (t < B && max_nodes >= 0 && graph_ptr[t + 1] - graph_ptr[t] > ((max_nodes > 0 && max_nodes < DGD_MAXN) ? max_nodes : DGD_MAXN)) { err[1] = epoch; err[3] = ~epoch; }
+    if (t < B && max_nodes >= 0 && dg_ldc<COH>(graph_ptr + (t + 1)) - dg_ldc<COH>(graph_ptr + (t)) > ((max_nodes > 0 && max_nodes < DGD_MAXN) ? max_nodes : DGD_MAXN)) { err[1] = epoch; err[3] = ~epoch; }
   }
   if (t < N) {
-    const float di = 1.0f / sqrtf((float)(rowptr[t + 1] - rowptr[t] + 1));
+    const float di = 1.0f / sqrtf((float)(dg_ldc<COH>(rowptr + (t + 1)) - dg_ldc<COH>(rowptr + (t)) + 1));
     dinv[t] = di;
     if (x) {      // pre-scaled raw features for the aggregate-first conv1 gather (one row load per edge, no dinv[j] load)
       for (int f = 0; f < F; ++f) xs[(size_t)t * F + f] = di * x[(size_t)t * F + f];
     }
   }
-  if (t <= B) graph_eptr[t] = rowptr[graph_ptr[t]];      // first edge position of each graph's rows
+  if (t <= B) graph_eptr[t] = dg_ldc<COH>(rowptr + (dg_ldc<COH>(graph_ptr + (t))));      // first edge position of each graph's rows
   if (t < E && (!bits || edge_check)) {      // (dense batches verify the reverse edges on the bitmap afterwards: dg_prep_sym_body)
     const int64_t s = ei[t], d = ei[(int64_t)E + t];
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
-      const int end = rowptr[d + 1];
-      int a = rowptr[d], b = end;
-      while (a < b) {
-        const int mid = (a + b) >> 1;
-        if (colidx[mid] < (int)s) a = mid + 1; else b = mid;
+      const int end = dg_ldc<COH>(rowptr + (d + 1));
+      int a = dg_ldc<COH>(rowptr + (d));
+      if (COH) {
+        // agent-coherent loads are memory round trips, not L2 hits: lower bound EIGHT-WAY -- seven probes per level, all in
+        // flight, then the <= 8 entries of the last segment together: two dependent round trips for rows of up to 64 neighbours
+        // where the binary search takes six.  (With plain loads the binary search is the faster one: measured.)
+        int len = end - a;
+        while (len > 8) {
+          int pv[7];
+#pragma unroll
+          for (int k = 0; k < 7; ++k) pv[k] = dg_ldc<COH>(colidx + (a + (int)(((int64_t)len * (k + 1)) >> 3)));
+          int j = 0;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) j += pv[k] < (int)s ? 1 : 0;                                     // (the row ascends)
+          const int lo = j == 0 ? 0 : (int)(((int64_t)len * j) >> 3) + 1;         // first position not known to be below s
+          const int hi = j == 7 ? len : (int)(((int64_t)len * (j + 1)) >> 3) + 1; // one past the first probe that is >= s
+          a += lo; len = hi - lo;
+        }
+        int cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv[k] = dg_ldc<COH>(colidx + (min(a + k, max(end - 1, 0))));
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hit = hit || (k < len && cv[k] == (int)s);
+        if (!hit) { err[1] = epoch; err[3] = ~epoch; }
+      } else {
+        int b = end;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (dg_ldc<COH>(colidx + (mid)) < (int)s) a = mid + 1; else b = mid;
+        }
+        if (!(a < end && dg_ldc<COH>(colidx + (a)) == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
       }
-      if (!(a < end && colidx[a] == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
     }
   }
 }

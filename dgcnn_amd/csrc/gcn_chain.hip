@@ -1436,6 +1436,7 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   }
 }
 
+#define CH_RIDER_ITEMS 2        // fused preparation (both phases in the training kernel's launch): work items per rider thread
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
 struct ChTail {
   unsigned int* err; unsigned int epoch;
@@ -1466,8 +1467,44 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                      float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChTail t,
                      unsigned long long* __restrict__ dbg, DgPrepRider rd) {
   if ((int)blockIdx.x >= B) {
-    dg_rider_phase_a(((int)blockIdx.x - B) * RD_THREADS + (int)threadIdx.x, rd);
-    return;
+    const int rb = (int)blockIdx.x - B;
+    if (rb < rd.nblk) {
+      if (rd.fused_b > 0) {
+        // phase A with agent-coherent stores of what phase B reads (dg_prep.h: no fence -- a release would write back this XCD's
+        // whole L2); __syncthreads() waits for every store of the workgroup (vmcnt(0)), then ONE relaxed increment publishes it
+#pragma unroll 1
+        for (int it = 0; it < CH_RIDER_ITEMS; ++it)      // (CH_RIDER_ITEMS items per thread: both phases' workgroups resident at once)
+          dg_rider_phase_a<true>((rb * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x, rd);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(rd.sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        dg_rider_phase_a(rb * RD_THREADS + (int)threadIdx.x, rd);
+      }
+      return;
+    }
+    // phase B of the same batch in the same launch: wait until EVERY phase-A workgroup has published (bounded; they were all
+    // dispatched before this workgroup), then the body that otherwise rides on k_wgrad.  The LDS row buffer is this launch's
+    // dynamic LDS, which a rider workgroup does not use otherwise.
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    if (threadIdx.x == 0) {
+      unsigned int spins = 0;
+      // (relaxed polls and NO acquire fence: an acquire invalidates this XCD's L2, out of which the graph workgroups of the same
+      //  launch live -- one per phase-B workgroup made the launch 80 us instead of 36; phase B reads phase A's outputs by
+      //  agent-coherent loads instead)
+      while ((int)(__hip_atomic_load(rd.sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rd.sync_target) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1u << 23)) { rd.err[1] = rd.epoch; rd.err[3] = ~rd.epoch; break; }      // (never seen; the batch is flagged)
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < CH_RIDER_ITEMS; ++it) {
+      const int tb = ((rb - rd.nblk) * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x;
+      dg_prep_fast_b_body<RD_THREADS, true, true>(tb, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv,
+                                                  rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0,
+                                                  rd.max_nodes, reinterpret_cast<unsigned int*>(rsm));
+    }
+    return;      // (no planning workgroup here: the launcher fuses only riders without an item table)
   }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
@@ -2233,7 +2270,8 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                                  float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1, hipStream_t s,
                                  const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, float* pb3, float* pb2, float* pb1,
-                                 int bf16) {
+                                 int bf16, int* fused_b_out) {
+  if (fused_b_out) *fused_b_out = 0;
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || !y)
     return DGCNN_EINVAL;
@@ -2251,7 +2289,27 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   t.gz6g = gz6; t.gz5g = gz5; t.gp1 = gp1; t.gp2 = gp2; t.gp3 = gp3; t.gas4 = gas4; t.gb4p = gb4p; t.lossv = lossv; t.ptail = ptail;
   DgPrepRider rd{};
   if (rider) rd = *rider;
+  rd.fused_b = 0;
+  // phase B of the next batch's preparation in THIS launch, behind phase A (dg_prep.h): the caller asked for it by handing in the
+  // counter; taken when both phases exist for this rider
+  // ... and when EVERY workgroup of the launch is resident from its start (one 1024-thread workgroup with this much LDS per CU): the
+  // phase-B workgroups then wait beside running phase-A workgroups and both phases are over long before the graph workgroups are.
+  // With more workgroups than CUs the riders only start when graph workgroups end, and two dependent phases at the launch's tail
+  // cost more than phase B costs k_wgrad (measured at 128 / 256 graphs: 55 / 101 us per step against 44 / 56).
+  static int cus[64];
+  const int dev = DgPerDeviceOnce::current();
+  if (cus[dev] == 0) { int v = 0; cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 1; }
+  const int na2 = (rd.nblk + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS, nb2 = (rd.nblk_b + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS;
+  if (fused_b_out && rd.mode == 0 && rd.nblk > 0 && rd.nblk_b > 0 && rd.sync_ctr && rd.sync_host && !rd.dmap &&
+      B + na2 + nb2 <= cus[dev] - 8) {
+    rd.nblk = na2;                       // (every rider thread takes CH_RIDER_ITEMS items of its phase)
+    rd.fused_b = nb2;
+    *rd.sync_host += (unsigned int)rd.nblk;
+    rd.sync_target = *rd.sync_host;
+    *fused_b_out = rd.fused_b;
+  }
   static_assert(ChQ<16, 4, CH_TRAIN_MAXN>::TOTAL >= RD_REGION0_BYTES + RD_SMALL_BYTES, "the readout's LDS plan aliases the chain's images");
+  static_assert(ChTrainLds<4>::TOTAL >= RD_THREADS * 8, "a rider workgroup's row buffer inside the launch's dynamic LDS");
   static DgPerDeviceOnce attr_once;
   if (attr_once.needed()) {
 #define CH_ATTR2(XI, WS, BFV) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_tail<XI, WS, BFV>), \
@@ -2261,7 +2319,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
       return DGCNN_ELAUNCH;
     attr_once.done();
   }
-#define CH_LT(XI, WS, BFV) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS, BFV>), dim3(B + rd.nblk), dim3(1024), ChTrainLds<WS>::TOTAL, s, \
+#define CH_LT(XI, WS, BFV) hipExtLaunchKernelGGL((k_chain_readout_tail<XI, WS, BFV>), dim3(B + rd.nblk + rd.fused_b), dim3(1024), ChTrainLds<WS>::TOTAL, s, \
                                                  ev_start, ev_stop, 0, N, B, F, graph_ptr, bits, dinv, xs, gw, ax, x1, x2, x3, x4, t,        \
                                                  dg_debug_buffer(), rd)
   if (bf16) { if (F <= 8) CH_LT(1, 4, true); else if (F <= 16) CH_LT(2, 4, true); else CH_LT(4, 8, true); }
