@@ -1436,7 +1436,9 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   }
 }
 
+#ifndef CH_RIDER_ITEMS
 #define CH_RIDER_ITEMS 2        // fused preparation (both phases in the training kernel's launch): work items per rider thread
+#endif
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
 struct ChTail {
   unsigned int* err; unsigned int epoch;
