@@ -311,6 +311,15 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
                                                     unsigned int* __restrict__ bits = nullptr,
                                                     int* __restrict__ dmap = nullptr, bool edge_check = false,
                                                     int max_nodes = 0, unsigned int* rowbuf_ext = nullptr) {
+  // neighbour id at position i of the CSR.  COH (both phases in one launch): NOT from phase A's int32 copy -- that would be an
+  // agent-coherent load, a memory transaction per probe: with ~15 of them per edge the reverse-edge check moved ~150 MB through
+  // the fabric beside the graph workgroups -- but from the batch's own sorted edge list, whose targets ARE the CSR's column ids
+  // (a stable input: ordinary cached loads), clamped the way phase A clamps its copy.
+  auto col_at = [&](int i) -> int {
+    if (COH) { const int64_t dd = ei[(int64_t)E + i]; return (uint64_t)dd < (uint64_t)N ? (int)dd : 0; }
+    return colidx[i];
+  };
+
   if (bits) {
     // dense per-graph block structures (dg_dense.h): bit (j - n0_g) of row i <=> i and j adjacent or i == j.  EIGHT LANES
     // per row: lane l takes neighbours l, l + 8, ... of the row (int32 colidx copy of phase A; the 8 lanes read 8
@@ -347,7 +356,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
         for (int e = rs + l8; e < re; e += 64) {
           int jj[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) jj[u] = dg_ldc<COH>(colidx + (min(e + 8 * u, re - 1))) - n0;
+          for (int u = 0; u < 8; ++u) jj[u] = col_at(min(e + 8 * u, re - 1)) - n0;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             int j = jj[u];
@@ -385,7 +394,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
         for (int e = rs + l8; e < re; e += 64) {
           int jj[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) jj[u] = dg_ldc<COH>(colidx + (min(e + 8 * u, re - 1))) - n0;
+          for (int u = 0; u < 8; ++u) jj[u] = col_at(min(e + 8 * u, re - 1)) - n0;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             if (e + 8 * u < re) {
@@ -435,37 +444,12 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
     if ((uint64_t)s < (uint64_t)N && (uint64_t)d < (uint64_t)N) {
       const int end = dg_ldc<COH>(rowptr + (d + 1));
       int a = dg_ldc<COH>(rowptr + (d));
-      if (COH) {
-        // agent-coherent loads are memory round trips, not L2 hits: lower bound EIGHT-WAY -- seven probes per level, all in
-        // flight, then the <= 8 entries of the last segment together: two dependent round trips for rows of up to 64 neighbours
-        // where the binary search takes six.  (With plain loads the binary search is the faster one: measured.)
-        int len = end - a;
-        while (len > 8) {
-          int pv[7];
-#pragma unroll
-          for (int k = 0; k < 7; ++k) pv[k] = dg_ldc<COH>(colidx + (a + (int)(((int64_t)len * (k + 1)) >> 3)));
-          int j = 0;
-#pragma unroll
-          for (int k = 0; k < 7; ++k) j += pv[k] < (int)s ? 1 : 0;                                     // (the row ascends)
-          const int lo = j == 0 ? 0 : (int)(((int64_t)len * j) >> 3) + 1;         // first position not known to be below s
-          const int hi = j == 7 ? len : (int)(((int64_t)len * (j + 1)) >> 3) + 1; // one past the first probe that is >= s
-          a += lo; len = hi - lo;
-        }
-        int cv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cv[k] = dg_ldc<COH>(colidx + (min(a + k, max(end - 1, 0))));
-        bool hit = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) hit = hit || (k < len && cv[k] == (int)s);
-        if (!hit) { err[1] = epoch; err[3] = ~epoch; }
-      } else {
-        int b = end;
-        while (a < b) {
-          const int mid = (a + b) >> 1;
-          if (dg_ldc<COH>(colidx + (mid)) < (int)s) a = mid + 1; else b = mid;
-        }
-        if (!(a < end && dg_ldc<COH>(colidx + (a)) == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
+      int b = end;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (col_at(mid) < (int)s) a = mid + 1; else b = mid;
       }
+      if (!(a < end && col_at(a) == (int)s)) { err[1] = epoch; err[3] = ~epoch; }
     }
   }
 }
