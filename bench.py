@@ -736,6 +736,9 @@ def main():
              "frac_of_peak_on_measured_traffic": None if traffic is None else round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
         if tail:
             r["frac_with_tail_model"] = round(tail_model_b / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            if traffic is not None:      # (the PMC passes count whole launches: at <= 64 graphs the launch also runs the riders)
+                r["traffic_note"] = ("the launch also carries both phases of the NEXT batch's graph preparation as rider workgroups "
+                                     "(int64 edge list in, CSR / dinv / bitmap out): counted in `traffic`, not in the model")
         if not (fused or chain):
             r["frac_counting_fused_output"] = round((bpl + extra_b) / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         return r
