@@ -69,11 +69,14 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
         for (int r = 0; r < world; ++r) {
           if (r == rank) continue;
           unsigned int spins = 0;
-          while ((int)(__hip_atomic_load(P.flag[r] + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
+          // (RELAXED polls, one acquire fence behind the last of them: an acquire load invalidates the caches on EVERY poll --
+          //  under the other workgroups' operand loads; measured inside the training kernel's launch)
+          while ((int)(__hip_atomic_load(P.flag[r] + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - tag) < 0) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > max_spins) return false;
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope
         return true;
       };
       auto mark_aborted = [&]() {            // sticky: the first aborted tag stays (only this workgroup ever writes the word)
@@ -101,10 +104,11 @@ k_allreduce_adam(DgPeers P, int world, int rank, unsigned int tag, float* __rest
       __hip_atomic_store(mine + DG_PW_GO, good ? tag : (tag | 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       unsigned int spins = 0, g;
-      while (((g = __hip_atomic_load(mine + DG_PW_GO, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) & 0x7fffffffu) != tag) {
+      while (((g = __hip_atomic_load(mine + DG_PW_GO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) & 0x7fffffffu) != tag) {
         __builtin_amdgcn_s_sleep(32);
         if (++spins > 4u * max_spins + 1024u) { g = 0x80000000u; err[1] = tag; break; }    // (workgroup 0 always decides first)
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // (system scope: the peers' gradients are read behind it)
       good = (g >> 31) ? 0 : 1;
     }
     ok = good;
