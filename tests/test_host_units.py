@@ -75,3 +75,21 @@ def test_flat_adam_without_torchs_step_wrapper_still_runs_hooks_schedulers_and_t
         assert torch.equal(p, q)
     assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 1e-2 * 0.25
     oa.zero_grad(set_to_none=False)
+
+
+def test_isa_audit_tool_reads_the_built_objects():
+    """tools/isa_audit.py (the audit that found the sunk / eagerly selected loads and the scalar re-reads)
+    disassembles the in-tree objects and reports the two patterns per kernel; the weight-gradient kernel's segment search is ONE
+    batch of scalar loads since that audit: no scalar load of the <false> instantiation's main path sits in a loop any more"""
+    import glob, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not glob.glob(os.path.join(root, "dgcnn_amd", "csrc", "*.o")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        import pytest
+        pytest.skip("no built objects / no llvm-objdump here")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_audit.py"), "k_lin_first32s|k_gcn_fwd32n"],
+                         capture_output=True, text=True, timeout=300).stdout
+    lines = [l for l in out.splitlines() if "instr" in l]
+    assert any("k_lin_first32s" in l for l in lines) and any("k_gcn_fwd32n" in l for l in lines), out
+    for l in lines:
+        if "k_gcn_fwd32n" in l:      # the narrow forward: no kernel-argument load behind its barrier
+            assert l.rstrip().endswith("s_load behind a barrier   0"), l
