@@ -327,3 +327,47 @@ def test_pipelined_steps_of_the_one_launch_kernel_track_the_oracle_trajectory():
         for p, off, key in zip(m._param_list(), m._offsets, KEYS):
             good, md, sc = grads_close(g[off:off + p.numel()], g_ref[key].reshape(-1))
             assert good, f"step {i} grad {key}: max diff {md:.3e} at scale {sc:.3e}"
+
+
+@pytest.mark.parametrize("violation", ["missing_reverse", "unsorted", "edge_leaves_graph"])
+def test_fused_preparation_flags_a_broken_promise_in_the_next_batch(violation):
+    """the NEXT batch's graph preparation runs as rider workgroups of the training kernel's launch (both phases, phase B behind a
+    device counter; the reverse-edge check reads the batch's own edge list there): a next batch whose coalesced + undirected
+    promise is violated must be flagged exactly as by the stand-alone preparation -- read_metrics raises -- and a clean next
+    batch must not be"""
+    from dgcnn_amd.batch import Batch
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    good = [synth.make_batch("COLLAB", 50, start=4000 + 50 * k) for k in range(3)]
+    assert all(g.coalesced_undirected and g.max_nodes <= 256 for g in good)
+    b = good[1]
+    ei = b.edge_index.clone()
+    if violation == "missing_reverse":
+        s, d = int(ei[0, 777]), int(ei[1, 777])
+        ei = ei[:, ~((ei[0] == d) & (ei[1] == s))]
+    elif violation == "unsorted":
+        ei[:, [100, 101]] = ei[:, [101, 100]]
+    else:      # an edge between two different graphs (both directions, list kept sorted by source)
+        ptr = torch.searchsorted(b.batch, torch.arange(b.num_graphs + 1))
+        u, v = int(ptr[0]), int(ptr[1])                                     # first node of graph 0, first node of graph 1
+        extra = torch.tensor([[u, v], [v, u]])
+        ei = torch.cat([ei, extra], 1)
+        order = torch.argsort(ei[0] * b.num_nodes + ei[1])
+        ei = ei[:, order]
+    bad = Batch(b.x, ei.contiguous(), b.batch, b.y, b.num_graphs, True, b.max_nodes, max(b.max_edges, ei.shape[1]))
+    for nxt, expect_error in ((good[1], False), (bad, True)):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train()
+        tr = Trainer(m)
+        tr.reset_metrics()
+        b0, b1 = good[0].to("cuda"), nxt.to("cuda")
+        tr.train_step(b0, b0.y, next_data=b1)          # (first step: no counter yet -- classic riders)
+        tr.train_step(b1, b1.y, next_data=b0)
+        tr.train_step(b0, b0.y, next_data=b1)          # the fused form prepares b1 here ...
+        tr.train_step(b1, b1.y)                        # ... and this step consumes it
+        torch.cuda.synchronize()
+        if expect_error:
+            with pytest.raises(_lib.DgcnnError):
+                tr.read_metrics()
+        else:
+            tr.read_metrics()
