@@ -5,11 +5,12 @@ in this repo's kernels:
   (2) scalar loads (`s_load_*`) that appear BEHIND the kernel's first barrier (kernel arguments / scalar memory re-read in
       front of a phase).
 usage: python tools/isa_audit.py [kernel-name regex]"""
-import os, re, subprocess, sys, tempfile
+import atexit, os, re, shutil, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LL = "/opt/rocm/lib/llvm/bin"
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 tmp = tempfile.mkdtemp()
+atexit.register(shutil.rmtree, tmp, ignore_errors=True)
 for o in sorted(os.listdir(os.path.join(R, "dgcnn_amd/csrc"))):
     if not o.endswith(".o"): continue
     b = o[:-2]
