@@ -348,7 +348,11 @@ static int dg_fill_assemble(const dgcnn_dataset* ds, const int64_t* ids, const i
   A->ds_xs = F <= DG_AF_MAX_F ? ds->xs : nullptr; A->ds_x = ds->x; A->ds_bits = ds->adj_bits; A->ds_y = ds->y;
   A->G = ds->G; A->Ntot = ds->Ntot;
   A->ids = ids; A->onode = onode; A->oedge = oedge; A->N = N; A->E = E; A->B = B; A->F = F;
-  const bool csr = !fm.dense;          // the dense form's forward AND backward read the bitmap only
+  // a CSR wherever a gather kernel can run for this batch.  The dense form's own forward and backward read the bitmap only,
+  // BUT (1) above the aggregate-first width conv1's own backward is the gather kernel in BOTH forms (dg_model_backward_impl:
+  // dW1 = gh^T x over the transposed CSR = the CSR under the symmetric promise), and (2) a forced graph-per-workgroup forward
+  // (k_fused_fwd / k_fused_fwd_d) stages its CSR slice whatever dg_form says, with the gather backward behind it
+  const bool csr = !fm.dense || F > DG_AF_MAX_F || (flags & DGCNN_FLAG_FORCE_FUSED) != 0;
   A->rowptr = csr ? dg_ptr<int32_t>(ws, wl.rowptr) : nullptr;
   A->colidx = csr && E > 0 ? dg_ptr<int32_t>(ws, wl.colidx) : nullptr;
   A->dinv = dg_ptr<float>(ws, wl.dinv); A->xs = dg_ptr<float>(ws, wl.hsA); A->x = x; A->batch = batch; A->y = ds->y ? y : nullptr;

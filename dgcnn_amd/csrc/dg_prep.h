@@ -4,7 +4,6 @@
 // each; the pipelined training step uses that idle capacity to prepare the NEXT batch's graph structure
 // (extra workgroups appended to the grid; same stream, so ordering is trivially safe).
 #pragma once
-#pragma once
 #include "dg_common.h"
 
 // batch assembly from a prepared dataset (dg_assemble.h: SURVEY N3) -- descriptor of one batch

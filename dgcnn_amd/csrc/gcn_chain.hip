@@ -2298,15 +2298,24 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   // phase-B workgroups then wait beside running phase-A workgroups and both phases are over long before the graph workgroups are.
   // With more workgroups than CUs the riders only start when graph workgroups end, and two dependent phases at the launch's tail
   // cost more than phase B costs k_wgrad (measured at 128 / 256 graphs: 55 / 101 us per step against 44 / 56).
-  static int cus[64];
+  static std::atomic<int> cus[64];      // compute units per device (0: not asked yet; the query is idempotent)
   const int dev = DgPerDeviceOnce::current();
-  if (cus[dev] == 0) { int v = 0; cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 1; }
+  int ncu = cus[dev].load(std::memory_order_relaxed);
+  if (ncu == 0) {
+    int v = 0;
+    ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 1;
+    cus[dev].store(ncu, std::memory_order_relaxed);
+  }
   const int na2 = (rd.nblk + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS, nb2 = (rd.nblk_b + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS;
+  unsigned int sync_prev = 0; bool sync_moved = false;
   if (fused_b_out && rd.mode == 0 && rd.nblk > 0 && rd.nblk_b > 0 && rd.sync_ctr && rd.sync_host && !rd.dmap &&
-      B + na2 + nb2 <= cus[dev] - 8) {
+      B + na2 + nb2 <= ncu - 8) {
     rd.nblk = na2;                       // (every rider thread takes CH_RIDER_ITEMS items of its phase)
     rd.fused_b = nb2;
-    *rd.sync_host += (unsigned int)rd.nblk;
+    // the host mirror of the phase-A counter moves with the launch: rolled back below if the launch fails (it would otherwise
+    // stay ahead of the device counter for the pipeline's life and every later phase-B workgroup would spin out its bound)
+    sync_prev = *rd.sync_host; sync_moved = true;
+    *rd.sync_host = sync_prev + (unsigned int)rd.nblk;
     rd.sync_target = *rd.sync_host;
     *fused_b_out = rd.fused_b;
   }
@@ -2327,7 +2336,10 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   if (bf16) { if (F <= 8) CH_LT(1, 4, true); else if (F <= 16) CH_LT(2, 4, true); else CH_LT(4, 8, true); }
   else { if (F <= 8) CH_LT(1, 4, false); else if (F <= 16) CH_LT(2, 4, false); else CH_LT(4, 8, false); }
 #undef CH_LT
-  DG_CHECK_LAUNCH();
+  if (hipGetLastError() != hipSuccess) {
+    if (sync_moved) { *rd.sync_host = sync_prev; if (fused_b_out) *fused_b_out = 0; }
+    return DGCNN_ELAUNCH;
+  }
   return DGCNN_OK;
 }
 

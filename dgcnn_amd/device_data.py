@@ -120,7 +120,7 @@ class PreparedBatch:
     :class:`dgcnn_amd.batch.Batch` except ``edge_index`` (None: the point is that no edge list exists)."""
 
     __slots__ = ("x", "edge_index", "batch", "y", "num_graphs", "coalesced_undirected", "max_nodes", "max_edges",
-                 "num_nodes", "num_edges", "dataset", "ids_ptr", "onode_ptr", "oedge_ptr", "_keep")
+                 "num_nodes", "num_edges", "dataset", "ids_ptr", "onode_ptr", "oedge_ptr", "mode_flags", "_keep")
 
     def __init__(self, dataset, x, batch, y, B, N, E, max_nodes, max_edges, ids_ptr, onode_ptr, oedge_ptr, keep=None):
         self.dataset = dataset
@@ -129,6 +129,8 @@ class PreparedBatch:
         self.coalesced_undirected = True
         self.max_nodes, self.max_edges = int(max_nodes), int(max_edges)
         self.ids_ptr, self.onode_ptr, self.oedge_ptr = int(ids_ptr), int(onode_ptr), int(oedge_ptr)
+        # a dataset prepared WITHOUT bitmap rows: its batches stay on the CSR kernels whatever their size would admit
+        self.mode_flags = 0 if getattr(dataset, "adj_bits", None) is not None else (_lib.FLAG_AGG_SPARSE | _lib.FLAG_NO_CHAIN)
         self._keep = keep
 
     def to(self, device, non_blocking: bool = False) -> "PreparedBatch":
@@ -148,9 +150,18 @@ class PreparedDataset(DeviceDataset):
     ``remove_self_loops`` (model.py:28) and the four ``gcn_norm`` calls inside the GCNConv layers (model.py:30-33).
     Needs coalesced undirected graphs (TU dataset files are); raises otherwise -- general edge lists stay on
     :class:`DeviceDataset`.  ``keep_edge_lists=False`` frees the int64 edge lists after preparation (nothing reads them
-    on the prepared path; ``assemble`` -- the per-batch path -- needs them)."""
+    on the prepared path; ``assemble`` -- the per-batch path -- needs them).
 
-    def __init__(self, graphs: Sequence[Graph], device="cuda", keep_edge_lists: bool = True):
+    ``bitmap``: the class-strided adjacency bitmap (31 words = 124 B per dataset node) only serves batches whose graphs all
+    have at most 512 nodes (the dense / chain kernel families).  ``None`` (default) builds it unless more than
+    ``BITMAP_SKIP_FRACTION`` of the graphs exceed that bound -- DD-like sets, where practically no batch is admissible and the
+    rows would be dead weight (41 MB for DD, hundreds of MB at REDDIT scale); ``True`` / ``False`` decide explicitly.  Without
+    it every batch carries ``mode_flags`` that keep it on the CSR kernels."""
+
+    BITMAP_MAX_NODES = 512
+    BITMAP_SKIP_FRACTION = 0.05
+
+    def __init__(self, graphs: Sequence[Graph], device="cuda", keep_edge_lists: bool = True, bitmap: Optional[bool] = None):
         super().__init__(graphs, device)
         if not self.coalesced_undirected or self.total_edges <= 0:
             raise _lib.DgcnnError("PreparedDataset needs coalesced undirected graphs with at least one edge "
@@ -162,11 +173,15 @@ class PreparedDataset(DeviceDataset):
         g_of_e = torch.repeat_interleave(gids, torch.from_numpy(self.edges_per_graph).to(dev))
         ei_global = (self.ei_all + self.node_ptr[g_of_e].unsqueeze(0)).contiguous()        # dataset-global node ids, one-time
         del g_of_e
+        if not keep_edge_lists:
+            self.ei_all = None              # (freed before the outputs are allocated: the peak is one copy of the edge list)
+        if bitmap is None:
+            bitmap = float((self.nodes_per_graph > self.BITMAP_MAX_NODES).mean()) <= self.BITMAP_SKIP_FRACTION
         self.rowptr = torch.empty(Nt + 1, dtype=torch.int32, device=dev)
         self.colidx = torch.empty(Et, dtype=torch.int32, device=dev)
         self.dinv = torch.empty(Nt, dtype=torch.float32, device=dev)
         self.xs = torch.empty(Nt * F, dtype=torch.float32, device=dev) if F <= 32 else None
-        self.adj_bits = torch.empty(int(L.dgcnn_dense_bitmap_words(Nt)), dtype=torch.int32, device=dev)
+        self.adj_bits = torch.empty(int(L.dgcnn_dense_bitmap_words(Nt)), dtype=torch.int32, device=dev) if bitmap else None
         scratch = torch.empty(2 * (G + 1), dtype=torch.int32, device=dev)
         err = torch.zeros(4, dtype=torch.int32, device=dev)
         d = _lib.Dataset()
@@ -174,7 +189,7 @@ class PreparedDataset(DeviceDataset):
         d.node_ptr, d.y, d.x = self.node_ptr.data_ptr(), self.y_all.data_ptr(), self.x_all.data_ptr()
         d.rowptr, d.colidx, d.dinv = self.rowptr.data_ptr(), self.colidx.data_ptr(), self.dinv.data_ptr()
         d.xs = self.xs.data_ptr() if self.xs is not None else None
-        d.adj_bits = self.adj_bits.data_ptr()
+        d.adj_bits = self.adj_bits.data_ptr() if self.adj_bits is not None else None
         self.desc = d
         self.desc_ref = _lib.ctypes.addressof(d)
         stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
@@ -187,8 +202,6 @@ class PreparedDataset(DeviceDataset):
             raise _lib.DgcnnError("PreparedDataset: the edge lists are not coalesced + undirected (sorted by (src,dst), no "
                                   "duplicates, no self loops, both directions present)")
         del ei_global, batch_all, scratch
-        if not keep_edge_lists:
-            self.ei_all = None
 
     def describe(self, ids: np.ndarray, out: dict, ids_ptr: int, onode_ptr: int, oedge_ptr: int, N: int, E: int,
                  max_nodes: int, max_edges: int, keep=None) -> PreparedBatch:

@@ -124,21 +124,29 @@ def _host_id() -> str:
 
 
 def _device_identity(device: torch.device) -> str:
-    """physical identity of ``device``: its uuid, else its PCI bus id -- NOT the local ordinal: ranks launched with their own
+    """physical identity of ``device``: uuid AND PCI address together -- NOT the local ordinal: ranks launched with their own
     HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES all see index 0, and different GPUs must not look like one device to the
-    same-device test that admits coarse-grained exchange memory"""
+    same-device test that admits coarse-grained exchange memory.  A uuid alone is not trusted: builds that report an all-zero
+    (or otherwise constant) uuid for every GPU would make distinct devices compare equal, so an all-zero uuid is dropped and
+    the PCI domain:bus:device is always part of the identity when the driver reports it; with neither, every rank counts as a
+    device of its own (coarse-grained memory is then refused across ranks)."""
+    import os
+    parts = []
     try:
         props = torch.cuda.get_device_properties(device)
-        for attr in ("uuid", "pci_bus_id"):
-            v = getattr(props, attr, None)
-            if v not in (None, "", 0):
-                dom = getattr(props, "pci_domain_id", 0)
-                return f"{attr}:{dom}:{v}" if attr == "pci_bus_id" else f"uuid:{v}"
+        u = getattr(props, "uuid", None)
+        if u not in (None, "", 0):
+            us = str(u)
+            if any(ch not in "0-{} " for ch in us):          # something other than zeros and separators
+                parts.append(f"uuid:{us}")
+        bus = getattr(props, "pci_bus_id", None)
+        if bus is not None and not (bus == 0 and getattr(props, "pci_device_id", 0) == 0 and not parts):
+            parts.append(f"pci:{getattr(props, 'pci_domain_id', 0)}:{bus}:{getattr(props, 'pci_device_id', 0)}")
     except Exception:
-        pass
-    # no identity available: every rank counts as its own device (coarse-grained memory is then refused across ranks)
-    import os
-    return f"unknown:{_host_id()}:{os.getpid()}"
+        parts = []
+    if not parts:
+        return f"unknown:{_host_id()}:{os.getpid()}"
+    return "|".join(parts)
 
 
 class PeerExchange:

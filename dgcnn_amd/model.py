@@ -310,7 +310,9 @@ class Model(nn.Module):
 
     def _flags_of(self, data) -> int:
         f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
-        return f | self._mode_flags()
+        # ``mode_flags``: a form restriction that belongs to the DATA (a PreparedDataset built without bitmap rows hands out
+        # batches that must stay on the CSR kernels: device_data.PreparedBatch)
+        return f | int(getattr(data, "mode_flags", 0) or 0) | self._mode_flags()
 
     def _max_nodes_of(self, data) -> int:
         """per-graph node bound (host-known hint) for the graph-per-workgroup path"""
@@ -341,15 +343,14 @@ class Model(nn.Module):
         """the four epoch-tagged error words of ONE workspace, already on the host (``Trainer.read_metrics`` fetches the words
         of both of its workspace slots together with the metrics in a single device-to-host copy)"""
         u = [v & 0xFFFFFFFF for v in words]
-        if True:
-            for k, msg in ((0, "edge_index holds a node id outside [0, N)"),
-                           (1, "a host-side promise about the batch does not hold: coalesced_undirected "
-                               "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
-                               "present), max_nodes (too small), or block-diagonality (an edge leaves its "
-                               "graph) -- the forward result of this batch is invalid")):
-                e = u[k]
-                if e != 0 and u[k + 2] == ((~e) & 0xFFFFFFFF) and (since < e <= now or (now < since and (e > since or e <= now))):
-                    raise _lib.DgcnnError(msg)
+        for k, msg in ((0, "edge_index holds a node id outside [0, N)"),
+                       (1, "a host-side promise about the batch does not hold: coalesced_undirected "
+                           "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
+                           "present), max_nodes (too small), or block-diagonality (an edge leaves its "
+                           "graph) -- the forward result of this batch is invalid")):
+            e = u[k]
+            if e != 0 and u[k + 2] == ((~e) & 0xFFFFFFFF) and (since < e <= now or (now < since and (e > since or e <= now))):
+                raise _lib.DgcnnError(msg)
 
     @staticmethod
     def _check_inputs(x, edge_index, batch):

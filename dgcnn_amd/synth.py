@@ -59,6 +59,9 @@ SHAPES: Dict[str, Shape] = {
     # DD-shape: n = clip(round(LogN(ln 240, 0.6)), 30, 5748), deg 5, F=90 (one-hot 89 + deg), C=2
     "DD": Shape("DD", 90, 2, 0, 89, 5.0,
                 lambda r: _clip_round(r.lognormal(np.log(240.0), 0.6), 30, 5748)),
+    # NCI1-shape (not a BASELINE config; the one TU shape ABOVE the aggregate-first width with small graphs): F=38, C=2
+    "NCI1": Shape("NCI1", 38, 2, 0, 37, 2.16,
+                  lambda r: _clip_round(r.normal(30.0, 10.0), 8, 111)),
     # IMDB-B-shape (not a BASELINE config; used as an extra small case): F=1, C=2
     "IMDB": Shape("IMDB", 1, 2, 0, 0, 9.0,
                   lambda r: _clip_round(r.normal(20.0, 6.0), 12, 136)),

@@ -215,7 +215,8 @@ class Trainer:
         if len(self._args_cache) >= self.ARGS_CACHE_MAX:      # bounded: every entry keeps its batch's tensors alive
             self._args_cache.clear()
         ent = (data, y, a, need, (x, ei, bt, yy), (N, E, B, F, C), _lib.ctypes.byref(a), x.device,
-               _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0,
+               (_lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0)
+               | int(getattr(data, "mode_flags", 0) or 0),
                (data.x, data.edge_index, data.batch))
         self._args_cache[id(data)] = ent
         return ent

@@ -6,19 +6,32 @@ import torch
 from dgcnn_amd import dist as ddist
 
 
-def test_device_identity_prefers_uuid_then_pci_bus_id_never_the_ordinal(monkeypatch):
+def test_device_identity_combines_uuid_and_pci_address_never_the_ordinal(monkeypatch):
     """ranks launched with their own HIP_VISIBLE_DEVICES all see ordinal 0: the same-device test of the one-shot exchange must
-    compare physical identities"""
-    props = types.SimpleNamespace(uuid="GPU-1234", pci_bus_id=7, pci_domain_id=0)
+    compare physical identities; an all-zero uuid is not an identity and the PCI address is always part of it
+    (builds that report one constant uuid for every GPU)"""
+    dev = torch.device("cuda", 0)
+    props = types.SimpleNamespace(uuid="GPU-1234", pci_bus_id=7, pci_domain_id=0, pci_device_id=0)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props)
-    assert ddist._device_identity(torch.device("cuda", 0)) == "uuid:GPU-1234"
+    a0 = ddist._device_identity(dev)
+    assert "uuid:GPU-1234" in a0 and "pci:0:7:0" in a0
+    props_b = types.SimpleNamespace(uuid="GPU-1234", pci_bus_id=9, pci_domain_id=0, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props_b)
+    assert ddist._device_identity(dev) != a0                              # one constant uuid, another bus: another device
+    zero = types.SimpleNamespace(uuid="00000000-0000-0000-0000-000000000000", pci_bus_id=7, pci_domain_id=1, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: zero)
+    z = ddist._device_identity(dev)
+    assert "uuid" not in z and z == "pci:1:7:0"
     props2 = types.SimpleNamespace(pci_bus_id=7, pci_domain_id=1)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props2)
-    a = ddist._device_identity(torch.device("cuda", 0))
-    assert a == "pci_bus_id:1:7"
+    a = ddist._device_identity(dev)
+    assert a == "pci:1:7:0"
     props3 = types.SimpleNamespace(pci_bus_id=9, pci_domain_id=1)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props3)
-    assert ddist._device_identity(torch.device("cuda", 0)) != a          # same ordinal, another bus: another device
+    assert ddist._device_identity(dev) != a                               # same ordinal, another bus: another device
+    nothing = types.SimpleNamespace(uuid="00000000-0000-0000-0000-000000000000")
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: nothing)
+    assert ddist._device_identity(dev).startswith("unknown:")            # zero uuid and no PCI address: no identity
 
     def boom(d):
         raise RuntimeError("no device")

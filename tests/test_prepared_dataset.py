@@ -31,7 +31,7 @@ def test_assembled_batch_equals_per_batch_preparation_bit_for_bit(name, G, B, fo
     graphs = synth.make_graphs(name, G, start=300)
     if force:        # a graph above the 512-node bound of the bitmap forms: no bitmap rows for it, its batch takes the CSR kernels
         graphs[3] = synth.make_graphs(name, 1, start=9000, force_first_n=force)[0]
-    ds = PreparedDataset(graphs)
+    ds = PreparedDataset(graphs, bitmap=True)
     rng = np.random.default_rng(5)
     ids = rng.permutation(G)[:B]
     if force:
@@ -73,6 +73,79 @@ def test_assembled_batch_equals_per_batch_preparation_bit_for_bit(name, G, B, fo
         assert torch.equal(a, b), p
 
 
+MODES = [("NCI1", 90, 50, dict(agg_mode="dense")),                       # dense form, F > 32: conv1's backward is the gather kernel
+         ("NCI1", 90, 50, dict()),                                        # (the library's own choice for that shape)
+         ("COLLAB", 90, 50, dict(agg_mode="dense", use_fused=True)),      # forced graph-per-workgroup forward in the dense form
+         ("COLLAB", 90, 50, dict(use_fused=True)),                        # ... and in the CSR form
+         ("PROTEINS", 80, 40, dict(agg_mode="dense", use_chain=False))]   # dense per-layer kernels, F <= 32: the bitmap alone
+
+
+@pytest.mark.parametrize("name,G,B,mode", MODES, ids=[f"{c[0]}-{'-'.join(f'{k}={v}' for k, v in c[3].items()) or 'auto'}" for c in MODES])
+def test_assembled_batch_carries_every_structure_its_forced_form_reads(name, G, B, mode):
+    """forms in which a kernel reads the CSR although dg_form says dense (conv1's own backward above the
+    aggregate-first width; a forced graph-per-workgroup forward): the assembled batch must give the per-batch path's
+    log-probabilities and gradients bit for bit.  The workspace slot's CSR is wiped between the two runs so that a structure the
+    assembly skipped cannot be inherited from the per-batch run."""
+    from dgcnn_amd.device_data import PreparedDataset
+    sh = synth.SHAPES[name]
+    graphs = [g for g in synth.make_graphs(name, G, start=700) if g.num_nodes <= 256]
+    ds = PreparedDataset(graphs)
+    ids = np.random.default_rng(11).permutation(len(graphs))[:B]
+    ref_b = collate([graphs[i] for i in ids])
+    pb = ds.batch_of(ids)
+    m = make_model(sh.num_features, sh.num_classes)
+    for k, v in mode.items():
+        setattr(m, k, v)
+    res = []
+    for data in (ref_b.to("cuda"), pb):
+        m.eval()
+        with torch.no_grad():
+            lp = m(data).clone()
+        m.check_errors()
+        m.train(); m._seed_base, m._fwd_count = 5, 0
+        m.zero_grad(set_to_none=True)
+        out = m(data)
+        torch.nn.functional.nll_loss(out, data.y).backward()
+        m.check_errors()
+        res.append((lp, [p.grad.detach().clone() for p in m._param_list()]))
+        for name_ in ("rowptr", "colidx"):      # wipe the CSR of this workspace slot (zeros: wrong numbers, never a wild read)
+            m.last_workspace_view(name_).zero_()
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b, p in zip(res[0][1], res[1][1], m.state_dict().keys()):
+        assert torch.equal(a, b), p
+
+
+def test_dataset_of_large_graphs_skips_the_bitmap_and_keeps_its_batches_on_the_csr_kernels():
+    """DD-like sets (more than 5 % of the graphs above 512 nodes): no bitmap rows are built (124 B per dataset node of dead
+    weight), every batch carries the CSR-only mode flags -- also a batch whose graphs would all admit the bitmap forms -- and
+    equals the per-batch path restricted to the same kernels bit for bit"""
+    from dgcnn_amd.device_data import PreparedDataset
+    sh = synth.SHAPES["DD"]
+    graphs = synth.make_graphs("DD", 48, start=300)
+    assert np.mean([g.num_nodes > 512 for g in graphs]) > 0.05
+    ds = PreparedDataset(graphs)
+    assert ds.adj_bits is None
+    small = np.array([i for i, g in enumerate(graphs) if g.num_nodes <= 256][:8])
+    mixed = np.arange(10)
+    m = make_model(sh.num_features, sh.num_classes)
+    for ids in (small, mixed):
+        pb = ds.batch_of(ids)
+        assert pb.mode_flags == (_lib.FLAG_AGG_SPARSE | _lib.FLAG_NO_CHAIN)
+        ref_b = collate([graphs[i] for i in ids])
+        m.agg_mode, m.use_chain = "sparse", False
+        m.eval()
+        with torch.no_grad():
+            lp_ref = m(ref_b.to("cuda")).clone()
+        m.check_errors()
+        del m.__dict__["agg_mode"], m.__dict__["use_chain"]
+        with torch.no_grad():
+            lp = m(pb).clone()
+        m.check_errors()
+        assert torch.equal(lp, lp_ref)
+    with pytest.raises(_lib.DgcnnError):
+        PreparedDataset(graphs, bitmap=False).batch_of(small).to("cpu")
+
+
 TRAJ = [("COLLAB", 260, 50), ("MUTAG", 200, 50), ("PROTEINS", 150, 32), ("COLLAB", 1400, 300), ("COLLAB", 2600, 600),
         ("DD", 60, 10)]
 
@@ -91,7 +164,7 @@ def test_prepared_loader_trains_the_same_trajectory_as_the_per_batch_loader(name
     G = len(graphs)
     out = []
     for prepared in (False, True):
-        ds = PreparedDataset(graphs) if prepared else DeviceDataset(graphs)
+        ds = PreparedDataset(graphs, bitmap=True) if prepared else DeviceDataset(graphs)
         m = make_model(sh.num_features, sh.num_classes)
         m._seed_base, m._fwd_count = 9, 0
         tr = Trainer(m)
