@@ -1440,6 +1440,48 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
 #define CH_RIDER_ITEMS 2        // fused preparation (both phases in the training kernel's launch): work items per rider thread
 #endif
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
+// the rider range of a one-launch kernel (blocks >= B): phase A of the next batch's graph preparation (or its whole assembly from a
+// prepared dataset), and -- `rd.fused_b` -- phase B of the same batch behind it in the same launch.  Shared by the training kernel
+// and the evaluation kernel.
+__device__ __forceinline__ void ch_rider_block(int rb, const DgPrepRider& rd) {
+  if (rb < rd.nblk) {
+    if (rd.fused_b > 0) {
+      // phase A with agent-coherent stores of what phase B reads (dg_prep.h: no fence -- a release would write back this XCD's
+      // whole L2); __syncthreads() waits for every store of the workgroup (vmcnt(0)), then ONE relaxed increment publishes it
+#pragma unroll 1
+      for (int it = 0; it < CH_RIDER_ITEMS; ++it)      // (CH_RIDER_ITEMS items per thread: both phases' workgroups resident at once)
+        dg_rider_phase_a<true>((rb * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x, rd);
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(rd.sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      dg_rider_phase_a(rb * RD_THREADS + (int)threadIdx.x, rd);
+    }
+    return;
+  }
+  // phase B of the same batch in the same launch: wait until EVERY phase-A workgroup has published (bounded; they were all
+  // dispatched before this workgroup), then the body that otherwise rides on k_wgrad.  The LDS row buffer is this launch's
+  // dynamic LDS, which a rider workgroup does not use otherwise.
+  extern __shared__ __attribute__((aligned(16))) char rsm[];
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    // (relaxed polls and NO acquire fence: an acquire invalidates this XCD's L2, out of which the graph workgroups of the same
+    //  launch live -- one per phase-B workgroup made the launch 80 us instead of 36; phase B reads phase A's outputs by
+    //  agent-coherent loads instead)
+    while ((int)(__hip_atomic_load(rd.sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rd.sync_target) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1u << 23)) { rd.err[1] = rd.epoch; rd.err[3] = ~rd.epoch; break; }      // (never seen; the batch is flagged)
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < CH_RIDER_ITEMS; ++it) {
+    const int tb = ((rb - rd.nblk) * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x;
+    dg_prep_fast_b_body<RD_THREADS, true, true>(tb, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv,
+                                                rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0,
+                                                rd.max_nodes, reinterpret_cast<unsigned int*>(rsm));
+  }
+  // (no planning workgroup here: the launcher fuses only riders without an item table)
+}
 struct ChTail {
   unsigned int* err; unsigned int epoch;
   const float* W4; float* gas3; float* pa4; int P1;      // conv4's backward rides along when pa4 != null (P1 >= B rows)
@@ -1468,46 +1510,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
                      const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
                      float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChTail t,
                      unsigned long long* __restrict__ dbg, DgPrepRider rd) {
-  if ((int)blockIdx.x >= B) {
-    const int rb = (int)blockIdx.x - B;
-    if (rb < rd.nblk) {
-      if (rd.fused_b > 0) {
-        // phase A with agent-coherent stores of what phase B reads (dg_prep.h: no fence -- a release would write back this XCD's
-        // whole L2); __syncthreads() waits for every store of the workgroup (vmcnt(0)), then ONE relaxed increment publishes it
-#pragma unroll 1
-        for (int it = 0; it < CH_RIDER_ITEMS; ++it)      // (CH_RIDER_ITEMS items per thread: both phases' workgroups resident at once)
-          dg_rider_phase_a<true>((rb * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x, rd);
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(rd.sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        dg_rider_phase_a(rb * RD_THREADS + (int)threadIdx.x, rd);
-      }
-      return;
-    }
-    // phase B of the same batch in the same launch: wait until EVERY phase-A workgroup has published (bounded; they were all
-    // dispatched before this workgroup), then the body that otherwise rides on k_wgrad.  The LDS row buffer is this launch's
-    // dynamic LDS, which a rider workgroup does not use otherwise.
-    extern __shared__ __attribute__((aligned(16))) char rsm[];
-    if (threadIdx.x == 0) {
-      unsigned int spins = 0;
-      // (relaxed polls and NO acquire fence: an acquire invalidates this XCD's L2, out of which the graph workgroups of the same
-      //  launch live -- one per phase-B workgroup made the launch 80 us instead of 36; phase B reads phase A's outputs by
-      //  agent-coherent loads instead)
-      while ((int)(__hip_atomic_load(rd.sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rd.sync_target) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1u << 23)) { rd.err[1] = rd.epoch; rd.err[3] = ~rd.epoch; break; }      // (never seen; the batch is flagged)
-      }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int it = 0; it < CH_RIDER_ITEMS; ++it) {
-      const int tb = ((rb - rd.nblk) * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x;
-      dg_prep_fast_b_body<RD_THREADS, true, true>(tb, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv,
-                                                  rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0,
-                                                  rd.max_nodes, reinterpret_cast<unsigned int*>(rsm));
-    }
-    return;      // (no planning workgroup here: the launcher fuses only riders without an item table)
-  }
+  if ((int)blockIdx.x >= B) { ch_rider_block((int)blockIdx.x - B, rd); return; }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
   const int yb = (threadIdx.x < 64) ? (int)t.y[blockIdx.x] : 0;
   // this graph's node range, read ONCE (scalar loads; the three later phases re-read it behind their barriers: a scalar-memory

@@ -121,7 +121,8 @@ def test_dataset_of_large_graphs_skips_the_bitmap_and_keeps_its_batches_on_the_c
     equals the per-batch path restricted to the same kernels bit for bit"""
     from dgcnn_amd.device_data import PreparedDataset
     sh = synth.SHAPES["DD"]
-    graphs = synth.make_graphs("DD", 48, start=300)
+    graphs = synth.make_graphs("DD", 40, start=300)
+    graphs += [synth.make_graphs("DD", 1, start=9100 + k, force_first_n=560 + 40 * k)[0] for k in range(4)]
     assert np.mean([g.num_nodes > 512 for g in graphs]) > 0.05
     ds = PreparedDataset(graphs)
     assert ds.adj_bits is None
