@@ -625,9 +625,9 @@ def main():
         torch.cuda.synchronize(dev)
         n2 = max(args.steps, 100)
         t1 = time.perf_counter()
-        for i in range(n2):
+        for i in range(n2):      # the SAME pipelined call as the headline, exp_avg = NULL: forward + backward, no optimizer (like for like)
             b = batches[i % nb]
-            tr.forward_backward(b, b.y, global_batch=gb)
+            tr.pipelined_step(b, b.y, batches[(i + 1) % nb], None, gb, fuse_adam=False)
         torch.cuda.synchronize(dev)
         extra["fwd_bwd_only_graphs_per_s_rank0"] = round(n2 * Bavg / (time.perf_counter() - t1), 1)
 

@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 18
+ABI_VERSION = 19
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -24,6 +24,8 @@ FLAG_AGG_DENSE = 32       # use it whenever the batch admits it (coalesced_undir
 FLAG_CHAIN = 128          # graph-chain kernels (conv1..conv4 of a graph inside one workgroup) whenever admissible
 FLAG_NO_CHAIN = 256       # never
 FLAG_BF16 = 64            # bf16 leg: pre-scaled linear outputs stored bf16, X.W on the bf16 matrix cores
+
+FORM_DENSE, FORM_CHAIN, FORM_CHAIN_TAIL, FORM_STEP, FORM_EVAL = 1, 2, 4, 8, 16      # dgcnn_forward_form bits
 
 K = 30
 CAT = 97
@@ -63,7 +65,9 @@ SIGNATURES = {
     "dgcnn_pipeline_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "dgcnn_pipeline_destroy": (c_int, [c_void_p]),
     "dgcnn_pipeline_train_step": (c_int, [c_void_p, ctypes.POINTER(StepArgs), ctypes.POINTER(StepArgs), c_void_p]),
+    "dgcnn_pipeline_eval_step": (c_int, [c_void_p, ctypes.POINTER(StepArgs), ctypes.POINTER(StepArgs), c_void_p]),
     "dgcnn_version": (c_int, []),
+    "dgcnn_eval_kernel_enable": (c_int, [c_int]),
     "dgcnn_param_layout": (c_int64, [c_int, c_int, ctypes.POINTER(c_int64)]),
     "dgcnn_workspace_bytes": (c_int64, [c_int] * 5),
     "dgcnn_workspace_offset": (c_int64, [c_char_p] + [c_int] * 5),

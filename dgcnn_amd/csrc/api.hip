@@ -282,6 +282,13 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
   return G;
 }
 
+// one-launch evaluation / inference kernel (k_chain_readout_eval): every graph in the chain form, one workgroup per graph
+static int g_eval_kernel = 1;      // dgcnn_eval_kernel_enable (tests / measurement A-B): 0 keeps chain forward + readout as two launches
+int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on ? 1 : 0; return prev; }
+static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
+  return g_eval_kernel != 0 && f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
+         max_nodes <= dg_chain_train_max_nodes();
+}
 // DGCNN_STEP_KERNEL=0 in the environment: the one-launch training kernel stops after conv4's backward and conv3 / conv2 / conv1
 // run as the two gather launches (the round-3 form; measurement A/B and a second route for the tests)
 static int g_step_kernel = -1;
@@ -301,8 +308,10 @@ int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
   const bool chain_tail = f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
                           max_nodes <= dg_chain_train_max_nodes();
   const bool step = chain_tail && dg_step_kernel_enabled() && B <= dg_grid1(N) && B <= dg_grid32(N) && dg_wgrad_takes_rider(B);
+  // evaluation / inference (no labels-with-backward): chain forward + readout in one launch under the same admissibility
+  const bool eval1 = dg_eval_kernel_admits(f, B, max_nodes);
   return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0) |
-         (step ? DGCNN_FORM_STEP : 0);
+         (step ? DGCNN_FORM_STEP : 0) | (eval1 ? DGCNN_FORM_EVAL : 0);
 }
 
 int dgcnn_model_prepare(int N, int E, int B, int F, int C, const float* x, const int64_t* edge_index,
@@ -402,6 +411,10 @@ int dgcnn_dataset_prepare(const dgcnn_dataset* ds, const int64_t* edge_index_glo
 // *rode = 1 when it was attached).  tt != null (training step with labels): the readout forward and the readout
 // backward run as ONE launch when the batch allows it; *tail_done = 1 then tells the backward to skip its first launch.
 struct DgTrainTail { const int64_t* y; float loss_scale; };
+// evaluation with labels: the batch's loss sum / #correct go to the device accumulator `metrics` (train.py:63-64); done = 1 when
+// the forward's own launch folded them in (k_chain_readout_eval; needs the pipeline's counter `ctr` + its host mirror), else the
+// caller launches k_eval_metrics behind it
+struct DgEvalTail { const int64_t* y; float* metrics; float loss_scale; int done; unsigned int* ctr; unsigned int* ctr_host; };
 // Pipelined large-batch step: the point of the step's launch sequence at which the side stream's graph preparation of the NEXT
 // batch is forked (an event recorded on the caller's stream right behind launch `at`; dgcnn_pipeline_train_step sets and
 // clears the request around its forward / backward calls).  Points: 1 chain forward, 2 readout forward, 3 classifier,
@@ -419,7 +432,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                  const float* x, const int64_t* edge_index, const int64_t* batch,
                                  void* ws, float* logp, int training, uint64_t seed, int flags, int max_nodes,
                                  int max_edges, uint32_t epoch, dgcnn_stream_t stream, const DgPrepRider* rider_a,
-                                 int* rode, const DgTrainTail* tt = nullptr, int* tail_done = nullptr) {
+                                 int* rode, const DgTrainTail* tt = nullptr, int* tail_done = nullptr, DgEvalTail* et = nullptr) {
   if (!params || !x || !ws || !logp || N <= 0 || B <= 0 || E < 0 || epoch == 0) return DGCNN_EINVAL;
   if (!(flags & DGCNN_FLAG_PREPARED) && (!batch || (E > 0 && !edge_index))) return DGCNN_EINVAL;      // (a prepared batch's structures are in ws)
   DgParams pl; DgWs wl;
@@ -516,6 +529,25 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
     // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
     // pb2 / pb1 = graph b's partials: k_wgrad sums B rows)
     *tail_done = step_kernel ? 3 : (B <= wl.P1 ? 2 : 1);
+    if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
+    return DGCNN_OK;
+  }
+  if (chain && !(tt && tail_done) && dg_eval_kernel_admits(fm, B, max_nodes)) {
+    // evaluation / inference (and the drop-in route's forward: everything the backward reads is saved as by the two launches this
+    // replaces): chain forward + readout forward of every graph in ONE launch; with labels, the batch's metrics too
+    int fused_b = 0;
+    const bool in_launch = et && et->y && et->metrics && et->ctr && et->ctr_host;      // metrics folded in by the launch's last workgroup
+    DG_TRY(dg_launch_chain_readout_eval(N, B, F, C, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
+                                        dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, dg_ptr<float>(ws, wl.pooled),
+                                        dg_ptr<int32_t>(ws, wl.perm), dg_ptr<float>(ws, wl.a5), dg_ptr<float>(ws, wl.a6),
+                                        dg_ptr<float>(ws, wl.a1d), dg_ptr<uint8_t>(ws, wl.drop_mask), logp, training, seed,
+                                        in_launch ? et->y : nullptr, in_launch ? et->loss_scale : 0.f, dg_ptr<float>(ws, wl.lossv),
+                                        in_launch ? et->ctr : nullptr, in_launch ? et->ctr_host : nullptr,
+                                        in_launch ? et->metrics : nullptr, dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a,
+                                        g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr, bf16,
+                                        (rider_a && rode) ? &fused_b : nullptr));
+    g_prof_which = -1;
+    if (in_launch) et->done = 1;
     if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
     return DGCNN_OK;
   }
@@ -773,7 +805,22 @@ struct DgPipeline {
   // this device counter for the phase-A workgroups of the same launch (dg_prep.h).  Created at the first rider, freed with the pipeline.
   unsigned int* sync_ctr = nullptr;
   unsigned int sync_count = 0;
+  // evaluation steps in the one-launch form: counter of finished graph workgroups (the last one of a launch folds the batch's
+  // metrics into the accumulator); a line of its own in the same allocation, monotonic, `ev_count` = its value after every launch
+  // issued so far
+  unsigned int* ev_ctr = nullptr;
+  unsigned int ev_count = 0;
 };
+// the pipeline's device counters (one 128-byte allocation, zeroed once on `s`): false = not available (callers keep the forms
+// that need none)
+static bool dg_pipeline_counters(DgPipeline* h, hipStream_t s) {
+  if (h->sync_ctr) return true;
+  unsigned int* c = nullptr;
+  if (hipMalloc(&c, 128) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemsetAsync(c, 0, 128, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c); return false; }
+  h->sync_ctr = c; h->sync_count = 0; h->ev_ctr = c + 16; h->ev_count = 0;
+  return true;
+}
 // From this many graphs per step on the next batch's preparation leaves the rider slots of the step's launches for the side
 // stream.  Why: at 2048 COLLAB graphs every launch of the step fills the chip, so rider blocks are ADDED time (k_readout_fwd
 // 34 -> 59 us with phase A behind its graph workgroups, k_tail_bwd 35 -> 53 us with phase B), while most launches of the step
@@ -803,6 +850,53 @@ int dgcnn_pipeline_destroy(void* handle) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->sync_ctr) (void)hipFree(h->sync_ctr);
   delete h;
+  return DGCNN_OK;
+}
+
+// the next batch's preparation as rider workgroups of this step's launches (below the side-stream regime): its assembly from a
+// prepared dataset (ONE phase), or phases A and B of the graph preparation from its coalesced undirected edge list.
+// *rider = rd when there is something to ride, else nullptr (general edge lists: prepared in-stream behind the step).
+static int dg_pipeline_rider(DgPipeline* h, const dgcnn_step_args* next, bool side_prep, hipStream_t s, DgPrepRider& rd,
+                             const DgPrepRider** rider_out) {
+  const DgPrepRider* rider = nullptr;
+  if (!side_prep && next && next->ds) {
+    // the next batch comes from a prepared dataset: its whole assembly (a copy with offset adds, dg_assemble.h) rides where
+    // phase A of a per-batch preparation rides; there is no phase B.  (A batch that needs the planning workgroup -- a forced
+    // dense form below the side-stream regime -- is assembled in-stream after the step instead.)
+    int32_t* ndmap = nullptr;
+    DG_TRY(dg_fill_assemble(next->ds, next->ds_ids, next->ds_onode, next->ds_oedge, next->N, next->E, next->B, next->C, next->ws,
+                            const_cast<float*>(next->x), const_cast<int64_t*>(next->batch), const_cast<int64_t*>(next->y),
+                            next->flags, next->max_nodes, next->epoch, &rd.as, &ndmap));
+    if (!ndmap) {
+      rd.mode = 1;
+      rd.nblk = dg_cdiv(dg_assemble_work(next->N, next->E, next->B, rd.as.colidx != nullptr), 1024);
+      rd.nblk_b = 0;
+      rider = &rd;
+    }
+  } else if (!side_prep && next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
+    DgWs nl;
+    DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
+    rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
+    rd.rowptr = dg_ptr<int32_t>(next->ws, nl.rowptr); rd.colidx = dg_ptr<int32_t>(next->ws, nl.colidx);
+    rd.rowptr_t = nullptr; rd.colidx_t = nullptr;      // (riders exist for undirected edge lists only: dg_csr_symmetric)
+    rd.graph_ptr = dg_ptr<int32_t>(next->ws, nl.graph_ptr); rd.graph_eptr = dg_ptr<int32_t>(next->ws, nl.graph_eptr);
+    rd.dinv = dg_ptr<float>(next->ws, nl.dinv); rd.err = dg_ptr<unsigned int>(next->ws, nl.err);
+    const bool naf = next->F <= DG_AF_MAX_F;
+    rd.x = naf ? next->x : nullptr; rd.xs = naf ? dg_ptr<float>(next->ws, nl.hsA) : nullptr; rd.F = next->F;
+    rd.epoch = next->epoch;
+    const DgForm nf = dg_form(next->N, next->E, next->B, next->F, next->flags, next->max_nodes);
+    if (nf.bitmap) {
+      rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = nf.plan ? dg_ptr<int>(next->ws, nl.dmap) : nullptr;
+      rd.edge_check = nf.edge_check;
+      rd.max_nodes = next->max_nodes;
+    }
+    rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
+    rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);
+    (void)dg_pipeline_counters(h, s);      // (once per pipeline; a failure only means that phase B keeps riding on k_wgrad)
+    rd.sync_ctr = h->sync_ctr; rd.sync_host = h->sync_ctr ? &h->sync_count : nullptr;
+    rider = &rd;
+  }
+  *rider_out = rider;
   return DGCNN_OK;
 }
 
@@ -856,49 +950,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
     DG_TRY(dg_assemble_args(cur, flags, epoch, s));
     flags |= DGCNN_FLAG_PREPARED;
   }
-  if (!side_prep && next && next->ds) {
-    // the next batch comes from a prepared dataset: its whole assembly (a copy with offset adds, dg_assemble.h) rides where
-    // phase A of a per-batch preparation rides; there is no phase B.  (A batch that needs the planning workgroup -- a forced
-    // dense form below the side-stream regime -- is assembled in-stream after the step instead.)
-    int32_t* ndmap = nullptr;
-    DG_TRY(dg_fill_assemble(next->ds, next->ds_ids, next->ds_onode, next->ds_oedge, next->N, next->E, next->B, next->C, next->ws,
-                            const_cast<float*>(next->x), const_cast<int64_t*>(next->batch), const_cast<int64_t*>(next->y),
-                            next->flags, next->max_nodes, next->epoch, &rd.as, &ndmap));
-    if (!ndmap) {
-      rd.mode = 1;
-      rd.nblk = dg_cdiv(dg_assemble_work(next->N, next->E, next->B, rd.as.colidx != nullptr), 1024);
-      rd.nblk_b = 0;
-      rider = &rd;
-    }
-  } else if (!side_prep && next && (next->flags & DGCNN_FLAG_COALESCED_UNDIRECTED) && next->E > 0) {
-    DgWs nl;
-    DG_TRY(dg_ws_layout(next->N, next->E, next->B, next->F, next->C, &nl));
-    rd.ei = next->edge_index; rd.batch = next->batch; rd.E = next->E; rd.N = next->N; rd.B = next->B;
-    rd.rowptr = dg_ptr<int32_t>(next->ws, nl.rowptr); rd.colidx = dg_ptr<int32_t>(next->ws, nl.colidx);
-    rd.rowptr_t = nullptr; rd.colidx_t = nullptr;      // (riders exist for undirected edge lists only: dg_csr_symmetric)
-    rd.graph_ptr = dg_ptr<int32_t>(next->ws, nl.graph_ptr); rd.graph_eptr = dg_ptr<int32_t>(next->ws, nl.graph_eptr);
-    rd.dinv = dg_ptr<float>(next->ws, nl.dinv); rd.err = dg_ptr<unsigned int>(next->ws, nl.err);
-    const bool naf = next->F <= DG_AF_MAX_F;
-    rd.x = naf ? next->x : nullptr; rd.xs = naf ? dg_ptr<float>(next->ws, nl.hsA) : nullptr; rd.F = next->F;
-    rd.epoch = next->epoch;
-    const DgForm nf = dg_form(next->N, next->E, next->B, next->F, next->flags, next->max_nodes);
-    if (nf.bitmap) {
-      rd.bits = dg_ptr<unsigned int>(next->ws, nl.adjbits); rd.dmap = nf.plan ? dg_ptr<int>(next->ws, nl.dmap) : nullptr;
-      rd.edge_check = nf.edge_check;
-      rd.max_nodes = next->max_nodes;
-    }
-    rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
-    rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);
-    if (!h->sync_ctr) {      // (once per pipeline; a failure only means that phase B keeps riding on k_wgrad)
-      unsigned int* c = nullptr;
-      if (hipMalloc(&c, 64) == hipSuccess) {
-        if (hipMemsetAsync(c, 0, 64, s) == hipSuccess) { h->sync_ctr = c; h->sync_count = 0; }
-        else { (void)hipGetLastError(); (void)hipFree(c); }
-      } else (void)hipGetLastError();
-    }
-    rd.sync_ctr = h->sync_ctr; rd.sync_host = h->sync_ctr ? &h->sync_count : nullptr;
-    rider = &rd;
-  }
+  DG_TRY(dg_pipeline_rider(h, next, side_prep, s, rd, &rider));
   int rode = 0, tail_done = 0;
   DgTrainTail tt;
   tt.y = cur->y; tt.loss_scale = cur->loss_scale;
@@ -960,6 +1012,61 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   return DGCNN_OK;
 }
 
+int dgcnn_pipeline_eval_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next, dgcnn_stream_t stream) {
+  if (!handle || !cur) return DGCNN_EINVAL;
+  DgPipeline* h = static_cast<DgPipeline*>(handle);
+  hipStream_t s = (hipStream_t)stream;
+  if (!cur->params || !cur->x || (!cur->batch && !cur->ds) || !cur->ws || !cur->logp || cur->N <= 0 || cur->B <= 0 || cur->E < 0 ||
+      cur->epoch == 0)
+    return DGCNN_EINVAL;
+  if (next && (next->ws == cur->ws || !next->ws || (!next->batch && !next->ds) || !next->x || next->N <= 0 || next->B <= 0 ||
+               next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index && !next->ds)))
+    return DGCNN_EINVAL;
+  const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B && h->pmaxn == cur->max_nodes;
+  const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;
+  if (prepared && !match) return DGCNN_EINVAL;
+  int flags = cur->flags & 0xFFFF;
+  uint32_t epoch = cur->epoch;
+  if (prepared) {
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED));
+    epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
+  }
+  h->prep_ws = nullptr;
+  if (cur->ds && !prepared) {        // first batch of a loop drawn from a prepared dataset: assemble in-stream, then run as prepared
+    DG_TRY(dg_assemble_args(cur, flags, epoch, s));
+    flags |= DGCNN_FLAG_PREPARED;
+  }
+  // riders below the regime where every launch fills the chip (there the next batch is prepared in-stream behind the forward:
+  // an evaluation loop has no backward under which a side stream's preparation could hide)
+  DgPrepRider rd{};
+  const DgPrepRider* rider = nullptr;
+  DG_TRY(dg_pipeline_rider(h, next, cur->B >= DG_SIDE_PREP_MIN_B, s, rd, &rider));
+  int rode = 0;
+  const bool with_metrics = cur->y && cur->metrics;
+  DgEvalTail et{cur->y, cur->metrics, cur->loss_scale, 0, nullptr, nullptr};
+  if (with_metrics && dg_pipeline_counters(h, s)) { et.ctr = h->ev_ctr; et.ctr_host = &h->ev_count; }
+  DG_TRY(dg_model_forward_impl(cur->N, cur->E, cur->B, cur->F, cur->C, cur->params, cur->x, cur->edge_index, cur->batch, cur->ws,
+                               cur->logp, 0, 0, flags, cur->max_nodes, cur->max_edges, epoch, stream, rider, &rode, nullptr, nullptr,
+                               with_metrics ? &et : nullptr));
+  if (with_metrics && !et.done) DG_TRY(dg_launch_eval_metrics(cur->B, cur->C, cur->logp, cur->y, cur->metrics, cur->loss_scale, s));
+  if (next) {
+    if (rode && rd.mode == 0) {
+      if (rode == 1) DG_TRY(dg_launch_prep_phase_b(&rd, s));          // (rode == 2: phase B ran inside the forward's launch)
+      if (rd.bits && !rd.edge_check)      // dense next batch: its reverse-edge check on the bitmap just built
+        DG_TRY(dg_launch_prep_sym(next->edge_index, next->E, next->N, next->B, next->batch, rd.graph_ptr, rd.bits,
+                                  reinterpret_cast<int32_t*>(rd.err), rd.epoch, s));
+    } else if (!rode) {
+      if (next->ds) DG_TRY(dg_assemble_args(next, next->flags, next->epoch, s));
+      else
+      DG_TRY(dgcnn_model_prepare(next->N, next->E, next->B, next->F, next->C, next->x, next->edge_index, next->batch, next->ws,
+                                 next->flags, next->max_nodes, next->epoch, stream));
+    }
+    h->prep_ws = next->ws; h->pN = next->N; h->pE = next->E; h->pB = next->B; h->pflags = next->flags;
+    h->pepoch = next->epoch; h->pmaxn = next->max_nodes;
+  }
+  return DGCNN_OK;
+}
+
 int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream) {
   if (!a || !a->params || !a->x || (!a->batch && !a->ds) || !a->ws || !a->logp || a->N <= 0 || a->B <= 0 || a->E < 0 || a->epoch == 0)
     return DGCNN_EINVAL;
@@ -968,9 +1075,12 @@ int dgcnn_model_eval_step(const dgcnn_step_args* a, dgcnn_stream_t stream) {
     DG_TRY(dg_assemble_args(a, eflags, a->epoch, (hipStream_t)stream));
     eflags |= DGCNN_FLAG_PREPARED;
   }
+  DgEvalTail et{a->y, a->metrics, a->loss_scale, 0, nullptr, nullptr};      // (no pipeline, no counter: k_eval_metrics behind the forward)
+  const bool with_metrics = a->y && a->metrics;
   DG_TRY(dg_model_forward_impl(a->N, a->E, a->B, a->F, a->C, a->params, a->x, a->edge_index, a->batch, a->ws, a->logp, 0, 0,
-                               eflags, a->max_nodes, a->max_edges, a->epoch, stream, nullptr, nullptr));
-  if (a->y && a->metrics)
+                               eflags, a->max_nodes, a->max_edges, a->epoch, stream, nullptr, nullptr, nullptr, nullptr,
+                               with_metrics ? &et : nullptr));
+  if (with_metrics && !et.done)
     DG_TRY(dg_launch_eval_metrics(a->B, a->C, a->logp, a->y, a->metrics, a->loss_scale, (hipStream_t)stream));
   return DGCNN_OK;
 }

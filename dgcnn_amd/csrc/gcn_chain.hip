@@ -1608,6 +1608,89 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
 }
 
 // =================================================================================================================
+// Evaluation / inference of a SMALL batch in ONE launch (round 5): the forward half of the training kernel above -- graph-chain
+// forward + readout forward of a graph on the same 1024 threads -- without any backward, partial rows or gradient hand-over.
+// This is the reference's test() loop body (/root/reference/train.py:57-64) and plain Model.forward (model.py:26-45).
+// Rider range as in training (the next batch's graph preparation, both phases when the grid is resident).
+// Metrics (train.py:63-64: loss sum and #correct of the batch), when labels AND a counter are given (the pipeline object owns
+// one: dgcnn_pipeline_eval_step): wave 0 of a graph's workgroup publishes its {logp[y], argmax == y} pair by an agent-coherent
+// store and adds one to the counter -- monotonic over the pipeline's life, the host passes the value it reaches with this
+// launch's last graph --; the LAST one to arrive sums the B pairs in k_eval_metrics' fixed order (tail.hip: 256 threads x
+// stride 256, then a binary tree) and adds them to the device accumulator -- the same additions in the same order as the
+// separate launch it replaces; nobody spins, nothing is fenced, no other wave waits.  (First form: an epoch-tagged 64-bit word
+// in the workspace bumped by compare-and-swap -- 50 workgroups retrying on one address made the launch 34 us whatever the graphs.)
+// =================================================================================================================
+struct ChEval {
+  unsigned int* err; unsigned int epoch;
+  int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
+  const int64_t* y; float* evl; unsigned int* ctr; unsigned int target; float* metrics; float scale;      // y == null: no metrics
+};
+template <int XI, int W1S, bool BF = false>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits,
+                     const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
+                     float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChEval t,
+                     unsigned long long* __restrict__ dbg, DgPrepRider rd) {
+  if ((int)blockIdx.x >= B) { ch_rider_block((int)blockIdx.x - B, rd); return; }
+  using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
+  const int b = blockIdx.x;
+  // (label and node range read once, up front: scalar / early loads, consumed behind the chain)
+  const int yraw = (t.y && threadIdx.x < 64) ? (int)t.y[b] : 0;
+  const int gn0 = graph_ptr[b], gn = graph_ptr[b + 1] - gn0;
+  if (threadIdx.x == 0 && gn > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* keys_lds = reinterpret_cast<float*>(smem + C::OFF_DV) + C::ROWS;      // (second parity set of the dinv array, as in training)
+  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN, BF>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4,
+                                                       nullptr, keys_lds);
+  __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
+  const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
+  dg_readout_fwd_body(M, b, gn0, gn, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
+                      t.training, t.seed, dbg);
+  if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
+  if (!t.y || threadIdx.x >= 64) return;      // (waves 1..15 are done; wave 0 wrote the log-probabilities (M.lg) itself: program order)
+  // ---- metrics: this graph's pair, then the last workgroup's fixed-order sum -- wave 0 only, no barrier -------------------------
+  const int lane = threadIdx.x;
+  {
+    const float v = lane < t.C ? M.lg[lane] : -INFINITY;
+    float mx = v;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const unsigned long long at = __builtin_amdgcn_ballot_w64(lane < t.C && v == mx);
+    const int am = at ? (int)__builtin_ctzll(at) : 0;      // first index of the maximum, as k_eval_metrics' scan
+    const bool ybad = (unsigned)yraw >= (unsigned)t.C;     // out-of-range label: NaN loss (sticky), no out-of-bounds read
+    const int yb = ybad ? 0 : yraw;
+    const float l = ybad ? __builtin_nanf("") : M.lg[yb];
+    if (lane == 0) {
+      __hip_atomic_store(t.evl + 2 * b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(t.evl + 2 * b + 1, (am == yb) ? 1.f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // (the pair is written through before the counter moves: vmcnt(0), no fence -- a release would write back this XCD's whole L2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
+  if (dbg && blockIdx.x == 0 && lane == 0) dbg[17] = clock64();
+  if (old + 1u != t.target) return;
+  // last workgroup: k_eval_metrics' sums (tail.hip: virtual thread v takes graphs v, v + 256, ... -- at most one here, B <= 256 --,
+  // then the binary tree 128, 64, ..., 1) with virtual threads l, l + 64, l + 128, l + 192 in lane l: the same additions
+  float sl[4], sc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int g = lane + 64 * q, gc = min(g, B - 1);
+    const float lv = __hip_atomic_load(t.evl + 2 * gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float cv = __hip_atomic_load(t.evl + 2 * gc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sl[q] = g < B ? 0.f - lv : 0.f;
+    sc[q] = g < B ? 0.f + cv : 0.f;
+  }
+  sl[0] += sl[2]; sl[1] += sl[3]; sc[0] += sc[2]; sc[1] += sc[3];      // st = 128
+  sl[0] += sl[1]; sc[0] += sc[1];                                      // st = 64
+  for (int st = 32; st >= 1; st >>= 1) { sl[0] += __shfl_down(sl[0], st); sc[0] += __shfl_down(sc[0], st); }
+  if (lane == 0) { t.metrics[0] += sl[0] * t.scale; t.metrics[1] += sc[0]; }
+}
+
+// =================================================================================================================
 // BACKWARD chain, conv4 and conv3 of a graph in one workgroup (replaces k_gcn_bwd1* and the layer-3 k_gcn_bwd32*):
 //   gh4[j]  = dinv[j] * sum_{i in N(j)+j} gas4[i]                       block product, ONE column (three bf16 parts as three
 //                                                                       columns of one B operand, as in the forward's conv4)
@@ -2264,6 +2347,18 @@ int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph
   return DGCNN_OK;
 }
 
+// compute units of the calling thread's device (asked once per device; the query is idempotent)
+static int dg_device_cus() {
+  static std::atomic<int> cus[64];
+  const int dev = DgPerDeviceOnce::current();
+  int ncu = cus[dev].load(std::memory_order_relaxed);
+  if (ncu == 0) {
+    int v = 0;
+    ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 1;
+    cus[dev].store(ncu, std::memory_order_relaxed);
+  }
+  return ncu;
+}
 int dg_chain_train_max_b() { return CH_ONESHOT_MAX_B; }
 int dg_chain_train_max_nodes() { return CH_TRAIN_MAXN; }
 
@@ -2301,14 +2396,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   // phase-B workgroups then wait beside running phase-A workgroups and both phases are over long before the graph workgroups are.
   // With more workgroups than CUs the riders only start when graph workgroups end, and two dependent phases at the launch's tail
   // cost more than phase B costs k_wgrad (measured at 128 / 256 graphs: 55 / 101 us per step against 44 / 56).
-  static std::atomic<int> cus[64];      // compute units per device (0: not asked yet; the query is idempotent)
-  const int dev = DgPerDeviceOnce::current();
-  int ncu = cus[dev].load(std::memory_order_relaxed);
-  if (ncu == 0) {
-    int v = 0;
-    ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 1;
-    cus[dev].store(ncu, std::memory_order_relaxed);
-  }
+  const int ncu = dg_device_cus();
   const int na2 = (rd.nblk + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS, nb2 = (rd.nblk_b + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS;
   unsigned int sync_prev = 0; bool sync_moved = false;
   if (fused_b_out && rd.mode == 0 && rd.nblk > 0 && rd.nblk_b > 0 && rd.sync_ctr && rd.sync_host && !rd.dmap &&
@@ -2341,6 +2429,70 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
 #undef CH_LT
   if (hipGetLastError() != hipSuccess) {
     if (sync_moved) { *rd.sync_host = sync_prev; if (fused_b_out) *fused_b_out = 0; }
+    return DGCNN_ELAUNCH;
+  }
+  return DGCNN_OK;
+}
+
+// chain forward + readout forward (+ metrics) of a small batch in one launch: evaluation / inference (round 5).  `rider` as in
+// dg_launch_chain_readout_tail (*fused_b_out > 0: phase B of the rider joined the launch).  y == null: no metrics.
+// evl [B][2] floats: workspace scratch of the metrics hand-over; ev_ctr / ev_host: the pipeline's device counter and its host mirror.
+int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
+                                 const float* xs, const float* params, const DgParams* pl, float* ax, float* x1, float* x2, float* x3,
+                                 float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d, uint8_t* drop_mask,
+                                 float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* evl,
+                                 unsigned int* ev_ctr, unsigned int* ev_host, float* metrics, int32_t* err, uint32_t epoch,
+                                 hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, int bf16,
+                                 int* fused_b_out) {
+  if (fused_b_out) *fused_b_out = 0;
+  if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
+      !dinv || !xs || (y && (!evl || !ev_ctr || !ev_host || !metrics)))
+    return DGCNN_EINVAL;
+  ChW gw;
+  gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
+  gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
+  ChEval t;
+  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
+  t.C = C; t.w = dg_tail_w(params, pl); t.pooled = pooled; t.perm = perm; t.a5g = a5; t.a6g = a6; t.a1dg = a1d; t.maskg = drop_mask;
+  t.logp = logp; t.training = training; t.seed = seed; t.y = y; t.evl = evl; t.ctr = ev_ctr; t.metrics = metrics;
+  t.scale = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;          // (as dg_launch_eval_metrics)
+  // the host mirror of the metrics counter moves with the launch (rolled back below if the launch fails)
+  const unsigned int ev_prev = y ? *ev_host : 0u;
+  if (y) { *ev_host = ev_prev + (unsigned int)B; t.target = *ev_host; } else t.target = 0u;
+  DgPrepRider rd{};
+  if (rider) rd = *rider;
+  rd.fused_b = 0;
+  const int ncu = dg_device_cus();
+  const int na2 = (rd.nblk + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS, nb2 = (rd.nblk_b + CH_RIDER_ITEMS - 1) / CH_RIDER_ITEMS;
+  unsigned int sync_prev = 0; bool sync_moved = false;
+  if (fused_b_out && rd.mode == 0 && rd.nblk > 0 && rd.nblk_b > 0 && rd.sync_ctr && rd.sync_host && !rd.dmap &&
+      B + na2 + nb2 <= ncu - 8) {      // (the whole grid resident from the start: see dg_launch_chain_readout_tail)
+    rd.nblk = na2;
+    rd.fused_b = nb2;
+    sync_prev = *rd.sync_host; sync_moved = true;
+    *rd.sync_host = sync_prev + (unsigned int)rd.nblk;
+    rd.sync_target = *rd.sync_host;
+    *fused_b_out = rd.fused_b;
+  }
+  static_assert(ChQ<16, 4, CH_TRAIN_MAXN>::TOTAL >= RD_THREADS * 8, "a rider workgroup's row buffer inside the launch's dynamic LDS");
+  static DgPerDeviceOnce attr_once;
+  if (attr_once.needed()) {
+#define CH_ATTR3(XI, WS, BFV) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_eval<XI, WS, BFV>), \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL) != hipSuccess)
+    if (CH_ATTR3(1, 4, false) || CH_ATTR3(2, 4, false) || CH_ATTR3(4, 8, false) || CH_ATTR3(1, 4, true) || CH_ATTR3(2, 4, true) ||
+        CH_ATTR3(4, 8, true))
+      return DGCNN_ELAUNCH;
+    attr_once.done();
+  }
+#define CH_LE(XI, WS, BFV) hipExtLaunchKernelGGL((k_chain_readout_eval<XI, WS, BFV>), dim3(B + rd.nblk + rd.fused_b), dim3(1024),            \
+                                                 (ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL), s, ev_start, ev_stop, 0, N, B, F, graph_ptr, bits, dinv, \
+                                                 xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
+  if (bf16) { if (F <= 8) CH_LE(1, 4, true); else if (F <= 16) CH_LE(2, 4, true); else CH_LE(4, 8, true); }
+  else { if (F <= 8) CH_LE(1, 4, false); else if (F <= 16) CH_LE(2, 4, false); else CH_LE(4, 8, false); }
+#undef CH_LE
+  if (hipGetLastError() != hipSuccess) {
+    if (sync_moved) { *rd.sync_host = sync_prev; if (fused_b_out) *fused_b_out = 0; }
+    if (y) *ev_host = ev_prev;
     return DGCNN_ELAUNCH;
   }
   return DGCNN_OK;

@@ -216,6 +216,18 @@ k_scale_x(int N, int F, const float* __restrict__ x, const float* __restrict__ d
   if (t < (int64_t)N * F) xs[t] = dinv[t / F] * x[t];
 }
 
+// phase B of a rider's preparation as a launch of its own: for hosts whose remaining launches carry no rider range (the
+// pipelined EVALUATION step behind a launch that carried phase A only)
+int dg_launch_prep_phase_b(const DgPrepRider* rd, hipStream_t s) {
+  if (!rd || rd->mode != 0 || rd->E <= 0 || rd->N <= 0 || rd->B <= 0) return DGCNN_EINVAL;
+  const int work_b = dg_prep_fast_work_b(rd->E, rd->N, rd->B, rd->bits != nullptr, rd->edge_check != 0);
+  hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 1024)), dim3(1024), 0, s, rd->ei, rd->E, rd->N, rd->B, rd->rowptr, rd->colidx,
+                     rd->graph_ptr, rd->graph_eptr, rd->dinv, rd->err, rd->epoch, rd->x ? rd->F : 0, rd->x, rd->xs, rd->batch, rd->bits,
+                     rd->bits ? rd->dmap : nullptr, rd->edge_check, rd->max_nodes);
+  DG_CHECK_LAUNCH();
+  return DGCNN_OK;
+}
+
 int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N, int B,
                    int32_t* rowptr, int32_t* colidx, int32_t* rowptr_t, int32_t* colidx_t,
                    float* dinv, int32_t* graph_ptr, int32_t* graph_eptr, int32_t* cnt_in, int32_t* cnt_out,

@@ -76,6 +76,7 @@ class Trainer:
         self._cur = 0
         self._pipe = None        # dgcnn_pipeline handle, created on first pipelined step
         self._pipe_fn = None
+        self._pipe_eval_fn = None
         self._p_flat = 0         # cached data_ptr()s of the trainer-lifetime buffers (pipelined step)
         self._p_grads = self._p_metrics = self._p_m = self._p_v = 0
         self._logp_views = {}
@@ -233,12 +234,13 @@ class Trainer:
         a.params, a.grads, a.metrics = self._p_flat, self._p_grads, self._p_metrics
 
     def pipelined_step(self, data, y, next_data=None, next_y=None, global_batch: Optional[int] = None,
-                       fuse_adam: bool = True) -> torch.Tensor:
+                       fuse_adam: bool = True, evaluate: bool = False) -> torch.Tensor:
         """``dgcnn_pipeline_train_step``: forward + backward (+ fused Adam) of ``data`` as one call; when
         ``next_data`` is given its graph structure is prepared during this step (extra workgroups on the step's
         two graph-per-workgroup launches) and the following ``pipelined_step(next_data, ...)`` skips its own
         preparation.  Bit-identical to ``train_step`` without look-ahead.  The Python side of a step is a dict
-        lookup and a handful of field stores (the host must stay ahead of a ~60 us GPU step)."""
+        lookup and a handful of field stores (the host must stay ahead of a ~60 us GPU step).
+        ``evaluate``: ``dgcnn_pipeline_eval_step`` instead -- forward in eval mode + metrics, same look-ahead (round 5)."""
         m = self.model
         ent = self._args_cache.get(id(data))
         if ent is None or ent[0] is not data or ent[1] is not y or not self._same_tensors(ent, data):
@@ -250,6 +252,7 @@ class Trainer:
             _lib.check(L.dgcnn_pipeline_create(_lib.ctypes.byref(h)), "dgcnn_pipeline_create")
             self._pipe = h
             self._pipe_fn = L.dgcnn_pipeline_train_step
+            self._pipe_eval_fn = L.dgcnn_pipeline_eval_step
         flat = m.flat_params_fast()
         if flat.data_ptr() != self._p_flat:         # model moved / re-flattened: refresh the cached pointers
             self._p_flat, self._p_grads, self._p_metrics = flat.data_ptr(), self.grads.data_ptr(), self.metrics.data_ptr()
@@ -274,15 +277,15 @@ class Trainer:
         if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
             lp = self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
             self._logp_views = {}
-        training = 1 if m.training else 0
+        training = 1 if (m.training and not evaluate) else 0
         a.ws, a.logp, a.params, a.grads, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_grads, self._p_metrics
-        if self._peer is not None and not fuse_adam:          # one-shot route: this step's buffer of the exchange block
+        if self._peer is not None and not fuse_adam and not evaluate:      # one-shot route: this step's buffer of the exchange block
             a.grads = self._peer.grad_ptr(self.step_count + 1)
         a.training = training
         a.seed = m._next_seed() if training else 0
         a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags()
         a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
-        if fuse_adam:
+        if fuse_adam and not evaluate:
             self.step_count += 1
             a.step = self.step_count
             a.exp_avg, a.exp_avg_sq = self._p_m, self._p_v
@@ -305,9 +308,9 @@ class Trainer:
             self._cur = 1 - slot
         else:
             self._cur = slot
-        rc = self._pipe_fn(self._pipe, aref, nref, torch._C._cuda_getCurrentRawStream(dev.index))
+        rc = (self._pipe_eval_fn if evaluate else self._pipe_fn)(self._pipe, aref, nref, torch._C._cuda_getCurrentRawStream(dev.index))
         if rc != 0:
-            _lib.check(rc, "dgcnn_pipeline_train_step")
+            _lib.check(rc, "dgcnn_pipeline_eval_step" if evaluate else "dgcnn_pipeline_train_step")
         self._ws = ws
         md = m.__dict__
         md["_last_ws"], md["_last_dims"] = ws, dims
@@ -345,50 +348,16 @@ class Trainer:
         return logp
 
     @torch.no_grad()
-    def eval_step(self, data, y, global_batch: Optional[int] = None) -> torch.Tensor:
-        """Body of the reference ``test()`` loop (train.py:59-64) as ONE C call (``dgcnn_model_eval_step``): forward in
-        eval mode + loss / #correct folded into the device-side metrics accumulator.  Data parallel: the batch loss is
-        scaled by 1/``global_batch`` (derived with one small all-reduce when not given) so that the ranks' contributions
-        add up to the global batch mean."""
-        m = self.model
+    def eval_step(self, data, y, global_batch: Optional[int] = None, next_data=None) -> torch.Tensor:
+        """Body of the reference ``test()`` loop (train.py:59-64) as ONE C call (``dgcnn_pipeline_eval_step``): forward in
+        eval mode + loss / #correct folded into the device-side metrics accumulator -- one launch where the batch admits the
+        one-launch evaluation kernel (``DGCNN_FORM_EVAL``).  ``next_data``: the batch the NEXT call (``eval_step`` or
+        ``train_step``) will be given -- its graph preparation then overlaps this one, as in training.  Data parallel: the
+        batch loss is scaled by 1/``global_batch`` (derived with one small all-reduce when not given) so that the ranks'
+        contributions add up to the global batch mean."""
         if global_batch is None and self._dp_world > 1 and self._allreduce is not None:
             global_batch = self._allreduce.global_batch(_batch_size_of(data), data.x.device)
-        ent = self._args_cache.get(id(data))
-        if ent is None or ent[0] is not data or ent[1] is not y or not self._same_tensors(ent, data):
-            ent = self._step_args(data, y)
-        a, need, dims, aref, dev = ent[2], ent[3], ent[5], ent[6], ent[7]
-        flat = m.flat_params_fast()
-        if flat.data_ptr() != self._p_flat:
-            self._p_flat, self._p_grads, self._p_metrics = flat.data_ptr(), self.grads.data_ptr(), self.metrics.data_ptr()
-            self._p_m, self._p_v = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
-        if self._prep_ent is not None:       # keep a slot that holds a prepared training batch intact
-            self._cur = 1 - self._prep_slot
-        sl = self._slots[self._cur]
-        if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
-            self._slot_ws(self._cur, need, dev)
-        ws = sl["ws"]
-        sl["dims"] = dims
-        B, C = dims[2], dims[4]
-        lp = self._logp
-        if lp is None or lp.shape[0] < B or lp.shape[1] != C or lp.device != dev:
-            lp = self._logp = torch.empty(max(B, 64), C, dtype=torch.float32, device=dev)
-            self._logp_views = {}
-        a.ws, a.logp, a.params, a.metrics = sl["ptr"], lp.data_ptr(), self._p_flat, self._p_metrics
-        a.training = 0
-        a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
-        a.flags = ent[8] | m._mode_flags()
-        a.epoch = m._next_epoch()
-        rc = _lib.lib().dgcnn_model_eval_step(aref, torch._C._cuda_getCurrentRawStream(
-            dev.index if dev.index is not None else torch.cuda.current_device()))
-        if rc != 0:
-            _lib.check(rc, "dgcnn_model_eval_step")
-        self._ws = ws
-        md = m.__dict__
-        md["_last_ws"], md["_last_dims"] = ws, dims
-        v = self._logp_views.get(B)
-        if v is None:
-            v = self._logp_views[B] = lp[:B]
-        return v
+        return self.pipelined_step(data, y, next_data, None, global_batch, fuse_adam=False, evaluate=True)
 
     def reset_metrics(self) -> None:
         self.metrics.zero_()
@@ -452,8 +421,12 @@ class Trainer:
         """``test()`` of train.py:49-66."""
         self.reset_metrics()
         nb = 0
-        for b in batches:
-            self.eval_step(b, b.y)
+        it = iter(batches)
+        cur = next(it, None)
+        while cur is not None:          # one batch of look-ahead, as in train_epoch
+            nxt = next(it, None)
+            self.eval_step(cur, cur.y, next_data=nxt)
             nb += 1
+            cur = nxt
         loss, correct = self.read_metrics()
         return loss / max(nb, 1), correct / max(num_samples, 1) * 100.0

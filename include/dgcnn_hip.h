@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 18
+#define DGCNN_ABI_VERSION 19
 
 /* error codes */
 #define DGCNN_OK            0
@@ -241,11 +241,18 @@ int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
 #define DGCNN_FORM_CHAIN_TAIL 4   /* a TRAINING step with labels runs chain forward + readout forward + readout backward as one launch */
 #define DGCNN_FORM_STEP 8         /* ... and the whole GCN backward of every graph in that same launch (round 4): the step is
                                    * k_chain_readout_tail + k_wgrad.  (DGCNN_STEP_KERNEL=0 in the environment keeps the round-3 form.) */
+#define DGCNN_FORM_EVAL 16        /* a forward WITHOUT an in-launch backward -- dgcnn_model_forward, dgcnn_model_eval_step,
+                                   * dgcnn_pipeline_eval_step: /root/reference/model.py:26-45 as called from train.py:57-62 -- runs
+                                   * chain forward + readout forward (+ the batch's metrics) as ONE launch, k_chain_readout_eval (round 5) */
 int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
 /* Test / measurement switch of DGCNN_FORM_STEP (process-wide; the environment variable DGCNN_STEP_KERNEL=0 sets the initial
  * value): on = 0 keeps the GCN backward of small training batches in launches of its own (the round-3 form), on = 1 restores the
  * default.  Returns the previous setting.  Replaces nothing of the reference (/root/reference/train.py:40 is one backward). */
 int dgcnn_step_kernel_enable(int on);
+/* Test / measurement switch of DGCNN_FORM_EVAL (process-wide): on = 0 keeps the chain forward and the readout forward of small
+ * batches as two launches (+ k_eval_metrics where labels are given) -- the round-4 form; on = 1 restores the default.  Returns the
+ * previous setting.  Replaces nothing of the reference (/root/reference/model.py:26-45 is one forward). */
+int dgcnn_eval_kernel_enable(int on);
 /* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
  * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:
  * DD at the reference's batch of 50, /root/reference/model.py:30-33 + train.py:40): on = 0 keeps the wave-per-node kernels, whose
@@ -384,6 +391,13 @@ int dgcnn_pipeline_create(void** handle);     /* one per training loop: remember
 int dgcnn_pipeline_destroy(void* handle);
 int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
                               dgcnn_stream_t stream);
+/* Pipelined evaluation step: dgcnn_model_eval_step(cur) -- the body of the reference's `test()` loop,
+ * /root/reference/train.py:57-64 -- with the NEXT batch's graph preparation (or its assembly from a prepared dataset)
+ * overlapped exactly as in dgcnn_pipeline_train_step: rider workgroups of the evaluation launch where the batch takes the
+ * one-launch form (DGCNN_FORM_EVAL), launches behind it otherwise.  cur->flags & DGCNN_FLAG_PREPARED says that `cur` is the
+ * batch the previous pipelined call (training or evaluation) prepared.  next == NULL: nothing is prepared ahead. */
+int dgcnn_pipeline_eval_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
+                             dgcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mini-batch assembly on the device: what the reference's `DataLoader(data_set[idx], batch_size, shuffle)`

@@ -230,8 +230,9 @@ def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
                                                       _lib.FLAG_AGG_SPARSE, _lib.FLAG_NO_CHAIN, _lib.FLAG_BF16, _lib.FLAG_FORCE_TILED)
     f = L.dgcnn_forward_form
     N50, E50 = 3800, 140000
-    assert f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8                # chain forward + one-launch training kernel + its in-kernel GCN backward
-    assert f(40, 80, 50, 1, CU, 4) == 2 | 4                        # fewer 16-node tiles than graphs: no partial row per graph, round-3 form
+    EV = _lib.FORM_EVAL                                            # (round 5) forwards without an in-launch backward: one launch too
+    assert f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8 | EV           # chain forward + one-launch training kernel + its in-kernel GCN backward
+    assert f(40, 80, 50, 1, CU, 4) == 2 | 4 | EV                   # fewer 16-node tiles than graphs: no partial row per graph, round-3 form
     assert f(N50, E50, 50, 1, CU, 300) == 0                        # a graph above 256 nodes in a small batch: gather kernels
     assert f(N50, E50, 50, 1, CU | CHAIN, 300) == 2                # ... unless asked for (no one-launch kernel above 256 nodes)
     assert f(N50, E50, 50, 1, 0, 180) == 0                         # no coalesced + undirected promise: no bitmap
@@ -241,7 +242,12 @@ def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
     assert f(N50, E50, 50, 1, CU | SPARSE, 180) == 0
     assert f(N50, E50, 50, 1, CU | TILED, 180) == 0
     assert f(N50, E50, 50, 1, CU | DENSE, 180) == 1 | 2            # dense backward forced: chain forward, separate readout launches
-    assert f(N50, E50, 50, 1, CU | BF16, 180) == 2 | 4 | 8         # bf16 leg: the same one-launch kernel (bf16 image in the forward half)
+    assert f(N50, E50, 50, 1, CU | BF16, 180) == 2 | 4 | 8 | EV    # bf16 leg: the same one-launch kernels (bf16 image in the forward half)
+    prev = L.dgcnn_eval_kernel_enable(0)                           # the switch of the one-launch evaluation kernel (tests, A/B)
+    try:
+        assert prev == 1 and f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8
+    finally:
+        L.dgcnn_eval_kernel_enable(prev)
     N2k, E2k = 153000, 5700000
     assert f(N2k, E2k, 2048, 1, CU, 250) == 1 | 2
     assert f(N2k, E2k, 2048, 1, CU, 600) == 0                      # above the dense bound of 512 nodes

@@ -1,7 +1,8 @@
 """GPU-box helper: time of the reference's test() loop body (train.py:59-64) through Trainer.eval_step, per batch of 50,
-batches resident on the device (raw edge lists: graph preparation of every batch inside the timed region).
+batches resident on the device (raw edge lists: graph preparation of every batch inside the timed region -- it rides on the
+previous batch's launch, as in Trainer.test_epoch).
 usage: python tools/eval_time.py [workload] [graphs per batch]"""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
 from dgcnn_amd import synth
 from dgcnn_amd.model import Model
@@ -12,12 +13,14 @@ bs = [synth.make_batch(name, G, start=G * k).to("cuda") for k in range(40)]
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.eval()
 tr = Trainer(m)
-for b in bs: tr.eval_step(b, b.y)
+nb = len(bs)
+LA = os.environ.get("EVAL_NO_LOOKAHEAD") is None      # EVAL_NO_LOOKAHEAD=1: every batch prepared by its own call
+for k, b in enumerate(bs): tr.eval_step(b, b.y, next_data=bs[(k + 1) % nb] if LA else None)      # (look-ahead as Trainer.test_epoch's)
 torch.cuda.synchronize()
 for rep in range(3):
     t0 = time.perf_counter()
     for _ in range(25):
-        for b in bs: tr.eval_step(b, b.y)
+        for k, b in enumerate(bs): tr.eval_step(b, b.y, next_data=bs[(k + 1) % nb] if LA else None)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (25 * len(bs))
     print(f"{name} x {G}: eval step {1e6 * dt:.1f} us/batch ({G / dt:,.0f} graphs/s)")
