@@ -246,6 +246,16 @@ static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
   return max_nodes <= 256 || N >= DG_DENSE_MIN_NODES;
 }
 struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
+#ifndef DG_INSYM_MIN_B
+#define DG_INSYM_MIN_B 96
+#endif
+// one-launch evaluation / inference kernel (k_chain_readout_eval): every graph in the chain form, one workgroup per graph
+static int g_eval_kernel = 1;      // dgcnn_eval_kernel_enable (tests / measurement A-B): 0 keeps chain forward + readout as two launches
+int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on ? 1 : 0; return prev; }
+static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
+  return g_eval_kernel != 0 && f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
+         max_nodes <= dg_chain_train_max_nodes();
+}
 static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   DgForm f;
   f.chain = dg_use_chain(N, E, B, F, flags, max_nodes);
@@ -255,7 +265,13 @@ static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   f.dense = dg_use_dense(N, E, B, (f.chain ? flags & ~DGCNN_FLAG_BF16 : flags), max_nodes);
   f.bitmap = f.dense || f.chain;
   f.plan = f.dense || (f.chain && dg_chain_needs_schedule(B));      // item table + graph schedule (one workgroup of phase B)
-  f.edge_check = (f.bitmap && !f.dense) ? 1 : 0;       // chain forward over a gather backward: phase B keeps the per-edge check
+  // reverse-edge check (the coalesced + undirected promise):
+  //   0  on the finished bitmap by a launch of its own (k_prep_sym: dense forms, every row of every graph available there);
+  //   1  per edge in phase B (binary search in the target's row): chain forward over a gather backward -- no third launch;
+  //   2  by the one-launch training / evaluation kernel itself on its LDS image of the graph's bitmap, from DG_INSYM_MIN_B graphs
+  //      on: there phase B is a rider of k_wgrad (it no longer fits beside the graph workgroups), and its per-edge searches
+  //      were that launch's duration (256 COLLAB graphs: 13.6 us of 17.8); below, phase B runs on idle CUs for free.
+  f.edge_check = (f.bitmap && !f.dense) ? ((B >= DG_INSYM_MIN_B && dg_eval_kernel_admits(f, B, max_nodes)) ? 2 : 1) : 0;
   return f;
 }
 // Sparse many-node batches on the launch-per-layer gather route (the narrow kernels' regime, gcn.hip: DD at the reference's
@@ -282,13 +298,6 @@ static DgDense dg_dense_view(const void* ws, const DgWs& wl, int N, int B) {
   return G;
 }
 
-// one-launch evaluation / inference kernel (k_chain_readout_eval): every graph in the chain form, one workgroup per graph
-static int g_eval_kernel = 1;      // dgcnn_eval_kernel_enable (tests / measurement A-B): 0 keeps chain forward + readout as two launches
-int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on ? 1 : 0; return prev; }
-static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
-  return g_eval_kernel != 0 && f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
-         max_nodes <= dg_chain_train_max_nodes();
-}
 // DGCNN_STEP_KERNEL=0 in the environment: the one-launch training kernel stops after conv4's backward and conv3 / conv2 / conv1
 // run as the two gather launches (the round-3 form; measurement A/B and a second route for the tests)
 static int g_step_kernel = -1;
@@ -524,7 +533,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
                                         wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr,
                                         step_kernel ? dg_ptr<float>(ws, wl.pb3) : nullptr, step_kernel ? dg_ptr<float>(ws, wl.pb2) : nullptr,
-                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16, (rider_a && rode) ? &fused_b : nullptr));
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16, (rider_a && rode) ? &fused_b : nullptr,
+                                        fm.edge_check == 2 ? 1 : 0));
     g_prof_which = -1;
     // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
     // pb2 / pb1 = graph b's partials: k_wgrad sums B rows)
@@ -545,7 +555,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         in_launch ? et->ctr : nullptr, in_launch ? et->ctr_host : nullptr,
                                         in_launch ? et->metrics : nullptr, dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a,
                                         g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr, bf16,
-                                        (rider_a && rode) ? &fused_b : nullptr));
+                                        (rider_a && rode) ? &fused_b : nullptr, fm.edge_check == 2 ? 1 : 0));
     g_prof_which = -1;
     if (in_launch) et->done = 1;
     if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
@@ -891,7 +901,7 @@ static int dg_pipeline_rider(DgPipeline* h, const dgcnn_step_args* next, bool si
       rd.max_nodes = next->max_nodes;
     }
     rd.nblk = dg_cdiv(dg_prep_fast_work(next->E, next->N, next->B, rd.bits != nullptr), 1024);
-    rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check != 0), 1024);
+    rd.nblk_b = dg_cdiv(dg_prep_fast_work_b(next->E, next->N, next->B, rd.bits != nullptr, rd.edge_check == 1), 1024);
     (void)dg_pipeline_counters(h, s);      // (once per pipeline; a failure only means that phase B keeps riding on k_wgrad)
     rd.sync_ctr = h->sync_ctr; rd.sync_host = h->sync_ctr ? &h->sync_count : nullptr;
     rider = &rd;

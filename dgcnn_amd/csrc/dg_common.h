@@ -482,14 +482,15 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  hipStream_t s, const struct DgPrepRider* rider = nullptr,
                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                                  float* pb3 = nullptr, float* pb2 = nullptr, float* pb1 = nullptr, int bf16 = 0,
-                                 int* fused_b_out = nullptr);      // != nullptr: phase B of the rider may join this launch; says if it did
+                                 int* fused_b_out = nullptr,       // != nullptr: phase B of the rider may join this launch; says if it did
+                                 int insym = 0);                   // 1: the kernel verifies the bitmap's symmetry (reverse edges) itself
 int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                                  const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                                  float* x3, float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d,
                                  uint8_t* drop_mask, float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale,
                                  float* evl, unsigned int* ev_ctr, unsigned int* ev_host, float* metrics, int32_t* err, uint32_t epoch,
                                  hipStream_t s, const struct DgPrepRider* rider = nullptr, hipEvent_t ev_start = nullptr,
-                                 hipEvent_t ev_stop = nullptr, int bf16 = 0, int* fused_b_out = nullptr);
+                                 hipEvent_t ev_stop = nullptr, int bf16 = 0, int* fused_b_out = nullptr, int insym = 0);
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                         float* x3, float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start = nullptr,

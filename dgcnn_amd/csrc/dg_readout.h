@@ -251,13 +251,16 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
 // 7 spilled registers = 58 MB of scratch traffic per launch at 2048 graphs).  Same arithmetic order: bit-identical.
 // HEAD = false (large batches): stops at conv6's output; classifier_1/2 and log_softmax run batched over graphs
 // (classifier.hip) instead of once per graph.
-template <bool BIG = false, bool HEAD = true>
+// IDLE (optional): work of the caller's that the 14 waves without a tile of conv5 do while waves 0 and 1 run it -- called as
+// idle(wave, lane) by every wave; must not touch the readout's LDS plan, must not contain a barrier
+struct RdNoIdle { __device__ __forceinline__ void operator()(int, int) const {} };
+template <bool BIG = false, bool HEAD = true, class IDLE = RdNoIdle>
 __device__ __forceinline__ void dg_readout_fwd_body(
     const RdSmem& M, int b, int n0, int n, int C, const TailW& w, const float* keys, int key_n0,
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ x3,
     const float* __restrict__ x4, float* __restrict__ pooled, int* __restrict__ perm, float* __restrict__ a5g,
     float* __restrict__ a6g, float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp,
-    int training, uint64_t seed, unsigned long long* dbg = nullptr) {
+    int training, uint64_t seed, unsigned long long* dbg = nullptr, const IDLE idle = IDLE{}) {
 #define RD_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
   float* sp = reinterpret_cast<float*>(M.region0);        // [2910]
   float* W5s = sp + 2912;                                 // [1552]
@@ -376,6 +379,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
 #pragma unroll
     for (int jq = 4; jq < 8; ++jq) wf[jq] = *reinterpret_cast<const float4*>(wr + 32 * jq);
   }
+  idle(wv, lane);
   dg_lds_barrier();
   RD_MARK(10);
   if (!BIG) {

@@ -778,7 +778,7 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
   if ((int)blockIdx.x >= P1) {   // rider range: phase B of the NEXT batch's graph preparation, when the step's readout
                                  // forward + backward ran as one launch (k_readout_tail carried phase A)
     dg_prep_fast_b_body(((int)blockIdx.x - P1) * 1024 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
-                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0,
+                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check == 1,
                         rd.max_nodes);
     if (rd.dmap && (int)blockIdx.x == P1) dg_prep_dense_plan((int)threadIdx.x, 1024, rd.B, rd.graph_ptr, rd.dmap);
     return;

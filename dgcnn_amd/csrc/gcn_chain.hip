@@ -1477,13 +1477,39 @@ __device__ __forceinline__ void ch_rider_block(int rb, const DgPrepRider& rd) {
   for (int it = 0; it < CH_RIDER_ITEMS; ++it) {
     const int tb = ((rb - rd.nblk) * CH_RIDER_ITEMS + it) * RD_THREADS + (int)threadIdx.x;
     dg_prep_fast_b_body<RD_THREADS, true, true>(tb, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv,
-                                                rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0,
+                                                rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check == 1,
                                                 rd.max_nodes, reinterpret_cast<unsigned int*>(rsm));
   }
   // (no planning workgroup here: the launcher fuses only riders without an item table)
 }
+// Reverse-edge half of the coalesced + undirected promise, verified by the one-launch kernels themselves (api.hip: edge_check == 2,
+// batches of DG_INSYM_MIN_B graphs or more, where phase B of the preparation rides on k_wgrad and its per-edge searches were that
+// launch's duration): the graph's bit matrix must be SYMMETRIC.  Checked on the chain forward's LDS image of the bitmap (`bl`,
+// row stride S; untouched by the readout) by the 14 waves that idle while waves 0 and 1 run conv5 on the matrix cores: item
+// (row i, word k) -- for every set bit j of the word, bit i of row j must be set; an asymmetric pair flags the batch (err[1],
+// epoch-tagged).  Nothing waits for it.  (First placement: the tile-less waves during conv1 -- the step kernel 38.7 -> 40.5 us at
+// 256 graphs, they share the SIMDs of the waves that carry the chain.)
+struct ChSymHook {
+  const unsigned int* bl; int n, S, K32; unsigned int* err; unsigned int epoch;
+  __device__ __forceinline__ void operator()(int wv, int lane) const {
+    if (!err || wv < 2) return;
+    unsigned int okb = 1u;
+    for (int it = ((wv - 2) << 6) + lane; it < 8 * n; it += 14 * 64) {
+      const int i = it >> 3, k = it & 7;
+      unsigned int wq = k < K32 ? bl[i * S + min(k, S - 1)] : 0u;
+      const unsigned int* colw = bl + (i >> 5);
+      while (wq) {
+        const int j0 = 32 * k + __builtin_ctz(wq); wq &= wq - 1u;
+        const int j1 = wq ? 32 * k + __builtin_ctz(wq) : j0; wq &= wq - (wq ? 1u : 0u);
+        const unsigned int r0 = colw[min(j0, n - 1) * S], r1 = colw[min(j1, n - 1) * S];      // (bits beyond n: flagged by graph preparation)
+        okb &= (r0 & r1) >> (i & 31);
+      }
+    }
+    if (!(okb & 1u)) { err[1] = epoch; err[3] = ~epoch; }
+  }
+};
 struct ChTail {
-  unsigned int* err; unsigned int epoch;
+  unsigned int* err; unsigned int epoch; int insym;      // insym: verify the bitmap's symmetry here (see ch_chain_body)
   const float* W4; float* gas3; float* pa4; int P1;      // conv4's backward rides along when pa4 != null (P1 >= B rows)
   float *pb3, *pb2, *pb1;                                // != null: conv3 / conv2 / conv1's backward too (one partial row per graph)
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
@@ -1552,8 +1578,11 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     const int b = blockIdx.x;
     const int n0 = gn0, n = gn;
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
+    const int nn_ = min(gn, CH_TRAIN_MAXN);
+    const ChSymHook hook{reinterpret_cast<const unsigned int*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_BL), nn_, 1 << dgd_class(max(nn_, 1)),
+                         (nn_ + 31) >> 5, t.insym ? t.err : nullptr, t.epoch};
     dg_readout_fwd_body(M, b, n0, n, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
-                        t.training, t.seed, dbg);
+                        t.training, t.seed, dbg, hook);
   }
   __syncthreads();
   using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
@@ -1621,7 +1650,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
 // in the workspace bumped by compare-and-swap -- 50 workgroups retrying on one address made the launch 34 us whatever the graphs.)
 // =================================================================================================================
 struct ChEval {
-  unsigned int* err; unsigned int epoch;
+  unsigned int* err; unsigned int epoch; int insym;
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
   const int64_t* y; float* evl; unsigned int* ctr; unsigned int target; float* metrics; float scale;      // y == null: no metrics
 };
@@ -1646,8 +1675,11 @@ k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, con
   __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
   const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
+  const int nn_ = min(gn, CH_TRAIN_MAXN);
+  const ChSymHook hook{reinterpret_cast<const unsigned int*>(smem + C::OFF_BL), nn_, 1 << dgd_class(max(nn_, 1)), (nn_ + 31) >> 5,
+                       t.insym ? t.err : nullptr, t.epoch};
   dg_readout_fwd_body(M, b, gn0, gn, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
-                      t.training, t.seed, dbg);
+                      t.training, t.seed, dbg, hook);
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
   if (!t.y || threadIdx.x >= 64) return;      // (waves 1..15 are done; wave 0 wrote the log-probabilities (M.lg) itself: program order)
   // ---- metrics: this graph's pair, then the last workgroup's fixed-order sum -- wave 0 only, no barrier -------------------------
@@ -2370,7 +2402,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
                                  float* gz6, float* gz5, float* gp1, float* gp2, float* gp3, float* gas4, float* gb4p, float* lossv,
                                  float* ptail, int32_t* err, uint32_t epoch, float* gas3, float* pa4, int P1, hipStream_t s,
                                  const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, float* pb3, float* pb2, float* pb1,
-                                 int bf16, int* fused_b_out) {
+                                 int bf16, int* fused_b_out, int insym) {
   if (fused_b_out) *fused_b_out = 0;
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || !y)
@@ -2379,7 +2411,7 @@ int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* grap
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   ChTail t;
-  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
+  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch; t.insym = insym;
   t.W4 = gw.W4; t.gas3 = gas3; t.pa4 = (pa4 && gas3 && P1 >= B) ? pa4 : nullptr; t.P1 = P1;
   // pb3 / pb2 / pb1 (B rows each): the WHOLE GCN backward of a graph follows its conv4 backward in the same workgroup
   const bool full = t.pa4 && pb3 && pb2 && pb1;
@@ -2443,7 +2475,7 @@ int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* grap
                                  float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* evl,
                                  unsigned int* ev_ctr, unsigned int* ev_host, float* metrics, int32_t* err, uint32_t epoch,
                                  hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, int bf16,
-                                 int* fused_b_out) {
+                                 int* fused_b_out, int insym) {
   if (fused_b_out) *fused_b_out = 0;
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
       !dinv || !xs || (y && (!evl || !ev_ctr || !ev_host || !metrics)))
@@ -2452,7 +2484,7 @@ int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* grap
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
   ChEval t;
-  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch;
+  t.err = reinterpret_cast<unsigned int*>(err); t.epoch = epoch; t.insym = insym;
   t.C = C; t.w = dg_tail_w(params, pl); t.pooled = pooled; t.perm = perm; t.a5g = a5; t.a6g = a6; t.a1dg = a1d; t.maskg = drop_mask;
   t.logp = logp; t.training = training; t.seed = seed; t.y = y; t.evl = evl; t.ctr = ev_ctr; t.metrics = metrics;
   t.scale = loss_scale != 0.f ? loss_scale : 1.0f / (float)B;          // (as dg_launch_eval_metrics)

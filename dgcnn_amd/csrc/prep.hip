@@ -190,7 +190,7 @@ k_prep_fast_b(const int64_t* __restrict__ ei, int E, int N, int B, const int* __
               const float* __restrict__ x, float* __restrict__ xs, const int64_t* __restrict__ batch,
               unsigned int* __restrict__ bits, int* __restrict__ dmap, int edge_check, int max_nodes) {
   dg_prep_fast_b_body<1024>(blockIdx.x * blockDim.x + threadIdx.x, ei, E, N, B, rowptr, colidx, graph_ptr, graph_eptr, dinv,
-                      err, epoch, x, xs, F, batch, bits, dmap, edge_check != 0, max_nodes);
+                      err, epoch, x, xs, F, batch, bits, dmap, edge_check == 1, max_nodes);
   if (dmap && blockIdx.x == 0) dg_prep_dense_plan(threadIdx.x, 1024, B, graph_ptr, dmap);
 }
 
@@ -220,7 +220,7 @@ k_scale_x(int N, int F, const float* __restrict__ x, const float* __restrict__ d
 // pipelined EVALUATION step behind a launch that carried phase A only)
 int dg_launch_prep_phase_b(const DgPrepRider* rd, hipStream_t s) {
   if (!rd || rd->mode != 0 || rd->E <= 0 || rd->N <= 0 || rd->B <= 0) return DGCNN_EINVAL;
-  const int work_b = dg_prep_fast_work_b(rd->E, rd->N, rd->B, rd->bits != nullptr, rd->edge_check != 0);
+  const int work_b = dg_prep_fast_work_b(rd->E, rd->N, rd->B, rd->bits != nullptr, rd->edge_check == 1);
   hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 1024)), dim3(1024), 0, s, rd->ei, rd->E, rd->N, rd->B, rd->rowptr, rd->colidx,
                      rd->graph_ptr, rd->graph_eptr, rd->dinv, rd->err, rd->epoch, rd->x ? rd->F : 0, rd->x, rd->xs, rd->batch, rd->bits,
                      rd->bits ? rd->dmap : nullptr, rd->edge_check, rd->max_nodes);
@@ -243,7 +243,7 @@ int dg_launch_prep(const int64_t* edge_index, int E, const int64_t* batch, int N
                        colidx, rowptr_t, colidx_t, graph_ptr, uerr, epoch, bits);
     DG_CHECK_LAUNCH();
     const bool scale = lf && lf->x && !lf->W && lf->F >= 1 && lf->F <= DGCNN_MAX_F;
-    const int work_b = dg_prep_fast_work_b(E, N, B, bits != nullptr, edge_check);
+    const int work_b = dg_prep_fast_work_b(E, N, B, bits != nullptr, edge_check == 1);
     hipLaunchKernelGGL(k_prep_fast_b, dim3(dg_cdiv(work_b, 1024)), dim3(1024), 0, s, edge_index, E, N, B, rowptr, colidx,
                        graph_ptr, graph_eptr, dinv, uerr, epoch, scale ? lf->F : 0, scale ? lf->x : nullptr,
                        scale ? lf->hs : nullptr, batch, bits, dmap, edge_check, max_nodes);

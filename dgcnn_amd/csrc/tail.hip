@@ -172,7 +172,7 @@ k_tail_bwd(int B, int C, TailW w, const int* __restrict__ graph_ptr, const int* 
                        // readout launch of this step's forward, complete by now)
     dg_prep_fast_b_body(role.idx * RD_THREADS + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr,
                         rd.colidx, rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits,
-                        rd.dmap, rd.edge_check != 0, rd.max_nodes);
+                        rd.dmap, rd.edge_check == 1, rd.max_nodes);
     if (rd.dmap && role.idx == 0) dg_prep_dense_plan((int)threadIdx.x, RD_THREADS, rd.B, rd.graph_ptr, rd.dmap);
     return;
   }
@@ -444,7 +444,7 @@ k_wgrad(WgArgs A, DgPrepRider rd, int nb_host) {
                                       // step's last and longest short kernel (7.4 us at batch 50): phase B (5 us alone)
                                       // disappears under it, whereas it stretched k_gcn_bwd1 from 4.8 to 6.1 us
     dg_prep_fast_b_body<256>(((int)blockIdx.x - nb_host) * 256 + (int)threadIdx.x, rd.ei, rd.E, rd.N, rd.B, rd.rowptr, rd.colidx,
-                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check != 0, rd.max_nodes);
+                        rd.graph_ptr, rd.graph_eptr, rd.dinv, rd.err, rd.epoch, rd.x, rd.xs, rd.F, rd.batch, rd.bits, rd.dmap, rd.edge_check == 1, rd.max_nodes);
     if (rd.dmap && (int)blockIdx.x == nb_host) dg_prep_dense_plan((int)threadIdx.x, 256, rd.B, rd.graph_ptr, rd.dmap);
     return;
   }

@@ -371,3 +371,40 @@ def test_fused_preparation_flags_a_broken_promise_in_the_next_batch(violation):
                 tr.read_metrics()
         else:
             tr.read_metrics()
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("violation", ["missing_reverse", "none"])
+def test_reverse_edge_check_inside_the_one_launch_kernels_from_96_graphs_on(mode, violation):
+    """from 96 graphs per batch on the reverse-edge half of the coalesced + undirected promise is verified by the one-launch
+    training / evaluation kernel itself, on the LDS image of each graph's bitmap (round 5: phase B of the preparation, a rider of
+    k_wgrad at these sizes, no longer searches every edge's reverse): one missing reverse edge in ONE graph of 128 must be
+    flagged, stand-alone and as the look-ahead batch of a pipelined step, and a clean batch must not be"""
+    from dgcnn_amd.batch import Batch
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    good = [batch_with_small_graphs("COLLAB", 128, start=6000 + 1000 * k) for k in range(2)]
+    b = good[1]
+    ei = b.edge_index.clone()
+    if violation == "missing_reverse":
+        e = int(ei.shape[1] * 0.61)
+        sn, dn = int(ei[0, e]), int(ei[1, e])
+        ei = ei[:, ~((ei[0] == dn) & (ei[1] == sn))]
+        assert ei.shape[1] == b.edge_index.shape[1] - 1
+    nxt = Batch(b.x, ei.contiguous(), b.batch, b.y, b.num_graphs, True, b.max_nodes, b.max_edges)
+    for pipelined in (False, True):
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(mode == "train")
+        tr = Trainer(m)
+        tr.reset_metrics()
+        fn = tr.train_step if mode == "train" else tr.eval_step
+        b0, b1 = good[0].to("cuda"), nxt.to("cuda")
+        if pipelined:
+            fn(b0, b0.y, next_data=b1)
+        fn(b1, b1.y)
+        torch.cuda.synchronize()
+        if violation == "none":
+            tr.read_metrics()
+        else:
+            with pytest.raises(_lib.DgcnnError):
+                tr.read_metrics()
