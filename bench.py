@@ -500,7 +500,10 @@ def main():
             model.compute_dtype = "bf16"
         if args.chain != "auto":
             model.use_chain = args.chain == "on"
-        return Trainer(model, process_group=pg, force_collective=force, one_shot=exchange["mode"] == "oneshot")
+        # one rank per GPU (the driver's launch): every rank owns its device; BENCH_SHARE_GPU (functional mode: several ranks on one
+        # GPU) withdraws the promise, and with it the in-launch wait of the fused preparation
+        return Trainer(model, process_group=pg, force_collective=force, one_shot=exchange["mode"] == "oneshot",
+                       exclusive_device=not share)
 
     def replicas_identical(t):
         """every rank holds bit-identical parameters (sum of squares and a strided checksum agree across ranks)"""

@@ -23,6 +23,7 @@ FLAG_AGG_SPARSE = 16      # never use the dense per-graph block aggregation
 FLAG_AGG_DENSE = 32       # use it whenever the batch admits it (coalesced_undirected, max_nodes <= 512)
 FLAG_CHAIN = 128          # graph-chain kernels (conv1..conv4 of a graph inside one workgroup) whenever admissible
 FLAG_NO_CHAIN = 256       # never
+FLAG_EXCLUSIVE_DEVICE = 512   # pipelined steps: nothing else runs on this device (admits the in-launch wait of the fused preparation)
 FLAG_BF16 = 64            # bf16 leg: pre-scaled linear outputs stored bf16, X.W on the bf16 matrix cores
 
 FORM_DENSE, FORM_CHAIN, FORM_CHAIN_TAIL, FORM_STEP, FORM_EVAL = 1, 2, 4, 8, 16      # dgcnn_forward_form bits
@@ -200,7 +201,7 @@ def ws_view(ws, name: str, N: int, E: int, B: int, F: int, C: int):
     """Typed torch view of a named workspace region (tests and tools)."""
     import torch
     shapes = {
-        "err": (torch.int32, (4,)), "rowptr": (torch.int32, (N + 1,)), "rowptr_t": (torch.int32, (N + 1,)),
+        "err": (torch.int32, (8,)), "rowptr": (torch.int32, (N + 1,)), "rowptr_t": (torch.int32, (N + 1,)),
         "colidx": (torch.int32, (E,)), "colidx_t": (torch.int32, (E,)), "dinv": (torch.float32, (N,)),
         "graph_ptr": (torch.int32, (B + 1,)),
         "x1": (torch.float32, (N, 32)), "x2": (torch.float32, (N, 32)), "x3": (torch.float32, (N, 32)),

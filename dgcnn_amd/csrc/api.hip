@@ -533,7 +533,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         dg_ptr<int32_t>(ws, wl.err), epoch, dg_ptr<float>(ws, wl.gasA), dg_ptr<float>(ws, wl.pa4),
                                         wl.P1, s, rider_a, g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr,
                                         step_kernel ? dg_ptr<float>(ws, wl.pb3) : nullptr, step_kernel ? dg_ptr<float>(ws, wl.pb2) : nullptr,
-                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16, (rider_a && rode) ? &fused_b : nullptr,
+                                        step_kernel ? dg_ptr<float>(ws, wl.pb1) : nullptr, bf16,
+                                        (rider_a && rode && (flags & DGCNN_FLAG_EXCLUSIVE_DEVICE)) ? &fused_b : nullptr,
                                         fm.edge_check == 2 ? 1 : 0));
     g_prof_which = -1;
     // 2: conv4's backward (gas3 in gasA, {dW4, db3} partials) rode along too; 3: the whole GCN backward did (row b of pa4 / pb3 /
@@ -555,7 +556,8 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         in_launch ? et->ctr : nullptr, in_launch ? et->ctr_host : nullptr,
                                         in_launch ? et->metrics : nullptr, dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a,
                                         g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr, bf16,
-                                        (rider_a && rode) ? &fused_b : nullptr, fm.edge_check == 2 ? 1 : 0));
+                                        (rider_a && rode && (flags & DGCNN_FLAG_EXCLUSIVE_DEVICE)) ? &fused_b : nullptr,
+                                        fm.edge_check == 2 ? 1 : 0));
     g_prof_which = -1;
     if (in_launch) et->done = 1;
     if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
@@ -930,7 +932,7 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   int flags = cur->flags;
   uint32_t epoch = cur->epoch;
   if (prepared) {
-    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED));
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_EXCLUSIVE_DEVICE));
     epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
   }
   h->prep_ws = nullptr;
@@ -1038,7 +1040,7 @@ int dgcnn_pipeline_eval_step(void* handle, const dgcnn_step_args* cur, const dgc
   int flags = cur->flags & 0xFFFF;
   uint32_t epoch = cur->epoch;
   if (prepared) {
-    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED));
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_EXCLUSIVE_DEVICE));
     epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
   }
   h->prep_ws = nullptr;

@@ -1469,7 +1469,9 @@ __device__ __forceinline__ void ch_rider_block(int rb, const DgPrepRider& rd) {
     //  agent-coherent loads instead)
     while ((int)(__hip_atomic_load(rd.sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rd.sync_target) < 0) {
       __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1u << 23)) { rd.err[1] = rd.epoch; rd.err[3] = ~rd.epoch; break; }      // (never seen; the batch is flagged)
+      // (never seen on an exclusive device; the batch is flagged through a word of its own -- err[4] / err[6]: "an in-launch wait
+      //  timed out", not "layout promise violated" -- and its structures stay incomplete)
+      if (++spins > (1u << 23)) { rd.err[4] = rd.epoch; rd.err[6] = ~rd.epoch; break; }
     }
   }
   __syncthreads();

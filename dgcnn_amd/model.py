@@ -347,7 +347,12 @@ class Model(nn.Module):
                        (1, "a host-side promise about the batch does not hold: coalesced_undirected "
                            "(edge_index sorted by (src,dst), no duplicates/self loops, reverse edges "
                            "present), max_nodes (too small), or block-diagonality (an edge leaves its "
-                           "graph) -- the forward result of this batch is invalid")):
+                           "graph) -- the forward result of this batch is invalid"),
+                       (4, "an in-launch wait of the pipelined graph preparation timed out: exclusive_device was promised "
+                           "but something else (a second process, another stream's waiting kernels) held the compute units "
+                           "-- the batch's structures are incomplete; use Trainer(..., exclusive_device=False)")):
+            if k + 2 >= len(u):
+                continue
             e = u[k]
             if e != 0 and u[k + 2] == ((~e) & 0xFFFFFFFF) and (since < e <= now or (now < since and (e > since or e <= now))):
                 raise _lib.DgcnnError(msg)

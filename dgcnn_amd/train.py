@@ -46,7 +46,13 @@ class Trainer:
     ARGS_CACHE_MAX = 128
 
     def __init__(self, model: Model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, force_collective: bool = False, one_shot: bool = False):
+                 process_group=None, force_collective: bool = False, one_shot: bool = False,
+                 exclusive_device: Optional[bool] = None):
+        """``exclusive_device``: the promise behind ``DGCNN_FLAG_EXCLUSIVE_DEVICE`` -- nothing else runs on this GPU while a
+        step is in flight -- which admits the form of a small batch's step whose launch ALSO carries both phases of the next
+        batch's graph preparation (workgroups of one launch waiting for each other on the device).  ``None``: True for a
+        single process, False under a process group of more than one rank (ranks may share a device: the tests of this
+        repository do); pass True when every rank owns its GPU (``bench.py`` does)."""
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.pg = process_group
@@ -59,6 +65,9 @@ class Trainer:
             import torch.distributed as dist
             self._dp_world = dist.get_world_size(process_group)
         self._err_checked = model._epoch      # forward tag up to which input errors have been surfaced
+        if exclusive_device is None:
+            exclusive_device = self._dp_world <= 1
+        self._excl = _lib.FLAG_EXCLUSIVE_DEVICE if exclusive_device else 0
         # one-shot exchange (dgcnn_amd.dist.PeerExchange): gradients land in peer-mapped memory, ONE kernel per rank sums
         # them in rank order and applies Adam -- instead of all_reduce + dgcnn_adam_step.  Opt-in (no multi-GPU timing yet).
         self._one_shot = bool(one_shot) and self._allreduce is not None
@@ -283,7 +292,7 @@ class Trainer:
             a.grads = self._peer.grad_ptr(self.step_count + 1)
         a.training = training
         a.seed = m._next_seed() if training else 0
-        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags()
+        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags() | self._excl
         a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam and not evaluate:
             self.step_count += 1
@@ -302,7 +311,7 @@ class Trainer:
             if nsl["ws"] is None or nent[3] > nsl["bytes"] or nsl["ws"].device != dev:
                 self._slot_ws(1 - slot, nent[3], dev)
             nsl["dims"] = nent[5]
-            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8] | m._mode_flags(), m._next_epoch()
+            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8] | m._mode_flags() | self._excl, m._next_epoch()
             nref = nent[6]
             self._prep_ent, self._prep_slot = nent, 1 - slot
             self._cur = 1 - slot
@@ -387,7 +396,7 @@ class Trainer:
             words = torch.cat([m.view(torch.int32)] + [_lib.ws_view(sl["ws"], "err", *sl["dims"]) for sl in slots]).tolist()
             v = torch.tensor(words[:2], dtype=torch.int32).view(torch.float32).tolist()
             for k in range(len(slots)):
-                self.model._check_err_words(words[2 + 4 * k: 6 + 4 * k], self._err_checked, self.model._epoch)
+                self.model._check_err_words(words[2 + 8 * k: 10 + 8 * k], self._err_checked, self.model._epoch)
             self._err_checked = self.model._epoch
         else:
             v = m.tolist()

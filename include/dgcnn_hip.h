@@ -76,6 +76,15 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
                                        backward chain).  Needs what the dense block form needs plus num_features <= 32; this
                                        flag asks for it whenever admissible ... */
 #define DGCNN_FLAG_NO_CHAIN    256   /* ... this one forbids it; neither: the library's cost model decides per batch */
+#define DGCNN_FLAG_EXCLUSIVE_DEVICE 512 /* dgcnn_pipeline_train_step / _eval_step: the caller promises that nothing else runs on this
+                                         * device while a step is in flight (no second process, no other stream with spin-waiting
+                                         * kernels).  Only then BOTH phases of the next batch's graph preparation join the one-launch
+                                         * kernel of a small batch -- its phase-B workgroups wait, on the device, for the phase-A
+                                         * workgroups of the same launch, which is deadlock-free only when no OTHER launch's waiting
+                                         * workgroups can hold the compute units the producers still need.  Without the promise
+                                         * phase B rides on the step's next launch as before round 4 (same results, ~2 us per step at
+                                         * the reference's batch of 50).  A wait that does not end is bounded (~4 s) and reported
+                                         * through err[4] / err[6], never as a layout error. */
 #define DGCNN_FUSED_MIN_GRAPHS (1 << 30) /* the fused path is never chosen automatically: the tiled kernels measured
                                             faster at every batch size (profiles/r01_sweep.txt); FORCE_FUSED selects it */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
@@ -223,10 +232,12 @@ int dgcnn_sortpool_bwd(int N, int B, const int32_t* graph_ptr, const int32_t* pe
  *   max_edges: host-known upper bound of the directed-edge count of any single graph (0 = unknown);
  *            lets the fused kernel also keep each graph's neighbour ids in LDS when they fit.
  *   epoch  : non-zero tag of this call.  Input errors are reported WITHOUT any host sync or
- *            memset through the workspace region "err" (4 x u32): the call is in error iff
+ *            memset through the workspace region "err" (8 x u32): the call is in error iff
  *            err[k] == epoch && err[k+2] == ~epoch  (k = 0: edge endpoint out of range,
- *            k = 1: COALESCED_UNDIRECTED promised but violated).  The caller checks at its
- *            next natural sync point.
+ *            k = 1: COALESCED_UNDIRECTED promised but violated, k = 4: an in-launch wait of the
+ *            pipelined preparation timed out -- DGCNN_FLAG_EXCLUSIVE_DEVICE promised on a shared
+ *            device; the batch's structures are incomplete).  The caller checks at its next
+ *            natural sync point.
  * ---------------------------------------------------------------------------------- */
 int dgcnn_model_forward(int N, int E, int B, int F, int C, const float* params,
                         const float* x, const int64_t* edge_index, const int64_t* batch,

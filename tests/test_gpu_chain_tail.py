@@ -408,3 +408,81 @@ def test_reverse_edge_check_inside_the_one_launch_kernels_from_96_graphs_on(mode
         else:
             with pytest.raises(_lib.DgcnnError):
                 tr.read_metrics()
+
+
+def _run_steps(batches, nsteps, exclusive, stream=None, hog=None):
+    """`nsteps` pipelined training steps over `batches` (round robin, look-ahead) on `stream`; returns the final parameters"""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    m = make_model(sh.num_features, sh.num_classes)
+    m.train(); m._seed_base, m._fwd_count = 21, 0
+    nb = len(batches)
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream())      # (the model was initialised on the current stream)
+    ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+    with ctx:
+        tr = Trainer(m, exclusive_device=exclusive)
+        tr.reset_metrics()
+        for i in range(nsteps):
+            if hog is not None:
+                hog()
+            tr.train_step(batches[i % nb], batches[i % nb].y, next_data=batches[(i + 1) % nb])
+    return m, tr
+
+
+def test_fused_preparation_beside_a_busy_second_stream_is_bit_identical_and_unflagged():
+    """the step kernel's in-launch wait (phase-B workgroups polling a counter that the phase-A workgroups of the
+    SAME launch advance) beside foreign work -- a second stream keeps every compute unit busy with long matrix products while 60
+    pipelined steps run.  Workgroups of one launch are dispatched in index order, so a waiter can never precede its producers;
+    the foreign kernels never wait for anything of ours.  Must equal the undisturbed run bit for bit, no batch flagged."""
+    batches = [batch_with_small_graphs("COLLAB", 50, start=7000 + 300 * k).to("cuda") for k in range(4)]
+    ref_m, ref_tr = _run_steps(batches, 60, exclusive=True)
+    torch.cuda.synchronize()
+    ref_tr.read_metrics()
+    ref = ref_m.flat_params.clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    junk = []
+
+    def hog():
+        with torch.cuda.stream(side):
+            junk.append(torch.mm(a, a))           # ~1 ms of every CU's time per call
+            if len(junk) > 4:
+                junk.pop(0)
+    main = torch.cuda.Stream()
+    main.wait_stream(torch.cuda.current_stream())
+    m, tr = _run_steps(batches, 60, exclusive=True, stream=main, hog=hog)
+    torch.cuda.synchronize()
+    tr.read_metrics()                              # raises if any batch was flagged (layout promise or wait time-out)
+    assert torch.equal(m.flat_params, ref)
+
+
+def test_two_trainers_on_two_streams_without_the_exclusive_promise_keep_the_classic_riders():
+    """two training loops in one process on two streams, interleaved launch by launch: the hazardous constellation for in-launch
+    waits (each launch's waiting workgroups could hold the compute units the other's producers need).  Without the promise
+    (exclusive_device=False) phase B rides on k_wgrad -- nobody waits on the device -- and both loops reproduce the single run"""
+    from dgcnn_amd.train import Trainer
+    sh = synth.SHAPES["COLLAB"]
+    batches = [batch_with_small_graphs("COLLAB", 50, start=7000 + 300 * k).to("cuda") for k in range(4)]
+    ref_m, ref_tr = _run_steps(batches, 24, exclusive=False)
+    torch.cuda.synchronize()
+    ref = ref_m.flat_params.clone()
+    ex_m, ex_tr = _run_steps(batches, 24, exclusive=True)      # (and the promise changes nothing but the launch that carries phase B)
+    torch.cuda.synchronize()
+    assert torch.equal(ex_m.flat_params, ref)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ms, trs = [], []
+    for st in streams:
+        m = make_model(sh.num_features, sh.num_classes)
+        m.train(); m._seed_base, m._fwd_count = 21, 0
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ms.append(m); trs.append(Trainer(m, exclusive_device=False))
+    for i in range(24):
+        for st, tr in zip(streams, trs):
+            with torch.cuda.stream(st):
+                tr.train_step(batches[i % 4], batches[i % 4].y, next_data=batches[(i + 1) % 4])
+    torch.cuda.synchronize()
+    for m, tr in zip(ms, trs):
+        tr.read_metrics()
+        assert torch.equal(m.flat_params, ref)
