@@ -390,6 +390,30 @@ struct DgStage {
   }
 };
 
+// 16 bytes per lane (N a multiple of 4, source and destination 16-byte aligned): a quarter of the vector-memory instructions --
+// every wave-level load costs the CU's address path ~14 cycles whatever its width, and a prologue that stages a few KB with
+// dword loads from all 16 waves is ~100 of them in front of the first barrier
+template <int N, int THREADS>
+struct DgStage4 {
+  static_assert(N % 4 == 0, "whole float4 pieces");
+  static constexpr int N4 = N / 4, IT = (N4 + THREADS - 1) / THREADS;
+  float4 v[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int t = tid + i * THREADS;
+      v[i] = *reinterpret_cast<const float4*>(src + 4 * (t < N4 ? t : 0));      // (unconditional on a clamped piece)
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int t = tid + i * THREADS;
+      if (t < N4) *reinterpret_cast<float4*>(dst + 4 * t) = v[i];
+    }
+  }
+};
+
 // ---- aggregate-first conv1 (F <= DG_AF_MAX_F) -------------------------------------------------------
 // One wavefront, one destination row.  Lane = (g = lane >> lfp neighbour group, q = lane & (2^lfp - 1) feature):
 // 64 >> lfp neighbours in flight per wave-instruction.  Returns, in every lane with q < F,

@@ -279,8 +279,8 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   const float bval = *bsrc;
   // conv5 / conv6 weights: loads issued now, held in registers over the sort (the key area may overlap W5s/W6s),
   // stored to LDS afterwards -- no memory round trip of theirs is left on the critical path
-  DgStage<NW5, RD_THREADS> st5;
-  DgStage<NW6, RD_THREADS> st6;
+  DgStage4<NW5, RD_THREADS> st5;
+  DgStage4<NW6, RD_THREADS> st6;
   if (!BIG) { st5.load(w.W5, tid); st6.load(w.W6, tid); }
   float wf2a = 0.f, wf2b = 0.f;                   // classifier_2 row of class `wv` (used at the very end: no cold load there)
   if (!BIG && wv < C) { wf2a = w.Wf2[wv * DGCNN_HID1 + lane]; wf2b = w.Wf2[wv * DGCNN_HID1 + lane + 64]; }

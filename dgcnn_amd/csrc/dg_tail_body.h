@@ -296,6 +296,9 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // conv5: pW5[o][m]      = sum_s gz5[o][s] sp[s][m]       -> [16 x 112(97)] = [16 x 32(30)] . [32 x 112] (7 tiles)
   // (written out per product: the generic tile helper's per-operand bounds tests and index arithmetic were most of these
   //  phases' instructions, and every wave of the workgroup executes them)
+  // (5b and 6 form ONE list of 17 + 14 = 31 matrix-core jobs dealt round robin: wave w takes jobs w and w + 16 -- two at most.  As two
+  //  loops, wave 0 carried three (jobs 0 and 16 of 5b, job 0 of 6) and was the phase's duration: every other wave waited at the
+  //  barrier behind it.)
   for (int job = wv; job < 17; job += RD_THREADS / 64) {
     const int mi = lane & 15, kq = lane >> 4;
     if (job < 10) {
@@ -355,7 +358,7 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   TB_MARK(6);
   // 6. conv5 data gradient = gradient wrt the pooled rows; scatter to the selected nodes
   // gsp[s][c] = sum_oc gz5[oc][s] W5[oc][c]  -> [32(30) x 112(97)] = [32 x 16] . [16 x 112]  (14 tiles, one wave each)
-  for (int job = wv; job < 14; job += RD_THREADS / 64) {
+  for (int job = (wv == 0 ? 16 : wv - 1); job < 14; job += RD_THREADS / 64) {      // (list position 17 + job = wave (job + 1) & 15's second job)
     const int mt = job / 7, nt = job - mt * 7;
     const int mi = lane & 15, kq = lane >> 4;
     const int srow = mt * 16 + mi, ccol = nt * 16 + mi;

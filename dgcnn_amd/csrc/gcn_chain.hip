@@ -592,25 +592,9 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     // graphs of <= ROWS/2 nodes keep TWO images, rows [0, ROWS/2) and [ROWS/2, ROWS) of every plane, and alternate between
     // them: a layer's output image is not the one still being read, so the barrier in front of its stores is not needed
     const int pong = (2 * n <= C::ROWS) ? (C::ROWS / 2) * 32 : 0;
-    // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < C::PB; ++j)
-      if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
-    if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
-    CH_T(14);
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-      const int it = tl + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
-      if (k < n) {
-        uint2 pk[3];
-        ch_split3_pack4(4 * qq + 0 < F ? pxs[j][0] : 0.f, 4 * qq + 1 < F ? pxs[j][1] : 0.f, 4 * qq + 2 < F ? pxs[j][2] : 0.f,
-                        4 * qq + 3 < F ? pxs[j][3] : 0.f, pk);
-        const int nb = qq >> 2, sl = qq & 3;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(H + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) = pk[p];
-      }
-    }
-    CH_T(15);
+    // ---- zeros first: they depend on nothing that was loaded, so their ~1 k cycles of stores are issued while the graph's data is
+    //      still in flight (they used to stand behind the data stores, i.e. behind the wait for the prefetch).  Disjoint from every
+    //      slot the staging below writes: no ordering between the two is needed.
     {   // zeros conv1 reads but nobody wrote: rows n..RU-1 of its planes, and the slots beyond the feature width
       const int sh = NBF + 1;                              // 4 * NBF slots per row
       for (int it = tl; it < (RU << sh); it += C::THREADS) {
@@ -632,6 +616,25 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
       if (pong && tl < 192)
         *reinterpret_cast<uint4*>(H + pong + (tl >> 5) * C::PS + (16 * T + ((tl >> 1) & 15)) * 32 + 16 * (tl & 1)) = make_uint4(0u, 0u, 0u, 0u);
     }
+    // ---- stage the graph: registers -> LDS images -----------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j)
+      if (tl + C::THREADS * j < n * S) bl[tl + C::THREADS * j] = pbit[j];
+    if (tl < C::ROWS) dv[tl] = tl < n ? pdv : 0.f;
+    CH_T(14);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int it = tl + C::THREADS * j, k = it >> lg, qq = it & ((1 << lg) - 1);
+      if (k < n) {
+        uint2 pk[3];
+        ch_split3_pack4(4 * qq + 0 < F ? pxs[j][0] : 0.f, 4 * qq + 1 < F ? pxs[j][1] : 0.f, 4 * qq + 2 < F ? pxs[j][2] : 0.f,
+                        4 * qq + 3 < F ? pxs[j][3] : 0.f, pk);
+        const int nb = qq >> 2, sl = qq & 3;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(H + (p * 2 + nb) * C::PS + k * 32 + 8 * (sl ^ ((k >> 2) & 3))) = pk[p];
+      }
+    }
+    CH_T(15);
     CH_T(1);                                              // 1: wait for the prefetched data + staging stores
     if (!LOOP) {          // (one graph per workgroup: the weight tables go to LDS only now, see the loads above)
       store_tables();
