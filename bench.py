@@ -633,6 +633,18 @@ def main():
             tr.pipelined_step(b, b.y, batches[(i + 1) % nb], None, gb, fuse_adam=False)
         torch.cuda.synchronize(dev)
         extra["fwd_bwd_only_graphs_per_s_rank0"] = round(n2 * Bavg / (time.perf_counter() - t1), 1)
+        # ---- the reference's test() loop body (train.py:57-64) on the same batches: Trainer.eval_step, look-ahead as test_epoch ----
+        if world == 1:
+            tr.model.eval()
+            for i in range(20):
+                tr.eval_step(batches[i % nb], batches[i % nb].y, next_data=batches[(i + 1) % nb])
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(n2):
+                tr.eval_step(batches[i % nb], batches[i % nb].y, next_data=batches[(i + 1) % nb])
+            torch.cuda.synchronize(dev)
+            extra["eval_step_us_rank0"] = round(1e6 * (time.perf_counter() - t1) / n2, 2)
+            tr.model.train()
 
     def measure_agg(trainer, bl, bl_cpu, nprof):
         """HIP events attached to the 32-wide aggregation dispatches (conv2 / conv3 round robin; conv1 too when F > 32)"""

@@ -1698,13 +1698,14 @@ k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, con
     const bool ybad = (unsigned)yraw >= (unsigned)t.C;     // out-of-range label: NaN loss (sticky), no out-of-bounds read
     const int yb = ybad ? 0 : yraw;
     const float l = ybad ? __builtin_nanf("") : M.lg[yb];
-    if (lane == 0) {
-      __hip_atomic_store(t.evl + 2 * b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(t.evl + 2 * b + 1, (am == yb) ? 1.f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // ONE 8-byte agent-coherent store {loss term, launch tag | correct} and, WITHOUT waiting for it, the counter: a pair that is
+    // still on its way when the last workgroup looks is recognised by its stale tag and polled (the store-then-wait-then-count
+    // form put a write-through round trip, ~1.3 k cycles, in front of every workgroup's counter increment)
+    if (lane == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(t.evl) + b,
+                         ((unsigned long long)((t.target << 1) | ((am == yb) ? 1u : 0u)) << 32) | __float_as_uint(l),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // (the pair is written through before the counter moves: vmcnt(0), no fence -- a release would write back this XCD's whole L2)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned int old = 0;
   if (lane == 0) old = __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
@@ -1713,13 +1714,27 @@ k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, con
   // last workgroup: k_eval_metrics' sums (tail.hip: virtual thread v takes graphs v, v + 256, ... -- at most one here, B <= 256 --,
   // then the binary tree 128, 64, ..., 1) with virtual threads l, l + 64, l + 128, l + 192 in lane l: the same additions
   float sl[4], sc[4];
+  {
+    const unsigned long long* ev = reinterpret_cast<const unsigned long long*>(t.evl);
+    unsigned long long pv[4];
+    unsigned int spins = 0;
+    for (;;) {
+      bool ok = true;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int g = lane + 64 * q, gc = min(g, B - 1);
-    const float lv = __hip_atomic_load(t.evl + 2 * gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float cv = __hip_atomic_load(t.evl + 2 * gc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sl[q] = g < B ? 0.f - lv : 0.f;
-    sc[q] = g < B ? 0.f + cv : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const int g = lane + 64 * q;
+        pv[q] = __hip_atomic_load(ev + min(g, B - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (g >= B || (unsigned int)(pv[q] >> 33) == (t.target & 0x7fffffffu));
+      }
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      if (++spins > (1u << 20)) { if (lane == 0) { t.err[4] = t.epoch; t.err[6] = ~t.epoch; } break; }      // (never seen)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = lane + 64 * q;
+      sl[q] = g < B ? 0.f - __uint_as_float((unsigned int)pv[q]) : 0.f;
+      sc[q] = g < B ? 0.f + (float)((unsigned int)(pv[q] >> 32) & 1u) : 0.f;
+    }
   }
   sl[0] += sl[2]; sl[1] += sl[3]; sc[0] += sc[2]; sc[1] += sc[3];      // st = 128
   sl[0] += sl[1]; sc[0] += sc[1];                                      // st = 64
