@@ -106,3 +106,32 @@ def test_isa_audit_tool_reads_the_built_objects():
     for l in lines:
         if "k_gcn_fwd32n" in l:      # the narrow forward: no kernel-argument load behind its barrier
             assert l.rstrip().endswith("s_load behind a barrier   0"), l
+
+
+def test_trainer_promises_an_exclusive_device_only_where_it_can_know():
+    """DGCNN_FLAG_EXCLUSIVE_DEVICE (round 5): the in-launch wait of the fused preparation is admitted by a promise of the caller.
+    A single-process Trainer makes it by default, an explicit False withdraws it, and the flag travels in the step arguments'
+    flags word next to the batch's layout promise -- it never changes which kernel family a batch takes."""
+    from dgcnn_amd import _lib
+    from dgcnn_amd.model import Model
+    from dgcnn_amd.train import Trainer
+    m = Model(1, 3)
+    assert Trainer(m)._excl == _lib.FLAG_EXCLUSIVE_DEVICE
+    assert Trainer(m, exclusive_device=False)._excl == 0
+    f = _lib.lib().dgcnn_forward_form
+    CU = _lib.FLAG_COALESCED_UNDIRECTED
+    assert f(3800, 140000, 50, 1, CU, 180) == f(3800, 140000, 50, 1, CU | _lib.FLAG_EXCLUSIVE_DEVICE, 180)
+    assert f(9600, 360000, 128, 1, CU, 200) == f(9600, 360000, 128, 1, CU | _lib.FLAG_EXCLUSIVE_DEVICE, 200)
+
+
+def test_data_can_restrict_its_own_forms():
+    """``mode_flags`` on a batch (a PreparedDataset built without bitmap rows hands them out) reach the library's flags through both
+    routes, Model.forward and the Trainer's cached step arguments"""
+    import types
+    from dgcnn_amd import _lib
+    from dgcnn_amd.model import Model
+    m = Model(1, 3)
+    d = types.SimpleNamespace(coalesced_undirected=True, mode_flags=_lib.FLAG_AGG_SPARSE | _lib.FLAG_NO_CHAIN)
+    fl = m._flags_of(d)
+    assert fl & _lib.FLAG_COALESCED_UNDIRECTED and fl & _lib.FLAG_AGG_SPARSE and fl & _lib.FLAG_NO_CHAIN
+    assert _lib.lib().dgcnn_forward_form(3800, 140000, 50, 1, fl, 180) == 0          # CSR gather kernels, whatever the sizes admit
