@@ -949,6 +949,12 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #ifdef CH_TIMING
     if (dbg && tid == 0) dbg[blockIdx.x * 16 + 11] += 1;
 #endif
+#ifdef CH_LOOP_END_BARRIER
+    // (two tiles per wave: conv4 reads its bitmap words from the LDS rows `bl` word by word; a wave that is done with its tiles
+    //  must not stage the NEXT graph's rows over them while another wave is still in conv4.  Not yet the default: built and read,
+    //  not yet run -- docs/rounds/r05.md, last section)
+    if (LOOP && TWO) dg_lds_barrier();
+#endif
     n0 = n0N; n = nN; par ^= 1;
   }
 #ifdef CH_TIMING
