@@ -2045,6 +2045,9 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         }
       }
     }
+#ifdef CH_LOOP_END_BARRIER
+    if (LOOP) dg_lds_barrier();      // (conv3's product reads `bl` word by word: see ch_chain_body's loop end; k_chain_bwd_b has this barrier)
+#endif
     n0 = n0N; n = nN; par ^= 1;
   }
   // ---- this workgroup's partial rows: the waves' accumulators combined in a fixed order ---------------------------------------
