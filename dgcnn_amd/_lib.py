@@ -131,7 +131,8 @@ class DgcnnError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libdgcnn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j4"]
+    # `racedelay`: the test build of the persistent chain kernels (tests/test_gpu_chain.py), next to the product library
+    cmd = ["make", "-C", CSRC, "-j4", "all", "racedelay"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

@@ -899,6 +899,12 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     CH_T(8);
     dg_lds_barrier();
     CH_T(9);
+#ifdef CH_RACE_DELAY
+    // test build only (tests/test_gpu_chain.py, variants/lib_racedelay.so): waves 0, 3, 6 enter the iteration's LAST phase ~30 k
+    // cycles late, so that every other wave is done with it -- and, were the loop-end barrier missing, would be re-staging `bl`
+    // for the next graph -- long before these waves read their bitmap words
+    if (LOOP && wave % 3 == 0) { for (int q = 0; q < 4; ++q) __builtin_amdgcn_s_sleep(127); }
+#endif
     // ---- conv4: the three parts of h4s are columns 0..2 of ONE B operand ---------------------------------------------------
     if (live0) {
       f32x4 a4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -949,10 +955,12 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
 #ifdef CH_TIMING
     if (dbg && tid == 0) dbg[blockIdx.x * 16 + 11] += 1;
 #endif
-#ifdef CH_LOOP_END_BARRIER
-    // (two tiles per wave: conv4 reads its bitmap words from the LDS rows `bl` word by word; a wave that is done with its tiles
-    //  must not stage the NEXT graph's rows over them while another wave is still in conv4.  Not yet the default: built and read,
-    //  not yet run -- docs/rounds/r05.md, last section)
+    // Loop end.  Two tiles per wave (TWO): conv4 reads its bitmap words from the LDS rows `bl` word by word; a wave that is done
+    // with its tiles must not stage the NEXT graph's rows over them while another wave is still in conv4 -> one LDS-only barrier.
+    // One tile per wave (!TWO): conv4 reads nothing the next staging writes -- its bitmap words are in registers (`wreg`, read
+    // behind the staging barrier, and every wave has passed three more barriers since), h4p / dv alternate with `par`, the image H
+    // was last read in conv3's product in front of the barrier at CH_T(8), the tables are constant -> no barrier needed.
+#ifndef CH_NO_LOOP_END_BARRIER      // (the unsafe form exists only to show that the race-delay test catches its absence: profiles/r06_race_test.txt)
     if (LOOP && TWO) dg_lds_barrier();
 #endif
     n0 = n0N; n = nN; par ^= 1;
@@ -1963,6 +1971,9 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
       }
     }
     dg_lds_barrier();
+#ifdef CH_RACE_DELAY
+    if (LOOP && wave % 3 == 0) { for (int q = 0; q < 4; ++q) __builtin_amdgcn_s_sleep(127); }      // (see ch_chain_body)
+#endif
 
     // ======== conv3 backward: per tile ========
 #pragma unroll
@@ -2045,8 +2056,8 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
         }
       }
     }
-#ifdef CH_LOOP_END_BARRIER
-    if (LOOP) dg_lds_barrier();      // (conv3's product reads `bl` word by word: see ch_chain_body's loop end; k_chain_bwd_b has this barrier)
+#ifndef CH_NO_LOOP_END_BARRIER
+    if (LOOP) dg_lds_barrier();      // (conv3's product reads `bl` word by word and the loop top re-stages `bl`: see ch_chain_body's loop end; k_chain_bwd_b has the same barrier)
 #endif
     n0 = n0N; n = nN; par ^= 1;
   }
