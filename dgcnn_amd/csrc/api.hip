@@ -252,9 +252,13 @@ struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
 // one-launch evaluation / inference kernel (k_chain_readout_eval): every graph in the chain form, one workgroup per graph
 static int g_eval_kernel = 1;      // dgcnn_eval_kernel_enable (tests / measurement A-B): 0 keeps chain forward + readout as two launches
 int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on ? 1 : 0; return prev; }
-static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
-  return g_eval_kernel != 0 && f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
+// (a pure function of the batch's numbers: what graph PREPARATION may rely on -- the process-wide switch is read by the forward only)
+static bool dg_one_launch_shape(const DgForm& f, int B, int max_nodes) {
+  return f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
          max_nodes <= dg_chain_train_max_nodes();
+}
+static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
+  return g_eval_kernel != 0 && dg_one_launch_shape(f, B, max_nodes);
 }
 static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   DgForm f;
@@ -271,7 +275,11 @@ static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   //   2  by the one-launch training / evaluation kernel itself on its LDS image of the graph's bitmap, from DG_INSYM_MIN_B graphs
   //      on: there phase B is a rider of k_wgrad (it no longer fits beside the graph workgroups), and its per-edge searches
   //      were that launch's duration (256 COLLAB graphs: 13.6 us of 17.8); below, phase B runs on idle CUs for free.
-  f.edge_check = (f.bitmap && !f.dense) ? ((B >= DG_INSYM_MIN_B && dg_eval_kernel_admits(f, B, max_nodes)) ? 2 : 1) : 0;
+  //      Decided from the batch's numbers and flags ALONE: preparation and forward of a batch are separate calls, and a
+  //      process-wide switch (dgcnn_eval_kernel_enable) may change between them; a forward that then takes the two-launch chain
+  //      route for such a batch runs the bitmap check as a launch of its own (dg_model_forward_impl).  DGCNN_FLAG_FORCE_FUSED /
+  //      _FORCE_TILED / _AGG_SPARSE / _NO_CHAIN never get here: dg_use_chain says no, and without a bitmap phase B searches every edge.
+  f.edge_check = (f.bitmap && !f.dense) ? ((B >= DG_INSYM_MIN_B && dg_one_launch_shape(f, B, max_nodes)) ? 2 : 1) : 0;
   return f;
 }
 // Sparse many-node batches on the launch-per-layer gather route (the narrow kernels' regime, gcn.hip: DD at the reference's
@@ -564,6 +572,11 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
     return DGCNN_OK;
   }
   if (chain) {
+    // the preparation of this batch left the reverse-edge check to a one-launch kernel (edge_check 2) and this forward is not one:
+    // the one-launch evaluation kernel is switched off (dgcnn_eval_kernel_enable(0)).  Check the bitmap here, as the dense forms do.
+    if (fm.edge_check == 2)
+      DG_TRY(dg_launch_prep_sym(edge_index, E, N, B, batch, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dg_ptr<int32_t>(ws, wl.err),
+                                epoch, s));
     DG_TRY(dg_launch_chain_fwd(N, B, F, max_nodes, dg_ptr<int32_t>(ws, wl.graph_ptr), G.bits, dinv, hsA, params, &pl,
                                dg_ptr<float>(ws, wl.ax), x1, x2, x3, x4, fm.plan ? dg_ptr<int32_t>(ws, wl.dmap) : nullptr, bf16, s,
                                g_prof_which >= 0 ? g_prof_a : nullptr,
@@ -912,6 +925,13 @@ static int dg_pipeline_rider(DgPipeline* h, const dgcnn_step_args* next, bool si
   return DGCNN_OK;
 }
 
+// flags that take part in dg_form / the forward's choice of kernel family: a batch prepared under one set is not "prepared" for a
+// step that names another
+static inline bool dg_form_flags_differ(int a, int b) {
+  const int m = DGCNN_FLAG_COALESCED_UNDIRECTED | DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_AGG_SPARSE |
+                DGCNN_FLAG_AGG_DENSE | DGCNN_FLAG_CHAIN | DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16;
+  return ((a ^ b) & m) != 0;
+}
 int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,
                               dgcnn_stream_t stream) {
   if (!handle || !cur) return DGCNN_EINVAL;
@@ -927,15 +947,20 @@ int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dg
   // (max_nodes takes part in the choice of the aggregation form, which decides what the preparation built)
   const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B &&
                      h->pmaxn == cur->max_nodes;
-  const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;     // the host says so explicitly ...
+  bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;           // the host says so explicitly ...
   if (prepared && !match) return DGCNN_EINVAL;                       // ... and it must be the batch we prepared
-  int flags = cur->flags;
+  // ... FOR the kernel family this step runs: the preparation's form (bitmap or not, who checks the reverse edges)
+  // followed from the flags it was given; a step that names another family now prepares again under its own flags
+  if (prepared && dg_form_flags_differ(cur->flags, h->pflags)) prepared = false;
+  int flags = cur->flags & ~DGCNN_FLAG_PREPARED;
   uint32_t epoch = cur->epoch;
   if (prepared) {
-    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_EXCLUSIVE_DEVICE));
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & DGCNN_FLAG_EXCLUSIVE_DEVICE);
     epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
   }
-  h->prep_ws = nullptr;
+  // a look-ahead preparation survives a step that neither consumes it, nor writes its workspace, nor prepares another batch
+  // (an evaluation step between two training steps, say): the one after that still finds it
+  if (h->prep_ws == cur->ws || next) h->prep_ws = nullptr;
 
   static const bool no_side = dg_knob("DG_NO_SIDE_PREP");      // A/B switch (DG_DEBUG_KNOBS builds only)
   // (a batch of a PREPARED dataset is never assembled on the side stream: the copy takes 16 us alone at 2048 graphs, but beside the
@@ -1035,15 +1060,18 @@ int dgcnn_pipeline_eval_step(void* handle, const dgcnn_step_args* cur, const dgc
                next->E < 0 || next->epoch == 0 || (next->E > 0 && !next->edge_index && !next->ds)))
     return DGCNN_EINVAL;
   const bool match = h->prep_ws == cur->ws && h->pN == cur->N && h->pE == cur->E && h->pB == cur->B && h->pmaxn == cur->max_nodes;
-  const bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;
+  bool prepared = (cur->flags & DGCNN_FLAG_PREPARED) != 0;
   if (prepared && !match) return DGCNN_EINVAL;
-  int flags = cur->flags & 0xFFFF;
+  if (prepared && dg_form_flags_differ(cur->flags, h->pflags)) prepared = false;      // (see dgcnn_pipeline_train_step)
+  int flags = cur->flags & 0xFFFF & ~DGCNN_FLAG_PREPARED;
   uint32_t epoch = cur->epoch;
   if (prepared) {
-    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & (DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_EXCLUSIVE_DEVICE));
+    flags = h->pflags | DGCNN_FLAG_PREPARED | (cur->flags & DGCNN_FLAG_EXCLUSIVE_DEVICE);
     epoch = h->pepoch;        // the error words of this workspace carry the preparation's tag
   }
-  h->prep_ws = nullptr;
+  // a look-ahead preparation survives a step that neither consumes it, nor writes its workspace, nor prepares another batch
+  // (an evaluation step between two training steps, say): the one after that still finds it
+  if (h->prep_ws == cur->ws || next) h->prep_ws = nullptr;
   if (cur->ds && !prepared) {        // first batch of a loop drawn from a prepared dataset: assemble in-stream, then run as prepared
     DG_TRY(dg_assemble_args(cur, flags, epoch, s));
     flags |= DGCNN_FLAG_PREPARED;

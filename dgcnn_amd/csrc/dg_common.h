@@ -129,7 +129,7 @@ static inline int dg_ws_layout(int N, int E, int B, int F, int C, DgWs* w) {
   w->P32 = dg_grid32(N);
   w->P1 = dg_grid1(N);
 #define R(name, bytes) do { w->name = o; o = dg_align(o + (int64_t)(bytes), 256); } while (0)
-  R(err, 16);
+  R(err, 32);        // 8 epoch-tagged words (include/dgcnn_hip.h: err[0..7])
   R(cnt_in, 4 * (n + 1));
   R(cnt_out, 4 * (n + 1));
   R(rowptr, 4 * (n + 1));

@@ -462,7 +462,13 @@ __device__ __forceinline__ void dg_prep_sym_body(int t, int N, int B, const int6
                                                  unsigned int* __restrict__ err, unsigned int epoch) {
   const int i = t >> 2, kq = t & 3;
   if (i >= N) return;
-  const int g = (int)batch[i];
+  int g;
+  if (batch) g = (int)batch[i];
+  else {          // (a PREPARED batch's forward may come without the batch vector: the last graph whose first node is <= i)
+    int lo = 0, hi = B;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (graph_ptr[mid] <= i) lo = mid; else hi = mid - 1; }
+    g = lo;
+  }
   if ((unsigned)g >= (unsigned)B) return;
   const int n0 = graph_ptr[g], ng = graph_ptr[g + 1] - n0, li = i - n0;
   if (ng > DGD_MAXN || li < 0 || li >= ng) return;                               // (flagged by phase B)

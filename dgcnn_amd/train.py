@@ -119,7 +119,7 @@ class Trainer:
                 # check: surface them now (one small copy; growth is rare) instead of losing them with the buffer
                 self.model.check_errors([(sl["ws"], sl["dims"])], since=self._err_checked)
             sl["ws"] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
-            sl["ws"][:16].zero_()          # error words of a fresh buffer: no stale tag can pass for a real one
+            sl["ws"][:32].zero_()          # error words of a fresh buffer: no stale tag can pass for a real one
             sl["bytes"] = sl["ws"].numel()
             sl["ptr"] = sl["ws"].data_ptr()
         return sl["ws"]
@@ -270,12 +270,16 @@ class Trainer:
         prepared = pe is ent          # the very cache entry that was prepared: same batch object AND the same tensors
         if prepared:
             slot = self._prep_slot               # its workspace was sized when it was handed in as `next`
-            m.__dict__["_epoch"] = a.epoch
+            if a.epoch > m.__dict__.get("_epoch", 0):      # (never backwards: a step may have run between its preparation and now)
+                m.__dict__["_epoch"] = a.epoch
         else:
             # (a prepared-but-abandoned batch keeps its slot untouched: use the other one)
             slot = self._cur if pe is None else 1 - self._prep_slot
             a.epoch = m._next_epoch()
-        self._prep_ent = None
+        # a look-ahead that this call neither consumes nor replaces stays valid (its slot is not the one used here): an
+        # eval_step between train_step(..., next_data=X) and train_step(X) does not throw X's preparation away
+        if prepared or pe is None or (next_data is not None and next_data is not data):
+            self._prep_ent = None
         sl = self._slots[slot]
         if sl["ws"] is None or need > sl["bytes"] or sl["ws"].device != dev:
             self._slot_ws(slot, need, dev)
@@ -315,7 +319,7 @@ class Trainer:
             nref = nent[6]
             self._prep_ent, self._prep_slot = nent, 1 - slot
             self._cur = 1 - slot
-        else:
+        elif self._prep_ent is None:
             self._cur = slot
         rc = (self._pipe_eval_fn if evaluate else self._pipe_fn)(self._pipe, aref, nref, torch._C._cuda_getCurrentRawStream(dev.index))
         if rc != 0:
@@ -361,7 +365,9 @@ class Trainer:
         """Body of the reference ``test()`` loop (train.py:59-64) as ONE C call (``dgcnn_pipeline_eval_step``): forward in
         eval mode + loss / #correct folded into the device-side metrics accumulator -- one launch where the batch admits the
         one-launch evaluation kernel (``DGCNN_FORM_EVAL``).  ``next_data``: the batch the NEXT call (``eval_step`` or
-        ``train_step``) will be given -- its graph preparation then overlaps this one, as in training.  Data parallel: the
+        ``train_step``) will be given -- its graph preparation then overlaps this one, as in training.  A look-ahead handed to an
+        EARLIER call and not yet consumed (``train_step(A, next_data=X)``, ``eval_step(Y)``, ``train_step(X)``) stays prepared
+        unless this call is given a ``next_data`` of its own, which replaces it.  Data parallel: the
         batch loss is scaled by 1/``global_batch`` (derived with one small all-reduce when not given) so that the ranks'
         contributions add up to the global batch mean."""
         if global_batch is None and self._dp_world > 1 and self._allreduce is not None:

@@ -341,7 +341,10 @@ int dgcnn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
  * dgcnn_pipeline_train_step(h, cur, next, stream), everything on `stream`:
  *   1. forward + backward (+Adam) of `cur`.  With DGCNN_FLAG_PREPARED in cur->flags (the host states that `cur`
  *      is the batch the previous call was given as `next`: same ws, N, E, B -- anything else is DGCNN_EINVAL)
- *      the step skips its own graph preparation, else it prepares in-stream first.
+ *      the step skips its own graph preparation, else it prepares in-stream first.  The preparation's form (bit-packed
+ *      adjacency or not, who verifies the reverse edges) follows from next->flags; if cur->flags names ANOTHER kernel family
+ *      than the flags it was prepared under (COALESCED_UNDIRECTED, FORCE_*, AGG_*, CHAIN / NO_CHAIN, BF16 differ), the step
+ *      prepares again under cur->flags -- no promise goes unverified (an unverified one would be read as its own transpose).
  *   2. if `next` != NULL: its graph structure (what dgcnn_model_prepare builds: CSR by target / by source, dinv,
  *      graph ranges -- a function of the batch only, never of the weights) is built DURING this step, by extra
  *      workgroups appended to two of the step's launches (the SortPooling+tail forward carries phase A; phase B
