@@ -47,6 +47,9 @@ def get_args(argv=None):
     p.add_argument('--host_loader', dest='device_loader', action='store_false',
                    help='collate every batch on the host like the reference DataLoader (default: dataset resident in HBM, '
                         'batches assembled on the device)')
+    p.add_argument('--exclusive-device', dest='exclusive_device', action='store_true',
+                   help='promise that nothing else runs on this GPU (admits the step form whose launch also carries the next '
+                        "batch's whole graph preparation; Trainer(exclusive_device=True))")
     return p.parse_args(argv)
 
 
@@ -78,7 +81,7 @@ def run(opt) -> dict:
     dev_set = DeviceDataset(data_set, opt.device) if (opt.device_loader and str(opt.device).startswith('cuda')) else None
     for fold in range(1, opt.folds + 1):
         model = Model(data_set.num_features, data_set.num_classes).to(opt.device)
-        trainer = Trainer(model)                        # Adam defaults, as Adam(model.parameters()) at train.py:99
+        trainer = Trainer(model, exclusive_device=opt.exclusive_device)      # Adam defaults, as Adam(model.parameters()) at train.py:99
         idx_dir = os.path.join(opt.data_root, opt.data_type)
         if opt.synthetic == 0 and os.path.isdir(os.path.join(idx_dir, '10fold_idx')):
             tr_idx, te_idx = read_fold_indices(idx_dir, fold)

@@ -50,9 +50,11 @@ class Trainer:
                  exclusive_device: Optional[bool] = None):
         """``exclusive_device``: the promise behind ``DGCNN_FLAG_EXCLUSIVE_DEVICE`` -- nothing else runs on this GPU while a
         step is in flight -- which admits the form of a small batch's step whose launch ALSO carries both phases of the next
-        batch's graph preparation (workgroups of one launch waiting for each other on the device).  ``None``: True for a
-        single process, False under a process group of more than one rank (ranks may share a device: the tests of this
-        repository do); pass True when every rank owns its GPU (``bench.py`` does)."""
+        batch's graph preparation (workgroups of one launch waiting for each other on the device).  A process cannot see what
+        other processes run on its GPU, so the default (``None``) is False: the promise is the CALLER's to make
+        (``bench.py`` and the measurement tools pass True where every rank owns its GPU, ``python train.py
+        --exclusive-device`` does).  Without it the next batch's phase B rides on ``k_wgrad`` -- no
+        workgroup ever waits for another, whatever else runs on the device."""
         self.model = model
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.pg = process_group
@@ -66,7 +68,7 @@ class Trainer:
             self._dp_world = dist.get_world_size(process_group)
         self._err_checked = model._epoch      # forward tag up to which input errors have been surfaced
         if exclusive_device is None:
-            exclusive_device = self._dp_world <= 1
+            exclusive_device = False
         self._excl = _lib.FLAG_EXCLUSIVE_DEVICE if exclusive_device else 0
         # one-shot exchange (dgcnn_amd.dist.PeerExchange): gradients land in peer-mapped memory, ONE kernel per rank sums
         # them in rank order and applies Adam -- instead of all_reduce + dgcnn_adam_step.  Opt-in (no multi-GPU timing yet).

@@ -110,14 +110,16 @@ def test_isa_audit_tool_reads_the_built_objects():
 
 def test_trainer_promises_an_exclusive_device_only_where_it_can_know():
     """DGCNN_FLAG_EXCLUSIVE_DEVICE (round 5): the in-launch wait of the fused preparation is admitted by a promise of the caller.
-    A single-process Trainer makes it by default, an explicit False withdraws it, and the flag travels in the step arguments'
-    flags word next to the batch's layout promise -- it never changes which kernel family a batch takes."""
+    Only the caller can make it (another process on the same GPU is invisible to this one): the default is no promise, an
+    explicit True makes it, and the flag travels in the step arguments' flags word next to the batch's layout promise -- it
+    never changes which kernel family a batch takes."""
     from dgcnn_amd import _lib
     from dgcnn_amd.model import Model
     from dgcnn_amd.train import Trainer
     m = Model(1, 3)
-    assert Trainer(m)._excl == _lib.FLAG_EXCLUSIVE_DEVICE
+    assert Trainer(m)._excl == 0
     assert Trainer(m, exclusive_device=False)._excl == 0
+    assert Trainer(m, exclusive_device=True)._excl == _lib.FLAG_EXCLUSIVE_DEVICE
     f = _lib.lib().dgcnn_forward_form
     CU = _lib.FLAG_COALESCED_UNDIRECTED
     assert f(3800, 140000, 50, 1, CU, 180) == f(3800, 140000, 50, 1, CU | _lib.FLAG_EXCLUSIVE_DEVICE, 180)

@@ -39,7 +39,7 @@ for name, mk in (("Adam(model.parameters())", lambda m: Adam(m.parameters())),
         loop(m, opt, crit, 50, sync); torch.cuda.synchronize()
         t0 = time.perf_counter(); loop(m, opt, crit, 300, sync); torch.cuda.synchronize()
         print(f"drop-in, {name:40s} item() syncs={sync}: {1e6 * (time.perf_counter() - t0) / 300:7.1f} us/step")
-m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train(); tr = Trainer(m)
+m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train(); tr = Trainer(m, exclusive_device=True)
 for i in range(50): tr.train_step(batches[i % 10], batches[i % 10].y, next_data=batches[(i + 1) % 10])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(300): tr.train_step(batches[i % 10], batches[i % 10].y, next_data=batches[(i + 1) % 10])

@@ -10,7 +10,7 @@ sh = synth.SHAPES[name]
 graphs = synth.make_graphs(name, G, labels="structure")
 for prepared in (False, True):
     torch.manual_seed(324)
-    m = Model(sh.num_features, sh.num_classes).to("cuda"); tr = Trainer(m)
+    m = Model(sh.num_features, sh.num_classes).to("cuda"); tr = Trainer(m, exclusive_device=True)
     gen = torch.Generator().manual_seed(1)
     ld = DeviceLoader(PreparedDataset(graphs) if prepared else DeviceDataset(graphs), 50, shuffle=True, generator=gen, prepared=prepared)
     tr.train_epoch(ld, G); torch.cuda.synchronize()

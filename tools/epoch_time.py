@@ -11,7 +11,7 @@ sh = synth.SHAPES[name]
 graphs = synth.make_graphs(name, G, labels="structure")
 for kind in ("host GraphLoader", "DeviceLoader", "DeviceLoader(prepared)"):
     torch.manual_seed(324)          # same initial weights for every loader: the three runs train the same trajectory
-    m = Model(sh.num_features, sh.num_classes).to("cuda"); tr = Trainer(m)
+    m = Model(sh.num_features, sh.num_classes).to("cuda"); tr = Trainer(m, exclusive_device=True)
     gen = torch.Generator().manual_seed(1)
     ld = GraphLoader(graphs, 50, shuffle=True, generator=gen, device="cuda") if kind.startswith("host") else \
         (DeviceLoader(PreparedDataset(graphs), 50, shuffle=True, generator=gen, prepared=True) if "prepared" in kind else

@@ -12,7 +12,7 @@ sh = synth.SHAPES[name]
 bs = [synth.make_batch(name, G, start=G * k).to("cuda") for k in range(40)]
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.eval()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 nb = len(bs)
 LA = os.environ.get("EVAL_NO_LOOKAHEAD") is None      # EVAL_NO_LOOKAHEAD=1: every batch prepared by its own call
 for k, b in enumerate(bs): tr.eval_step(b, b.y, next_data=bs[(k + 1) % nb] if LA else None)      # (look-ahead as Trainer.test_epoch's)

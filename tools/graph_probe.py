@@ -13,7 +13,7 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
 batches = [synth.make_batch("COLLAB", B, start=i * B).to(dev) for i in range(P)]
 m = Model(batches[0].x.shape[1], 3).to(dev); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 for _ in range(3):
     for b in batches:
         tr.train_step(b, b.y)

@@ -8,7 +8,7 @@ sh = synth.SHAPES["COLLAB"]
 batches = [b.to("cuda") for b in synth.make_batches("COLLAB", 500, 50)]
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 for pf in (False, True):
     for i in range(50):
         tr.train_step(batches[i % 10], batches[i % 10].y, next_data=batches[(i + 1) % 10] if pf else None)

@@ -11,7 +11,7 @@ BS = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 b = synth.make_batch("COLLAB", BS, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 names = ["start", "loads+stage", "classifier_1 (mfma)+stores", "barrier", "classifier_2", "log_softmax+loss", "gz1+partials", "classifier_1 back"]

@@ -9,7 +9,7 @@ sh = synth.SHAPES["COLLAB"]
 b = synth.make_batch("COLLAB", 50, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 rn = {8: "topk", 9: "gather+Wstage", 10: "conv5", 11: "pool+conv6", 12: "fc1", 13: "fc2+lsm"}

@@ -20,7 +20,7 @@ b.coalesced_undirected = True
 print(f"{name} x {G}: workgroup 0 = graph of {graphs[order[0]].num_nodes} nodes (batch max {max(g.num_nodes for g in graphs)})")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 dbg = torch.zeros(80, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 rn = {8: "topk", 9: "gather+Wstage", 10: "conv5", 11: "pool+conv6", 12: "fc1", 13: "fc2+lsm"}

@@ -10,7 +10,7 @@ BS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 b = synth.make_batch("COLLAB", BS, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
 L.dgcnn_debug_phase_clocks(dbg.data_ptr())
 names = ["start", "stage+dlogit", "fc2 bwd+partial", "fc1^T (gflat)", "conv6 bwd", "pool/relu", "W5/W6 partials", "scatter"]

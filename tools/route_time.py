@@ -19,7 +19,7 @@ for label, bs, chain in (("<=256 default", small, None), ("257..512 default", bi
     torch.manual_seed(324)
     m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
     if chain is not None: m.use_chain = chain
-    tr = Trainer(m)
+    tr = Trainer(m, exclusive_device=True)
     nb = len(bs)
     for i in range(3 * nb): tr.train_step(bs[i % nb], bs[i % nb].y, next_data=bs[(i + 1) % nb])
     torch.cuda.synchronize()

@@ -12,7 +12,7 @@ bs = [synth.make_batch(name, G, start=G * k).to("cuda") for k in range(40)]
 nb = len(bs)
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda")
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 for mode in ("eval", "train"):
     m.train(mode == "train")
     fn = tr.train_step if mode == "train" else tr.eval_step

@@ -11,7 +11,7 @@ BS = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 b = synth.make_batch("COLLAB", BS, start=0).to("cuda")
 torch.manual_seed(324)
 m = Model(sh.num_features, sh.num_classes).to("cuda"); m.train()
-tr = Trainer(m)
+tr = Trainer(m, exclusive_device=True)
 dbg = torch.zeros(1024 + 4 * BS + 64, dtype=torch.int64, device="cuda")
 for it in range(3): tr.train_step(b, b.y)
 torch.cuda.synchronize()
