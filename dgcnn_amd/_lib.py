@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")   # env override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 19
+ABI_VERSION = 20
 FLAG_COALESCED_UNDIRECTED = 1
 FLAG_FORCE_FUSED = 2
 FLAG_FORCE_TILED = 4
@@ -24,6 +24,7 @@ FLAG_AGG_DENSE = 32       # use it whenever the batch admits it (coalesced_undir
 FLAG_CHAIN = 128          # graph-chain kernels (conv1..conv4 of a graph inside one workgroup) whenever admissible
 FLAG_NO_CHAIN = 256       # never
 FLAG_EXCLUSIVE_DEVICE = 512   # pipelined steps: nothing else runs on this device (admits the in-launch wait of the fused preparation)
+FLAG_INFERENCE = 1024     # forward-only use of the batch: one-launch evaluation kernel also for graphs of 257..512 nodes (ABI v20)
 FLAG_BF16 = 64            # bf16 leg: pre-scaled linear outputs stored bf16, X.W on the bf16 matrix cores
 
 FORM_DENSE, FORM_CHAIN, FORM_CHAIN_TAIL, FORM_STEP, FORM_EVAL = 1, 2, 4, 8, 16      # dgcnn_forward_form bits

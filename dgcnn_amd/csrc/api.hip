@@ -243,7 +243,11 @@ static bool dg_use_chain(int N, int E, int B, int F, int flags, int max_nodes) {
   if (flags & DGCNN_FLAG_CHAIN) return true;
   // small batches (one workgroup per graph): a graph above 256 nodes would run two tiles per wave and set the launch's
   // duration; large batches: graphs above the persistent kernel's size class take a second launch, worth it there
-  return max_nodes <= 256 || N >= DG_DENSE_MIN_NODES;
+  if (max_nodes <= 256 || N >= DG_DENSE_MIN_NODES) return true;
+  // forward-only use of a small batch with a graph of 257..512 nodes (DGCNN_FLAG_INFERENCE, round 6): the one-launch evaluation
+  // kernel takes it (two tiles per wave) -- there is no backward whose gather kernels would want the CSR route instead
+  return (flags & DGCNN_FLAG_INFERENCE) && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() &&
+         max_nodes <= dg_chain_eval_max_nodes();
 }
 struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
 #ifndef DG_INSYM_MIN_B
@@ -251,14 +255,22 @@ struct DgForm { bool dense, chain, bitmap, plan; int edge_check; };
 #endif
 // one-launch evaluation / inference kernel (k_chain_readout_eval): every graph in the chain form, one workgroup per graph
 static int g_eval_kernel = 1;      // dgcnn_eval_kernel_enable (tests / measurement A-B): 0 keeps chain forward + readout as two launches
-int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on ? 1 : 0; return prev; }
+int dgcnn_eval_kernel_enable(int on) { const int prev = g_eval_kernel; g_eval_kernel = on <= 0 ? 0 : (on >= 2 ? 2 : 1); return prev; }
 // (a pure function of the batch's numbers: what graph PREPARATION may rely on -- the process-wide switch is read by the forward only)
 static bool dg_one_launch_shape(const DgForm& f, int B, int max_nodes) {
   return f.chain && !f.dense && B <= dg_chain_train_max_b() && B <= dg_readout_tail_max_b() && max_nodes > 0 &&
          max_nodes <= dg_chain_train_max_nodes();
 }
-static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes) {
-  return g_eval_kernel != 0 && dg_one_launch_shape(f, B, max_nodes);
+// Evaluation / inference forward in one launch.  Graphs of <= 256 nodes: whenever the batch has the one-launch shape.  A batch with
+// a graph of 257..512 nodes (round 6: the kernel's two-tiles-per-wave form; test() on PROTEINS-like sets stays one launch): when
+// the caller names the forward-only use -- DGCNN_FLAG_INFERENCE, which is also what makes dg_use_chain build the bitmap for such a
+// small batch -- or the switch is at 2.  The switch only chooses between two routes over the SAME prepared structures
+// (f.chain => the bitmap exists): it may change between preparation and forward.
+static bool dg_eval_kernel_admits(const DgForm& f, int B, int max_nodes, int flags) {
+  if (g_eval_kernel == 0) return false;
+  if (dg_one_launch_shape(f, B, max_nodes)) return true;
+  return (g_eval_kernel >= 2 || (flags & DGCNN_FLAG_INFERENCE)) && f.chain && !f.dense && B <= dg_chain_train_max_b() &&
+         B <= dg_readout_tail_max_b() && max_nodes > dg_chain_train_max_nodes() && max_nodes <= dg_chain_eval_max_nodes();
 }
 static DgForm dg_form(int N, int E, int B, int F, int flags, int max_nodes) {
   DgForm f;
@@ -326,7 +338,7 @@ int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes) {
                           max_nodes <= dg_chain_train_max_nodes();
   const bool step = chain_tail && dg_step_kernel_enabled() && B <= dg_grid1(N) && B <= dg_grid32(N) && dg_wgrad_takes_rider(B);
   // evaluation / inference (no labels-with-backward): chain forward + readout in one launch under the same admissibility
-  const bool eval1 = dg_eval_kernel_admits(f, B, max_nodes);
+  const bool eval1 = dg_eval_kernel_admits(f, B, max_nodes, flags);
   return (f.dense ? DGCNN_FORM_DENSE : 0) | (f.chain ? DGCNN_FORM_CHAIN : 0) | (chain_tail ? DGCNN_FORM_CHAIN_TAIL : 0) |
          (step ? DGCNN_FORM_STEP : 0) | (eval1 ? DGCNN_FORM_EVAL : 0);
 }
@@ -551,7 +563,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
     if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
     return DGCNN_OK;
   }
-  if (chain && !(tt && tail_done) && dg_eval_kernel_admits(fm, B, max_nodes)) {
+  if (chain && !(tt && tail_done) && dg_eval_kernel_admits(fm, B, max_nodes, flags)) {
     // evaluation / inference (and the drop-in route's forward: everything the backward reads is saved as by the two launches this
     // replaces): chain forward + readout forward of every graph in ONE launch; with labels, the batch's metrics too
     int fused_b = 0;
@@ -565,7 +577,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
                                         in_launch ? et->metrics : nullptr, dg_ptr<int32_t>(ws, wl.err), epoch, s, rider_a,
                                         g_prof_which >= 0 ? g_prof_a : nullptr, g_prof_which >= 0 ? g_prof_b : nullptr, bf16,
                                         (rider_a && rode && (flags & DGCNN_FLAG_EXCLUSIVE_DEVICE)) ? &fused_b : nullptr,
-                                        fm.edge_check == 2 ? 1 : 0));
+                                        fm.edge_check == 2 ? 1 : 0, max_nodes));
     g_prof_which = -1;
     if (in_launch) et->done = 1;
     if (rider_a && rode) *rode = fused_b > 0 ? 2 : 1;
@@ -929,7 +941,7 @@ static int dg_pipeline_rider(DgPipeline* h, const dgcnn_step_args* next, bool si
 // step that names another
 static inline bool dg_form_flags_differ(int a, int b) {
   const int m = DGCNN_FLAG_COALESCED_UNDIRECTED | DGCNN_FLAG_FORCE_FUSED | DGCNN_FLAG_FORCE_TILED | DGCNN_FLAG_AGG_SPARSE |
-                DGCNN_FLAG_AGG_DENSE | DGCNN_FLAG_CHAIN | DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16;
+                DGCNN_FLAG_AGG_DENSE | DGCNN_FLAG_CHAIN | DGCNN_FLAG_NO_CHAIN | DGCNN_FLAG_BF16 | DGCNN_FLAG_INFERENCE;
   return ((a ^ b) & m) != 0;
 }
 int dgcnn_pipeline_train_step(void* handle, const dgcnn_step_args* cur, const dgcnn_step_args* next,

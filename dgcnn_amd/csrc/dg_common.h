@@ -497,6 +497,7 @@ int dg_launch_chain_bwd_b(int N, int B, int Fa, const int32_t* graph_ptr, const 
                           int32_t* dmap, hipStream_t s, const int32_t* gpsel = nullptr);
 int dg_chain_train_max_b();
 int dg_chain_train_max_nodes();
+int dg_chain_eval_max_nodes();       // largest graph of the one-launch EVALUATION kernel (512)
 int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                                  const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                                  float* x3, float* x4, float* pooled, int32_t* perm, float* a5, float* a6, float* a1d,
@@ -514,7 +515,8 @@ int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* grap
                                  uint8_t* drop_mask, float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale,
                                  float* evl, unsigned int* ev_ctr, unsigned int* ev_host, float* metrics, int32_t* err, uint32_t epoch,
                                  hipStream_t s, const struct DgPrepRider* rider = nullptr, hipEvent_t ev_start = nullptr,
-                                 hipEvent_t ev_stop = nullptr, int bf16 = 0, int* fused_b_out = nullptr, int insym = 0);
+                                 hipEvent_t ev_stop = nullptr, int bf16 = 0, int* fused_b_out = nullptr, int insym = 0,
+                                 int max_nodes = 256);      // (max_nodes in 257..512: the two-tiles-per-wave instantiation)
 int dg_launch_chain_fwd(int N, int B, int F, int max_nodes, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
                         const float* xs, const float* params, const struct DgParams* pl, float* ax, float* x1, float* x2,
                         float* x3, float* x4, int32_t* dmap, int bf16, hipStream_t s, hipEvent_t ev_start = nullptr,

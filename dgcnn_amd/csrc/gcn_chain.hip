@@ -1456,6 +1456,7 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
 #ifndef CH_RIDER_ITEMS
 #define CH_RIDER_ITEMS 2        // fused preparation (both phases in the training kernel's launch): work items per rider thread
 #endif
+#define CH_EVAL_MAXN 512       // largest graph of the one-launch evaluation kernel's two-tiles-per-wave form (round 6)
 #define CH_TRAIN_MAXN 256      // largest graph of the one-launch training kernel (host hint max_nodes, verified: a larger one is flagged)
 // the rider range of a one-launch kernel (blocks >= B): phase A of the next batch's graph preparation (or its whole assembly from a
 // prepared dataset), and -- `rd.fused_b` -- phase B of the same batch behind it in the same launch.  Shared by the training kernel
@@ -1673,30 +1674,35 @@ struct ChEval {
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
   const int64_t* y; float* evl; unsigned int* ctr; unsigned int target; float* metrics; float scale;      // y == null: no metrics
 };
-template <int XI, int W1S, bool BF = false>
+// MAXN = MAXN: one row tile per wave, the bitmap words of the tile in registers (the form every batch of graphs of <= 256
+// nodes takes).  MAXN = CH_EVAL_MAXN (512, round 6): two row tiles per wave -- the chain body of k_chain_fwd_q<16, .., LOOP = false>,
+// 149 KB of LDS, no static arrays here -- so that test() on PROTEINS / DD-like batches with a graph of 257..512 nodes stays ONE
+// launch too; the readout ranks such a graph's keys by radix select (dg_select_topk above 256 keys).  No bitmap-symmetry hook
+// in that form (api.hip leaves the reverse-edge check to the one-launch kernels only for batches of graphs of <= 256 nodes).
+template <int XI, int W1S, bool BF = false, int MAXN = CH_TRAIN_MAXN>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, const unsigned* __restrict__ bits,
                      const float* __restrict__ dinv, const float* __restrict__ xs, ChW gw, float* __restrict__ axg,
                      float* __restrict__ x1, float* __restrict__ x2, float* __restrict__ x3, float* __restrict__ x4, ChEval t,
                      unsigned long long* __restrict__ dbg, DgPrepRider rd) {
   if ((int)blockIdx.x >= B) { ch_rider_block((int)blockIdx.x - B, rd); return; }
-  using C = ChQ<16, W1S, CH_TRAIN_MAXN>;
+  using C = ChQ<16, W1S, MAXN>;
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[15] = clock64();
   const int b = blockIdx.x;
   // (label and node range read once, up front: scalar / early loads, consumed behind the chain)
   const int yraw = (t.y && threadIdx.x < 64) ? (int)t.y[b] : 0;
   const int gn0 = graph_ptr[b], gn = graph_ptr[b + 1] - gn0;
-  if (threadIdx.x == 0 && gn > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
+  if (threadIdx.x == 0 && gn > MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* keys_lds = reinterpret_cast<float*>(smem + C::OFF_DV) + C::ROWS;      // (second parity set of the dinv array, as in training)
-  ch_chain_body<16, XI, W1S, false, CH_TRAIN_MAXN, BF>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4,
+  ch_chain_body<16, XI, W1S, false, MAXN, BF>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4,
                                                        nullptr, keys_lds);
   __syncthreads();        // (full barrier, vmcnt(0): this graph's x1..x4 rows are written; the LDS images are dead)
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
   const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
-  const int nn_ = min(gn, CH_TRAIN_MAXN);
+  const int nn_ = min(gn, MAXN);
   const ChSymHook hook{reinterpret_cast<const unsigned int*>(smem + C::OFF_BL), nn_, 1 << dgd_class(max(nn_, 1)), (nn_ + 31) >> 5,
-                       t.insym ? t.err : nullptr, t.epoch};
+                       (MAXN <= 256 && t.insym) ? t.err : nullptr, t.epoch};
   dg_readout_fwd_body(M, b, gn0, gn, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
                       t.training, t.seed, dbg, hook);
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
@@ -2433,6 +2439,7 @@ static int dg_device_cus() {
 }
 int dg_chain_train_max_b() { return CH_ONESHOT_MAX_B; }
 int dg_chain_train_max_nodes() { return CH_TRAIN_MAXN; }
+int dg_chain_eval_max_nodes() { return CH_EVAL_MAXN; }
 
 // chain forward + readout forward + readout backward of a small batch in one launch (training step with labels)
 int dg_launch_chain_readout_tail(int N, int B, int F, int C, const int32_t* graph_ptr, const uint32_t* bits, const float* dinv,
@@ -2515,11 +2522,13 @@ int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* grap
                                  float* logp, int training, uint64_t seed, const int64_t* y, float loss_scale, float* evl,
                                  unsigned int* ev_ctr, unsigned int* ev_host, float* metrics, int32_t* err, uint32_t epoch,
                                  hipStream_t s, const DgPrepRider* rider, hipEvent_t ev_start, hipEvent_t ev_stop, int bf16,
-                                 int* fused_b_out, int insym) {
+                                 int* fused_b_out, int insym, int max_nodes) {
   if (fused_b_out) *fused_b_out = 0;
   if (N <= 0 || B <= 0 || B > CH_ONESHOT_MAX_B || !err || F < 1 || F > DG_AF_MAX_F || C < 1 || C > DGCNN_MAX_C || !graph_ptr || !bits ||
-      !dinv || !xs || (y && (!evl || !ev_ctr || !ev_host || !metrics)))
+      !dinv || !xs || (y && (!evl || !ev_ctr || !ev_host || !metrics)) || max_nodes <= 0 || max_nodes > CH_EVAL_MAXN)
     return DGCNN_EINVAL;
+  const bool wide = max_nodes > CH_TRAIN_MAXN;      // a graph of 257..512 nodes: the two-tiles-per-wave instantiation
+  if (wide) insym = 0;
   ChW gw;
   gw.W1 = params + pl->off[0]; gw.b1 = params + pl->off[1]; gw.W2 = params + pl->off[2]; gw.b2 = params + pl->off[3];
   gw.W3 = params + pl->off[4]; gw.b3 = params + pl->off[5]; gw.W4 = params + pl->off[6]; gw.b4 = params + pl->off[7];
@@ -2551,16 +2560,24 @@ int dg_launch_chain_readout_eval(int N, int B, int F, int C, const int32_t* grap
   if (attr_once.needed()) {
 #define CH_ATTR3(XI, WS, BFV) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_eval<XI, WS, BFV>), \
                                hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL) != hipSuccess)
+#define CH_ATTR3W(XI, WS, BFV) (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_readout_eval<XI, WS, BFV, CH_EVAL_MAXN>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ChQ<16, WS, CH_EVAL_MAXN>::TOTAL) != hipSuccess)
     if (CH_ATTR3(1, 4, false) || CH_ATTR3(2, 4, false) || CH_ATTR3(4, 8, false) || CH_ATTR3(1, 4, true) || CH_ATTR3(2, 4, true) ||
-        CH_ATTR3(4, 8, true))
+        CH_ATTR3(4, 8, true) || CH_ATTR3W(1, 4, false) || CH_ATTR3W(2, 4, false) || CH_ATTR3W(4, 8, false) || CH_ATTR3W(1, 4, true) ||
+        CH_ATTR3W(2, 4, true) || CH_ATTR3W(4, 8, true))
       return DGCNN_ELAUNCH;
     attr_once.done();
   }
-#define CH_LE(XI, WS, BFV) hipExtLaunchKernelGGL((k_chain_readout_eval<XI, WS, BFV>), dim3(B + rd.nblk + rd.fused_b), dim3(1024),            \
-                                                 (ChQ<16, WS, CH_TRAIN_MAXN>::TOTAL), s, ev_start, ev_stop, 0, N, B, F, graph_ptr, bits, dinv, \
+  static_assert(ChQ<16, 8, CH_EVAL_MAXN>::TOTAL <= 160 * 1024, "the two-tiles-per-wave form fits one CU's LDS (no static arrays in this kernel)");
+  static_assert(ChQ<16, 4, CH_EVAL_MAXN>::OFF_DV >= RD_REGION0_BYTES + RD_SMALL_BYTES,
+                "the readout's LDS plan stays below the key copy (second dinv set) it ranks");
+#define CH_LE(XI, WS, BFV, MX) hipExtLaunchKernelGGL((k_chain_readout_eval<XI, WS, BFV, MX>), dim3(B + rd.nblk + rd.fused_b), dim3(1024),  \
+                                                 (ChQ<16, WS, MX>::TOTAL), s, ev_start, ev_stop, 0, N, B, F, graph_ptr, bits, dinv, \
                                                  xs, gw, ax, x1, x2, x3, x4, t, dg_debug_buffer(), rd)
-  if (bf16) { if (F <= 8) CH_LE(1, 4, true); else if (F <= 16) CH_LE(2, 4, true); else CH_LE(4, 8, true); }
-  else { if (F <= 8) CH_LE(1, 4, false); else if (F <= 16) CH_LE(2, 4, false); else CH_LE(4, 8, false); }
+#define CH_LE2(XI, WS, BFV) do { if (wide) CH_LE(XI, WS, BFV, CH_EVAL_MAXN); else CH_LE(XI, WS, BFV, CH_TRAIN_MAXN); } while (0)
+  if (bf16) { if (F <= 8) CH_LE2(1, 4, true); else if (F <= 16) CH_LE2(2, 4, true); else CH_LE2(4, 8, true); }
+  else { if (F <= 8) CH_LE2(1, 4, false); else if (F <= 16) CH_LE2(2, 4, false); else CH_LE2(4, 8, false); }
+#undef CH_LE2
 #undef CH_LE
   if (hipGetLastError() != hipSuccess) {
     if (sync_moved) { *rd.sync_host = sync_prev; if (fused_b_out) *fused_b_out = 0; }

@@ -312,7 +312,16 @@ class Model(nn.Module):
         f = _lib.FLAG_COALESCED_UNDIRECTED if getattr(data, "coalesced_undirected", False) else 0
         # ``mode_flags``: a form restriction that belongs to the DATA (a PreparedDataset built without bitmap rows hands out
         # batches that must stay on the CSR kernels: device_data.PreparedBatch)
-        return f | int(getattr(data, "mode_flags", 0) or 0) | self._mode_flags()
+        f |= int(getattr(data, "mode_flags", 0) or 0) | self._mode_flags()
+        if not torch.is_grad_enabled():
+            f |= self._inference_flag()
+        return f
+
+    def _inference_flag(self) -> int:
+        """``DGCNN_FLAG_INFERENCE`` for a forward no backward can follow (``torch.no_grad()``, ``Trainer.eval_step``) when the
+        model attribute ``inference_one_launch`` is set: small batches with a graph of 257..512 nodes then take the one-launch
+        evaluation kernel (round 6; opt-in until it has a measured line)."""
+        return _lib.FLAG_INFERENCE if self.__dict__.get("inference_one_launch") else 0
 
     def _max_nodes_of(self, data) -> int:
         """per-graph node bound (host-known hint) for the graph-per-workgroup path"""

@@ -298,7 +298,8 @@ class Trainer:
             a.grads = self._peer.grad_ptr(self.step_count + 1)
         a.training = training
         a.seed = m._next_seed() if training else 0
-        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags() | self._excl
+        inf = m._inference_flag() if evaluate else 0      # (forward-only use: part of the preparation's form, like the family flags)
+        a.flags = ent[8] | (_lib.FLAG_PREPARED if prepared else 0) | m._mode_flags() | self._excl | inf
         a.loss_scale = 0.0 if global_batch is None else 1.0 / float(global_batch)
         if fuse_adam and not evaluate:
             self.step_count += 1
@@ -317,7 +318,8 @@ class Trainer:
             if nsl["ws"] is None or nent[3] > nsl["bytes"] or nsl["ws"].device != dev:
                 self._slot_ws(1 - slot, nent[3], dev)
             nsl["dims"] = nent[5]
-            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8] | m._mode_flags() | self._excl, m._next_epoch()
+            # (the look-ahead is prepared for the kind of step this one is; a step of the other kind prepares again itself)
+            na.ws, na.flags, na.epoch = nsl["ptr"], nent[8] | m._mode_flags() | self._excl | inf, m._next_epoch()
             nref = nent[6]
             self._prep_ent, self._prep_slot = nent, 1 - slot
             self._cur = 1 - slot

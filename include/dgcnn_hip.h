@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGCNN_ABI_VERSION 19
+#define DGCNN_ABI_VERSION 20
 
 /* error codes */
 #define DGCNN_OK            0
@@ -85,6 +85,13 @@ typedef void* dgcnn_stream_t;   /* a hipStream_t */
                                          * phase B rides on the step's next launch as before round 4 (same results, ~2 us per step at
                                          * the reference's batch of 50).  A wait that does not end is bounded (~4 s) and reported
                                          * through err[4] / err[6], never as a layout error. */
+#define DGCNN_FLAG_INFERENCE 1024      /* (ABI v20) the batch is only ever run FORWARD (the body of the reference's test() loop,
+                                        * /root/reference/train.py:57-62; inference): a small batch (<= 256 graphs) whose largest
+                                        * graph has 257..512 nodes is then prepared for, and run by, the one-launch evaluation kernel's
+                                        * two-tiles-per-wave form instead of the launch-per-layer route a training step of such a batch
+                                        * takes.  Part of the preparation's form like the other family flags: give it to the
+                                        * preparation AND the forward of a batch (the pipeline calls prepare again when they differ).
+                                        * Results: same arithmetic as the chain forward + readout launches. */
 #define DGCNN_FUSED_MIN_GRAPHS (1 << 30) /* the fused path is never chosen automatically: the tiled kernels measured
                                             faster at every batch size (profiles/r01_sweep.txt); FORCE_FUSED selects it */
 /* The caller PROMISES the edge list is coalesced and undirected: sorted by (source,target), no
@@ -261,8 +268,9 @@ int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
  * default.  Returns the previous setting.  Replaces nothing of the reference (/root/reference/train.py:40 is one backward). */
 int dgcnn_step_kernel_enable(int on);
 /* Test / measurement switch of DGCNN_FORM_EVAL (process-wide): on = 0 keeps the chain forward and the readout forward of small
- * batches as two launches (+ k_eval_metrics where labels are given) -- the round-4 form; on = 1 restores the default.  Returns the
- * previous setting.  Replaces nothing of the reference (/root/reference/model.py:26-45 is one forward). */
+ * batches as two launches (+ k_eval_metrics where labels are given) -- the round-4 form; on = 1 restores the default; on = 2
+ * (ABI v20) additionally takes the one-launch form for chain-form batches with a graph of 257..512 nodes without
+ * DGCNN_FLAG_INFERENCE (e.g. under DGCNN_FLAG_CHAIN).  Returns the previous setting.  Replaces nothing of the reference (/root/reference/model.py:26-45 is one forward). */
 int dgcnn_eval_kernel_enable(int on);
 /* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
  * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:

@@ -248,6 +248,19 @@ def test_forward_form_is_a_pure_function_of_host_known_numbers(built_lib):
         assert prev == 1 and f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8
     finally:
         L.dgcnn_eval_kernel_enable(prev)
+    # round 6 (ABI v20): forward-only use of a small batch with a graph of 257..512 nodes -> chain form + the one-launch evaluation
+    # kernel (never the training forms); beyond 512 nodes or 256 graphs the flag changes nothing; switch at 2: chain-form batches too
+    INF = _lib.FLAG_INFERENCE
+    assert f(N50, E50, 50, 1, CU | INF, 300) == 2 | EV and f(N50, E50, 50, 1, CU | INF, 512) == 2 | EV
+    assert f(N50, E50, 50, 1, CU | INF, 513) == 0 and f(N50, E50, 50, 1, CU | INF, 180) == f(N50, E50, 50, 1, CU, 180)
+    assert f(N50, E50, 50, 90, CU | INF, 300) == 0 and f(N50, E50, 50, 1, INF, 300) == 0
+    assert f(N50 * 6, E50 * 6, 300, 1, CU | INF, 300) == f(N50 * 6, E50 * 6, 300, 1, CU, 300)
+    prev = L.dgcnn_eval_kernel_enable(2)
+    try:
+        assert f(N50, E50, 50, 1, CU | CHAIN, 300) == 2 | EV and f(N50, E50, 50, 1, CU, 300) == 0
+        assert f(N50, E50, 50, 1, CU, 180) == 2 | 4 | 8 | EV
+    finally:
+        L.dgcnn_eval_kernel_enable(prev)
     N2k, E2k = 153000, 5700000
     assert f(N2k, E2k, 2048, 1, CU, 250) == 1 | 2
     assert f(N2k, E2k, 2048, 1, CU, 600) == 0                      # above the dense bound of 512 nodes

@@ -56,3 +56,4 @@ python bench.py --batch 256 --steps 200 --warmup 20 --pool 8 $Q --prep dataset >
 bash tools/kstats.sh ${T}_b256_dataset --batch 256 --pool 8 --no-dropin --prep dataset > /dev/null
 python tools/eval_time.py DD 50 >> $OUT/${T}_eval_time.txt 2>&1
 ls -la $OUT | tail -40
+python tools/eval_route_time.py PROTEINS 50 > $OUT/${T}_eval_route_time.txt 2>&1      # one-launch evaluation of batches with a 257..512-node graph
