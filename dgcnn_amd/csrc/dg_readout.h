@@ -45,7 +45,9 @@ __device__ __forceinline__ void dg_select_topk(const float* __restrict__ x4, int
     // (this thread's first key is requested BEFORE the barrier, unconditionally on a clamped node: behind it the load was a round
     //  trip of its own in front of the LDS store)
     const float k0 = x4[n0 + max(min(tid, n - 1), 0)];
+#ifndef RD_TOPK_NO_ENTRY_BARRIER      // (measurement: callers that placed a full barrier right in front of this function do not need it)
     dg_lds_barrier();
+#endif
     SK_MARK(1);
     if (tid < npad) keys[tid] = tid < n ? dg_pack_key(k0, tid) : ~0ull;
     for (int t = tid + T; t < npad; t += T) keys[t] = t < n ? dg_pack_key(x4[n0 + t], t) : ~0ull;
@@ -253,7 +255,13 @@ __device__ __forceinline__ RdSmem dg_rd_carve(void* region0, void* small) {
 // (classifier.hip) instead of once per graph.
 // IDLE (optional): work of the caller's that the 14 waves without a tile of conv5 do while waves 0 and 1 run it -- called as
 // idle(wave, lane) by every wave; must not touch the readout's LDS plan, must not contain a barrier
-struct RdNoIdle { __device__ __forceinline__ void operator()(int, int) const {} };
+// ... and at_fc2(tid): called by every thread at the start of the classifier_2 phase, where 13 of the 16 waves have nothing to do and
+// classifier_1's forward rows have just left their registers (the one-launch training kernel requests classifier_1's rows for the
+// BACKWARD there: 176 wave-level loads, ~2.5 k cycles of the CU's address path, that used to stand in front of the backward's first barrier)
+struct RdNoIdle {
+  __device__ __forceinline__ void operator()(int, int) const {}
+  __device__ __forceinline__ void at_fc2(int) const {}
+};
 template <bool BIG = false, bool HEAD = true, class IDLE = RdNoIdle>
 __device__ __forceinline__ void dg_readout_fwd_body(
     const RdSmem& M, int b, int n0, int n, int C, const TailW& w, const float* keys, int key_n0,
@@ -458,6 +466,7 @@ __device__ __forceinline__ void dg_readout_fwd_body(
   }
   dg_lds_barrier();
   RD_MARK(12);
+  idle.at_fc2(tid);
   // classifier_2: 128 -> C, wave per class
   for (int c = wv; c < C; c += RD_THREADS / 64) {
     const float* wr = w.Wf2 + c * DGCNN_HID1;

@@ -15,7 +15,8 @@
 // body of the readout backward for graph b (one workgroup of RD_THREADS threads); shared by k_tail_bwd and the merged
 // training kernel k_readout_tail (forward readout + this, one launch)
 struct TbExt { const float *sp, *W5s, *W6s, *lg, *flat, *a5s, *a1s; const int* sel; int yb;
-               const float *wf2s, *x4l, *dvl; int n0, n; };     // (LDSOPS: n0 / n = the graph's node range, read once by the caller)     // (optional LDS copies: classifier_2's rows [<= 16][128]; conv4's outputs and dinv by LOCAL node)      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
+               const float *wf2s, *x4l, *dvl; int n0, n;
+               const float4* wpre; };      // (wpre != null: classifier_1's rows of this thread, already requested by the forward half)     // (LDSOPS: n0 / n = the graph's node range, read once by the caller)     // (optional LDS copies: classifier_2's rows [<= 16][128]; conv4's outputs and dinv by LOCAL node)      // merged kernel: operands the forward left in LDS (+ the label, loaded at kernel start)
 // the one-launch training kernel whose GCN backward follows in the same workgroup: the SortPooling gradient STAYS IN LDS in its
 // sparse form -- the <= 30 selected nodes' rows gpL [30][96] (columns of x1 | x2 | x3), gas4L [n <= 256] (zero except the
 // selected nodes) and slotmap [n] (node -> row of gpL, -1 = not selected) -- instead of the dense slabs gp1..gp3 [N,32] and
@@ -118,7 +119,10 @@ __device__ __forceinline__ void dg_tail_bwd_body(
   // 704 threads = 8 row groups (16 rows each) x 88 column quads: 16 x 16-byte loads per thread (one quarter of the
   // vector-memory instructions a dword-per-lane mapping needs for the same 180 KB)
   float4 wpre[BIG ? 1 : 16];
-  if (HEAD && !BIG && tid < 2 * DGCNN_FLAT) {
+  if (HEAD && !BIG && ext.wpre) {
+#pragma unroll
+    for (int j = 0; j < (BIG ? 1 : 16); ++j) wpre[j] = ext.wpre[j];
+  } else if (HEAD && !BIG && tid < 2 * DGCNN_FLAT) {
     const int rg = tid / 88, mq = tid - rg * 88;
     const float* wc = w.Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
 #pragma unroll

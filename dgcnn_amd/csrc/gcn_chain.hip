@@ -1509,8 +1509,21 @@ __device__ __forceinline__ void ch_rider_block(int rb, const DgPrepRider& rd) {
 // (row i, word k) -- for every set bit j of the word, bit i of row j must be set; an asymmetric pair flags the batch (err[1],
 // epoch-tagged).  Nothing waits for it.  (First placement: the tile-less waves during conv1 -- the step kernel 38.7 -> 40.5 us at
 // 256 graphs, they share the SIMDs of the waves that carry the chain.)
+#ifndef CH_EARLY_WPRE
+#define CH_EARLY_WPRE 0      // 1: classifier_1's rows for the backward requested in the forward's fc2 phase (candidate of round 5, never yet run on a GPU: off; 0: at the backward's start)
+#endif
 struct ChSymHook {
   const unsigned int* bl; int n, S, K32; unsigned int* err; unsigned int epoch;
+  float4* wpre; const float* Wf1;      // training kernel: classifier_1's rows for the backward, requested in the forward's fc2 phase
+  __device__ __forceinline__ void at_fc2(int tid) const {
+    if (!wpre) return;
+    // (same mapping as dg_tail_bwd_body: 704 threads = 8 row groups x 88 column quads, 16 x 16-byte loads each; unconditional on a
+    //  clamped thread so that the loads are countable and nothing waits for them here)
+    const int tc = min(tid, 2 * DGCNN_FLAT - 1), rg = tc / 88, mq = tc - rg * 88;
+    const float* wc = Wf1 + (size_t)(rg * 16) * DGCNN_FLAT + 4 * mq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wpre[j] = *reinterpret_cast<const float4*>(wc + (size_t)j * DGCNN_FLAT);
+  }
   __device__ __forceinline__ void operator()(int wv, int lane) const {
     if (!err || wv < 2) return;
     unsigned int okb = 1u;
@@ -1586,6 +1599,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     W2op[d] = w2; W3op[d] = w3;
   }
   TbExt ext{};
+  float4 wpre_regs[16];      // classifier_1's rows for the backward half (this thread's 16 x 16 bytes), in flight from the forward's fc2 phase on
   {
     const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
     const float* sp = reinterpret_cast<const float*>(M.region0);
@@ -1600,7 +1614,8 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[14] = clock64();
     const int nn_ = min(gn, CH_TRAIN_MAXN);
     const ChSymHook hook{reinterpret_cast<const unsigned int*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_BL), nn_, 1 << dgd_class(max(nn_, 1)),
-                         (nn_ + 31) >> 5, t.insym ? t.err : nullptr, t.epoch};
+                         (nn_ + 31) >> 5, t.insym ? t.err : nullptr, t.epoch, CH_EARLY_WPRE ? wpre_regs : nullptr, t.w.Wf1};
+    ext.wpre = CH_EARLY_WPRE ? wpre_regs : nullptr;
     dg_readout_fwd_body(M, b, n0, n, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
                         t.training, t.seed, dbg, hook);
   }
@@ -1702,7 +1717,7 @@ k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, con
   const RdSmem M = dg_rd_carve(smem, smem + RD_REGION0_BYTES);
   const int nn_ = min(gn, MAXN);
   const ChSymHook hook{reinterpret_cast<const unsigned int*>(smem + C::OFF_BL), nn_, 1 << dgd_class(max(nn_, 1)), (nn_ + 31) >> 5,
-                       (MAXN <= 256 && t.insym) ? t.err : nullptr, t.epoch};
+                       (MAXN <= 256 && t.insym) ? t.err : nullptr, t.epoch, nullptr, nullptr};
   dg_readout_fwd_body(M, b, gn0, gn, t.C, t.w, keys_lds, 0, x1, x2, x3, x4, t.pooled, t.perm, t.a5g, t.a6g, t.a1dg, t.maskg, t.logp,
                       t.training, t.seed, dbg, hook);
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[16] = clock64();
