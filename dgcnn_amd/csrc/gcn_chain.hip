@@ -1689,7 +1689,7 @@ struct ChEval {
   int C; TailW w; float* pooled; int* perm; float *a5g, *a6g, *a1dg; uint8_t* maskg; float* logp; int training; uint64_t seed;
   const int64_t* y; float* evl; unsigned int* ctr; unsigned int target; float* metrics; float scale;      // y == null: no metrics
 };
-// MAXN = MAXN: one row tile per wave, the bitmap words of the tile in registers (the form every batch of graphs of <= 256
+// MAXN = CH_TRAIN_MAXN: one row tile per wave, the bitmap words of the tile in registers (the form every batch of graphs of <= 256
 // nodes takes).  MAXN = CH_EVAL_MAXN (512, round 6): two row tiles per wave -- the chain body of k_chain_fwd_q<16, .., LOOP = false>,
 // 149 KB of LDS, no static arrays here -- so that test() on PROTEINS / DD-like batches with a graph of 257..512 nodes stays ONE
 // launch too; the readout ranks such a graph's keys by radix select (dg_select_topk above 256 keys).  No bitmap-symmetry hook

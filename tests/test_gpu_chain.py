@@ -215,26 +215,3 @@ def test_chain_path_flags_a_max_nodes_hint_that_is_too_small(bs, hint):
     torch.cuda.synchronize()
     with pytest.raises(_lib.DgcnnError):
         tr.read_metrics()
-
-
-def test_persistent_chain_kernels_on_1100_graphs_of_129_to_256_nodes():
-    """the loop-end barrier of k_chain_fwd_q / k_chain_bwd_a is unconditional; this is the batch built to need
-    it (tests/race_case.py): vs the fp64 oracle, vs the per-layer dense route, bit for bit vs the one-graph-per-workgroup form"""
-    from race_case import run_case
-    run_case()
-
-
-def test_persistent_chain_kernels_with_three_waves_stalled_before_the_last_phase():
-    """the same case on variants/lib_racedelay.so (-DCH_RACE_DELAY: waves 0, 3, 6 sleep ~30 k cycles in front of conv4 of the
-    forward walk and conv3's backward of the backward walk, i.e. in front of the reads the next graph's staging would overwrite).
-    Without the loop-end barriers this fails (profiles/r06_race_test.txt keeps that run); with them it must pass."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "dgcnn_amd", "variants", "lib_racedelay.so")
-    assert os.path.exists(lib), f"{lib} missing: __graft_entry__.build() makes it (make -C dgcnn_amd/csrc racedelay)"
-    env = dict(os.environ, DGCNN_HIP_LIB=lib)
-    res = subprocess.run([sys.executable, os.path.join(here, "race_case.py")], env=env, stdout=subprocess.PIPE,
-                         stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert res.returncode == 0 and "RACE_CASE_OK" in res.stdout, res.stdout[-3000:]

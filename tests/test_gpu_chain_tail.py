@@ -410,100 +410,6 @@ def test_reverse_edge_check_inside_the_one_launch_kernels_from_96_graphs_on(mode
                 tr.read_metrics()
 
 
-@pytest.mark.parametrize("violation", ["missing_reverse", "none"])
-def test_reverse_edge_check_when_the_one_launch_evaluation_kernel_is_switched_off_after_preparation(violation):
-    """the decision to leave the reverse-edge check to a one-launch kernel (>= 96 graphs) is a function of the
-    batch alone; a forward that takes the two-launch chain route for such a batch (dgcnn_eval_kernel_enable(0), also when the switch
-    flips BETWEEN a look-ahead preparation and the step that consumes it) checks the bitmap in a launch of its own"""
-    from dgcnn_amd.batch import Batch
-    from dgcnn_amd.train import Trainer
-    sh = synth.SHAPES["COLLAB"]
-    good = [batch_with_small_graphs("COLLAB", 128, start=6000 + 1000 * k) for k in range(2)]
-    b = good[1]
-    ei = b.edge_index.clone()
-    if violation == "missing_reverse":
-        e = int(ei.shape[1] * 0.37)
-        sn, dn = int(ei[0, e]), int(ei[1, e])
-        ei = ei[:, ~((ei[0] == dn) & (ei[1] == sn))]
-    nxt = Batch(b.x, ei.contiguous(), b.batch, b.y, b.num_graphs, True, b.max_nodes, b.max_edges)
-    L = _lib.lib()
-    prev = L.dgcnn_eval_kernel_enable(1)
-    try:
-        for flip in ("before_everything", "between_preparation_and_forward"):
-            m = make_model(sh.num_features, sh.num_classes)
-            m.eval()
-            tr = Trainer(m)
-            tr.reset_metrics()
-            b0, b1 = good[0].to("cuda"), nxt.to("cuda")
-            L.dgcnn_eval_kernel_enable(0 if flip == "before_everything" else 1)
-            tr.eval_step(b0, b0.y, next_data=b1)          # b1 is prepared here (riders of this launch / launches behind it)
-            L.dgcnn_eval_kernel_enable(0)
-            tr.eval_step(b1, b1.y)                        # ... and consumed by the two-launch chain route
-            torch.cuda.synchronize()
-            if violation == "none":
-                tr.read_metrics()
-            else:
-                with pytest.raises(_lib.DgcnnError):
-                    tr.read_metrics()
-            # stand-alone forward (its own preparation) through the same route
-            m2 = make_model(sh.num_features, sh.num_classes)
-            m2.eval()
-            with torch.no_grad():
-                m2(b1)
-            if violation == "none":
-                m2.check_errors()
-            else:
-                with pytest.raises(_lib.DgcnnError):
-                    m2.check_errors()
-    finally:
-        L.dgcnn_eval_kernel_enable(prev)
-
-
-@pytest.mark.parametrize("mode", ["train", "eval"])
-@pytest.mark.parametrize("family", ["use_fused", "sparse", "no_chain"])
-def test_a_look_ahead_preparation_is_not_reused_by_a_step_that_names_another_kernel_family(mode, family):
-    """ADVICE r5 (medium), the pipeline half: 128 graphs are prepared as the look-ahead of a default step (reverse edges left to
-    the one-launch kernel), then the model is told to take another family (forced graph-per-workgroup forward / CSR gather / no
-    chain) before the step that consumes them: that step prepares again under its own flags, so the one missing reverse edge is
-    flagged, and the clean batch's result equals the same family's without any look-ahead"""
-    from dgcnn_amd.train import Trainer
-    sh = synth.SHAPES["COLLAB"]
-    good = [batch_with_small_graphs("COLLAB", 128, start=6000 + 1000 * k) for k in range(2)]
-    b = good[1]
-    ei = b.edge_index.clone()
-    e = int(ei.shape[1] * 0.83)
-    sn, dn = int(ei[0, e]), int(ei[1, e])
-    bad = Batch(b.x, ei[:, ~((ei[0] == dn) & (ei[1] == sn))].contiguous(), b.batch, b.y, b.num_graphs, True, b.max_nodes, b.max_edges)
-
-    def switch(m):
-        if family == "use_fused":
-            m.use_fused = True
-        elif family == "sparse":
-            m.agg_mode = "sparse"
-        else:
-            m.use_chain = False
-
-    outs = []
-    for nxt, look_ahead in ((bad, True), (b, True), (b, False)):
-        m = make_model(sh.num_features, sh.num_classes)
-        m.train(mode == "train"); m._seed_base, m._fwd_count = 9, 0
-        tr = Trainer(m)
-        tr.reset_metrics()
-        fn = tr.train_step if mode == "train" else tr.eval_step
-        b0, b1 = good[0].to("cuda"), nxt.to("cuda")
-        fn(b0, b0.y, next_data=b1 if look_ahead else None)
-        switch(m)
-        lp = fn(b1, b1.y).clone()
-        torch.cuda.synchronize()
-        if nxt is bad:
-            with pytest.raises(_lib.DgcnnError):
-                tr.read_metrics()
-        else:
-            tr.read_metrics()
-            outs.append(lp)
-    assert torch.equal(outs[0], outs[1])
-
-
 def _run_steps(batches, nsteps, exclusive, stream=None, hog=None):
     """`nsteps` pipelined training steps over `batches` (round robin, look-ahead) on `stream`; returns the final parameters"""
     from dgcnn_amd.train import Trainer

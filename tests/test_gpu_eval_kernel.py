@@ -147,36 +147,3 @@ def test_eval_metrics_with_a_label_out_of_range_poison_the_loss_not_the_memory()
     tr.eval_step(b, y)
     with pytest.raises(_lib.DgcnnError):
         tr.read_metrics()
-
-
-@pytest.mark.parametrize("bs", [50, 128])
-def test_a_look_ahead_preparation_survives_an_evaluation_step_in_between(bs):
-    """train_step(A, next_data=X); eval_step(Y); train_step(X) -- the evaluation step runs in the other workspace
-    slot and leaves X's preparation (host entry and the pipeline object's record) in place; the trajectory is bit-identical to the
-    one without the evaluation step, and the evaluation's log-probabilities to a stand-alone evaluation of Y"""
-    sh = synth.SHAPES["COLLAB"]
-    A, X, Y = (small_batch("COLLAB", bs, start=3000 + 700 * k).to("cuda") for k in range(3))
-    res = []
-    for with_eval in (True, False):
-        m = make_model(sh.num_features, sh.num_classes)
-        m.train(); m._seed_base, m._fwd_count = 13, 0
-        tr = Trainer(m)
-        tr.reset_metrics()
-        tr.train_step(A, A.y, next_data=X)
-        lp_y = None
-        if with_eval:
-            pe = tr._prep_ent
-            assert pe is not None
-            lp_y = tr.eval_step(Y, Y.y).clone()
-            assert tr._prep_ent is pe                     # still prepared
-        tr.train_step(X, X.y)
-        torch.cuda.synchronize()
-        tr.read_metrics()
-        res.append((m.flat_params.clone(), lp_y))
-    assert torch.equal(res[0][0], res[1][0])
-    m = make_model(sh.num_features, sh.num_classes)
-    m.train(); m._seed_base, m._fwd_count = 13, 0
-    tr = Trainer(m)
-    tr.train_step(A, A.y)
-    assert torch.equal(tr.eval_step(Y, Y.y), res[0][1])
-    tr.read_metrics()
