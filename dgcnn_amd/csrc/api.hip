@@ -624,7 +624,7 @@ static int dg_model_forward_impl(int N, int E, int B, int F, int C, const float*
   DG_TRY(dg_launch_gcn_fwd32(1, N, rowptr, colidx, dinv, hsA, params + pl.off[5], x3, params + pl.off[6], h4s, s,
                              DG_PROF_A(2), DG_PROF_B(2), E));
   g_prof_which = -1;
-  DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s));
+  DG_TRY(dg_launch_gcn_fwd1(N, rowptr, colidx, dinv, h4s, params + pl.off[7], x4, s, E));
   }
   if (tt && tail_done && !dense && B <= dg_readout_tail_max_b()) {
     // training step: readout forward + backward in one launch (operands of the backward stay on the CU that made them)
@@ -775,7 +775,7 @@ static int dg_model_backward_impl(int N, int E, int B, int F, int C, const float
   } else {
   // conv4 backward (+ start of conv3's): gas4 -> gas3 (in gasA), partial {dW4, db3}
   DG_TRY(dg_launch_gcn_bwd1(N, rowptr_t, colidx_t, dinv, gas4, params + pl.off[6], x3, gp3, gasA,
-                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr, gpsel));
+                            dg_ptr<float>(ws, wl.pa4), wl.P1, s, (tail_done && !wg_rider) ? rider_b : nullptr, gpsel, E));
   // conv3 backward: gas3 (gasA) -> gas2 (gasB), partial {dW3, db2}
   DG_TRY(dg_launch_gcn_bwd32(0, N, 32, rowptr_t, colidx_t, dinv, gasA, params + pl.off[4], x2, gp2, gasB,
                              dg_ptr<float>(ws, wl.pb3), wl.P32, s, nullptr, 0, nullptr, E, gpsel));

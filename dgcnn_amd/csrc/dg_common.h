@@ -557,11 +557,11 @@ int dg_launch_gcn_fwd32(int mode, int N, const int32_t* rowptr, const int32_t* c
                         hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int E = -1);
 int dg_narrow_gather_enable(int on);      // run-time A/B switch of the eight-lanes-per-node forms (gcn.hip); returns the previous setting
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                       const float* h4s, const float* bias, float* x4, hipStream_t s);
+                       const float* h4s, const float* bias, float* x4, hipStream_t s, int E = -1);      // E: directed edges without self loops (< 0: unknown)
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
                        float* gas3, float* pa4, int P1, hipStream_t s, const struct DgPrepRider* rider = nullptr,
-                       const int32_t* gpsel = nullptr);
+                       const int32_t* gpsel = nullptr, int E = -1);
 // readout forward + readout backward of a training step (labels) as ONE launch (tail.hip)
 int dg_launch_readout_tail(int N, int B, int C, const float* params, const DgParams* pl, const int32_t* graph_ptr,
                            const float* x1, const float* x2, const float* x3, const float* x4, float* pooled, int32_t* perm,

@@ -480,7 +480,9 @@ k_gcn_fwd32p(int N, int numTiles, const int* __restrict__ rowptr, const int* __r
 // ---------------------------------------------------------------------------------------------
 #define DG_NARROW_MAX_DEG 8
 static int g_narrow = 1;
-int dg_narrow_gather_enable(int on) { const int prev = g_narrow; g_narrow = on ? 1 : 0; return prev; }
+// 0: wave per node everywhere; 1 (default): the 32-wide narrow forms; 2 (round 6, opt-in until measured): also the scalar
+// narrow forms of conv4's two gathers (k_gcn_fwd1n / k_gcn_bwd1n)
+int dg_narrow_gather_enable(int on) { const int prev = g_narrow; g_narrow = on <= 0 ? 0 : (on >= 2 ? 2 : 1); return prev; }
 // E: directed edges of the batch without the self loops (< 0: unknown -> the wave-per-node forms)
 static inline bool dg_use_narrow(int N, int E) {
   return g_narrow && E >= 0 && dg_cdiv(N, DG_TILE) > DG_SMALL_GRID_TILES && (int64_t)E <= (int64_t)DG_NARROW_MAX_DEG * N;
@@ -746,9 +748,54 @@ k_gcn_fwd1(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx
   }
 }
 
+// NARROW form of the scalar gather (round 6): eight lanes per destination node, lane q of the group takes the
+// node's neighbours q, q + 8, ...; a wave owns 8 nodes.  At DD's degree of ~5 the wave-per-node form above keeps 5 of 64 lanes
+// busy and needs 14.5 k waves for a batch of 50; this one 1.8 k.  The group's sum runs dg_wave_sum's first two steps (quad
+// swaps on the DPP path) and then adds the two quads: for rows of <= 8 neighbours -- one value per lane -- these are the SAME
+// fp32 additions the wave-per-node form performs on its lanes 0..7 (its other lanes add zeros), so the results are bit-identical
+// there; longer rows accumulate q, q + 8, ... per lane first and agree to summation-order rounding.
+// The total is returned in every lane of the group.
+__device__ __forceinline__ float dg_gather_row1_n(const float* __restrict__ src, const int* __restrict__ col, int start, int cnt,
+                                                  int lane) {
+  const int q = lane & 7;
+  int mx = cnt;                                          // trip count: the longest row among the wave's eight nodes
+  mx = max(mx, __shfl_xor(mx, 8)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+  mx = __builtin_amdgcn_readfirstlane(mx);
+  float s = 0.f;
+  for (int base = 0; base < mx; base += 8) {
+    const bool h = base + q < cnt;
+    const int cj = h ? col[start + base + q] : 0;        // (node 0 stands in where the row has ended: a valid address, never added)
+    const float v = src[cj];
+    if (h) s += v;
+  }
+  s += DG_DPP(s, 0xB1, 0xf);    // quad_perm:[1,0,3,2]
+  s += DG_DPP(s, 0x4E, 0xf);    // quad_perm:[2,3,0,1]
+  s += __shfl_xor(s, 4);        // the group's two quads
+  return s;
+}
+#define DG_NB1 32                  // destination nodes per 256-thread workgroup of the scalar narrow forward
+__global__ void __launch_bounds__(256)
+k_gcn_fwd1n(int N, const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ dinv,
+            const float* __restrict__ h4s, const float* __restrict__ bias, float* __restrict__ x4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float b = bias[0];
+  const int i = (int)blockIdx.x * DG_NB1 + w * 8 + (lane >> 3);
+  const bool valid = i < N;
+  const int ic = valid ? i : N - 1;                      // (clamped: every load below is unconditional)
+  const int start = rowptr[ic], end = rowptr[ic + 1];
+  const float hself = h4s[ic], di = dinv[ic];            // issued before the gather, not after it
+  const float s = dg_gather_row1_n(h4s, colidx, start, valid ? end - start : 0, lane) + hself;
+  if (valid && (lane & 7) == 0) x4[i] = dg_tanh(fmaf(di, s, b));
+}
+
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
-                       const float* h4s, const float* bias, float* x4, hipStream_t s) {
+                       const float* h4s, const float* bias, float* x4, hipStream_t s, int E) {
   if (N <= 0) return DGCNN_EINVAL;
+  if (g_narrow >= 2 && dg_use_narrow(N, E)) {
+    hipLaunchKernelGGL(k_gcn_fwd1n, dim3(dg_cdiv(N, DG_NB1)), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
   int grid = dg_cdiv(N, 4);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(k_gcn_fwd1, dim3(grid), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
@@ -820,10 +867,72 @@ k_gcn_bwd1(int N, const int* __restrict__ rowptr_t, const int* __restrict__ coli
   }
 }
 
+// NARROW form of k_gcn_bwd1 (round 6, no rider range): eight lanes per node -- lane q of a group gathers neighbours q, q + 8, ...
+// of the scalar gas4 (dg_gather_row1_n) and then owns the 16-byte chunk q of the node's 128-byte rows (x3, gp3, gas3), as in the
+// 32-wide narrow kernels.  256 threads = 32 nodes per pass; P1 workgroups, workgroup p takes node blocks p, p + P1, ...; every
+// workgroup writes its row of pa4 (zeros where it had no node: k_wgrad sums all P1 rows).  Partial sums: per lane over its passes,
+// then over the wave's eight groups (xor 8, 16, 32) and the four waves, all in a fixed order.
+__global__ void __launch_bounds__(256)
+k_gcn_bwd1n(int N, const int* __restrict__ rowptr_t, const int* __restrict__ colidx_t, const float* __restrict__ dinv,
+            const float* __restrict__ gas4, const float* __restrict__ W4, const float* __restrict__ x3,
+            const float* __restrict__ gp3, float* __restrict__ gas3, float* __restrict__ pa4, int P1,
+            const int* __restrict__ gpsel) {
+  __shared__ __attribute__((aligned(16))) float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 3, q = lane & 7;
+  const float4 w4 = *reinterpret_cast<const float4*>(W4 + 4 * q);
+  float4 pW = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nblk = (N + DG_NB1 - 1) / DG_NB1;
+  for (int blk = blockIdx.x; blk < nblk; blk += P1) {
+    const int j = blk * DG_NB1 + w * 8 + g;
+    const bool valid = j < N;
+    const int jc = valid ? j : N - 1;
+    const int start = rowptr_t[jc], end = rowptr_t[jc + 1];
+    // everything that does not depend on the gather is requested before it (unconditional loads on clamped / redirected addresses)
+    const int gsel = *(gpsel ? gpsel + jc : &dg_one_word);
+    const float* gprow = gsel ? gp3 + (size_t)jc * 32 : dg_zero_row;
+    const float4 xv = *reinterpret_cast<const float4*>(x3 + (size_t)jc * 32 + 4 * q);
+    const float4 gpv = *reinterpret_cast<const float4*>(gprow + 4 * q);
+    const float dj = dinv[jc], gself = gas4[jc];
+    const float sg = dg_gather_row1_n(gas4, colidx_t, start, valid ? end - start : 0, lane) + gself;
+    const float gh = dj * sg;
+    if (valid) {
+      float4 ga;
+      ga.x = fmaf(gh, w4.x, gpv.x) * (1.f - xv.x * xv.x);
+      ga.y = fmaf(gh, w4.y, gpv.y) * (1.f - xv.y * xv.y);
+      ga.z = fmaf(gh, w4.z, gpv.z) * (1.f - xv.z * xv.z);
+      ga.w = fmaf(gh, w4.w, gpv.w) * (1.f - xv.w * xv.w);
+      *reinterpret_cast<float4*>(gas3 + (size_t)j * 32 + 4 * q) = make_float4(dj * ga.x, dj * ga.y, dj * ga.z, dj * ga.w);
+      pW.x = fmaf(gh, xv.x, pW.x); pW.y = fmaf(gh, xv.y, pW.y); pW.z = fmaf(gh, xv.z, pW.z); pW.w = fmaf(gh, xv.w, pW.w);
+      pb.x += ga.x; pb.y += ga.y; pb.z += ga.z; pb.w += ga.w;
+    }
+  }
+  // the wave's eight groups (lanes with the same q), fixed order; then the four waves
+  float v[8] = {pW.x, pW.y, pW.z, pW.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    v[u] += __shfl_xor(v[u], 8);
+    v[u] += __shfl_xor(v[u], 16);
+    v[u] += __shfl_xor(v[u], 32);
+  }
+  if (g == 0) {      // lane q holds channels 4q .. 4q + 3 of dW4 (v[0..3]) and db3 (v[4..7])
+    *reinterpret_cast<float4*>(&red[w][4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&red[w][32 + 4 * q]) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    pa4[(size_t)blockIdx.x * 64 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, const float* dinv,
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
-                       float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider, const int32_t* gpsel) {
+                       float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider, const int32_t* gpsel, int E) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
+  if (g_narrow >= 2 && !rider && dg_use_narrow(N, E) && (((uintptr_t)x3 | (uintptr_t)gp3 | (uintptr_t)gas3 | (uintptr_t)W4) & 15) == 0) {
+    hipLaunchKernelGGL(k_gcn_bwd1n, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3, pa4, P1, gpsel);
+    DG_CHECK_LAUNCH();
+    return DGCNN_OK;
+  }
   DgPrepRider rd{};
   if (rider) rd = *rider;
   hipLaunchKernelGGL(k_gcn_bwd1, dim3(P1 + rd.nblk_b), dim3(1024), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3,

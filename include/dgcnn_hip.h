@@ -275,7 +275,9 @@ int dgcnn_eval_kernel_enable(int on);
 /* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
  * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:
  * DD at the reference's batch of 50, /root/reference/model.py:30-33 + train.py:40): on = 0 keeps the wave-per-node kernels, whose
- * results the narrow forms reproduce bit for bit; on = 1 restores the default.  Returns the previous setting (process-wide).
+ * results the narrow forms reproduce bit for bit; on = 1 restores the default; on = 2 (ABI v20, opt-in until measured) also takes
+ * eight-lanes-per-node forms of conv4's two SCALAR gathers (k_gcn_fwd1n / k_gcn_bwd1n: bit-identical for rows of <= 8 neighbours,
+ * summation-order rounding beyond).  Returns the previous setting (process-wide).
  * Do not toggle it between dgcnn_model_forward and dgcnn_model_backward of the SAME batch: on this route the switch also decides
  * whether the readout backward leaves the SortPooling-gradient slabs sparse (flag word per node), and the backward's layer
  * kernels must read them the way the forward half of the step wrote them. */

@@ -284,3 +284,44 @@ def test_wide_eval_kernel_through_the_switch_for_chain_form_batches_and_a_traini
     assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-4
     assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-6      # the training step itself is the same route either way
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4
+
+
+# ---- 4. eight-lanes-per-node forms of conv4's two scalar gathers (dgcnn_narrow_gather_enable(2), opt-in) --------
+SCALAR_CASES = [("DD", 50, None), ("DD", 50, 5748), ("hub7", 0, None), ("hub40", 0, None)]
+
+
+@pytest.mark.parametrize("name,bs,force", SCALAR_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in SCALAR_CASES])
+def test_scalar_narrow_gathers_vs_fp64_oracle_and_vs_the_wave_per_node_forms(name, bs, force):
+    """k_gcn_fwd1n / k_gcn_bwd1n (gcn.hip): the whole model against the fp64 oracle with the switch at 2 (forward, every gradient),
+    and conv4's output against the wave-per-node form: bit for bit on nodes of in-degree <= 8 (the same fp32 additions), within
+    summation-order rounding on the others (hubs of degree up to 699, duplicate edges, self loops, isolated nodes in the hub batch)"""
+    from parity_util import check_backward_parity
+    from test_gpu_narrow import hub_batch
+    L = _lib.lib()
+    if name.startswith("hub"):
+        F, C = int(name[3:]), 2
+        b_cpu = hub_batch(F)
+    else:
+        sh = synth.SHAPES[name]
+        F, C = sh.num_features, sh.num_classes
+        b_cpu = synth.make_batch(name, bs, start=3000, force_first_n=force)
+    assert b_cpu.num_nodes > 4096 and b_cpu.num_edges <= 8 * b_cpu.num_nodes          # the admission rule of the narrow forms
+    m = make_model(F, C)
+    sd = cpu_state_dict(m)
+    x4 = {}
+    prev = L.dgcnn_narrow_gather_enable(1)
+    try:
+        for level in (2, 1):
+            L.dgcnn_narrow_gather_enable(level)
+            check_forward_parity(m, b_cpu, sd)
+            x4[level] = m.last_workspace_view("x4").cpu().clone()
+            if level == 2:
+                check_backward_parity(m, b_cpu, sd)
+    finally:
+        L.dgcnn_narrow_gather_enable(prev)
+    ei = b_cpu.edge_index
+    keep = ei[0] != ei[1]                                            # (self loops are removed; duplicates count with multiplicity)
+    indeg = torch.bincount(ei[1][keep], minlength=b_cpu.num_nodes)
+    small = indeg <= 8
+    assert bool(small.any()) and torch.equal(x4[2][small], x4[1][small])
+    assert float((x4[2] - x4[1]).abs().max()) <= 1e-6
