@@ -324,4 +324,4 @@ def test_scalar_narrow_gathers_vs_fp64_oracle_and_vs_the_wave_per_node_forms(nam
     indeg = torch.bincount(ei[1][keep], minlength=b_cpu.num_nodes)
     small = indeg <= 8
     assert bool(small.any()) and torch.equal(x4[2][small], x4[1][small])
-    assert float((x4[2] - x4[1]).abs().max()) <= 1e-6
+    assert float((x4[2] - x4[1]).abs().max()) <= 4e-6
