@@ -479,13 +479,17 @@ k_gcn_fwd32p(int N, int numTiles, const int* __restrict__ rowptr, const int* __r
 // results are bit-identical to the wave-per-node kernels (tests/test_gpu_kernels.py compares the two forms exactly).
 // ---------------------------------------------------------------------------------------------
 #define DG_NARROW_MAX_DEG 8
-static int g_narrow = 1;
+static int g_narrow = -1;      // (-1: not yet read; DGCNN_NARROW_GATHER=0|1|2 in the environment sets the initial value, default 1)
+static inline int dg_narrow_level() {
+  if (g_narrow < 0) { const char* e = getenv("DGCNN_NARROW_GATHER"); g_narrow = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+  return g_narrow;
+}
 // 0: wave per node everywhere; 1 (default): the 32-wide narrow forms; 2 (round 6, opt-in until measured): also the scalar
 // narrow forms of conv4's two gathers (k_gcn_fwd1n / k_gcn_bwd1n)
-int dg_narrow_gather_enable(int on) { const int prev = g_narrow; g_narrow = on <= 0 ? 0 : (on >= 2 ? 2 : 1); return prev; }
+int dg_narrow_gather_enable(int on) { const int prev = dg_narrow_level(); g_narrow = on <= 0 ? 0 : (on >= 2 ? 2 : 1); return prev; }
 // E: directed edges of the batch without the self loops (< 0: unknown -> the wave-per-node forms)
 static inline bool dg_use_narrow(int N, int E) {
-  return g_narrow && E >= 0 && dg_cdiv(N, DG_TILE) > DG_SMALL_GRID_TILES && (int64_t)E <= (int64_t)DG_NARROW_MAX_DEG * N;
+  return dg_narrow_level() && E >= 0 && dg_cdiv(N, DG_TILE) > DG_SMALL_GRID_TILES && (int64_t)E <= (int64_t)DG_NARROW_MAX_DEG * N;
 }
 int dg_narrow_applies(int N, int E) { return dg_use_narrow(N, E) ? 1 : 0; }
 __device__ __forceinline__ float4 dg_gather_row32_n(const float* __restrict__ src, const int* __restrict__ col, int start,
@@ -791,7 +795,7 @@ k_gcn_fwd1n(int N, const int* __restrict__ rowptr, const int* __restrict__ colid
 int dg_launch_gcn_fwd1(int N, const int32_t* rowptr, const int32_t* colidx, const float* dinv,
                        const float* h4s, const float* bias, float* x4, hipStream_t s, int E) {
   if (N <= 0) return DGCNN_EINVAL;
-  if (g_narrow >= 2 && dg_use_narrow(N, E)) {
+  if (dg_narrow_level() >= 2 && dg_use_narrow(N, E)) {
     hipLaunchKernelGGL(k_gcn_fwd1n, dim3(dg_cdiv(N, DG_NB1)), dim3(256), 0, s, N, rowptr, colidx, dinv, h4s, bias, x4);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
@@ -928,7 +932,7 @@ int dg_launch_gcn_bwd1(int N, const int32_t* rowptr_t, const int32_t* colidx_t, 
                        const float* gas4, const float* W4, const float* x3, const float* gp3,
                        float* gas3, float* pa4, int P1, hipStream_t s, const DgPrepRider* rider, const int32_t* gpsel, int E) {
   if (N <= 0 || P1 <= 0) return DGCNN_EINVAL;
-  if (g_narrow >= 2 && !rider && dg_use_narrow(N, E) && (((uintptr_t)x3 | (uintptr_t)gp3 | (uintptr_t)gas3 | (uintptr_t)W4) & 15) == 0) {
+  if (dg_narrow_level() >= 2 && !rider && dg_use_narrow(N, E) && (((uintptr_t)x3 | (uintptr_t)gp3 | (uintptr_t)gas3 | (uintptr_t)W4) & 15) == 0) {
     hipLaunchKernelGGL(k_gcn_bwd1n, dim3(P1), dim3(256), 0, s, N, rowptr_t, colidx_t, dinv, gas4, W4, x3, gp3, gas3, pa4, P1, gpsel);
     DG_CHECK_LAUNCH();
     return DGCNN_OK;
