@@ -44,8 +44,10 @@ k_classifier(int B, int C, TailW w, const float* __restrict__ a6g, float* __rest
   // every kernel argument is brought into scalar registers NOW (an empty use): left to the compiler, the output pointers were
   // loaded where they are first used -- scalar-cache round trips with `s_waitcnt lgkmcnt(0)` between the phases of a workgroup
   // that is one latency chain
+#ifndef DG_EMU
   asm volatile("" :: "s"(a1dg), "s"(maskg), "s"(logp), "s"(y), "s"(dlogit), "s"(gz1g), "s"(gz6g), "s"(lossv), "s"(ptail), "s"(seed),
                "s"(training), "s"(loss_scale), "s"(w.Wf2), "s"(w.bf1), "s"(w.bf2));
+#endif
   __shared__ __attribute__((aligned(16))) float fl[CL_GB * CL_FS];       // conv6 outputs of the 16 graphs (ReLU mask of the way back)
   __shared__ __attribute__((aligned(16))) float a1s[CL_GB * CL_HS];      // classifier_1 outputs after ReLU / dropout
   __shared__ __attribute__((aligned(16))) float gz1s[CL_GB * CL_HS];     // gradient wrt classifier_1's pre-activation

@@ -4,6 +4,24 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../include/dgcnn_hip.h"
+// ---- the few places where the sources speak ISA, behind macros: the CPU SIMT emulation build (-DDG_EMU: emu/, test infrastructure)
+// compiles the SAME sources as plain C++ ----------------------------------------------------------------------------------------
+#ifdef DG_EMU
+#define DG_DYN_SMEM(T, name) T* const name = reinterpret_cast<T*>(dg_emu::dyn_smem())
+#define DG_WAIT_LGKM() do { } while (0)
+#define DG_OPAQUE_V(x) asm volatile("" : "+m"(x))
+#define DG_OPAQUE_S(x) asm volatile("" : "+m"(x))
+// The emulation runs a wave's lanes ONE AFTER THE OTHER between wave-level operations; the hardware runs them in lockstep.  Where
+// the code relies on lockstep order between lanes of a wave for plain memory accesses ("every lane clears the slot, then lane 0
+// fills it"; a lane reading what another lane of its wave just stored), this marker makes the lanes meet.  Nothing on the GPU.
+#define DG_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define DG_LOCKSTEP() do { } while (0)
+#define DG_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) T name[]      // the launch's dynamic LDS, under the kernel's name and element type
+#define DG_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define DG_OPAQUE_V(x) asm volatile("" : "+v"(x))      // the value becomes opaque to the optimizer (vector / scalar register)
+#define DG_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#endif
 
 #define DG_WAVE 64
 #define DG_TILE 16            // destination nodes per workgroup tile in the F=32 GCN kernels
@@ -310,9 +328,13 @@ __device__ __forceinline__ void dg_adam_elem(float g, float m, float v, float p,
 }
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL stores/loads are NOT drained
 // (a plain __syncthreads() waits vmcnt(0), i.e. a full HBM write round trip per barrier)
+#ifdef DG_EMU
+__device__ __forceinline__ void dg_lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void dg_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#endif
 __device__ __forceinline__ float4 dg_add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
@@ -430,7 +452,7 @@ __device__ __forceinline__ float dg_af_gather(const float* __restrict__ xsrc, co
   float acc = 0.f, vself = 0.f;
   if (g == 0 && qa) {
     if (PRESCALED) vself = xsrc[self * F + q];
-    else { vself = dsrc[self] * xsrc[(size_t)self * F + q]; asm volatile("" : "+v"(vself)); }
+    else { vself = dsrc[self] * xsrc[(size_t)self * F + q]; DG_OPAQUE_V(vself); }
   }
   for (int base = start; base < end; base += 64) {
     const int cnt = min(64, end - base);
@@ -445,7 +467,7 @@ __device__ __forceinline__ float dg_af_gather(const float* __restrict__ xsrc, co
         v[u] = 0.f;
         if (idx < cnt && qa) {
           if (PRESCALED) v[u] = xsrc[j * F + q];
-          else { v[u] = dsrc[j] * xsrc[(size_t)j * F + q]; asm volatile("" : "+v"(v[u])); }
+          else { v[u] = dsrc[j] * xsrc[(size_t)j * F + q]; DG_OPAQUE_V(v[u]); }
         }
       }
 #pragma unroll

@@ -387,7 +387,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
         __shared__ unsigned int rowbuf[EXTBUF ? 1 : (THREADS / 8) * 16];
         unsigned int* rb = (EXTBUF ? rowbuf_ext : rowbuf) + (threadIdx.x >> 3) * 16;
         rb[l8] = 0u; rb[l8 + 8] = 0u;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DG_WAIT_LGKM();
         unsigned int cur = 0u;
         int cw = 0;
         for (int e = rs + l8; e < re; e += 64) {
@@ -409,7 +409,7 @@ __device__ __forceinline__ void dg_prep_fast_b_body(int t, const int64_t* __rest
           }
         }
         if (cur) __hip_atomic_fetch_or(&rb[cw], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DG_WAIT_LGKM();
         if (ok) {
           unsigned int* rw = bits + (size_t)N * (S - 1) + (size_t)row * S;
 #pragma unroll

@@ -96,7 +96,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
             float* __restrict__ a1dg, uint8_t* __restrict__ maskg, float* __restrict__ logp, int training,
             uint64_t seed, unsigned int* __restrict__ err, unsigned int epoch, unsigned long long* dbg) {
 #define FG_MARK(k) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   const int b = blockIdx.x;
   // one round trip: node range and edge range of this graph
   const int n0 = graph_ptr[b], n1 = graph_ptr[b + 1];
@@ -155,7 +155,7 @@ k_fused_fwd(int F, int C, int nmax, int emax_lds, size_t region0_bytes, FgW gw, 
     for (int t = tid; t < n * F; t += FG_THREADS) {
       const int i = t / F;
       float v = dinv[n0 + i] * xin[(size_t)n0 * F + t];
-      asm volatile("" : "+v"(v));
+      DG_OPAQUE_V(v);
       H[t] = v;
     }
   }

@@ -57,7 +57,7 @@ k_lin_first32(int N, int F, const float* __restrict__ x, const float* __restrict
               const float* __restrict__ dinv, void* __restrict__ hsv) {
   float* hs = reinterpret_cast<float*>(hsv);
   unsigned short* hb = reinterpret_cast<unsigned short*>(hsv);
-  extern __shared__ __attribute__((aligned(16))) float Wt[];   // [F][32] (transposed: conflict-free)
+  DG_DYN_SMEM(float, Wt);   // [F][32] (transposed: conflict-free)
   for (int t = threadIdx.x; t < 32 * F; t += blockDim.x) {
     const int c = t / F, k = t - c * F;
     Wt[k * 32 + c] = W[t];
@@ -98,7 +98,7 @@ k_lin_first32s(int N, int F, const float* __restrict__ x, const float* __restric
                const float* __restrict__ dinv, void* __restrict__ hsv) {
   float* hs = reinterpret_cast<float*>(hsv);
   unsigned short* hb = reinterpret_cast<unsigned short*>(hsv);
-  extern __shared__ __attribute__((aligned(16))) float lsm[];     // [32][F] weights | 4 x [16][F] tiles | 4 floats of slack
+  DG_DYN_SMEM(float, lsm);     // [32][F] weights | 4 x [16][F] tiles | 4 floats of slack
   float* Ws = lsm;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* xs = lsm + 32 * F + w * 16 * F;                 // this wave's tile (32 F and 16 F floats: multiples of 16 bytes)
@@ -972,7 +972,7 @@ k_gcn_bwd32(int N, int F, int numTiles, const int* __restrict__ rowptr_t, const 
   __shared__ float gat[AF ? DG_TILE : 1][DG_LDS_PAD];          // AF: ga_1 tile
   __shared__ float axs[AF ? DG_TILE * DG_AF_MAX_F : 1];        // AF: ax tile [16][Fa]
   float accA = 0.f;                                            // AF: dW1[c][k], thread t = k*32 + c
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // FIRST: [16][F] raw-input tile
+  DG_DYN_SMEM(float, xs);   // FIRST: [16][F] raw-input tile
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 3, q = lane & 7;
@@ -1276,7 +1276,7 @@ k_gcn_bwd32n1(int N, int F, int numTiles, const int* __restrict__ rowptr_t, cons
               const float* __restrict__ dinv, const float* __restrict__ gas, const float* __restrict__ xraw,
               float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float ght[DG_NB][DG_LDS_PAD];
-  extern __shared__ __attribute__((aligned(16))) float xs[];    // [32][F]
+  DG_DYN_SMEM(float, xs);    // [32][F]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 3, q = lane & 7;

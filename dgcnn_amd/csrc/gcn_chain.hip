@@ -36,7 +36,11 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+#ifdef DG_EMU
+#define CH_LDS
+#else
 #define CH_LDS __attribute__((address_space(3)))
+#endif
 
 struct ChW { const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4; };
 
@@ -109,7 +113,7 @@ k_chain_fwd(int N, int F, const int* __restrict__ graph_ptr, const unsigned* __r
             const float* __restrict__ xs, ChW gw, float* __restrict__ axg, float* __restrict__ x1, float* __restrict__ x2,
             float* __restrict__ x3, float* __restrict__ x4, int nmin, const int* __restrict__ sched, const int* __restrict__ nbig_p) {
   using C = ChCfg<WAVES, TPW, PING>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -480,7 +484,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
   // x4_lds (the one-launch training kernel): conv4's outputs are ALSO left in LDS, indexed by local node -- they are the
   // SortPooling keys the same workgroup reads next, and from LDS it need not wait for its own global stores to land first
   using C = ChQ<WAVES, W1S, MAXN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -588,7 +592,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
     //  below is loop-invariant, gets hoisted out of the graph walk and SPILLED -- and each reload is a scratch load followed by
     //  s_waitcnt vmcnt(0), which also waits for the next graph's prefetch: 7 of them made conv4's 3 MFMAs take 5.7 k cycles)
     int tl = tid;
-    asm volatile("" : "+v"(tl));
+    DG_OPAQUE_V(tl);
     // graphs of <= ROWS/2 nodes keep TWO images, rows [0, ROWS/2) and [ROWS/2, ROWS) of every plane, and alternate between
     // them: a layer's output image is not the one still being read, so the barrier in front of its stores is not needed
     const int pong = (2 * n <= C::ROWS) ? (C::ROWS / 2) * 32 : 0;
@@ -928,7 +932,7 @@ ch_chain_body(int N, int B, int F, const int* __restrict__ sched, const int* __r
         for (int rr = 0; rr < 4; ++rr) { s1[ti][rr] = __shfl_xor(a4[ti][rr], 1); s2[ti][rr] = __shfl_xor(a4[ti][rr], 2); }
       if (nl == 0) {
         int kqv = kq;
-        asm volatile("" : "+v"(kqv));        // (see the staging: nothing below may be hoisted out of the graph walk)
+        DG_OPAQUE_V(kqv);        // (see the staging: nothing below may be hoisted out of the graph walk)
 #pragma unroll
         for (int ti = 0; ti < (TWO ? 2 : 1); ++ti) {
           const int mm = 16 * (wave + WAVES * ti) + 4 * kqv;
@@ -1479,7 +1483,7 @@ __device__ __forceinline__ void ch_rider_block(int rb, const DgPrepRider& rd) {
   // phase B of the same batch in the same launch: wait until EVERY phase-A workgroup has published (bounded; they were all
   // dispatched before this workgroup), then the body that otherwise rides on k_wgrad.  The LDS row buffer is this launch's
   // dynamic LDS, which a rider workgroup does not use otherwise.
-  extern __shared__ __attribute__((aligned(16))) char rsm[];
+  DG_DYN_SMEM(char, rsm);
   if (threadIdx.x == 0) {
     unsigned int spins = 0;
     // (relaxed polls and NO acquire fence: an acquire invalidates this XCD's L2, out of which the graph workgroups of the same
@@ -1578,7 +1582,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
   if (threadIdx.x == 0 && gn > CH_TRAIN_MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
   // (the keys' LDS copy lives in the unused second parity set of the dinv array: beyond the readout's LDS plan, which aliases
   //  the images, and untouched until conv4's backward at the end of this kernel reads the FIRST set)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   float* keys_lds = reinterpret_cast<float*>(smem + ChQ<16, W1S, CH_TRAIN_MAXN>::OFF_DV) + ChQ<16, W1S, CH_TRAIN_MAXN>::ROWS;
 #ifdef CH_FINE
   unsigned long long* const chain_dbg = dbg;
@@ -1640,7 +1644,7 @@ k_chain_readout_tail(int N, int B, int F, const int* __restrict__ graph_ptr, con
     constexpr int NBA = W1S == 8 ? 2 : 1;
 #ifdef CH_REPEAT_BWD      // measurement build: the GCN backward twice (second pass: warm instruction cache; results are garbage)
     int reps_ = 2;
-    asm volatile("" : "+s"(reps_));
+    DG_OPAQUE_S(reps_);
 #pragma unroll 1
     for (int rep_ = 0; rep_ < reps_; ++rep_) {
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && rep_ == 1) { for (int k = 16; k < 22; ++k) dbg[k + 8] = dbg[k]; dbg[16] = clock64(); }
@@ -1708,7 +1712,7 @@ k_chain_readout_eval(int N, int B, int F, const int* __restrict__ graph_ptr, con
   const int yraw = (t.y && threadIdx.x < 64) ? (int)t.y[b] : 0;
   const int gn0 = graph_ptr[b], gn = graph_ptr[b + 1] - gn0;
   if (threadIdx.x == 0 && gn > MAXN) { t.err[1] = t.epoch; t.err[3] = ~t.epoch; }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   float* keys_lds = reinterpret_cast<float*>(smem + C::OFF_DV) + C::ROWS;      // (second parity set of the dinv array, as in training)
   ch_chain_body<16, XI, W1S, false, MAXN, BF>(N, B, F, nullptr, nullptr, graph_ptr, bits, dinv, xs, gw, axg, x1, x2, x3, x4,
                                                        nullptr, keys_lds);
@@ -1834,7 +1838,7 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
               float* __restrict__ gas2, float* __restrict__ pa4, int P1, float* __restrict__ pb3, int P32,
               const int* __restrict__ gpsel) {
   using C = ChB<WAVES, MAXN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -1895,7 +1899,7 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
     int tl = tid;
-    asm volatile("" : "+v"(tl));      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
+    DG_OPAQUE_V(tl);      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
     // ---- stage: bitmap rows, dinv, gas4 as three bf16 parts (zeros up to RU) ------------------------------------------------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)
@@ -2134,7 +2138,7 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
               const float* __restrict__ W2, const float* __restrict__ x1, const float* __restrict__ gp1, const float* __restrict__ axg,
               float* __restrict__ pb2, float* __restrict__ pb1, int P32, const int* __restrict__ gpsel) {
   using C = ChB<WAVES, MAXN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
@@ -2190,7 +2194,7 @@ k_chain_bwd_b(int N, int B, int Fa, const int* __restrict__ sched, const int* __
     const int K32 = (n + 31) >> 5, T = (n + 15) >> 4, RU = 32 * K32;
     const int S = 1 << dgd_class(max(n, 1));
     int tl = tid;
-    asm volatile("" : "+v"(tl));      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
+    DG_OPAQUE_V(tl);      // (per-iteration copy: no address piece of the staging is hoisted out of the walk and spilled)
     // ---- stage: bitmap rows, dinv, and the graph's gas2 rows as three bf16 parts (item = row k, 4-column slot q of 8) -------
 #pragma unroll
     for (int j = 0; j < C::PB; ++j)

@@ -1101,7 +1101,7 @@ k_fused_fwd_d(int F, int C, FdW gw, TailW tw, const float* __restrict__ xin, con
   const unsigned long long tstart_ = clock64();
 #endif
   FD_MARK(0);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DG_DYN_SMEM(char, smem);
   // LDS plan: [Ht0 | Ht1] (2 x 37.5 KiB; the readout's 32-KiB region aliases it afterwards) | xt tiles 12 x 2304 B |
   //           bits 192 x 6 x 4 | dv, x4s (192 floats each) | tab | readout small
   unsigned short* Ht0 = reinterpret_cast<unsigned short*>(smem);
@@ -1177,7 +1177,7 @@ k_fused_fwd_d(int F, int C, FdW gw, TailW tw, const float* __restrict__ xin, con
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float xv = 0.f;
-        if (r0 + i < n) { xv = dinv[n0 + r0 + i] * xin[(size_t)(n0 + r0 + i) * F + c]; asm volatile("" : "+v"(xv)); }
+        if (r0 + i < n) { xv = dinv[n0 + r0 + i] * xin[(size_t)(n0 + r0 + i) * F + c]; DG_OPAQUE_V(xv); }
         v[i] = xv;
       }
       fd_store_hs4(Ht0, c, r0, v);

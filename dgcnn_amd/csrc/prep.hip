@@ -112,6 +112,7 @@ k_prep_sort_rows(int N, const int* __restrict__ rowptr, int* __restrict__ colidx
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + w;   // rows 0..N-1 -> CSR by target, N..2N-1 -> CSR by source
   long_row[w] = -1;   // each wave owns its slot; published by the barrier below
+  DG_LOCKSTEP();
   if (r < 2 * N) {
     const int* rp = r < N ? rowptr : rowptr_t;
     int* col = r < N ? colidx : colidx_t;

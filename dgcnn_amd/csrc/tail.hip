@@ -206,8 +206,8 @@ k_tail_bwd_walk(int B, int per, int C, TailW w, const int* __restrict__ graph_pt
   const int b0 = (int)blockIdx.x * per;
   for (int it = 0; it < per; ++it) {
     int b = b0 + it, tl = (int)threadIdx.x;
-    asm volatile("" : "+s"(b));
-    asm volatile("" : "+v"(tl));
+    DG_OPAQUE_S(b);
+    DG_OPAQUE_V(tl);
     if (b >= B) break;
     dg_tail_bwd_body<true, false, false>(b, B, C, w, graph_ptr, perm, dinv, x4, a5g, a6g, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
                                          nullptr, nullptr, gz6g, gz5g, gp1, gp2, gp3, gas4, gb4p, nullptr, ptail, pooled, nullptr,

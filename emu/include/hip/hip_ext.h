@@ -1,0 +1,1 @@
+#include <hip/hip_runtime.h>

@@ -1,0 +1,300 @@
+// CPU SIMT emulation of the HIP subset dgcnn_amd/csrc uses -- TEST INFRASTRUCTURE, never shipped, never the thing measured.
+//
+// Why it exists (round 6): the GPU pool was closed to this repository for the whole round; the kernels could be compiled for gfx950
+// but not run.  This header + emu/emu_rt.cpp let the SAME kernel sources be compiled as plain C++ (clang++ -x c++ -DDG_EMU) into
+// dgcnn_amd/libdgcnn_emu.so, in which a launch executes every workgroup in turn, every lane as a fibre, with wave-level operations
+// (shuffles, DPP, ballot, readlane, MFMA, the LDS transpose read) and workgroup barriers resolved by a scheduler.  It checks
+// ARITHMETIC AND INDEXING of device code against the oracle -- not timing, not memory ordering, not races (lanes run one at a time).
+// Its semantics of the wave-level instructions are calibrated by the kernels that have green GPU records from rounds 1-5: those
+// reproduce the fp64 oracle under it (tests/test_emu_*.py).  Nothing under dgcnn_amd/ loads this library.
+#pragma once
+#ifndef DG_EMU
+#error "emu/include is only for -DDG_EMU builds"
+#endif
+#define __HIPCC__ 1
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include <algorithm>
+#include <functional>
+#include <utility>
+#include <type_traits>
+// (HIP's min / max accept mixed integer types)
+template <class A, class B> static inline typename std::common_type<A, B>::type min(A a, B b) { return b < a ? b : a; }
+template <class A, class B> static inline typename std::common_type<A, B>::type max(A a, B b) { return a < b ? b : a; }
+
+// ---- qualifiers ---------------------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __constant__ static const
+
+// ---- vector types -------------------------------------------------------------------------------------------------------------
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---- runtime (emu/emu_rt.cpp) ---------------------------------------------------------------------------------------------------
+namespace dg_emu {
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;      // of the lane that is running (one lane runs at a time)
+char* dyn_smem();
+void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
+void barrier();                                                   // workgroup barrier
+// wave-level exchange: every live lane of the wave deposits `in` (nbytes) and receives all 64 deposits + the active mask
+struct WaveBuf { const void* in[64]; uint64_t mask; int lane; };
+// a wave-level operation is identified by its place in the SOURCE (file, line, column), not by a code address: the optimizer
+// duplicates call sites (a select in front of a shuffle becomes two branches with a copy of the shuffle each), and the lanes of
+// one logical instruction must still meet
+struct Site { const char* file; int line, col; };
+const WaveBuf& wave_exchange(const void* in, unsigned nbytes, Site site);
+void wave_release();                                              // (the lane has consumed the exchange buffer)
+uint64_t clock();
+}  // namespace dg_emu
+#define threadIdx dg_emu::g_threadIdx
+#define blockIdx dg_emu::g_blockIdx
+#define blockDim dg_emu::g_blockDim
+#define gridDim dg_emu::g_gridDim
+static const int warpSize = 64;
+
+static inline void __syncthreads() { dg_emu::barrier(); }
+static inline unsigned long long clock64() { return dg_emu::clock(); }
+static inline unsigned long long wall_clock64() { return dg_emu::clock(); }
+
+// one wave-level operation: F(lane, buf) computes this lane's result from all deposits
+template <class T, class F>
+static inline __attribute__((noinline)) auto dg_emu_waveop(const T& v, F f, dg_emu::Site site) -> decltype(f(0, *(const dg_emu::WaveBuf*)nullptr)) {
+  const dg_emu::WaveBuf& b = dg_emu::wave_exchange(&v, (unsigned)sizeof(T), site);
+  auto r = f(b.lane, b);
+  dg_emu::wave_release();
+  return r;
+}
+#define DG_EMU_IN(T, b, l) (*reinterpret_cast<const T*>((b).in[(l)]))
+#define DG_EMU_ACTIVE(b, l) ((((b).mask) >> (l)) & 1ull)
+
+// ---- shuffles, ballot, readlane -------------------------------------------------------------------------------------------------
+template <class T> static inline __attribute__((always_inline)) T __shfl(T v, int src, int width = 64, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  struct In { T v; int src; } in{v, src};
+  return dg_emu_waveop(in, [width](int lane, const dg_emu::WaveBuf& b) {
+    const int s = (lane & ~(width - 1)) + (DG_EMU_IN(In, b, lane).src & (width - 1));
+    return DG_EMU_ACTIVE(b, s) ? DG_EMU_IN(In, b, s).v : DG_EMU_IN(In, b, lane).v;
+  }, dg_emu::Site{file_, line_, col_});
+}
+template <class T> static inline __attribute__((always_inline)) T __shfl_xor(T v, int m, int width = 64, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(v, [m, width](int lane, const dg_emu::WaveBuf& b) {
+    const int s = lane ^ m;
+    return ((s & ~(width - 1)) == (lane & ~(width - 1)) && DG_EMU_ACTIVE(b, s)) ? DG_EMU_IN(T, b, s) : DG_EMU_IN(T, b, lane);
+  }, dg_emu::Site{file_, line_, col_});
+}
+template <class T> static inline __attribute__((always_inline)) T __shfl_up(T v, unsigned d, int width = 64, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(v, [d, width](int lane, const dg_emu::WaveBuf& b) {
+    const int s = lane - (int)d;
+    return (s >= (lane & ~(width - 1)) && DG_EMU_ACTIVE(b, s)) ? DG_EMU_IN(T, b, s) : DG_EMU_IN(T, b, lane);
+  }, dg_emu::Site{file_, line_, col_});
+}
+template <class T> static inline __attribute__((always_inline)) T __shfl_down(T v, unsigned d, int width = 64, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(v, [d, width](int lane, const dg_emu::WaveBuf& b) {
+    const int s = lane + (int)d;
+    return (s < (lane & ~(width - 1)) + width && DG_EMU_ACTIVE(b, s)) ? DG_EMU_IN(T, b, s) : DG_EMU_IN(T, b, lane);
+  }, dg_emu::Site{file_, line_, col_});
+}
+static inline __attribute__((always_inline)) unsigned long long __builtin_amdgcn_ballot_w64(bool p, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(p, [](int, const dg_emu::WaveBuf& b) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (DG_EMU_ACTIVE(b, l) && DG_EMU_IN(bool, b, l)) m |= 1ull << l;
+    return m;
+  }, dg_emu::Site{file_, line_, col_});
+}
+static inline __attribute__((always_inline)) unsigned long long __ballot(int p, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) { return __builtin_amdgcn_ballot_w64(p != 0, file_, line_, col_); }
+static inline __attribute__((always_inline)) int __builtin_amdgcn_readfirstlane(int v, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(v, [](int, const dg_emu::WaveBuf& b) { return DG_EMU_IN(int, b, __builtin_ctzll(b.mask)); }, dg_emu::Site{file_, line_, col_});
+}
+static inline __attribute__((always_inline)) int __builtin_amdgcn_readlane(int v, int l, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  return dg_emu_waveop(v, [l](int, const dg_emu::WaveBuf& b) { return DG_EMU_ACTIVE(b, l) ? DG_EMU_IN(int, b, l) : 0; }, dg_emu::Site{file_, line_, col_});
+}
+static inline __attribute__((always_inline)) void __builtin_amdgcn_wave_barrier(const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  int z = 0;
+  (void)dg_emu_waveop(z, [](int, const dg_emu::WaveBuf&) { return 0; }, dg_emu::Site{file_, line_, col_});
+}
+
+// DPP (the controls the sources use: quad_perm, row_ror, row_bcast15 / 31; bound_ctrl: an invalid source reads 0; rows outside
+// row_mask keep `old`)
+static inline __attribute__((always_inline)) int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  (void)bank_mask; (void)bound_ctrl;
+  return dg_emu_waveop(src, [old, ctrl, row_mask](int lane, const dg_emu::WaveBuf& b) {
+    const int row = lane >> 4, li = lane & 15;
+    if (!((row_mask >> row) & 1)) return old;
+    int s = -1;
+    if (ctrl >= 0 && ctrl <= 0xFF) s = (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);                     // quad_perm
+    else if (ctrl >= 0x121 && ctrl <= 0x12F) s = (lane & ~15) + ((li - (ctrl - 0x120)) & 15);              // row_ror:n
+    else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int t = li - (ctrl - 0x110); s = t >= 0 ? (lane & ~15) + t : -1; }   // row_shr:n
+    else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int t = li + (ctrl - 0x100); s = t < 16 ? (lane & ~15) + t : -1; }   // row_shl:n
+    else if (ctrl == 0x142) s = row >= 1 ? (row << 4) - 1 : -1;                                            // row_bcast:15
+    else if (ctrl == 0x143) s = row >= 2 ? 31 : -1;                                                        // row_bcast:31
+    else abort();
+    if (s < 0 || !DG_EMU_ACTIVE(b, s)) return 0;
+    return DG_EMU_IN(int, b, s);
+  }, dg_emu::Site{file_, line_, col_});
+}
+
+// ---- matrix instructions --------------------------------------------------------------------------------------------------------
+typedef float dg_emu_f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: lane l holds A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16]; D[m = 4 (l / 16) + r][n = l % 16]
+static inline __attribute__((always_inline)) dg_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, dg_emu_f32x4 c, int, int, int, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  struct In { float a, b; } in{a, b};
+  return dg_emu_waveop(in, [c](int lane, const dg_emu::WaveBuf& w) {
+    dg_emu_f32x4 d = c;
+    const int n = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * (lane >> 4) + r;
+      float acc = d[r];
+      for (int k = 0; k < 4; ++k) acc = fmaf(DG_EMU_IN(In, w, 16 * k + m).a, DG_EMU_IN(In, w, 16 * k + n).b, acc);
+      d[r] = acc;
+    }
+    return d;
+  }, dg_emu::Site{file_, line_, col_});
+}
+typedef __bf16 dg_emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline float dg_emu_bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// v_mfma_f32_16x16x32_bf16: lane l holds eight k-values of row m = l % 16 (A) / column n = l % 16 (B), k-group l / 16
+static inline __attribute__((always_inline)) dg_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(dg_emu_bf16x8 a, dg_emu_bf16x8 b, dg_emu_f32x4 c, int, int, int, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  struct In { unsigned short a[8], b[8]; } in;
+  memcpy(in.a, &a, 16); memcpy(in.b, &b, 16);
+  return dg_emu_waveop(in, [c](int lane, const dg_emu::WaveBuf& w) {
+    dg_emu_f32x4 d = c;
+    const int n = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * (lane >> 4) + r;
+      float acc = d[r];
+      for (int kg = 0; kg < 4; ++kg) {
+        const In& A = DG_EMU_IN(In, w, 16 * kg + m);
+        const In& B = DG_EMU_IN(In, w, 16 * kg + n);
+        for (int e = 0; e < 8; ++e) acc = fmaf(dg_emu_bf2f(A.a[e]), dg_emu_bf2f(B.b[e]), acc);
+      }
+      d[r] = acc;
+    }
+    return d;
+  }, dg_emu::Site{file_, line_, col_});
+}
+// ds_read_b64_tr_b16: inside each group of 16 lanes the 16 x 4 fetched 16-bit elements form 4 rows of 16 (row j = the fetches of
+// lanes 4j .. 4j + 3, concatenated); lane l receives column l of the four rows
+typedef short dg_emu_s16x4 __attribute__((ext_vector_type(4)));
+static inline __attribute__((always_inline)) dg_emu_s16x4 __builtin_amdgcn_ds_read_tr16_b64_v4i16(const dg_emu_s16x4* p, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
+  dg_emu_s16x4 mine;
+  memcpy(&mine, p, 8);
+  return dg_emu_waveop(mine, [](int lane, const dg_emu::WaveBuf& w) {
+    dg_emu_s16x4 r;
+    const int g = lane & ~15, l = lane & 15;
+    for (int j = 0; j < 4; ++j) r[j] = DG_EMU_IN(dg_emu_s16x4, w, g + 4 * j + (l >> 2))[l & 3];
+    return r;
+  }, dg_emu::Site{file_, line_, col_});
+}
+
+// ---- per-lane builtins ----------------------------------------------------------------------------------------------------------
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {      // v_perm_b32: bytes 0..3 = s1, 4..7 = s0
+  const uint64_t src = ((uint64_t)s0 << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned c = (sel >> (8 * i)) & 0xff;
+    unsigned byte = c <= 7 ? (unsigned)((src >> (8 * c)) & 0xff) : (c == 0x0c ? 0u : 0xffu);
+    r |= byte << (8 * i);
+  }
+  return r;
+}
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_s_sleep(n) do { } while (0)
+#define __builtin_amdgcn_sched_barrier(n) do { } while (0)
+#define __builtin_amdgcn_fence(...) do { } while (0)
+#define __builtin_amdgcn_s_waitcnt(n) do { } while (0)
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
+// ---- atomics (one lane runs at a time; __hip_atomic_* are clang builtins on the host too) ------------------------------------------------------------------------
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 1
+#endif
+#ifndef __HIP_MEMORY_SCOPE_SYSTEM
+#define __HIP_MEMORY_SCOPE_SYSTEM 2
+#endif
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
+#ifndef __HIP_MEMORY_SCOPE_WAVEFRONT
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 4
+#endif
+template <class T, class V> static inline T atomicAdd(T* p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class V> static inline T atomicOr(T* p, V v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <class T, class V> static inline T atomicMin(T* p, V v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class V> static inline T atomicMax(T* p, V v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+
+// ---- host API -------------------------------------------------------------------------------------------------------------------
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorUnknown 999
+typedef struct dg_emu_stream* hipStream_t;
+typedef struct dg_emu_event* hipEvent_t;
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+#define hipEventDisableTiming 2
+#define hipStreamNonBlocking 1
+#define hipMemcpyHostToDevice 1
+#define hipDeviceMallocFinegrained 1
+#define hipIpcMemLazyEnablePeerAccess 1
+#define hipDeviceAttributeMultiprocessorCount 63
+struct hipIpcMemHandle_t { char reserved[64]; };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+static inline hipError_t hipMalloc(void* pp, size_t n) { void* p = malloc(n ? n : 1); *reinterpret_cast<void**>(pp) = p; return p ? hipSuccess : hipErrorUnknown; }
+template <class T> static inline hipError_t hipMalloc(T** pp, size_t n) { return hipMalloc(reinterpret_cast<void*>(pp), n); }
+static inline hipError_t hipExtMallocWithFlags(void** pp, size_t n, int) { return hipMalloc(reinterpret_cast<void*>(pp), n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, int, int) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h, &p, sizeof(p)); return hipSuccess; }
+static inline hipError_t hipIpcOpenMemHandle(void** pp, hipIpcMemHandle_t h, int) { memcpy(pp, &h, sizeof(void*)); return hipSuccess; }
+static inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+
+// (function templates like HIP's own: an argument such as `ChQ<W, WS>::TOTAL` carries a comma no macro could take)
+template <class K, class... A>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
+  dg_emu::launch(grid, block, shmem, [=]() { kernel(args...); });
+}
+template <class K, class... A>
+static inline void hipExtLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, hipEvent_t, hipEvent_t, int, A... args) {
+  dg_emu::launch(grid, block, shmem, [=]() { kernel(args...); });
+}

@@ -21,10 +21,23 @@ def pytest_configure(config):
         pass
 
 
+EMU = os.environ.get("DGCNN_EMU") == "1"      # run the GPU tests on the CPU SIMT emulation (tests/emu_util.py; small sizes only)
+# GPU tests that cannot mean anything under the emulation: second streams / processes, timing, the test builds of the library
+EMU_SKIP = ("two_trainers_on_two_streams", "busy_second_stream", "two_processes", "one_shot", "three_waves_stalled", "isa_audit")
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible and they were not
     explicitly selected, so a plain ``pytest tests`` works in the CPU container."""
     import torch
+    if EMU:
+        import emu_util
+        emu_util.install_global()
+        skip = pytest.mark.skip(reason="not meaningful on the CPU emulation")
+        for it in items:
+            if any(k in it.name for k in EMU_SKIP):
+                it.add_marker(skip)
+        return
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")
