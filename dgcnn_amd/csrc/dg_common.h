@@ -8,7 +8,7 @@
 // compiles the SAME sources as plain C++ ----------------------------------------------------------------------------------------
 #ifdef DG_EMU
 #define DG_DYN_SMEM(T, name) T* const name = reinterpret_cast<T*>(dg_emu::dyn_smem())
-#define DG_WAIT_LGKM() do { } while (0)
+#define DG_WAIT_LGKM() __builtin_amdgcn_wave_barrier()      // (stands where lanes of one wave exchange data through LDS in program order: see DG_LOCKSTEP)
 #define DG_OPAQUE_V(x) asm volatile("" : "+m"(x))
 #define DG_OPAQUE_S(x) asm volatile("" : "+m"(x))
 // The emulation runs a wave's lanes ONE AFTER THE OTHER between wave-level operations; the hardware runs them in lockstep.  Where

@@ -167,6 +167,7 @@ __device__ __forceinline__ void dg_prep_dense_plan(int tid, int T, int B, const 
       const unsigned long long below = same & ((1ull << lane) - 1ull);
       const int myrank = __builtin_popcountll(below);
       if (lane < 33) swc[wave][lane] = 0;                      // (the wave's own row: program order, no barrier)
+      DG_LOCKSTEP();
       if (below == 0ull && bin < 33) swc[wave][bin] = __builtin_popcountll(same);
       __syncthreads();
       if (g < B) {

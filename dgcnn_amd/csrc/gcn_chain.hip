@@ -1044,6 +1044,7 @@ __device__ __forceinline__ void ch_conv4_bwd_graph(int n0, int n, const unsigned
       const float4 dq = *reinterpret_cast<const float4*>(dv + 16 * wave + 4 * kq);
       *reinterpret_cast<float4*>(g4t + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
     }
+    DG_LOCKSTEP();
     const float gh = g4t[nl];
     const float dn = dv[m];
     const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
@@ -1162,11 +1163,13 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   };
   // the wave's 16 x 32 tile (row = node of the tile): a lane puts the 8 values of its node (columns 4 kq .. +3, 16 + 4 kq .. +3) ...
   auto tile_put = [&](const float (&v)[8]) {
+    DG_LOCKSTEP();      // (every lane is done with the tile's previous contents)
     *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(gt + nl * CH_GT_LD + 16 + 4 * kq) = make_float4(v[4], v[5], v[6], v[7]);
   };
   // ... and takes the lane = column layout: out[mb][s] = tile[node 4 kq + s][16 mb + nl]      (same wave: program order)
   auto tile_cols = [&](float (&out)[2][4]) {
+    DG_LOCKSTEP();      // (every lane has put its row)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1174,6 +1177,7 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
   };
   // ... or the column sums over the 16 nodes: lane l receives column l & 31 (both halves of the wave hold it)
   auto tile_colsum = [&]() {
+    DG_LOCKSTEP();
     const float* cp = gt + (lane >> 5) * (8 * CH_GT_LD) + (lane & 31);
     float a = cp[0];
 #pragma unroll
@@ -1238,6 +1242,7 @@ __device__ __forceinline__ void ch_gcn_bwd_graph(int n0, int n, int Fa, char* H,
       const float4 dq = *reinterpret_cast<const float4*>(dv + mt + 4 * kq);
       *reinterpret_cast<float4*>(g4t + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
     }
+    DG_LOCKSTEP();
     const float gh = g4t[nl];
     const float4 w4a = *reinterpret_cast<const float4*>(W4 + 4 * kq), w4b = *reinterpret_cast<const float4*>(W4 + 16 + 4 * kq);
     const float xv[8] = {x3a.x, x3a.y, x3a.z, x3a.w, x3b.x, x3b.y, x3b.z, x3b.w};
@@ -1967,6 +1972,7 @@ k_chain_bwd_a(int N, int B, const int* __restrict__ sched, const int* __restrict
             *reinterpret_cast<float4*>(g4t + 16 * ti + 4 * kq) = make_float4(dq.x * tot[0], dq.y * tot[1], dq.z * tot[2], dq.w * tot[3]);
           }
         }
+        DG_LOCKSTEP();
         const float gh = g4t[16 * ti + nl];              // (same wave wrote it: program order + lgkmcnt)
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         const float gv[8] = {ga_.x, ga_.y, ga_.z, ga_.w, gb_.x, gb_.y, gb_.z, gb_.w};
