@@ -1,0 +1,163 @@
+"""Device code on the CPU SIMT emulation (emu/, tests/emu_util.py) -- part of the `-m "not gpu"` suite, small sizes.
+
+The kernel sources are compiled as plain C++ against a stand-in for the HIP headers and run lane by lane; wave-level instructions
+and workgroup barriers are resolved by a scheduler.  What this checks is the ARITHMETIC AND INDEXING of the kernels against the
+fp64 oracle; what it cannot check is timing, memory ordering and races.  Two kinds of cases:
+
+* calibration -- kernels with green GPU records from rounds 1-5 (the one-launch evaluation kernel, the one-launch training kernel,
+  the launch-per-layer gather route, graph preparation): they must reproduce the oracle here too, which pins the emulation's
+  reading of the matrix instructions, the DPP controls and the LDS transpose read;
+* round 6 -- device code that had never run on a GPU when it was committed (the pool was closed): the 512-node evaluation kernel,
+  the persistent chain kernels with their loop-end barrier, the bitmap check of the two-launch chain route.
+
+The full GPU suite runs on the emulation with `DGCNN_EMU=1 python -m pytest tests -m gpu` (hours of CPU; profiles/r06_emu_gputest.txt)."""
+import numpy as np
+import pytest
+import torch
+
+from dgcnn_amd import _lib, synth
+from dgcnn_amd.batch import Batch
+from dgcnn_amd.train import Trainer
+from emu_util import emulated, read_metrics
+from oracle import ref_dense
+from parity_util import (check_backward_parity, check_forward_parity, cpu_state_dict, gpu_xcat, grads_close, make_model)
+from test_gpu_dense import _sized_batch
+
+KEYS = ["conv1.lin.weight", "conv1.bias", "conv2.lin.weight", "conv2.bias", "conv3.lin.weight", "conv3.bias", "conv4.lin.weight",
+        "conv4.bias", "conv5.weight", "conv5.bias", "conv6.weight", "conv6.bias", "classifier_1.weight", "classifier_1.bias",
+        "classifier_2.weight", "classifier_2.bias"]
+
+
+def form_of(L, m, b, extra=0):
+    fl = m._mode_flags() | (_lib.FLAG_COALESCED_UNDIRECTED if b.coalesced_undirected else 0) | extra
+    return L.dgcnn_forward_form(b.num_nodes, b.num_edges, b.num_graphs, int(b.x.shape[1]), fl, int(b.max_nodes or 0))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    with emulated() as L:
+        yield L
+
+
+# ---- calibration: kernels with green GPU records -------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,bs", [("MUTAG", 6), ("COLLAB", 3), ("PROTEINS", 5)])
+def test_emu_calibration_one_launch_eval_kernel(emu, name, bs):
+    sh = synth.SHAPES[name]
+    b = synth.make_batch(name, bs, start=10)
+    while b.max_nodes > 256:
+        b = synth.make_batch(name, bs, start=b.num_nodes)
+    m = make_model(sh.num_features, sh.num_classes, device="cpu")
+    assert form_of(emu, m, b) & _lib.FORM_EVAL
+    check_forward_parity(m, b, cpu_state_dict(m))
+
+
+def _step_grads_vs_oracle(m, b):
+    sd = cpu_state_dict(m)
+    m.train(); m._seed_base, m._fwd_count = 11, 0
+    tr = Trainer(m)
+    tr.reset_metrics()
+    tr.train_step(b, b.y)
+    lsum, _ = read_metrics(tr)
+    perm, mask = m.last_workspace_view("perm"), m.last_workspace_view("drop_mask")
+    logp_ref, loss_ref, g_ref, aux = ref_dense.loss_and_grads_dense(sd, b.x, b.edge_index, b.batch, b.y, b.num_graphs,
+                                                                    dropout_mask=mask, perm_override=perm)
+    assert float((gpu_xcat(m).double() - aux["xcat"].detach()).abs().max()) <= 2e-5
+    assert abs(lsum - float(loss_ref)) < 1e-5
+    for p, off, key in zip(m._param_list(), m._offsets, KEYS):
+        good, md, sc = grads_close(tr.grads[off:off + p.numel()], g_ref[key].reshape(-1))
+        assert good, f"grad {key}: max diff {md:.3e} at scale {sc:.3e}"
+
+
+@pytest.mark.parametrize("sizes,F", [([20, 17, 33], 3), ([130, 9], 12)])
+def test_emu_calibration_one_launch_training_kernel_and_wgrad(emu, sizes, F):
+    """k_chain_readout_tail (chain forward + readout + readout backward + the whole GCN backward of a graph) + k_wgrad (+ Adam)"""
+    b = _sized_batch(sizes, F=F, seed=3)
+    m = make_model(F, 2, device="cpu")
+    assert form_of(emu, m, b) & _lib.FORM_STEP
+    _step_grads_vs_oracle(m, b)
+
+
+def test_emu_calibration_launch_per_layer_gather_route(emu):
+    """general edge list (no layout promise: duplicates, a self loop, a directed edge): general graph preparation, the wave-per-node
+    gather kernels forward and backward, k_readout_tail / k_tail_bwd, k_wgrad"""
+    g = torch.Generator().manual_seed(5)
+    n = 40                                                   # graph 0: nodes 0..24, graph 1: nodes 25..39
+    s0, d0 = torch.randint(0, 25, (100,), generator=g), torch.randint(0, 25, (100,), generator=g)
+    s1, d1 = torch.randint(25, 40, (60,), generator=g), torch.randint(25, 40, (60,), generator=g)
+    src, dst = torch.cat([s0, s1]), torch.cat([d0, d1])
+    ei = torch.stack([torch.cat([src, dst, torch.tensor([3, 3, 30])]), torch.cat([dst, src, torch.tensor([3, 9, 31])])])
+    b = Batch(torch.randn(n, 4, generator=g), ei, torch.cat([torch.zeros(25), torch.ones(15)]).long(), torch.tensor([0, 1]), 2)
+    m = make_model(4, 2, device="cpu")
+    sd = cpu_state_dict(m)
+    assert form_of(emu, m, b) == 0
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
+
+
+# ---- round 6: device code that had not run on a GPU when it was committed -------------------------------------------------------
+@pytest.mark.parametrize("sizes,F", [([257, 40], 3), ([300, 512, 5], 20)])
+def test_emu_round6_wide_eval_kernel(emu, sizes, F):
+    """k_chain_readout_eval<.., MAXN = 512> (DGCNN_FLAG_INFERENCE) vs the fp64 oracle and vs the launch-per-layer route"""
+    b = _sized_batch(sizes, F=F, seed=sum(sizes))
+    m = make_model(F, 2, device="cpu")
+    sd = cpu_state_dict(m)
+    assert not form_of(emu, m, b) & _lib.FORM_EVAL
+    m.inference_one_launch = True
+    assert form_of(emu, m, b, _lib.FLAG_INFERENCE) & _lib.FORM_EVAL
+    logp, _, _, _ = check_forward_parity(m, b, sd)
+    xw = gpu_xcat(m)
+    m.inference_one_launch = False
+    logp2, _, _, _ = check_forward_parity(m, b, sd)
+    assert float((xw - gpu_xcat(m)).abs().max()) <= 4e-6 and float((logp - logp2).abs().max()) <= 1e-4
+    # ... and through Trainer.eval_step with the metrics folded in by the launch's last workgroup
+    m.inference_one_launch = True
+    tr = Trainer(m)
+    tr.reset_metrics()
+    lp = tr.eval_step(b, b.y).clone()
+    loss, correct = read_metrics(tr)
+    assert torch.equal(lp, logp)
+    want_loss = float(-(logp[torch.arange(b.num_graphs), b.y]).sum() / b.num_graphs)
+    assert abs(loss - want_loss) <= 1e-5 and correct == float((logp.argmax(1) == b.y).sum())
+
+
+def test_emu_round6_persistent_chain_kernels_walk_several_graphs(emu):
+    """k_chain_fwd_q<8, .., LOOP> and k_chain_bwd_a / _b<8, LOOP> with more graphs than persistent workgroups (every workgroup
+    walks >= 2 graphs, loop-end barriers executed), graphs of 129..150 nodes among tiny ones: forward and every gradient vs fp64"""
+    rng = np.random.default_rng(2)
+    sizes = [int(v) for v in rng.integers(3, 9, size=524)]
+    for k in (0, 7, 300, 523):
+        sizes[k] = int(rng.integers(129, 151))
+    b = _sized_batch(sizes, seed=8)
+    m = make_model(3, 2, device="cpu")
+    sd = cpu_state_dict(m)
+    m.agg_mode, m.use_chain = "dense", True
+    f = form_of(emu, m, b)
+    assert f & _lib.FORM_CHAIN and f & _lib.FORM_DENSE and b.num_graphs > 512
+    check_forward_parity(m, b, sd)
+    check_backward_parity(m, b, sd)
+
+
+def test_emu_round6_two_launch_chain_route_checks_the_bitmap_itself(emu):
+    """100 graphs prepared with the reverse-edge check left to a one-launch kernel, consumed by the two-launch chain route
+    (dgcnn_eval_kernel_enable(0)): one missing reverse edge is flagged, a clean batch is not"""
+    sizes = [6] * 99 + [9]
+    good = _sized_batch(sizes, seed=4)
+    ei = good.edge_index
+    e = int(ei.shape[1] * 0.6)
+    sn, dn = int(ei[0, e]), int(ei[1, e])
+    bad = Batch(good.x, ei[:, ~((ei[0] == dn) & (ei[1] == sn))].contiguous(), good.batch, good.y, good.num_graphs, True,
+                good.max_nodes, good.max_edges)
+    prev = emu.dgcnn_eval_kernel_enable(0)
+    try:
+        for b, flagged in ((good, False), (bad, True)):
+            m = make_model(3, 2, device="cpu")
+            m.eval()
+            with torch.no_grad():
+                m(b)
+            if flagged:
+                with pytest.raises(_lib.DgcnnError):
+                    m.check_errors()
+            else:
+                m.check_errors()
+    finally:
+        emu.dgcnn_eval_kernel_enable(prev)
