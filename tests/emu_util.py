@@ -18,10 +18,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "emu")
-EMU_LIB = os.path.join(EMU_DIR, "libdgcnn_emu.so")
+EMU_LIB = os.environ.get("DGCNN_EMU_LIB") or os.path.join(EMU_DIR, "libdgcnn_emu.so")      # (env: a variant build, see emu/Makefile)
 
 
 def build_emu(verbose: bool = False) -> str:
+    if os.environ.get("DGCNN_EMU_LIB"):
+        return EMU_LIB
     res = subprocess.run(["make", "-C", EMU_DIR, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
