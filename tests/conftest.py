@@ -23,7 +23,8 @@ def pytest_configure(config):
 
 EMU = os.environ.get("DGCNN_EMU") == "1"      # run the GPU tests on the CPU SIMT emulation (tests/emu_util.py; small sizes only)
 # GPU tests that cannot mean anything under the emulation: second streams / processes, timing, the test builds of the library
-EMU_SKIP = ("two_trainers_on_two_streams", "busy_second_stream", "two_processes", "one_shot", "three_waves_stalled", "isa_audit")
+EMU_SKIP = ("two_trainers_on_two_streams", "busy_second_stream", "two_processes", "one_shot", "three_waves_stalled", "isa_audit",
+            "in_a_subprocess", "two_rank")
 
 
 def pytest_collection_modifyitems(config, items):
