@@ -161,3 +161,40 @@ def test_emu_round6_two_launch_chain_route_checks_the_bitmap_itself(emu):
                 m.check_errors()
     finally:
         emu.dgcnn_eval_kernel_enable(prev)
+
+
+# ---- the GPU tests themselves, a quick subset, on the emulation -------------------------------------------------------------------
+QUICK_GPU_TESTS = [
+    "tests/test_gpu_kernels.py",                                                   # every C entry point vs the oracle (85 cases)
+    "tests/test_gpu_model.py::test_golden_fixture_forward",                        # tests/golden/*.npz through Model.forward
+    "tests/test_gpu_model.py::test_golden_fixture_gradients",
+    "tests/test_gpu_model.py::test_golden_step_fixture_loss_grads_and_post_adam_parameters",
+    "tests/test_gpu_eval_kernel.py::test_golden_fixtures_through_the_eval_kernel",
+    "tests/test_gpu_chain_tail.py::test_golden_step_fixture_through_the_one_launch_kernel",
+    "tests/test_gpu_chain_tail.py::test_golden_fixture_training_mode_through_the_one_launch_kernel",
+    "tests/test_gpu_chain.py::test_chain_boundary_sizes_isolated_nodes_and_single_node_graphs",
+    "tests/test_gpu_chain.py::test_chain_raw_feature_widths",
+    "tests/test_gpu_dense.py::test_dense_boundary_sizes_isolated_nodes_and_single_node_graphs",
+    "tests/test_tudataset.py",
+]
+
+
+def test_emu_quick_subset_of_the_gpu_tests_in_a_subprocess():
+    """`DGCNN_EMU=1 python -m pytest -m gpu <quick subset>`: the GPU tests run VERBATIM on the emulation library (tests/conftest.py
+    maps "cuda" to the CPU for that process) -- the golden fixtures through the forward, the evaluation kernel and the one-launch
+    training kernel, every C entry point, the chain / dense kernels at their size-class boundaries, the TU reader's device path.
+    A subprocess because the device mapping is process-wide and must not leak into the tests that check the product REFUSES CPU tensors."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from emu_util import ROOT, build_emu
+    build_emu()
+    env = dict(os.environ, DGCNN_EMU="1")
+    env.pop("DGCNN_HIP_LIB", None)
+    nw = max(1, min(4, os.cpu_count() or 1))
+    res = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-n", str(nw), "-p", "no:cacheprovider"] + QUICK_GPU_TESTS,
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = res.stdout[-3000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert res.returncode == 0 and m and int(m.group(1)) >= 120 and "failed" not in tail.split("\n")[-2], tail
