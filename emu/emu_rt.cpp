@@ -19,9 +19,9 @@ namespace dg_emu {
 Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 static const size_t kStack = 512 * 1024;
-static const size_t kSmem = 256 * 1024;
-alignas(256) static char g_smem[kSmem];
-char* dyn_smem() { return g_smem; }
+static const size_t kSmem = 160 * 1024;      // one CU's LDS: a launch asking for more than the hardware has is refused
+static char* g_smem = nullptr;               // the launch's dynamic LDS: exactly the bytes asked for, from the heap -- so that an
+char* dyn_smem() { return g_smem; }          // -fsanitize=address build of the emulation (make ... EXTRA=-fsanitize=address) sees overruns
 
 enum State { RUNNABLE, AT_WAVEOP, AT_BARRIER, DONE };
 struct Lane {
@@ -90,6 +90,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
       if (p == MAP_FAILED) { perror("dg_emu: mmap"); abort(); }
       g_lanes[t].stack = static_cast<char*>(p);
     }
+  void* sm = nullptr;
+  if (posix_memalign(&sm, 256, shmem ? shmem : 16)) { perror("dg_emu: posix_memalign"); abort(); }
+  memset(sm, 0xA5, shmem ? shmem : 16);       // (LDS is not zero-initialised on the hardware either)
+  g_smem = static_cast<char*>(sm);
   g_body = &body;
   g_blockDim = Idx{block.x, 1, 1};
   g_gridDim = Idx{grid.x, 1, 1};
@@ -151,5 +155,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
     }
   }
   g_body = nullptr;
+  free(g_smem);
+  g_smem = nullptr;
 }
 }  // namespace dg_emu
