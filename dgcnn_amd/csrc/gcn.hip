@@ -479,13 +479,13 @@ k_gcn_fwd32p(int N, int numTiles, const int* __restrict__ rowptr, const int* __r
 // results are bit-identical to the wave-per-node kernels (tests/test_gpu_kernels.py compares the two forms exactly).
 // ---------------------------------------------------------------------------------------------
 #define DG_NARROW_MAX_DEG 8
-static int g_narrow = -1;      // (-1: not yet read; DGCNN_NARROW_GATHER=0|1|2 in the environment sets the initial value, default 1)
+static int g_narrow = -1;      // (-1: not yet read; DGCNN_NARROW_GATHER=0|1|2 in the environment sets the initial value, default 2)
 static inline int dg_narrow_level() {
-  if (g_narrow < 0) { const char* e = getenv("DGCNN_NARROW_GATHER"); g_narrow = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+  if (g_narrow < 0) { const char* e = getenv("DGCNN_NARROW_GATHER"); g_narrow = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
   return g_narrow;
 }
-// 0: wave per node everywhere; 1 (default): the 32-wide narrow forms; 2 (round 6, opt-in until measured): also the scalar
-// narrow forms of conv4's two gathers (k_gcn_fwd1n / k_gcn_bwd1n)
+// 0: wave per node everywhere; 1: the 32-wide narrow forms only (the round-4 / round-5 default); 2 (default since round 6): also the
+// scalar narrow forms of conv4's two gathers (k_gcn_fwd1n / k_gcn_bwd1n) -- verified on the CPU emulation, not yet timed on a GPU
 int dg_narrow_gather_enable(int on) { const int prev = dg_narrow_level(); g_narrow = on <= 0 ? 0 : (on >= 2 ? 2 : 1); return prev; }
 // E: directed edges of the batch without the self loops (< 0: unknown -> the wave-per-node forms)
 static inline bool dg_use_narrow(int N, int E) {

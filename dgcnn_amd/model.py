@@ -318,10 +318,11 @@ class Model(nn.Module):
         return f
 
     def _inference_flag(self) -> int:
-        """``DGCNN_FLAG_INFERENCE`` for a forward no backward can follow (``torch.no_grad()``, ``Trainer.eval_step``) when the
-        model attribute ``inference_one_launch`` is set: small batches with a graph of 257..512 nodes then take the one-launch
-        evaluation kernel (round 6; opt-in until it has a measured line)."""
-        return _lib.FLAG_INFERENCE if self.__dict__.get("inference_one_launch") else 0
+        """``DGCNN_FLAG_INFERENCE`` for a forward no backward can follow (``torch.no_grad()``, ``Trainer.eval_step``): small batches
+        with a graph of 257..512 nodes then take the one-launch evaluation kernel too (round 6: ``test()`` of the reference,
+        train.py:49-66, is one launch per batch on PROTEINS-like sets).  On unless the model attribute ``inference_one_launch`` is
+        set to False (A/B, tests).  Not yet timed on a GPU (the pool was closed in round 6): verified on the CPU emulation only."""
+        return 0 if self.__dict__.get("inference_one_launch") is False else _lib.FLAG_INFERENCE
 
     def _max_nodes_of(self, data) -> int:
         """per-graph node bound (host-known hint) for the graph-per-workgroup path"""

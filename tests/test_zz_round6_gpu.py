@@ -254,6 +254,7 @@ def test_wide_eval_kernel_through_the_switch_for_chain_form_batches_and_a_traini
     m = make_model(sh.num_features, sh.num_classes)
     sd = cpu_state_dict(m)
     m.use_chain = True
+    m.inference_one_launch = False          # (this half is about the SWITCH: no inference flag on the forward)
     prev = L.dgcnn_eval_kernel_enable(1)
     try:
         assert not form_of(m, b_cpu) & _lib.FORM_EVAL
@@ -286,7 +287,7 @@ def test_wide_eval_kernel_through_the_switch_for_chain_form_batches_and_a_traini
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4
 
 
-# ---- 4. eight-lanes-per-node forms of conv4's two scalar gathers (dgcnn_narrow_gather_enable(2), opt-in) --------
+# ---- 4. eight-lanes-per-node forms of conv4's two scalar gathers (dgcnn_narrow_gather_enable(2), the default since round 6) --------
 SCALAR_CASES = [("DD", 50, None), ("DD", 50, 5748), ("hub7", 0, None), ("hub40", 0, None)]
 
 
