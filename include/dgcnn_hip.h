@@ -268,14 +268,14 @@ int dgcnn_forward_form(int N, int E, int B, int F, int flags, int max_nodes);
  * default.  Returns the previous setting.  Replaces nothing of the reference (/root/reference/train.py:40 is one backward). */
 int dgcnn_step_kernel_enable(int on);
 /* Test / measurement switch of DGCNN_FORM_EVAL (process-wide): on = 0 keeps the chain forward and the readout forward of small
- * batches as two launches (+ k_eval_metrics where labels are given) -- the round-4 form; on = 1 restores the default; on = 2
+ * batches as two launches (+ k_eval_metrics where labels are given) -- the round-4 form; on = 1 restores the round-5 default; on = 2
  * (ABI v20) additionally takes the one-launch form for chain-form batches with a graph of 257..512 nodes without
  * DGCNN_FLAG_INFERENCE (e.g. under DGCNN_FLAG_CHAIN).  Returns the previous setting.  Replaces nothing of the reference (/root/reference/model.py:26-45 is one forward). */
 int dgcnn_eval_kernel_enable(int on);
 /* Test / measurement switch of the eight-lanes-per-node ("narrow") gather kernels that the launch-per-layer route of
  * dgcnn_model_forward / dgcnn_model_backward takes for sparse batches of many nodes (more than 4096 nodes, mean in-degree <= 8:
  * DD at the reference's batch of 50, /root/reference/model.py:30-33 + train.py:40): on = 0 keeps the wave-per-node kernels, whose
- * results the narrow forms reproduce bit for bit; on = 1 restores the default; on = 2 (ABI v20, opt-in until measured) also takes
+ * results the narrow forms reproduce bit for bit; on = 1 restores the default; on = 2 (ABI v20, the default since round 6; DGCNN_NARROW_GATHER in the environment sets the initial value) also takes
  * eight-lanes-per-node forms of conv4's two SCALAR gathers (k_gcn_fwd1n / k_gcn_bwd1n: bit-identical for rows of <= 8 neighbours,
  * summation-order rounding beyond).  Returns the previous setting (process-wide).
  * Do not toggle it between dgcnn_model_forward and dgcnn_model_backward of the SAME batch: on this route the switch also decides
