@@ -57,6 +57,6 @@ bash tools/kstats.sh ${T}_b256_dataset --batch 256 --pool 8 --no-dropin --prep d
 python tools/eval_time.py DD 50 >> $OUT/${T}_eval_time.txt 2>&1
 ls -la $OUT | tail -40
 python tools/eval_route_time.py PROTEINS 50 > $OUT/${T}_eval_route_time.txt 2>&1      # one-launch evaluation of batches with a 257..512-node graph
-# DD at batch 50 with the scalar narrow gathers of conv4 (round 6, opt-in): bench line + kernel stats beside the default's
-DGCNN_NARROW_GATHER=2 python bench.py --workload DD --steps 200 --warmup 20 $Q > $OUT/${T}_bench_dd_narrow2.json 2>> $OUT/${T}_bench.err
-DGCNN_NARROW_GATHER=2 bash tools/kstats.sh ${T}_dd_narrow2 --workload DD --no-dropin > /dev/null
+# DD at batch 50 WITHOUT the scalar narrow gathers of conv4 (round 6 made them the default): the round-5 form beside the default's lines
+DGCNN_NARROW_GATHER=1 python bench.py --workload DD --steps 200 --warmup 20 $Q > $OUT/${T}_bench_dd_narrow1.json 2>> $OUT/${T}_bench.err
+DGCNN_NARROW_GATHER=1 bash tools/kstats.sh ${T}_dd_narrow1 --workload DD --no-dropin > /dev/null
