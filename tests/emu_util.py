@@ -24,7 +24,10 @@ EMU_LIB = os.environ.get("DGCNN_EMU_LIB") or os.path.join(EMU_DIR, "libdgcnn_emu
 def build_emu(verbose: bool = False) -> str:
     if os.environ.get("DGCNN_EMU_LIB"):
         return EMU_LIB
-    res = subprocess.run(["make", "-C", EMU_DIR, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lk:      # (xdist workers all arrive here: one make at a time)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        res = subprocess.run(["make", "-C", EMU_DIR, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
     if res.returncode != 0 or not os.path.exists(EMU_LIB):
