@@ -318,11 +318,13 @@ class Model(nn.Module):
         return f
 
     def _inference_flag(self) -> int:
-        """``DGCNN_FLAG_INFERENCE`` for a forward no backward can follow (``torch.no_grad()``, ``Trainer.eval_step``): small batches
-        with a graph of 257..512 nodes then take the one-launch evaluation kernel too (round 6: ``test()`` of the reference,
-        train.py:49-66, is one launch per batch on PROTEINS-like sets).  On unless the model attribute ``inference_one_launch`` is
-        set to False (A/B, tests).  Not yet timed on a GPU (the pool was closed in round 6): verified on the CPU emulation only."""
-        return 0 if self.__dict__.get("inference_one_launch") is False else _lib.FLAG_INFERENCE
+        """``DGCNN_FLAG_INFERENCE`` for a forward no backward can follow (``torch.no_grad()``, ``Trainer.eval_step``) when the model
+        attribute ``inference_one_launch`` is set: small batches with a graph of 257..512 nodes then take the one-launch evaluation
+        kernel too (round 6: ``test()`` of the reference, train.py:49-66, one launch per batch on PROTEINS-like sets).  Verified on
+        the CPU emulation; OFF by default because it is not expected to be faster: the launch lasts as long as its largest graph,
+        whose block products grow with n^2 (round 5 measured the two-tiles-per-wave chain forward of such batches ~13 us SLOWER
+        than the four gather launches it replaces) -- `tools/eval_route_time.py` decides on the first GPU call."""
+        return _lib.FLAG_INFERENCE if self.__dict__.get("inference_one_launch") else 0
 
     def _max_nodes_of(self, data) -> int:
         """per-graph node bound (host-known hint) for the graph-per-workgroup path"""
