@@ -42,6 +42,36 @@ static uint64_t g_clock = 0;
 static bool g_trace = false;
 
 uint64_t clock() { return ++g_clock; }
+static int g_in_atomic = 0;
+void atomic_begin() { ++g_in_atomic; }
+void atomic_end() { --g_in_atomic; }
+
+// ---- LDS race detector (builds with -fsanitize-coverage=trace-pc-guard,trace-loads,trace-stores: emu/Makefile `race`) -----------
+// Every plain load / store of the kernel sources calls a hook with its address.  For addresses inside the launch's dynamic LDS or
+// the section of the static __shared__ arrays, a shadow word remembers the wave that last wrote it and the waves that read it IN THE
+// CURRENT BARRIER EPOCH (the epoch advances whenever the workgroup barrier opens).  Two DIFFERENT waves touching the same word in one
+// epoch, at least one of them writing, is a data race on the hardware whatever order this emulation happened to run them in --
+// independent of timing, which is exactly what a GPU test cannot promise.  Accesses inside atomic operations are exempt; lanes of one
+// wave are not checked against each other (lockstep: DG_LOCKSTEP documents those places).
+struct Shadow { uint32_t wepoch, wwave, repoch, rmask; };
+static bool g_race = false;
+static uint32_t g_epoch = 1;
+static size_t g_shmem = 0;
+static std::vector<Shadow> g_sh_dyn, g_sh_static;
+extern "C" char __start_dg_lds[] __attribute__((weak));
+extern "C" char __stop_dg_lds[] __attribute__((weak));
+static unsigned g_race_reports = 0;
+static const void* g_race_pcs[64];
+unsigned long long g_race_total = 0;
+static void race_report(const char* kind, const char* where, size_t off, unsigned wave_a, unsigned wave_b, const void* pc) {
+  ++g_race_total;
+  for (unsigned i = 0; i < g_race_reports; ++i) if (g_race_pcs[i] == pc) return;
+  if (g_race_reports >= 64) return;
+  g_race_pcs[g_race_reports++] = pc;
+  fprintf(stderr, "dg_emu RACE %s: %s LDS +%zu, block %u, waves %u and %u in one barrier epoch, pc %p\n",
+          kind, where, off, g_blockIdx.x, wave_a, wave_b, pc);
+}
+
 static bool site_eq(const Site& a, const Site& b) { return a.line == b.line && a.col == b.col && (a.file == b.file || !strcmp(a.file, b.file)); }
 static bool site_less(const Site& a, const Site& b) {
   const int c = a.file == b.file ? 0 : strcmp(a.file, b.file);
@@ -49,6 +79,27 @@ static bool site_less(const Site& a, const Site& b) {
   return a.line != b.line ? a.line < b.line : a.col < b.col;
 }
 
+static inline void lds_access(const void* a, unsigned n, bool wr, const void* pc) {
+  if (!g_race || !g_cur || g_in_atomic) return;
+  const char* p = static_cast<const char*>(a);
+  Shadow* sh; size_t off; const char* where;
+  if (g_smem && p >= g_smem && p < g_smem + g_shmem) { off = (size_t)(p - g_smem); sh = g_sh_dyn.data(); where = "dynamic"; }
+  else if (__start_dg_lds && p >= __start_dg_lds && p < __stop_dg_lds) { off = (size_t)(p - __start_dg_lds); sh = g_sh_static.data(); where = "static"; }
+  else return;
+  const uint32_t wave = g_cur->tid >> 6;
+  for (size_t w = off >> 2; w <= (off + n - 1) >> 2; ++w) {
+    Shadow& s = sh[w];
+    if (wr) {
+      if (s.wepoch == g_epoch && s.wwave != wave) race_report("write/write", where, 4 * w, s.wwave, wave, pc);
+      if (s.repoch == g_epoch && (s.rmask & ~(1u << wave))) race_report("read/write", where, 4 * w, (unsigned)__builtin_ctz(s.rmask & ~(1u << wave)), wave, pc);
+      s.wepoch = g_epoch; s.wwave = wave;
+    } else {
+      if (s.wepoch == g_epoch && s.wwave != wave) race_report("write/read", where, 4 * w, s.wwave, wave, pc);
+      if (s.repoch != g_epoch) { s.repoch = g_epoch; s.rmask = 0; }
+      s.rmask |= 1u << wave;
+    }
+  }
+}
 static void lane_entry() {
   (*g_body)();
   g_cur->st = DONE;
@@ -76,7 +127,11 @@ void wave_release() {}
 
 void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
   static bool init = false;
-  if (!init) { init = true; g_trace = getenv("DG_EMU_TRACE") != nullptr; }
+  if (!init) {
+    init = true; g_trace = getenv("DG_EMU_TRACE") != nullptr; g_race = getenv("DG_EMU_RACE") != nullptr;
+    if (g_race && __start_dg_lds) g_sh_static.assign((size_t)(__stop_dg_lds - __start_dg_lds) / 4 + 2, Shadow{0, 0, 0, 0});
+    if (g_race) g_sh_dyn.assign(kSmem / 4 + 2, Shadow{0, 0, 0, 0});
+  }
   const unsigned nthr = block.x * block.y * block.z;
   if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1 || nthr == 0 || nthr > 1024 || (nthr & 63) || shmem > kSmem) {
     fprintf(stderr, "dg_emu: unsupported launch shape grid (%u,%u,%u) block (%u,%u,%u) shmem %zu\n", grid.x, grid.y, grid.z, block.x,
@@ -94,12 +149,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
   if (posix_memalign(&sm, 256, shmem ? shmem : 16)) { perror("dg_emu: posix_memalign"); abort(); }
   memset(sm, 0xA5, shmem ? shmem : 16);       // (LDS is not zero-initialised on the hardware either)
   g_smem = static_cast<char*>(sm);
+  g_shmem = shmem;
   g_body = &body;
   g_blockDim = Idx{block.x, 1, 1};
   g_gridDim = Idx{grid.x, 1, 1};
   const unsigned nw = nthr / 64;
   for (unsigned b = 0; b < grid.x; ++b) {
     g_blockIdx = Idx{b, 0, 0};
+    ++g_epoch;                                   // (a new workgroup: nothing of the previous one's accesses counts)
     for (unsigned t = 0; t < nthr; ++t) {
       Lane& l = g_lanes[t];
       l.tid = t; l.st = RUNNABLE; l.in = nullptr; l.site = Site{nullptr, 0, 0};
@@ -152,10 +209,23 @@ void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
         if (g_lanes[t].st == AT_WAVEOP || g_lanes[t].st == RUNNABLE) { fprintf(stderr, "dg_emu: scheduler invariant broken\n"); abort(); }
         if (g_lanes[t].st == AT_BARRIER) g_lanes[t].st = RUNNABLE;
       }
+      ++g_epoch;                                 // the barrier opens: a new epoch of the race detector
     }
   }
   g_body = nullptr;
+  g_cur = nullptr;
   free(g_smem);
   g_smem = nullptr;
 }
 }  // namespace dg_emu
+
+// instrumentation hooks (clang -fsanitize-coverage=trace-pc-guard,trace-loads,trace-stores); this file itself is built without them
+extern "C" {
+unsigned long long dg_emu_race_count() { return dg_emu::g_race_total; }
+void __sanitizer_cov_trace_pc_guard(uint32_t*) {}
+void __sanitizer_cov_trace_pc_guard_init(uint32_t*, uint32_t*) {}
+#define DG_HOOK(N)                                                                                                          \
+  void __sanitizer_cov_load##N(void* a) { dg_emu::lds_access(a, N, false, __builtin_return_address(0)); }                      \
+  void __sanitizer_cov_store##N(void* a) { dg_emu::lds_access(a, N, true, __builtin_return_address(0)); }
+DG_HOOK(1) DG_HOOK(2) DG_HOOK(4) DG_HOOK(8) DG_HOOK(16)
+}

@@ -30,22 +30,25 @@ template <class A, class B> static inline typename std::common_type<A, B>::type 
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+// every static __shared__ array lives in ONE section: the LDS race detector (emu_rt.cpp, -DDG_EMU_RACE builds) finds them by address
+#define __shared__ static __attribute__((section("dg_lds")))
 #define __constant__ static const
 
 // ---- vector types -------------------------------------------------------------------------------------------------------------
-struct alignas(8) float2 { float x, y; };
-struct alignas(16) float4 { float x, y, z, w; };
-struct alignas(8) int2 { int x, y; };
-struct alignas(16) int4 { int x, y, z, w; };
-struct alignas(8) uint2 { unsigned x, y; };
-struct alignas(16) uint4 { unsigned x, y, z, w; };
-static inline float2 make_float2(float x, float y) { return float2{x, y}; }
-static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
-static inline int2 make_int2(int x, int y) { return int2{x, y}; }
-static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
-static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
-static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+// (real vector types, not structs of four members: a struct copy becomes a memcpy / memset intrinsic, which the race detector's
+//  load / store instrumentation does not see; .x .y .z .w work on clang's extended vectors)
+typedef float float2 __attribute__((ext_vector_type(2)));
+typedef float float4 __attribute__((ext_vector_type(4)));
+typedef int int2 __attribute__((ext_vector_type(2)));
+typedef int int4 __attribute__((ext_vector_type(4)));
+typedef unsigned uint2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint4 __attribute__((ext_vector_type(4)));
+static inline float2 make_float2(float x, float y) { float2 v = {x, y}; return v; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 v = {x, y, z, w}; return v; }
+static inline int2 make_int2(int x, int y) { int2 v = {x, y}; return v; }
+static inline int4 make_int4(int x, int y, int z, int w) { int4 v = {x, y, z, w}; return v; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v = {x, y}; return v; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v = {x, y, z, w}; return v; }
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -67,6 +70,8 @@ struct Site { const char* file; int line, col; };
 const WaveBuf& wave_exchange(const void* in, unsigned nbytes, Site site);
 void wave_release();                                              // (the lane has consumed the exchange buffer)
 uint64_t clock();
+void atomic_begin();                                              // (race detector: accesses of an atomic operation are not plain accesses;
+void atomic_end();                                                //  out-of-line so that the optimizer cannot cancel the pair)
 }  // namespace dg_emu
 #define threadIdx dg_emu::g_threadIdx
 #define blockIdx dg_emu::g_blockIdx
@@ -197,8 +202,7 @@ static inline __attribute__((always_inline)) dg_emu_f32x4 __builtin_amdgcn_mfma_
 // lanes 4j .. 4j + 3, concatenated); lane l receives column l of the four rows
 typedef short dg_emu_s16x4 __attribute__((ext_vector_type(4)));
 static inline __attribute__((always_inline)) dg_emu_s16x4 __builtin_amdgcn_ds_read_tr16_b64_v4i16(const dg_emu_s16x4* p, const char* file_ = __builtin_FILE(), int line_ = __builtin_LINE(), int col_ = __builtin_COLUMN()) {
-  dg_emu_s16x4 mine;
-  memcpy(&mine, p, 8);
+  const dg_emu_s16x4 mine = *p;      // (a typed load, not memcpy: the race detector's instrumentation sees loads, not intrinsics)
   return dg_emu_waveop(mine, [](int lane, const dg_emu::WaveBuf& w) {
     dg_emu_s16x4 r;
     const int g = lane & ~15, l = lane & 15;
@@ -244,10 +248,11 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 #ifndef __HIP_MEMORY_SCOPE_WAVEFRONT
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 4
 #endif
-template <class T, class V> static inline T atomicAdd(T* p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }
-template <class T, class V> static inline T atomicOr(T* p, V v) { T o = *p; *p = (T)(o | (T)v); return o; }
-template <class T, class V> static inline T atomicMin(T* p, V v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class V> static inline T atomicMax(T* p, V v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+struct dg_emu_atomic_scope { dg_emu_atomic_scope() { dg_emu::atomic_begin(); } ~dg_emu_atomic_scope() { dg_emu::atomic_end(); } };
+template <class T, class V> static inline T atomicAdd(T* p, V v) { dg_emu_atomic_scope sc; T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class V> static inline T atomicOr(T* p, V v) { dg_emu_atomic_scope sc; T o = *p; *p = (T)(o | (T)v); return o; }
+template <class T, class V> static inline T atomicMin(T* p, V v) { dg_emu_atomic_scope sc; T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class V> static inline T atomicMax(T* p, V v) { dg_emu_atomic_scope sc; T o = *p; if ((T)v > o) *p = (T)v; return o; }
 
 // ---- host API -------------------------------------------------------------------------------------------------------------------
 typedef int hipError_t;
