@@ -198,3 +198,47 @@ def test_emu_quick_subset_of_the_gpu_tests_in_a_subprocess():
     tail = res.stdout[-3000:]
     m = re.search(r"(\d+) passed", tail)
     assert res.returncode == 0 and m and int(m.group(1)) >= 120 and "failed" not in tail.split("\n")[-2], tail
+
+
+# ---- LDS race detector (emu_rt.cpp; `make -C emu race`) ---------------------------------------------------------------------------
+def test_emu_race_detector_finds_no_cross_wave_lds_race_in_the_default_build():
+    """The emulation library built with load / store instrumentation keeps, per LDS word, the wave that wrote it and the waves that
+    read it in the current barrier epoch; two different waves on one word in one epoch, one of them writing, is a race on the
+    hardware whatever the timing.  Run in a subprocess (its own library): the persistent chain kernels walking several graphs per
+    workgroup (the loop-end barrier's case), the one-launch training kernel + k_wgrad, the evaluation kernel, the
+    gather route -- parity AND zero race events.  (The same batch shapes on a build WITHOUT the loop-end barriers: 67 k / 177 k
+    events and wrong results: profiles/r06_race_test.txt.)"""
+    import os
+    import subprocess
+    import sys
+    from emu_util import EMU_DIR, ROOT
+    res = subprocess.run(["make", "-C", EMU_DIR, "race", "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lib = os.path.join(EMU_DIR, "libdgcnn_emu_race.so")
+    assert res.returncode == 0 and os.path.exists(lib), res.stdout[-3000:]
+    code = r'''
+import sys, ctypes
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import torch
+from emu_util import emulated
+from dgcnn_amd.train import Trainer
+from parity_util import make_model, cpu_state_dict, check_forward_parity, check_backward_parity
+from test_gpu_dense import _sized_batch
+with emulated() as L:
+    L.dg_emu_race_count.restype = ctypes.c_ulonglong
+    b = _sized_batch([150, 140, 133] + [6] * 300 + [129, 9] * 3, seed=8)        # more graphs than persistent workgroups: walks of 2..3
+    m = make_model(3, 2, device="cpu"); sd = cpu_state_dict(m)
+    m.agg_mode, m.use_chain = "dense", True
+    check_forward_parity(m, b, sd); check_backward_parity(m, b, sd)
+    b2 = _sized_batch([130, 40, 9], F=12, seed=3)
+    m2 = make_model(12, 2, device="cpu"); sd2 = cpu_state_dict(m2)
+    check_forward_parity(m2, b2, sd2)                                         # evaluation kernel
+    m2.train(); tr = Trainer(m2); tr.train_step(b2, b2.y); tr.read_metrics()   # step kernel + k_wgrad
+    m3 = make_model(12, 2, device="cpu"); sd3 = cpu_state_dict(m3)
+    m3.use_chain, m3.agg_mode = False, "sparse"
+    check_backward_parity(m3, b2, sd3)                                        # gather route
+    print("RACE_EVENTS", L.dg_emu_race_count())
+'''
+    env = dict(os.environ, DG_EMU_RACE="1", DGCNN_EMU_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=1500)
+    assert r.returncode == 0 and "RACE_EVENTS 0" in r.stdout, r.stdout[-3000:]
