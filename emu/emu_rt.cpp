@@ -10,6 +10,7 @@
 //   * when every live lane of the workgroup is parked at the barrier, the barrier opens.
 // One lane runs at a time: no data race can show here, no memory-ordering bug, no timing.  What shows is arithmetic and indexing.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <ucontext.h>
 #include <sys/mman.h>
 #include <stdio.h>
@@ -68,8 +69,11 @@ static void race_report(const char* kind, const char* where, size_t off, unsigne
   for (unsigned i = 0; i < g_race_reports; ++i) if (g_race_pcs[i] == pc) return;
   if (g_race_reports >= 64) return;
   g_race_pcs[g_race_reports++] = pc;
-  fprintf(stderr, "dg_emu RACE %s: %s LDS +%zu, block %u, waves %u and %u in one barrier epoch, pc %p\n",
-          kind, where, off, g_blockIdx.x, wave_a, wave_b, pc);
+  Dl_info di;
+  const bool have = dladdr(pc, &di) != 0 && di.dli_fbase;
+  fprintf(stderr, "dg_emu RACE %s: %s LDS +%zu, block %u, waves %u and %u in one barrier epoch, at %s+0x%zx (llvm-symbolizer -e <lib> <offset>)\n",
+          kind, where, off, g_blockIdx.x, wave_a, wave_b, have ? di.dli_fname : "?",
+          have ? (size_t)((const char*)pc - (const char*)di.dli_fbase) : (size_t)pc);
 }
 
 static bool site_eq(const Site& a, const Site& b) { return a.line == b.line && a.col == b.col && (a.file == b.file || !strcmp(a.file, b.file)); }
