@@ -71,9 +71,12 @@ static void race_report(const char* kind, const char* where, size_t off, unsigne
   g_race_pcs[g_race_reports++] = pc;
   Dl_info di;
   const bool have = dladdr(pc, &di) != 0 && di.dli_fbase;
-  fprintf(stderr, "dg_emu RACE %s: %s LDS +%zu, block %u, waves %u and %u in one barrier epoch, at %s+0x%zx (llvm-symbolizer -e <lib> <offset>)\n",
+  FILE* out = stderr;
+  if (const char* lp = getenv("DG_EMU_RACE_LOG")) { FILE* f = fopen(lp, "a"); if (f) out = f; }      // (xdist workers: stderr is swallowed)
+  fprintf(out, "dg_emu RACE %s: %s LDS +%zu, block %u, waves %u and %u in one barrier epoch, at %s+0x%zx (llvm-symbolizer -e <lib> <offset>)\n",
           kind, where, off, g_blockIdx.x, wave_a, wave_b, have ? di.dli_fname : "?",
           have ? (size_t)((const char*)pc - (const char*)di.dli_fbase) : (size_t)pc);
+  if (out != stderr) fclose(out);
 }
 
 static bool site_eq(const Site& a, const Site& b) { return a.line == b.line && a.col == b.col && (a.file == b.file || !strcmp(a.file, b.file)); }
